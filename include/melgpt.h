@@ -1,0 +1,104 @@
+/* melgpt.h - C ABI of libmelgpt_hip.so: the MI355X (gfx950) kernels behind the
+ * mel-spectrogram -> VQ-codebook -> GPT hot path of karchkha/MelSpec_GPT_VQVAE.
+ *
+ * The reference has no FFI layer of its own (it is pure PyTorch); this ABI is the
+ * boundary a maintainer binds with ctypes from the reference's Python modules
+ * (INTEGRATION.md shows the stubs).  Each entry point names the reference code it
+ * replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated otherwise; no torch types;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); launches are
+ *     asynchronous, no entry point synchronises, allocates or frees;
+ *   - return value: MELGPT_OK or a negative MELGPT_ERR_* (arguments are validated on the
+ *     host BEFORE anything is launched; the Python shim turns errors into exceptions);
+ *   - dtype codes: MELGPT_F32 (parity lane, exact-f32 MFMA) / MELGPT_BF16 (throughput
+ *     lane, bf16 storage + f32 accumulation).
+ */
+#ifndef MELGPT_H
+#define MELGPT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MELGPT_ABI_VERSION 1
+
+enum { MELGPT_F32 = 0, MELGPT_BF16 = 1 };
+
+enum {
+  MELGPT_OK = 0,
+  MELGPT_ERR_BAD_ARG = -1,     /* null pointer / non-positive size */
+  MELGPT_ERR_UNSUPPORTED = -2, /* shape or dtype outside what the kernel was built for */
+  MELGPT_ERR_LAUNCH = -3,      /* hipGetLastError() != hipSuccess after the launch */
+  MELGPT_ERR_ALIGN = -4        /* pointer / stride not aligned as required */
+};
+
+int melgpt_abi_version(void);
+const char* melgpt_strerror(int code);
+
+/* ===================================================================== VQ codebook
+ * Nearest-neighbour lookup = VectorQuantizer.forward, vqvae/big_model_attn_gan.py:19-54
+ * (distances :28-30, argmin :33 first-index tie-break, gather :36-40, MSE terms :43-45,
+ * straight-through value :49, code histogram for the perplexity :50-51).
+ *
+ * Latent element (n, c), n in [0,N), c in [0,D):
+ *     z[(n / inner) * stride_outer + (n % inner) * stride_inner + c * stride_c]   (element units)
+ * which covers NCHW (inner = H*W, stride_outer = D*H*W, stride_inner = 1, stride_c = H*W) and
+ * channels-last / flat (N,D) (inner = N, stride_inner = D, stride_c = 1).
+ *
+ * codebook   (K, D) f32 row-major.  Built for D = 256, K = 128 (big_model_attn_gan.py:522, minGPT.py:242).
+ * indices    out (N,) int64 - row-major order n = b*H*W + h*W + w, as info[2] in the reference.
+ * quantized  optional out, same dtype/addressing as z: x + (E[idx] - x)   (:49 forward value)
+ * sq_err     optional out (grid,) f32: per-workgroup partial sums of (E[idx]-x)^2, reduced in
+ *            fixed order by melgpt_vq_finalize (deterministic; no float atomics)
+ * histogram  optional in/out (K,) int32 code counts (integer atomics); caller zeroes it.
+ * `grid_out` (host pointer, optional) receives the number of workgroups = valid length of sq_err.
+ * F32 lane: the cross term is an exact k-ordered f32 FMA chain (f32 MFMA); oracle/vq_argmin.c
+ * reproduces it bit for bit.  BF16 lane: z is bf16, the codebook is rounded to bf16 in-kernel.
+ */
+int melgpt_vq_argmin_fwd(const void* z, int z_dtype, int64_t n_vectors, int dim, int64_t inner,
+                         int64_t stride_outer, int64_t stride_inner, int64_t stride_c,
+                         const float* codebook, int num_codes, int64_t* indices, void* quantized,
+                         float* sq_err, int32_t* histogram, int* grid_out, void* stream);
+
+/* Same, plus `distances`: optional out (N,K) f32 = the matrix of :28-30 (inspection / bit-exact tests). */
+int melgpt_vq_argmin_fwd_ex(const void* z, int z_dtype, int64_t n_vectors, int dim, int64_t inner,
+                            int64_t stride_outer, int64_t stride_inner, int64_t stride_c,
+                            const float* codebook, int num_codes, int64_t* indices, void* quantized,
+                            float* sq_err, int32_t* histogram, float* distances, int* grid_out,
+                            void* stream);
+
+/* max workgroups melgpt_vq_argmin_fwd will ever use (size sq_err with it). */
+int melgpt_vq_max_grid(void);
+
+/* loss = mse + commitment*mse (:43-45), perplexity = exp(-sum p log(p+1e-10)) (:50-51).
+ * out[0] = loss, out[1] = perplexity, out[2] = mse. */
+int melgpt_vq_finalize(const float* sq_err, int n_partials, const int32_t* histogram, int num_codes,
+                       int64_t n_vectors, int dim, float commitment_cost, float* out, void* stream);
+
+/* get_codebook_entry, big_model_attn_gan.py:56-71: out(n, c) = codebook[indices[n]][c], same
+ * addressing convention as z above. */
+int melgpt_vq_gather(const int64_t* indices, int64_t n_vectors, const float* codebook, int num_codes,
+                     int dim, void* out, int out_dtype, int64_t inner, int64_t stride_outer,
+                     int64_t stride_inner, int64_t stride_c, void* stream);
+
+/* one-hot `encodings` (N,K) f32 of :36-37 (API-compat output only; the hot path never builds it). */
+int melgpt_vq_onehot(const int64_t* indices, int64_t n_vectors, int num_codes, float* encodings,
+                     void* stream);
+
+/* backward of VectorQuantizer.forward through `quantized` (STE, :49) and `loss` (:43-45):
+ *   dz(n,c)        = g_q(n,c) + g_loss * 2*commitment/(N*D) * (x - E[idx])
+ *   dcodebook[k,c] += sum_{n: idx[n]=k} g_loss * 2/(N*D) * (E[k] - x(n,c))       (f32 atomics)
+ * g_q may be NULL (treated as 0); g_loss is a device scalar (may be NULL = 0). */
+int melgpt_vq_bwd(const void* z, const void* g_quantized, int dtype, int64_t n_vectors, int dim,
+                  int64_t inner, int64_t stride_outer, int64_t stride_inner, int64_t stride_c,
+                  const float* codebook, int num_codes, const int64_t* indices, const float* g_loss,
+                  float commitment_cost, void* dz, float* dcodebook, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MELGPT_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of libmelgpt_hip.so (the C ABI declared in include/melgpt.h).
+
+PyTorch is only plumbing here: it owns device memory and the HIP stream; every launch goes
+through the C ABI with raw device pointers.  There is NO fallback: if the shared library is
+missing or a call is made without a GPU tensor, this module raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libmelgpt_hip.so")
+
+F32, BF16 = 0, 1
+_p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_u64 = C.c_uint64
+
+
+class MelgptError(RuntimeError):
+    pass
+
+
+# name -> argtypes (restype is int unless listed in _RESTYPE)
+_PROTOS = {
+    "melgpt_abi_version": [],
+    "melgpt_strerror": [_i],
+    "melgpt_vq_argmin_fwd": [_p, _i, _l, _i, _l, _l, _l, _l, _p, _i, _p, _p, _p, _p, _p, _p],
+    "melgpt_vq_argmin_fwd_ex": [_p, _i, _l, _i, _l, _l, _l, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p],
+    "melgpt_vq_max_grid": [],
+    "melgpt_vq_finalize": [_p, _i, _p, _i, _l, _i, _f, _p, _p],
+    "melgpt_vq_gather": [_p, _l, _p, _i, _i, _p, _i, _l, _l, _l, _l, _p],
+    "melgpt_vq_onehot": [_p, _l, _i, _p, _p],
+    "melgpt_vq_bwd": [_p, _p, _i, _l, _i, _l, _l, _l, _l, _p, _i, _p, _p, _f, _p, _p, _p],
+}
+_RESTYPE = {"melgpt_strerror": C.c_char_p}
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library; raises MelgptError (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MelgptError(
+                f"{LIB_PATH} is missing - build it with `python -m melspec_gpt_vqvae_amd.build` "
+                "(or __graft_entry__.build()). There is no CPU / eager fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, args in _PROTOS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = _RESTYPE.get(name, C.c_int)
+        _lib = L
+    return _lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = lib().melgpt_strerror(code).decode()
+        raise MelgptError(f"{what or 'melgpt call'} failed: {msg} ({code})")
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)
+
+
+def ptr(t):
+    """device pointer of a tensor (or None)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MelgptError("melgpt kernels need GPU tensors (got a CPU tensor); there is no CPU fallback")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise MelgptError(f"unsupported dtype {dt}: the kernels are built for float32 and bfloat16")

@@ -1,0 +1,102 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/melgpt.h"
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+#define MELGPT_CHECK(cond, code) \
+  do {                           \
+    if (!(cond)) return (code);  \
+  } while (0)
+
+static inline int melgpt_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MELGPT_OK : MELGPT_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------- bf16 <-> f32 (RNE; NaN stays NaN via cast)
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  // plain cast semantic (round-to-nearest-even); hipcc lowers __bf16 casts to v_cvt_pk_bf16_f32 on gfx950
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <>
+struct Elem<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// ---------------------------------------------------------------- wave64 reductions (DPP/shuffle based)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------- buffer resources (OOB loads return 0)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
+// ---------------------------------------------------------------- Philox4x32-10 (counter-based dropout masks)
+struct Philox4 {
+  unsigned x, y, z, w;
+};
+__device__ __forceinline__ Philox4 philox4x32_10(unsigned long long seed, unsigned long long ctr_lo,
+                                                 unsigned ctr_hi) {
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+  unsigned c0 = (unsigned)ctr_lo, c1 = (unsigned)(ctr_lo >> 32), c2 = ctr_hi, c3 = 0x9E3779B9u;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+    unsigned n1 = (unsigned)p1;
+    unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    unsigned n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Philox4{c0, c1, c2, c3};
+}
+// keep-mask for 4 consecutive elements whose first linear index is 4*q: bit i set = element kept.
+// `thresh` = round(p_drop * 2^32) clamped; element kept iff random >= thresh.
+__device__ __forceinline__ unsigned dropout_keep4(unsigned long long seed, unsigned stream_id,
+                                                  unsigned long long q, unsigned thresh) {
+  Philox4 r = philox4x32_10(seed, q, stream_id);
+  return (r.x >= thresh ? 1u : 0u) | (r.y >= thresh ? 2u : 0u) | (r.z >= thresh ? 4u : 0u) |
+         (r.w >= thresh ? 8u : 0u);
+}

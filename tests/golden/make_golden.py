@@ -1,0 +1,402 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz by importing and RUNNING the real
+reference (karchkha/MelSpec_GPT_VQVAE, mounted read-only at /root/reference) on CPU.
+
+Run from the repo root in the build container:  python tests/golden/make_golden.py
+The reference cannot travel to the GPU box, so only these small input/output vectors
+(and this script) are committed.  Nothing here is imported by the product package.
+
+Import recipe: pytorch_lightning / torchvision / albumentations are not
+installed and the reference's `datasets/` dir (no __init__.py) is shadowed by the
+HuggingFace package, so tiny `sys.modules` stand-ins are installed *for the import only*;
+none of them touches the arithmetic being recorded.
+"""
+from __future__ import annotations
+
+import importlib.machinery
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True  # never leave __pycache__ inside /root/reference
+REF = os.environ.get("MELGPT_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import synth  # noqa: E402
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, loader=None)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    class LightningModule(nn.Module):
+        def log(self, *a, **k):
+            pass
+
+        def print(self, *a, **k):
+            pass
+
+    _stub("pytorch_lightning", LightningModule=LightningModule, LightningDataModule=object,
+          Callback=object, seed_everything=lambda *a, **k: None)
+    tv = _stub("torchvision")
+    tv.transforms = _stub("torchvision.transforms", Compose=object)
+    tv.utils = _stub("torchvision.utils")
+    _stub("albumentations")
+    ds = _stub("datasets")
+    ds.__path__ = []
+    ds.datamodule = _stub("datasets.datamodule", DataModule=object)
+    sys.path.insert(0, REF)
+    import transformer.minGPT as ref_gpt
+    import transformer.encoders as ref_enc
+    import transformer.decoders as ref_dec
+    import vqvae.big_model_attn_gan as ref_vq
+    return ref_gpt, ref_enc, ref_dec, ref_vq
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def load_sd(module, sd_np, strict=True):
+    sd = {k: t(v) for k, v in sd_np.items()}
+    missing = module.load_state_dict(sd, strict=False)
+    # only the constant `mask` buffers may be missing from a synthetic state_dict
+    bad = [k for k in missing.missing_keys if not k.endswith("mask")]
+    assert not bad and not missing.unexpected_keys, (bad, missing.unexpected_keys)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+# ------------------------------------------------------------------------------ VQ
+def top2_gap_ulps(flat, emb):
+    """distance formula of big_model_attn_gan.py:28-30 in fp32, then gap between the two
+    smallest distances in units of ulp(min distance)."""
+    d = (torch.sum(flat ** 2, dim=1, keepdim=True) + torch.sum(emb ** 2, dim=1)
+         - 2 * torch.matmul(flat, emb.t()))
+    v, _ = torch.topk(d, 2, dim=1, largest=False)
+    ulp = np.spacing(np.abs(v[:, 0].numpy()).astype(np.float32))
+    return ((v[:, 1] - v[:, 0]).numpy() / ulp).astype(np.float32), torch.topk(d, 2, dim=1, largest=False)[1].numpy()
+
+
+def gen_vq(ref_vq):
+    print("VQ")
+    for tag, cb in (("normal", "normal"), ("default", "default")):
+        vq = ref_vq.VectorQuantizer(128, 256, 0.25)
+        if cb == "normal":
+            E = synth.normal(11, (128, 256))
+        else:
+            E = synth.uniform(12, (128, 256), -1 / 128, 1 / 128)
+        vq._embedding.weight.data.copy_(t(E))
+        scale = 1.0 if cb == "normal" else 0.02
+        z = synth.normal(10, (2, 256, 5, 53)) * np.float32(scale)
+        zt = t(z).requires_grad_(True)
+        loss, q, (perp, enc, idx) = vq(zt)
+        # gradient semantics (STE + the two MSE terms)
+        g = synth.normal(13, q.shape)
+        (loss * 3.0 + (q * t(g)).sum()).backward()
+        flat = t(z).permute(0, 2, 3, 1).reshape(-1, 256)
+        gap, top2 = top2_gap_ulps(flat, vq._embedding.weight.data)
+        save(f"vq_small_{tag}", z_seed=10, z_scale=scale, codebook_seed=(11 if cb == "normal" else 12),
+             upstream_seed=13, loss=loss.item(), quantized=q.detach().numpy(),
+             perplexity=perp.item(), indices=idx.numpy().astype(np.int16), gap_ulps=gap, top2=top2.astype(np.int16),
+             enc_rowsum=enc.sum(1).numpy(), dz=zt.grad.numpy(),
+             dcodebook=vq._embedding.weight.grad.numpy())
+        gcb = vq.get_codebook_entry(idx.squeeze(1), (2, 5, 53, 256))
+        assert torch.equal(gcb, q.detach() * 0 + gcb)
+        save(f"vq_gather_{tag}", indices=idx.numpy().astype(np.int16), out=gcb.detach().numpy())
+
+    # B=64 (config 2): only seeds + indices are stored
+    vq = ref_vq.VectorQuantizer(128, 256, 0.25)
+    E = synth.normal(21, (128, 256))
+    vq._embedding.weight.data.copy_(t(E))
+    z = synth.normal(20, (64, 256, 5, 53))
+    with torch.no_grad():
+        loss, q, (perp, enc, idx) = vq(t(z))
+    flat = t(z).permute(0, 2, 3, 1).reshape(-1, 256)
+    gap, top2 = top2_gap_ulps(flat, t(E))
+    save("vq_b64", z_seed=20, codebook_seed=21, indices=idx.numpy().astype(np.int16).ravel(),
+         gap_ulps=gap, top2=top2.astype(np.int16), loss=loss.item(), perplexity=perp.item(),
+         q_checksum=float(q.double().sum()), q_abs_checksum=float(q.double().abs().sum()))
+
+    # exact ties: duplicated codebook rows -> lowest index must win (torch.argmin semantics)
+    E = synth.normal(31, (128, 256))
+    E[77] = E[5]
+    E[100] = E[5]
+    E[64] = E[63]
+    vq._embedding.weight.data.copy_(t(E))
+    z = synth.normal(30, (1, 256, 5, 53))
+    zz = z.reshape(256, 265)
+    zz[:, 0] = E[5]       # exactly on a triplicated code
+    zz[:, 1] = E[63]      # exactly on a duplicated code
+    zz[:, 2] = 0.0        # all-zero vector
+    z = zz.reshape(1, 256, 5, 53)
+    with torch.no_grad():
+        _, _, (_, _, idx) = vq(t(z))
+    assert idx[0, 0] == 5 and idx[1, 0] == 63
+    save("vq_ties", z=z, codebook=E, indices=idx.numpy().astype(np.int16).ravel())
+
+
+# ----------------------------------------------------------------------- attention
+def gen_attention(ref_gpt):
+    print("CausalSelfAttention / Block")
+    for n_unmasked in (0, 265):
+        cfg = ref_gpt.GPTConfig(128, 265, n_embd=128, n_head=2, attn_pdrop=0.0, resid_pdrop=0.0,
+                                n_unmasked=n_unmasked)
+        att = ref_gpt.CausalSelfAttention(cfg)
+        sd = {}
+        for j, nm in enumerate(("key", "query", "value", "proj")):
+            sd[f"{nm}.weight"] = synth.normal(100 + j, (128, 128), 0.08)
+            sd[f"{nm}.bias"] = synth.normal(110 + j, (128,), 0.05)
+        load_sd(att, sd)
+        x = synth.normal(120, (2, 265, 128))
+        xt = t(x).requires_grad_(True)
+        y, a = att(xt)
+        gy = synth.normal(121, y.shape)
+        (y * t(gy)).sum().backward()
+        out = dict(x=x, gy=gy, y=y.detach().numpy(), att=a.detach().numpy()[:1].astype(np.float32),
+                   att_rowsum=a.detach().sum(-1).numpy(), dx=xt.grad.numpy())
+        for nm, p in att.named_parameters():
+            out["w." + nm] = sd[nm]
+            out["g." + nm] = p.grad.numpy()
+        save(f"attn_u{n_unmasked}", **out)
+
+    # one Block, tuple-in/tuple-out (minGPT.py:107-119)
+    cfg = ref_gpt.GPTConfig(128, 265, n_embd=128, n_head=2, attn_pdrop=0.0, resid_pdrop=0.0, n_unmasked=0)
+    blk = ref_gpt.Block(cfg)
+    args = synth.gpt_args(n_layer=1, n_head=2, n_embd=128, block_size=265)
+    full = synth.gpt_state_dict(args, 7)
+    sd = {k[len("blocks.0."):]: v for k, v in full.items() if k.startswith("blocks.0.")}
+    load_sd(blk, sd)
+    x = synth.normal(130, (2, 265, 128))
+    xt = t(x).requires_grad_(True)
+    y, a = blk((xt, None))
+    gy = synth.normal(131, y.shape)
+    (y * t(gy)).sum().backward()
+    out = dict(x=x, gy=gy, y=y.detach().numpy(), dx=xt.grad.numpy(), sd_seed=7)
+    for nm, p in blk.named_parameters():
+        out["g." + nm] = p.grad.numpy()
+    save("block", **out)
+
+
+# ------------------------------------------------------------------------------ GPT
+def gen_gpt(ref_gpt):
+    print("GPT / GPTClass")
+    # (a) small 2-layer class-conditioned GPT: everything stored
+    args = synth.gpt_args(n_layer=2, n_head=4, n_embd=256)
+    m = ref_gpt.GPTClass(args)
+    sd = synth.gpt_state_dict(args, 1)
+    load_sd(m, sd)
+    m.eval()
+    x = synth.randint(200, 0, 128, (2, 265))
+    c = synth.randint(201, 0, 8, (2, 1))
+    logits, _, att = m(t(x)[:, :-1], t(c))
+    loss = nn.functional.cross_entropy(logits.reshape(-1, 128), t(x).reshape(-1))
+    loss.backward()
+    out = dict(x=x, c=c, logits=logits.detach().numpy(), loss=loss.item(),
+               att=att.detach().numpy()[:1, :2], sd_seed=1)
+    for nm, p in m.named_parameters():
+        out["gnorm." + nm] = float(p.grad.double().norm())
+    for nm in ("tok_emb.weight", "embedder.weight", "pos_emb", "head.weight", "ln_f.weight",
+               "blocks.0.attn.key.bias", "blocks.1.mlp.0.bias", "blocks.1.ln2.weight"):
+        out["g." + nm] = dict(m.named_parameters())[nm].grad.numpy()
+    out["g.blocks.0.mlp.2.weight"] = dict(m.named_parameters())["blocks.0.mlp.2.weight"].grad.numpy()
+    save("gptclass_small", **out)
+
+    # (b) GPT.forward with targets, unmasked (= GPTEncoder's transformer) + last_linear
+    args = synth.gpt_args(n_layer=2, n_head=4, n_embd=256, block_size=265, fix_var=0)
+    m = ref_gpt.GPT(args, n_unmasked=265, last_linear=512, block_size=265)
+    sd = synth.gpt_state_dict(args, 2, block_size=265, with_embedder=False, out_features=512)
+    load_sd(m, sd)
+    x = synth.randint(210, 0, 128, (2, 265))
+    logits, _, att = m(t(x))
+    save("gpt_unmasked_small", x=x, logits_last=logits.detach().numpy()[:, -1],
+         logits_sum=float(logits.double().sum()), att_last_row=att.detach().numpy()[:, :, -1], sd_seed=2)
+
+    # (c) VAS-size (C=1024, H=16) 2-layer model: logits + loss + grad norms
+    args = synth.gpt_args(n_layer=2, n_head=16, n_embd=1024)
+    m = ref_gpt.GPTClass(args)
+    sd = synth.gpt_state_dict(args, 3)
+    load_sd(m, sd)
+    x = synth.randint(220, 0, 128, (2, 265))
+    c = synth.randint(221, 0, 8, (2, 1))
+    logits, _, att = m(t(x)[:, :-1], t(c))
+    loss = nn.functional.cross_entropy(logits.reshape(-1, 128), t(x).reshape(-1))
+    loss.backward()
+    out = dict(x=x, c=c, logits=logits.detach().numpy(), loss=loss.item(), sd_seed=3,
+               att_b0h3=att.detach().numpy()[0, 3])
+    for nm, p in m.named_parameters():
+        out["gnorm." + nm] = float(p.grad.double().norm())
+    save("gptclass_vas2", **out)
+
+    # (d) full 24-layer VAS model: loss only (weights regenerated from the seed)
+    args = synth.gpt_args(n_layer=24, n_head=16, n_embd=1024)
+    m = ref_gpt.GPTClass(args)
+    sd = synth.gpt_state_dict(args, 4)
+    load_sd(m, sd)
+    del sd
+    x = synth.randint(230, 0, 128, (2, 265))
+    c = synth.randint(231, 0, 8, (2, 1))
+    with torch.no_grad():
+        logits, _, _ = m(t(x)[:, :-1], t(c))
+        loss = nn.functional.cross_entropy(logits.reshape(-1, 128), t(x).reshape(-1))
+    save("gptclass_vas24", x=x, c=c, loss=loss.item(), logits_b0_t17=logits[0, 17].numpy(),
+         logits_b1_last=logits[1, -1].numpy(), sd_seed=4)
+
+    # (e) reference init statistics + optimizer grouping (minGPT.py:159-166, 618-665)
+    torch.manual_seed(0)
+    args = synth.gpt_args(n_layer=24, n_head=16, n_embd=1024)
+    m = ref_gpt.GPTClass(args)
+    decay, no_decay = set(), set()
+    for mn, mod in m.named_modules():
+        for pn, p in mod.named_parameters():
+            fpn = "%s.%s" % (mn, pn) if mn else pn
+            if pn.endswith("bias"):
+                no_decay.add(fpn)
+            elif pn.endswith("weight") and isinstance(mod, nn.Linear):
+                decay.add(fpn)
+            elif pn.endswith("weight") and isinstance(mod, (nn.LayerNorm, nn.Embedding)):
+                no_decay.add(fpn)
+    no_decay.add("pos_emb")
+    save("gpt_optim_groups", decay=np.array(sorted(decay)), no_decay=np.array(sorted(no_decay)),
+         n_params=sum(p.numel() for p in m.parameters()),
+         embedder_std=float(m.embedder.weight.std()), tok_emb_std=float(m.tok_emb.weight.std()),
+         keys=np.array(list(m.state_dict().keys())))
+
+
+def gen_lit(ref_gpt):
+    """Lit_minGPT.forward/shared_step/sample/get_x/make_idx (minGPT.py:260-456)."""
+    print("Lit_minGPT")
+
+    class Lit(ref_gpt.Lit_minGPT):
+        def datamodule_loader(self):
+            self.data = None
+
+    args = synth.gpt_args(n_layer=2, n_head=4, n_embd=256, reconstruct_spec="", device="cpu", batch_size=2)
+    lit = Lit(args)
+    load_sd(lit.transformer, synth.gpt_state_dict(args, 1))
+    lit.eval()
+    codes = synth.randint(300, 0, 128, (2, 5, 53))
+    target = synth.randint(301, 0, 8, (2,))
+    batch = {"codes": t(codes), "target": t(target)}
+    x = lit.get_x(batch)
+    loss = lit.shared_step(batch, 0)
+    fwd, bwd = lit.make_idx(5, 53)
+    assert torch.equal(lit.code_reader(t(codes).reshape(2, 265)), x)
+    x0 = x[:, :9]
+    xs, att = lit.sample(x0, lit.get_c(batch), steps=16, sample=False)
+    xk, _ = lit.sample(x0, lit.get_c(batch), steps=4, sample=False, top_k=5, temperature=0.7)
+    save("lit_mingpt", codes=codes, target=target, x=x.numpy(), loss=loss.item(), fwd_idx=fwd.numpy(),
+         bwd_idx=bwd.numpy(), greedy16=xs.numpy(), greedy4_topk=xk.numpy(), att_shape=np.array(att.shape),
+         att_last=att.numpy()[:, :, -1], sd_seed=1)
+
+
+def gen_vae(ref_gpt, ref_enc, ref_dec):
+    """GPTEncoder / GPTDecoder and the ELBO pieces of GPT_VAE.loss (Lit_GPT_VAE.py:176-195)."""
+    print("GPT-VAE")
+    args = synth.gpt_args(n_layer=2, n_head=4, n_embd=256, block_size=265, fix_var=0)
+    enc = ref_enc.GPTEncoder(args, n_unmasked=265, last_linear=512)
+    dec = ref_dec.GPTDecoder(args, block_size=266)
+    load_sd(enc.transformer, synth.gpt_state_dict(args, 5, block_size=265, with_embedder=False, out_features=512))
+    load_sd(dec.transformer, synth.gpt_state_dict(args, 6, block_size=266, with_embedder=False))
+    x = synth.randint(400, 0, 128, (2, 265))
+    mu, logvar, _ = enc(t(x))
+    eps = synth.normal(401, (2, 1, 256))
+    z = mu.unsqueeze(1) + t(eps) * (0.5 * logvar).exp().unsqueeze(1)
+    KL = 0.5 * (mu.pow(2) + logvar.exp() - logvar - 1).sum(dim=1)
+    rec = dec.reconstruct_error(t(x), z)
+    kl_w = 0.3
+    loss = (rec.mean(dim=1) + kl_w * KL).mean()
+    loss.backward()
+    out = dict(x=x, eps=eps, mu=mu.detach().numpy(), logvar=logvar.detach().numpy(), KL=KL.detach().numpy(),
+               rec=rec.detach().numpy(), loss=loss.item(), kl_weight=kl_w, enc_seed=5, dec_seed=6)
+    for nm, p in enc.transformer.named_parameters():
+        out["enc.gnorm." + nm] = float(p.grad.double().norm())
+    for nm, p in dec.transformer.named_parameters():
+        out["dec.gnorm." + nm] = float(p.grad.double().norm())
+    dec.eval()
+    with torch.no_grad():
+        xs, _ = dec.sample(t(x)[:, :3], z.detach(), steps=8, sample=False)
+    out["dec_greedy8"] = xs.numpy()
+    save("gpt_vae_small", **out)
+
+
+# ---------------------------------------------------------------------------- VQVAE
+def gen_vqvae(ref_vq):
+    print("VQVAE encoder / decoder")
+    # (a) narrow model (ch=32), odd-ish geometry 80x848 is kept: the attention level must be 5x53
+    hp = dict(ch=32, ch_mult=(1, 1, 2, 2, 4), num_res_blocks=2, z_channels=64)
+    enc = ref_vq.Encoder(ch=32, out_ch=1, ch_mult=(1, 1, 2, 2, 4), num_res_blocks=2, attn_resolutions=[53],
+                         in_channels=1, resolution=848, z_channels=64, double_z=False)
+    dec = ref_vq.Decoder(ch=32, out_ch=1, ch_mult=(1, 1, 2, 2, 4), num_res_blocks=2, attn_resolutions=[53],
+                         in_channels=1, resolution=848, z_channels=64, double_z=False)
+    load_sd(enc, synth.encoder_state_dict(40, **hp))
+    load_sd(dec, synth.decoder_state_dict(40, **hp))
+    x = 2 * synth.mel_tiles(41, 1)[:, None, :, 6:854] - 1
+    with torch.no_grad():
+        h = enc(t(x))
+        taps = {}
+        hh = enc.conv_in(t(x))
+        taps["conv_in_sum"] = float(hh.double().sum())
+        hh = enc.down[0].block[0](hh, None)
+        taps["d0b0_sum"] = float(hh.double().sum())
+        taps["d0b0_patch"] = hh[0, :, 10:12, 100:104].numpy()
+        zq = synth.normal(42, (1, 64, 5, 53))
+        y = dec(t(zq))
+    save("vqvae_narrow", x=x, enc_out=h.numpy(), dec_in=zq, dec_out=y.numpy(), seed=40, **taps)
+
+    # (b) full-size (ch=128): one tile through encode + VQ, decoder on a quantised latent
+    m = ref_vq.LitVQVAE(num_embeddings=128, embedding_dim=256)
+    sd = synth.vqvae_state_dict(50)
+    missing = m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    assert all(k.startswith("discriminator.") for k in missing.missing_keys), missing.missing_keys[:5]
+    assert not missing.unexpected_keys
+    m.eval()
+    x = 2 * synth.mel_tiles(51, 2)[:, None, :, 6:854] - 1
+    with torch.no_grad():
+        z = m.encode(t(x))
+        loss, q, (perp, enc1h, idx) = m._vq_vae(z)
+        flat = z.permute(0, 2, 3, 1).reshape(-1, 256)
+        gap, top2 = top2_gap_ulps(flat, m._vq_vae._embedding.weight.data)
+        rec = m.decode(q[:1])
+    save("vqvae_full", x=x, z=z.numpy(), indices=idx.numpy().astype(np.int16).ravel(), gap_ulps=gap,
+         top2=top2.astype(np.int16), vq_loss=loss.item(), perplexity=perp.item(),
+         rec=rec.numpy(), seed=50,
+         sd_keys=np.array([k for k in m.state_dict().keys()]))
+
+
+def main():
+    torch.manual_seed(synth.SEED)
+    torch.set_num_threads(8)
+    ref_gpt, ref_enc, ref_dec, ref_vq = import_reference()
+    which = set(sys.argv[1:]) or {"vq", "attn", "gpt", "lit", "vae", "vqvae"}
+    if "vq" in which:
+        gen_vq(ref_vq)
+    if "attn" in which:
+        gen_attention(ref_gpt)
+    if "gpt" in which:
+        gen_gpt(ref_gpt)
+    if "lit" in which:
+        gen_lit(ref_gpt)
+    if "vae" in which:
+        gen_vae(ref_gpt, ref_enc, ref_dec)
+    if "vqvae" in which:
+        gen_vqvae(ref_vq)
+    assert not any("__pycache__" in d for d, _, _ in os.walk(REF)), "bytecode leaked into reference"
+
+
+if __name__ == "__main__":
+    main()

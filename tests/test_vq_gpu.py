@@ -1,0 +1,136 @@
+"""GPU parity of the VQ codebook lookup (csrc/vq.hip, via the C ABI) against the CPU oracle and the
+golden vectors recorded from the real reference (VectorQuantizer.forward, big_model_attn_gan.py:19-54)."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from util import check_indices_with_tie_policy, golden, rel_err, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _flat(z):
+    return np.ascontiguousarray(z.transpose(0, 2, 3, 1).reshape(-1, z.shape[1]))
+
+
+@pytest.mark.parametrize("layout", ["nchw", "channels_last"])
+def test_f32_lane_bit_exact_vs_c_oracle_and_reference_b64(layout):
+    """BASELINE config 2 size (B=64 -> 16 960 vectors).  HIP F32 lane == oracle/vq_argmin.c bit for bit
+    (indices AND every distance); == the reference's indices outside the listed near-ties."""
+    from melspec_gpt_vqvae_amd.vqvae.quantizer import vq_lookup
+    from oracle import vq_c
+
+    g = golden("vq_b64")
+    z = synth.normal(int(g["z_seed"]), (64, 256, 5, 53))
+    E = synth.normal(int(g["codebook_seed"]), (128, 256))
+    zt = t(z, DEV)
+    if layout == "channels_last":
+        zt = zt.contiguous(memory_format=torch.channels_last)
+    r = vq_lookup(zt, t(E, DEV), want_distances=True)
+    ref = vq_c.vq_argmin_f32(_flat(z), E, want_distances=True, want_quantized=True)
+    idx = r["indices"].cpu().numpy()
+    assert np.array_equal(idx, ref["indices"]), "HIP F32 lane must equal the C oracle bit for bit"
+    assert np.array_equal(r["distances"].cpu().numpy().view(np.uint32), ref["distances"].view(np.uint32)), \
+        "distances are an exact k-ordered FMA chain on both sides"
+    n_near = check_indices_with_tie_policy(idx, g["indices"], g["gap_ulps"], g["top2"])
+    print("near-tie vectors:", n_near)
+    q = r["quantized"].permute(0, 2, 3, 1).reshape(-1, 256).cpu().numpy()
+    assert np.array_equal(q, ref["quantized"])
+    sq = float(r["sq_err"][: r["grid"]].double().sum())
+    assert abs(sq - ref["sq_err"]) <= 1e-5 * ref["sq_err"]
+    hist = r["histogram"].cpu().numpy()
+    assert np.array_equal(hist, np.bincount(idx, minlength=128))
+
+
+@pytest.mark.parametrize("tag", ["normal", "default"])
+@pytest.mark.parametrize("layout", ["nchw", "channels_last"])
+def test_module_forward_backward_vs_reference(tag, layout):
+    from melspec_gpt_vqvae_amd.vqvae.quantizer import VectorQuantizer
+
+    g = golden(f"vq_small_{tag}")
+    z = synth.normal(int(g["z_seed"]), (2, 256, 5, 53)) * np.float32(g["z_scale"])
+    E = synth.normal(11, (128, 256)) if tag == "normal" else synth.uniform(12, (128, 256), -1 / 128, 1 / 128)
+    vq = VectorQuantizer(128, 256, 0.25).to(DEV)
+    assert list(vq.state_dict().keys()) == ["_embedding.weight"]
+    vq._embedding.weight.data.copy_(t(E))
+    zt = t(z, DEV)
+    if layout == "channels_last":
+        zt = zt.contiguous(memory_format=torch.channels_last)
+    zt.requires_grad_(True)
+    loss, q, (perp, enc, idx) = vq(zt)
+    assert idx.shape == (530, 1) and idx.dtype == torch.int64 and enc.shape == (530, 128)
+    assert np.array_equal(idx.cpu().numpy().ravel(), g["indices"].ravel().astype(np.int64))
+    assert np.array_equal(q.detach().cpu().numpy(), g["quantized"])           # x + (q - x), fp32, exact
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))  # tolerance: 1e-5 rel
+    assert abs(perp.item() - float(g["perplexity"])) <= 1e-4 * float(g["perplexity"])
+    assert np.array_equal(enc.sum(1).cpu().numpy(), g["enc_rowsum"])
+    assert np.array_equal(enc.argmax(1).cpu().numpy(), g["indices"].ravel())
+    up = t(synth.normal(int(g["upstream_seed"]), q.shape), DEV)
+    (loss * 3.0 + (q * up).sum()).backward()
+    assert np.allclose(zt.grad.cpu().numpy(), g["dz"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(vq._embedding.weight.grad.cpu().numpy(), g["dcodebook"], rtol=1e-4, atol=1e-6)
+    gg = golden(f"vq_gather_{tag}")
+    out = vq.get_codebook_entry(t(gg["indices"].astype(np.int64), DEV).squeeze(1), (2, 5, 53, 256))
+    assert np.array_equal(out.cpu().numpy(), gg["out"])
+
+
+def test_exact_ties_and_edges():
+    """duplicated codebook rows -> lowest index; all-zero vector; ragged N (not a multiple of the tile)."""
+    from melspec_gpt_vqvae_amd.vqvae.quantizer import vq_lookup
+    from oracle import vq_c
+
+    g = golden("vq_ties")
+    r = vq_lookup(t(g["z"], DEV), t(g["codebook"], DEV))
+    idx = r["indices"].cpu().numpy()
+    assert idx[0] == 5 and idx[1] == 63
+    assert np.array_equal(idx, g["indices"].astype(np.int64))
+    for n in (1, 15, 17, 63, 65, 265):
+        z = synth.normal(900 + n, (1, 256, 1, n))
+        E = synth.normal(901, (128, 256))
+        for dt in (torch.float32, torch.bfloat16):
+            rr = vq_lookup(t(z, DEV).to(dt), t(E, DEV))
+            zz = t(z).to(dt).float().numpy()
+            Eo = t(E).to(dt).float().numpy() if dt == torch.bfloat16 else E
+            ref = vq_c.vq_argmin_f32(_flat(zz), Eo)
+            assert np.array_equal(rr["indices"].cpu().numpy(), ref["indices"]), (n, dt)
+
+
+@pytest.mark.parametrize("layout", ["nchw", "channels_last"])
+def test_bf16_lane_b64(layout):
+    """bf16 lane: latents AND codebook rounded to bf16 on both sides (products exact, f32 accumulate).
+    Oracle = C restatement on the rounded inputs; MFMA's internal summation order is not a plain chain,
+    so near-ties (top-2 gap < 64 ulp of the distance) may pick either of the two nearest codes."""
+    from melspec_gpt_vqvae_amd.vqvae.quantizer import vq_lookup
+    from oracle import vq_c
+
+    z = synth.normal(20, (64, 256, 5, 53))
+    E = synth.normal(21, (128, 256))
+    zb = t(z).to(torch.bfloat16)
+    Eb = t(E).to(torch.bfloat16).float().numpy()
+    zt = zb.to(DEV)
+    if layout == "channels_last":
+        zt = zt.contiguous(memory_format=torch.channels_last)
+    r = vq_lookup(zt, t(E, DEV), want_distances=True)
+    ref = vq_c.vq_argmin_f32(_flat(zb.float().numpy()), Eb, want_distances=True, want_quantized=True)
+    d = np.sort(ref["distances"], axis=1)
+    gap = (d[:, 1] - d[:, 0]) / np.spacing(np.abs(d[:, 0]))
+    top2 = np.argsort(ref["distances"], axis=1, kind="stable")[:, :2]
+    n_near = check_indices_with_tie_policy(r["indices"].cpu().numpy(), ref["indices"], gap, top2, ulp_thresh=64.0)
+    print("bf16 lane near-ties (<64 ulp):", n_near)
+    assert rel_err(r["distances"].cpu().numpy(), ref["distances"]) < 1e-5
+    q = r["quantized"].float().permute(0, 2, 3, 1).reshape(-1, 256).cpu().numpy()
+    qref = t(ref["quantized"]).to(torch.bfloat16).float().numpy()
+    same = r["indices"].cpu().numpy() == ref["indices"]
+    assert np.array_equal(q[same], qref[same])
+    sq = float(r["sq_err"][: r["grid"]].double().sum())
+    assert abs(sq - ref["sq_err"]) <= 1e-3 * ref["sq_err"]
+
+
+def test_product_fails_loudly_without_gpu_tensor():
+    from melspec_gpt_vqvae_amd import _ffi
+    from melspec_gpt_vqvae_amd.vqvae.quantizer import vq_lookup
+
+    with pytest.raises(_ffi.MelgptError):
+        vq_lookup(torch.zeros(1, 256, 5, 53), torch.zeros(128, 256))

@@ -1,0 +1,41 @@
+"""Helpers shared by the tests (test infrastructure)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def t(x, device=None, dtype=None):
+    v = torch.from_numpy(np.ascontiguousarray(x))
+    if dtype is not None:
+        v = v.to(dtype)
+    if device is not None:
+        v = v.to(device)
+    return v
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def check_indices_with_tie_policy(got, want, gap_ulps, top2, ulp_thresh=8.0):
+    """SURVEY §8a tie policy: indices must be bit-identical wherever the reference's two smallest
+    distances are >= `ulp_thresh` ulp apart; on the listed near-ties either of the two nearest codes
+    is accepted.  Returns the number of near-tie vectors (reported by the caller)."""
+    got = np.asarray(got).astype(np.int64).ravel()
+    want = np.asarray(want).astype(np.int64).ravel()
+    near = np.asarray(gap_ulps).ravel() < ulp_thresh
+    bad = np.nonzero((got != want) & ~near)[0]
+    assert bad.size == 0, f"{bad.size} index mismatches outside near-ties, first at {bad[:5]}"
+    nt = np.nonzero(near)[0]
+    for n in nt:
+        assert got[n] in (int(top2[n][0]), int(top2[n][1])), (n, got[n], top2[n])
+    return int(near.sum())
