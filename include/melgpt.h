@@ -98,6 +98,38 @@ int melgpt_vq_bwd(const void* z, const void* g_quantized, int dtype, int64_t n_v
                   const float* codebook, int num_codes, const int64_t* indices, const float* g_loss,
                   float commitment_cost, void* dz, float* dcodebook, void* stream);
 
+/* ===================================================================== GEMM (+ fused epilogues)
+ * C[b][m,n] = epi( alpha * sum_k A[b](m,k) * B[b](n,k) ), row-major C with leading dimension ldc.
+ *   a_kmajor = 0: A(m,k) = A[m*lda + k]   (nn.Linear input, reduction index contiguous)
+ *   a_kmajor = 1: A(m,k) = A[k*lda + m]   (transposed operand, e.g. dY^T in a weight gradient)
+ *   b_kmajor likewise for B(n,k): 0 = nn.Linear weight (out,in) as stored by the reference
+ *   (transformer/minGPT.py:56-63,100-105,149); 1 = the same weight used in the input-gradient product.
+ * epilogue order: v = alpha*acc + bias[n]; C2 = v (optional pre-activation copy);
+ *   act: MELGPT_ACT_GELU -> exact-erf GELU (nn.GELU(), minGPT.py:102);
+ *        MELGPT_ACT_GELU_GRAD -> v *= gelu'(R[m,n])  (R is the saved pre-activation, not a residual);
+ *   dropout(drop_p) with Philox4x32-10 keyed by (seed, stream_id, element index)  (minGPT.py:88,104);
+ *   v += R[m,n] (residual, minGPT.py:115,117);  if accumulate: v += C[m,n];  store as dtype or f32.
+ * dtype: MELGPT_F32 -> exact f32 MFMA; MELGPT_BF16 -> bf16 operands, f32 accumulate.  bias is f32.
+ * Alignment: all pointers 16 B; N % 4 == 0; K, lda, ldb and batch strides multiples of 16 bytes.   */
+enum { MELGPT_ACT_NONE = 0, MELGPT_ACT_GELU = 1, MELGPT_ACT_GELU_GRAD = 2 };
+
+int melgpt_gemm(const void* A, int a_kmajor, long long lda, long long strideA, const void* B, int b_kmajor,
+                long long ldb, long long strideB, void* C, long long ldc, long long strideC, int M, int N,
+                int K, int batch, int dtype, int out_f32, int accumulate, float alpha, const float* bias,
+                int act, const void* R, long long ldr, long long strideR, void* C2, float drop_p,
+                unsigned long long seed, unsigned stream_id, void* stream);
+
+/* 3x3 / 1x1 convolution as implicit GEMM over an NHWC activation (torch.nn.Conv2d sites of
+ * vqvae/big_model_attn_gan.py:85-99,108-112,151-159,176-186,247-251,313-317,403-422,578-579).
+ *   x (B,H,W,Cin) dtype; wpack (Cout, KH, KW, Cin) dtype (repacked from the reference's OIHW f32);
+ *   y (B,OH,OW,Cout); bias (Cout) f32 or NULL; residual (B,OH,OW,Cout) or NULL (ResnetBlock x+h, :135).
+ *   pad_t/pad_l: zero padding at top/left (bottom/right implied by OH/OW: Downsample pads (0,1,0,1), :152);
+ *   upsample = 1 folds F.interpolate(scale=2, 'nearest') (:183) into the input addressing.
+ *   Cin must be a multiple of 64 (bf16) / 32 (f32).                                                 */
+int melgpt_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, const void* wpack, int Cout, int KH,
+                       int KW, int stride, int pad_t, int pad_l, int OH, int OW, int upsample,
+                       const float* bias, const void* residual, void* y, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,9 @@ _PROTOS = {
     "melgpt_vq_gather": [_p, _l, _p, _i, _i, _p, _i, _l, _l, _l, _l, _p],
     "melgpt_vq_onehot": [_p, _l, _i, _p, _p],
     "melgpt_vq_bwd": [_p, _p, _i, _l, _i, _l, _l, _l, _l, _p, _i, _p, _p, _f, _p, _p, _p],
+    "melgpt_gemm": [_p, _i, _l, _l, _p, _i, _l, _l, _p, _l, _l, _i, _i, _i, _i, _i, _i, _i, _f, _p, _i, _p, _l, _l,
+                    _p, _f, _u64, C.c_uint, _p],
+    "melgpt_conv2d_nhwc": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],
 }
 _RESTYPE = {"melgpt_strerror": C.c_char_p}
 

@@ -1,0 +1,425 @@
+// Tiled MFMA GEMM for gfx950 with fused epilogues - the workhorse behind every nn.Linear of minGPT
+// (reference transformer/minGPT.py:56-63,76-78,88,100-105,149,188), their backward passes, and the
+// VQ-VAE convolutions (implicit GEMM over NHWC activations; reference vqvae/big_model_attn_gan.py:85-99,
+// 151-159,176-186,203-207,247-251,403-422,578-579).
+//
+//   C[m,n] = epilogue( alpha * sum_k A(m,k) * B(n,k) )          (optionally batched over blockIdx.z)
+//
+//   * 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 4x4 MFMA tiles of 16x16),
+//     K step = 128 bytes per row (64 bf16 / 32 f32), LDS double buffer (2 x 32 KiB -> 2 workgroups / CU).
+//   * operands are staged global -> VGPR -> LDS with 16-byte buffer loads whose out-of-range lanes return 0
+//     (edges, conv padding and ragged K cost nothing); the loads of tile t+1 are issued before the MFMAs
+//     of tile t and written to LDS after them.
+//   * layouts: ROW = reduction index contiguous, read with ds_read_b128 from an XOR-swizzled image
+//              KMAJ = reduction index strided (transposed operand): bf16 uses ds_read_b64_tr_b16
+//                     (hardware transpose), f32 plain b32 reads - no transposed copies are ever made
+//              CONV = implicit im2col of an NHWC activation (3x3 / 1x1, stride 1|2, asymmetric pad,
+//                     optional nearest x2 upsample folded into the addressing)
+//   * MFMA roles are swapped (weights/B rows feed the A port) so that each lane ends up holding 4
+//     CONSECUTIVE output columns of one output row -> vector stores, float4 bias loads and one Philox4
+//     call per 4 dropout decisions.
+//   * T = bf16 : v_mfma_f32_16x16x32_bf16, f32 accumulate.   T = f32 : v_mfma_f32_16x16x4_f32 (exact f32
+//     FMA chain) - the parity lane.  Fragment addressing is identical for both.
+//   * workgroup -> tile mapping is XCD-aware (consecutive tiles of one A row-panel share an L2).
+#include "common.h"
+
+namespace {
+
+enum { LAY_ROW = 0, LAY_KMAJ = 1, LAY_CONV = 2 };
+
+struct GemmParams {
+  const void* A;
+  const void* B;
+  void* C;
+  void* C2;           // optional second output (pre-activation), same dtype/ld as C
+  const float* bias;  // (N,) f32 or null
+  const void* R;      // residual (ACT none/gelu) or pre-activation (MELGPT_ACT_GELU_GRAD); dtype T
+  int M, N, K;
+  long long lda, ldb, ldc, ldr;
+  long long sA, sB, sC, sR;  // batch strides (elements)
+  unsigned a_bytes, b_bytes;  // addressable bytes of ONE batch of A / B (loads beyond return 0)
+  int out_f32, accumulate, act;
+  float alpha;
+  float drop_scale;  // 1/(1-p), or 0 when dropout is off
+  unsigned drop_thresh;
+  unsigned long long seed;
+  unsigned stream_id;
+  // implicit-GEMM convolution (A = NHWC input)
+  int cH, cW, cC, OH, OW, cstride, pad_t, pad_l, ups, KW;
+};
+
+template <typename T>
+struct Tr;
+template <>
+struct Tr<bf16_t> {
+  static constexpr int ES = 2, KSTEP = 64;
+};
+template <>
+struct Tr<float> {
+  static constexpr int ES = 4, KSTEP = 32;
+};
+
+constexpr int BM = 128, BN = 128, TILE_BYTES = 16384;
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ------------------------------------------------------------------------------- LDS addressing
+__device__ __forceinline__ int row_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
+template <typename T>
+__device__ __forceinline__ int kmaj_off(int krow, int lc) {
+  if constexpr (Tr<T>::ES == 2) {
+    int s = (krow & 3) | (((krow >> 3) & 1) << 2);
+    return krow * 256 + ((lc ^ (s << 1)) << 4);
+  } else {
+    return krow * 512 + ((lc ^ (((krow >> 2) & 7) << 2)) << 4);
+  }
+}
+
+// fragment of a 16-wide (m or n) sub-tile `st` for k-substep ks (0/1): 16 bytes per lane
+template <typename T, int LAY>
+__device__ __forceinline__ u32x4 load_frag(const char* tile, int st, int ks, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  if constexpr (LAY != LAY_KMAJ) {
+    return *(const u32x4*)(tile + row_off(st * 16 + i, 4 * ks + g));
+  } else if constexpr (Tr<T>::ES == 2) {
+    const int q = i >> 2, p = i & 3;
+    const int k0 = 32 * ks + 8 * g + q;
+    const int lc = 2 * st + (p >> 1);
+    const int a0 = kmaj_off<T>(k0, lc) + (p & 1) * 8;
+    const int a1 = kmaj_off<T>(k0 + 4, lc) + (p & 1) * 8;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + a1));
+    s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(u32x4, f);
+  } else {
+    const int mn = 16 * st + i;
+    u32x4 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int krow = 16 * ks + 4 * g + e;
+      f[e] = *(const unsigned*)(tile + kmaj_off<T>(krow, mn >> 2) + (mn & 3) * 4);
+    }
+    return f;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void mma(f32x4& acc, u32x4 a, u32x4 b) {
+  if constexpr (Tr<T>::ES == 2) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), acc,
+                                                  0, 0, 0);
+  } else {
+    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], acc, 0, 0, 0);
+  }
+}
+
+constexpr unsigned OOB = 0xFFFFFFF0u;
+
+// ---------------------------------------------------------------------------------- the kernel
+template <typename T, int ALAY, int BLAY>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
+  constexpr int ES = Tr<T>::ES, KSTEP = Tr<T>::KSTEP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 16K | B 16K]
+
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1;
+
+  // XCD-aware tile order (bijective for any grid size)
+  const int tilesN = (p.N + BN - 1) / BN;
+  int wg;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x, qd = nwg >> 3, rm = nwg & 7, xcd = b & 7;
+    wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (b >> 3);
+  }
+  const int m0 = (wg / tilesN) * BM, n0 = (wg % tilesN) * BN;
+  const int bz = blockIdx.z;
+
+  const char* Ab = (const char*)p.A + (long long)bz * p.sA * ES;
+  const char* Bb = (const char*)p.B + (long long)bz * p.sB * ES;
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(Bb, p.b_bytes);
+
+  // ---- per-thread staging plan: 4 chunks of 16 B for A and 4 for B per K step
+  unsigned a_base[4], b_base[4];
+  int a_lds[4], b_lds[4];
+  int cy[4], cx[4];  // conv only: top-left input coordinate of the output pixel
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = t + 256 * i;
+    if constexpr (ALAY == LAY_ROW) {
+      const int row = q >> 3, ch = q & 7;
+      a_base[i] = (unsigned)(((long long)(m0 + row) * p.lda) * ES) + ch * 16;
+      a_lds[i] = row_off(row, ch);
+    } else if constexpr (ALAY == LAY_KMAJ) {
+      constexpr int CPR = 128 * ES / 16;
+      const int krow = q / CPR, lc = q % CPR;
+      const bool ok = m0 + lc * (16 / ES) < p.M;
+      a_base[i] = ok ? (unsigned)(((long long)krow * p.lda + m0) * ES) + lc * 16 : OOB;
+      a_lds[i] = kmaj_off<T>(krow, lc);
+    } else {
+      const int row = q >> 3, ch = q & 7;
+      const int m = m0 + row;
+      const int ohw = p.OH * p.OW;
+      const int bb = m / ohw, rem = m - bb * ohw;
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      cy[i] = (m < p.M) ? oy * p.cstride - p.pad_t : -100000;
+      cx[i] = ox * p.cstride - p.pad_l;
+      a_base[i] = (unsigned)((long long)bb * p.cH * p.cW * p.cC * ES) + ch * 16;
+      a_lds[i] = row_off(row, ch);
+    }
+    if constexpr (BLAY == LAY_ROW) {
+      const int row = q >> 3, ch = q & 7;
+      b_base[i] = (unsigned)(((long long)(n0 + row) * p.ldb) * ES) + ch * 16;
+      b_lds[i] = row_off(row, ch);
+    } else {
+      constexpr int CPR = 128 * ES / 16;
+      const int krow = q / CPR, lc = q % CPR;
+      const bool ok = n0 + lc * (16 / ES) < p.N;
+      b_base[i] = ok ? (unsigned)(((long long)krow * p.ldb + n0) * ES) + lc * 16 : OOB;
+      b_lds[i] = kmaj_off<T>(krow, lc);
+    }
+  }
+
+  u32x4 ar[4], br[4];
+  auto issue = [&](int kt) {
+    const int k0 = kt * KSTEP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned off;
+      if constexpr (ALAY == LAY_ROW) {
+        const int ch = (t + 256 * i) & 7;
+        off = (k0 * ES + ch * 16 < p.K * ES) ? a_base[i] + k0 * ES : OOB;
+      } else if constexpr (ALAY == LAY_KMAJ) {
+        off = (a_base[i] == OOB) ? OOB : a_base[i] + (unsigned)((long long)k0 * p.lda * ES);
+      } else {
+        const int tap = k0 / p.cC, ci0 = k0 - tap * p.cC;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        int iy = cy[i] + ky, ix = cx[i] + kx;
+        const bool ok = iy >= 0 && ix >= 0 && iy < (p.cH << p.ups) && ix < (p.cW << p.ups);
+        iy >>= p.ups;
+        ix >>= p.ups;
+        off = ok ? a_base[i] + (unsigned)((iy * p.cW + ix) * p.cC + ci0) * ES : OOB;
+      }
+      ar[i] = buf_load16(ra, off);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned off;
+      if constexpr (BLAY == LAY_ROW) {
+        const int ch = (t + 256 * i) & 7;
+        off = (k0 * ES + ch * 16 < p.K * ES) ? b_base[i] + k0 * ES : OOB;
+      } else {
+        off = (b_base[i] == OOB) ? OOB : b_base[i] + (unsigned)((long long)k0 * p.ldb * ES);
+      }
+      br[i] = buf_load16(rb, off);
+    }
+  };
+  auto commit = [&](int buf) {
+    char* sa = smem + buf * 2 * TILE_BYTES;
+    char* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(u32x4*)(sa + a_lds[i]) = ar[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(u32x4*)(sb + b_lds[i]) = br[i];
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + KSTEP - 1) / KSTEP;
+  issue(0);
+  commit(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) issue(kt + 1);
+    const char* sa = smem + cur * 2 * TILE_BYTES;
+    const char* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 fa[4], fb[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) fa[mt] = load_frag<T, ALAY>(sa, wm * 4 + mt, ks, lane);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) fb[nt] = load_frag<T, BLAY>(sb, wn * 4 + nt, ks, lane);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) mma<T>(acc[mt][nt], fb[nt], fa[mt]);  // rows = n, cols = m
+    }
+    if (kt + 1 < nk) commit(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------------------ epilogue
+  const int i16 = lane & 15, g = lane >> 4;
+  char* Cb = (char*)p.C + (long long)bz * p.sC * (p.out_f32 ? 4 : ES);
+  char* C2b = p.C2 ? (char*)p.C2 + (long long)bz * p.sC * (p.out_f32 ? 4 : ES) : nullptr;
+  const char* Rb = p.R ? (const char*)p.R + (long long)bz * p.sR * ES : nullptr;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int n = n0 + wn * 64 + nt * 16 + g * 4;
+    if (n >= p.N) continue;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + wm * 64 + mt * 16 + i16;
+      if (m >= p.M) continue;
+      f32x4 v = acc[mt][nt] * p.alpha + bv;
+      if (C2b) {
+        if (p.out_f32 || ES == 4) *(f32x4*)(C2b + ((long long)m * p.ldc + n) * 4) = v;
+        else *(u32x2*)(C2b + ((long long)m * p.ldc + n) * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      }
+      f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+      if (Rb) {
+        if constexpr (ES == 4) {
+          rv = *(const f32x4*)(Rb + ((long long)m * p.ldr + n) * 4);
+        } else {
+          u32x2 r = *(const u32x2*)(Rb + ((long long)m * p.ldr + n) * 2);
+          rv = f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xFFFF0000u),
+                     __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xFFFF0000u)};
+        }
+      }
+      if (p.act == MELGPT_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
+      } else if (p.act == MELGPT_ACT_GELU_GRAD) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad(rv[e]);
+      }
+      if (p.drop_scale != 0.f) {
+        const unsigned long long e0 = ((unsigned long long)bz * p.M + m) * (unsigned long long)p.N + n;
+        const unsigned keep = dropout_keep4(p.seed, p.stream_id, e0 >> 2, p.drop_thresh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (keep >> e & 1) ? v[e] * p.drop_scale : 0.f;
+      }
+      if (Rb && p.act != MELGPT_ACT_GELU_GRAD) v += rv;
+      if (p.out_f32 || ES == 4) {
+        float* dst = (float*)(Cb + ((long long)m * p.ldc + n) * 4);
+        if (p.accumulate) v += *(const f32x4*)dst;
+        *(f32x4*)dst = v;
+      } else {
+        u32x2* dst = (u32x2*)(Cb + ((long long)m * p.ldc + n) * 2);
+        if (p.accumulate) {
+          u32x2 o = *dst;
+          v += f32x4{__uint_as_float(o[0] << 16), __uint_as_float(o[0] & 0xFFFF0000u),
+                     __uint_as_float(o[1] << 16), __uint_as_float(o[1] & 0xFFFF0000u)};
+        }
+        *dst = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      }
+    }
+  }
+}
+
+template <typename T, int ALAY, int BLAY>
+int launch(const GemmParams& p, int batch, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)gemm_kernel<T, ALAY, BLAY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            4 * TILE_BYTES) != hipSuccess)
+      return MELGPT_ERR_LAUNCH;
+    attr = true;
+  }
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  hipLaunchKernelGGL((gemm_kernel<T, ALAY, BLAY>), dim3(tiles, 1, batch), dim3(256), 4 * TILE_BYTES, s, p);
+  return melgpt_launch_status();
+}
+
+template <typename T>
+int dispatch(const GemmParams& p, int alay, int blay, int batch, hipStream_t s) {
+  if (alay == LAY_ROW && blay == LAY_ROW) return launch<T, LAY_ROW, LAY_ROW>(p, batch, s);
+  if (alay == LAY_ROW && blay == LAY_KMAJ) return launch<T, LAY_ROW, LAY_KMAJ>(p, batch, s);
+  if (alay == LAY_KMAJ && blay == LAY_KMAJ) return launch<T, LAY_KMAJ, LAY_KMAJ>(p, batch, s);
+  if (alay == LAY_KMAJ && blay == LAY_ROW) return launch<T, LAY_KMAJ, LAY_ROW>(p, batch, s);
+  if (alay == LAY_CONV && blay == LAY_ROW) return launch<T, LAY_CONV, LAY_ROW>(p, batch, s);
+  return MELGPT_ERR_UNSUPPORTED;
+}
+
+bool fits32(long long rows, long long ld, int es) { return (rows + 130) * ld * es < 0xFFFFFF00LL; }
+
+}  // namespace
+
+extern "C" int melgpt_gemm(const void* A, int a_kmajor, long long lda, long long strideA, const void* B,
+                           int b_kmajor, long long ldb, long long strideB, void* C, long long ldc,
+                           long long strideC, int M, int N, int K, int batch, int dtype, int out_f32,
+                           int accumulate, float alpha, const float* bias, int act, const void* R,
+                           long long ldr, long long strideR, void* C2, float drop_p,
+                           unsigned long long seed, unsigned stream_id, void* stream) {
+  MELGPT_CHECK(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(dtype == MELGPT_F32 || dtype == MELGPT_BF16, MELGPT_ERR_UNSUPPORTED);
+  const int es = dtype == MELGPT_F32 ? 4 : 2, vec = 16 / es;
+  MELGPT_CHECK(act >= MELGPT_ACT_NONE && act <= MELGPT_ACT_GELU_GRAD, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK(act != MELGPT_ACT_GELU_GRAD || R, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(drop_p >= 0.f && drop_p < 1.f, MELGPT_ERR_BAD_ARG);
+  // 16-byte vector accesses everywhere
+  MELGPT_CHECK(N % 4 == 0 && K % vec == 0 && lda % vec == 0 && ldb % vec == 0 && ldc % 4 == 0 &&
+                   strideA % vec == 0 && strideB % vec == 0 && strideC % 4 == 0,
+               MELGPT_ERR_ALIGN);
+  MELGPT_CHECK(!a_kmajor || M % vec == 0, MELGPT_ERR_ALIGN);
+  MELGPT_CHECK(!b_kmajor || N % vec == 0, MELGPT_ERR_ALIGN);
+  MELGPT_CHECK((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)R | (uintptr_t)C2 | (uintptr_t)bias) & 15) == 0,
+               MELGPT_ERR_ALIGN);
+  MELGPT_CHECK(!R || (ldr % 4 == 0 && strideR % 4 == 0), MELGPT_ERR_ALIGN);
+  GemmParams p{};
+  p.A = A; p.B = B; p.C = C; p.C2 = C2; p.bias = bias; p.R = R;
+  p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
+  p.sA = strideA; p.sB = strideB; p.sC = strideC; p.sR = strideR;
+  const long long a_rows = a_kmajor ? K : M, a_cols = a_kmajor ? M : K;
+  const long long b_rows = b_kmajor ? K : N, b_cols = b_kmajor ? N : K;
+  MELGPT_CHECK(lda >= a_cols && ldb >= b_cols && ldc >= N, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(fits32(a_rows, lda, es) && fits32(b_rows, ldb, es), MELGPT_ERR_UNSUPPORTED);
+  p.a_bytes = (unsigned)(((a_rows - 1) * lda + a_cols) * es);
+  p.b_bytes = (unsigned)(((b_rows - 1) * ldb + b_cols) * es);
+  p.out_f32 = out_f32; p.accumulate = accumulate; p.act = act; p.alpha = alpha;
+  if (drop_p > 0.f) {
+    p.drop_scale = 1.0f / (1.0f - drop_p);
+    double th = (double)drop_p * 4294967296.0;
+    p.drop_thresh = th >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)th;
+  }
+  p.seed = seed; p.stream_id = stream_id;
+  hipStream_t s = (hipStream_t)stream;
+  const int alay = a_kmajor ? LAY_KMAJ : LAY_ROW, blay = b_kmajor ? LAY_KMAJ : LAY_ROW;
+  return dtype == MELGPT_F32 ? dispatch<float>(p, alay, blay, batch, s) : dispatch<bf16_t>(p, alay, blay, batch, s);
+}
+
+extern "C" int melgpt_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, const void* wpack, int Cout, int KH,
+                                  int KW, int stride, int pad_t, int pad_l, int OH, int OW, int upsample,
+                                  const float* bias, const void* residual, void* y, int dtype, void* stream) {
+  MELGPT_CHECK(x && wpack && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0,
+               MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(dtype == MELGPT_F32 || dtype == MELGPT_BF16, MELGPT_ERR_UNSUPPORTED);
+  const int es = dtype == MELGPT_F32 ? 4 : 2, kstep = dtype == MELGPT_F32 ? 32 : 64;
+  MELGPT_CHECK((KH == 3 && KW == 3) || (KH == 1 && KW == 1), MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK(Cin % kstep == 0 && Cout % 4 == 0, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK(stride == 1 || stride == 2, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK(upsample == 0 || upsample == 1, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK((((uintptr_t)x | (uintptr_t)wpack | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)bias) & 15) == 0,
+               MELGPT_ERR_ALIGN);
+  const long long in_bytes = (long long)B * H * W * Cin * es;
+  const long long M = (long long)B * OH * OW;
+  MELGPT_CHECK(in_bytes < 0xFFFFFF00LL && M < 0x7FFFFF00LL, MELGPT_ERR_UNSUPPORTED);
+  GemmParams p{};
+  p.A = x; p.B = wpack; p.C = y; p.bias = bias; p.R = residual;
+  p.M = (int)M; p.N = Cout; p.K = KH * KW * Cin;
+  p.lda = Cin; p.ldb = p.K; p.ldc = Cout; p.ldr = Cout;
+  p.a_bytes = (unsigned)in_bytes;
+  p.b_bytes = (unsigned)((long long)Cout * p.K * es);
+  p.alpha = 1.0f;
+  p.cH = H; p.cW = W; p.cC = Cin; p.OH = OH; p.OW = OW; p.cstride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+  p.ups = upsample; p.KW = KW;
+  hipStream_t s = (hipStream_t)stream;
+  return dtype == MELGPT_F32 ? dispatch<float>(p, LAY_CONV, LAY_ROW, 1, s)
+                             : dispatch<bf16_t>(p, LAY_CONV, LAY_ROW, 1, s);
+}

@@ -1,0 +1,690 @@
+// HBM-bound row kernels of the minGPT training step for gfx950: LayerNorm, embedding stem, cross entropy,
+// dropout replay, column sums, fused AdamW, casts.  One 64-lane wavefront owns one row; every global access
+// is a 16-byte vector; reductions are xor-shuffles inside the wave (no LDS, no atomics -> deterministic).
+// Reference call sites: transformer/minGPT.py:97-98,141 (nn.LayerNorm), :170-180 (tok_emb/pos_emb/drop),
+// :197,:416 (F.cross_entropy), :660-664 (AdamW); transformer/decoders.py:20-21,64-68 (per-token CE).
+#include "common.h"
+
+namespace {
+
+template <typename T>
+struct V16;  // a 16-byte vector of T unpacked to floats
+template <>
+struct V16<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void ld(const float* p, float* o) {
+    f32x4 v = *(const f32x4*)p;
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  }
+  static __device__ __forceinline__ void st(float* p, const float* o) { *(f32x4*)p = f32x4{o[0], o[1], o[2], o[3]}; }
+};
+template <>
+struct V16<bf16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void ld(const bf16_t* p, float* o) {
+    u32x4 v = *(const u32x4*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[2 * i] = __uint_as_float(v[i] << 16);
+      o[2 * i + 1] = __uint_as_float(v[i] & 0xFFFF0000u);
+    }
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float* o) {
+    *(u32x4*)p = u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
+                       pack_bf16x2(o[6], o[7])};
+  }
+};
+
+constexpr int LN_MAXCH = 8;  // chunks per lane kept in registers: C <= 64*8*(16/ES) = 4096 bf16 / 2048 f32
+
+__device__ __forceinline__ void keep_mask(unsigned long long seed, unsigned sid, unsigned long long e0, int n,
+                                          unsigned thresh, float scale, float* v) {
+  // e0 is a multiple of 4; n in {4, 8}
+  for (int q = 0; q < n / 4; ++q) {
+    unsigned k = dropout_keep4(seed, sid, (e0 >> 2) + q, thresh);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[4 * q + e] = (k >> e & 1) ? v[4 * q + e] * scale : 0.f;
+  }
+}
+
+// ================================================================================== LayerNorm
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            long long M, int C, float eps) {
+  constexpr int N = V16<T>::N;
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = C / N;
+  const T* xr = x + row * C;
+  float v[LN_MAXCH][N];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      V16<T>::ld(xr + ch * N, v[i]);
+#pragma unroll
+      for (int e = 0; e < N; ++e) s += v[i][e];
+    }
+  }
+  const float mu = wave_sum(s) / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    if (lane + 64 * i < nch) {
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        float d = v[i][e] - mu;
+        ss = fmaf(d, d, ss);
+      }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(ss) / (float)C + eps);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+  T* yr = y + row * C;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      float o[N];
+#pragma unroll
+      for (int e4 = 0; e4 < N; e4 += 4) {
+        f32x4 gm = *(const f32x4*)(gamma + ch * N + e4), bt = *(const f32x4*)(beta + ch * N + e4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e4 + e] = (v[i][e4 + e] - mu) * rs * gm[e] + bt[e];
+      }
+      V16<T>::st(yr + ch * N, o);
+    }
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma   [+ add_in]   [then optional dropout replay
+// into a second output `dx_drop` = keep(dx)*scale, which is the gradient of the dropout-ed branch input]
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            const T* __restrict__ add_in, T* __restrict__ dx,
+                                                            float* __restrict__ partials, long long M, int C) {
+  constexpr int N = V16<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  const int nch = C / N;
+  float dg[LN_MAXCH][N], db[LN_MAXCH][N];
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i)
+#pragma unroll
+    for (int e = 0; e < N; ++e) dg[i][e] = db[i][e] = 0.f;
+
+  for (long long row = wave; row < M; row += nwaves) {
+    const float mu = mean[row], rs = rstd[row];
+    float g[LN_MAXCH][N], xh[LN_MAXCH][N];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        float d[N], xv[N];
+        V16<T>::ld(dy + row * C + ch * N, d);
+        V16<T>::ld(x + row * C + ch * N, xv);
+#pragma unroll
+        for (int e4 = 0; e4 < N; e4 += 4) {
+          f32x4 gm = *(const f32x4*)(gamma + ch * N + e4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xhat = (xv[e4 + e] - mu) * rs;
+            const float gg = d[e4 + e] * gm[e];
+            xh[i][e4 + e] = xhat;
+            g[i][e4 + e] = gg;
+            s1 += gg;
+            s2 = fmaf(gg, xhat, s2);
+            dg[i][e4 + e] = fmaf(d[e4 + e], xhat, dg[i][e4 + e]);
+            db[i][e4 + e] += d[e4 + e];
+          }
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)C, c2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        float o[N];
+        if (add_in) V16<T>::ld(add_in + row * C + ch * N, o);
+        else {
+#pragma unroll
+          for (int e = 0; e < N; ++e) o[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < N; ++e) o[e] += rs * (g[i][e] - c1 - xh[i][e] * c2);
+        V16<T>::st(dx + row * C + ch * N, o);
+      }
+    }
+  }
+  if (partials) {
+    float* pg = partials + (long long)wave * 2 * C;
+    float* pb = pg + C;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+#pragma unroll
+        for (int e4 = 0; e4 < N; e4 += 4) {
+          *(f32x4*)(pg + ch * N + e4) = f32x4{dg[i][e4], dg[i][e4 + 1], dg[i][e4 + 2], dg[i][e4 + 3]};
+          *(f32x4*)(pb + ch * N + e4) = f32x4{db[i][e4], db[i][e4 + 1], db[i][e4 + 2], db[i][e4 + 3]};
+        }
+      }
+    }
+  }
+}
+
+// out[c] (+)= scale * sum_{r<R} part[r*ld + c]  - fixed order => deterministic
+__global__ void reduce_rows_kernel(const float* __restrict__ part, int R, long long ld, int ncols,
+                                   float* __restrict__ out, int accumulate, float scale) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = 0;
+  for (; r + 3 < R; r += 4) {
+    s0 += part[(long long)r * ld + c];
+    s1 += part[(long long)(r + 1) * ld + c];
+    s2 += part[(long long)(r + 2) * ld + c];
+    s3 += part[(long long)(r + 3) * ld + c];
+  }
+  for (; r < R; ++r) s0 += part[(long long)r * ld + c];
+  float s = ((s0 + s1) + (s2 + s3)) * scale;
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// column sums of a (M,N) matrix in dtype T into partials[(gridDim.y)][N]; second stage = reduce_rows_kernel
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ a, long long M, int N, long long lda,
+                                                             float* __restrict__ partials) {
+  constexpr int NV = V16<T>::N;
+  const int ch = blockIdx.x * 64 + (threadIdx.x & 63);  // chunk column
+  const int rsub = threadIdx.x >> 6;                    // 4 row phases per block
+  const int nch = N / NV;
+  float acc[NV];
+#pragma unroll
+  for (int e = 0; e < NV; ++e) acc[e] = 0.f;
+  if (ch < nch) {
+    for (long long r = (long long)blockIdx.y * 4 + rsub; r < M; r += (long long)gridDim.y * 4) {
+      float v[NV];
+      V16<T>::ld(a + r * lda + ch * NV, v);
+#pragma unroll
+      for (int e = 0; e < NV; ++e) acc[e] += v[e];
+    }
+  }
+  __shared__ float sh[4][64][NV + 1];
+#pragma unroll
+  for (int e = 0; e < NV; ++e) sh[rsub][threadIdx.x & 63][e] = acc[e];
+  __syncthreads();
+  if (rsub == 0 && ch < nch) {
+    const int l = threadIdx.x & 63;
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+      partials[(long long)blockIdx.y * N + ch * NV + e] = (sh[0][l][e] + sh[1][l][e]) + (sh[2][l][e] + sh[3][l][e]);
+  }
+}
+
+// ================================================================================== embedding stem
+// out[b,t,:] = drop( (t < n_pre ? PRE(b,t) : tok_emb[idx[b,t-n_pre]]) + pos_emb[t] )
+//   PRE = pre_table[pre_idx[b*n_pre+t]]  (GPTClass.embedder, minGPT.py:207-212)  or  pre_vals[b,t,:] (f32)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ idx, const float* __restrict__ tok,
+                                                        const float* __restrict__ pos,
+                                                        const long long* __restrict__ pre_idx,
+                                                        const float* __restrict__ pre_table,
+                                                        const float* __restrict__ pre_vals, int n_pre, int B, int Tt,
+                                                        int C, int V, T* __restrict__ out, float drop_scale,
+                                                        unsigned thresh, unsigned long long seed, unsigned sid) {
+  constexpr int N = V16<T>::N;
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int Ttot = Tt + n_pre;
+  if (row >= (long long)B * Ttot) return;
+  const int b = (int)(row / Ttot), tt = (int)(row % Ttot);
+  const float* src;
+  if (tt < n_pre) {
+    src = pre_idx ? pre_table + pre_idx[(long long)b * n_pre + tt] * C : pre_vals + ((long long)b * n_pre + tt) * C;
+  } else {
+    long long k = idx[(long long)b * Tt + (tt - n_pre)];
+    k = k < 0 ? 0 : (k >= V ? V - 1 : k);
+    src = tok + k * C;
+  }
+  const float* pr = pos + (long long)tt * C;
+  for (int ch = lane; ch < C / N; ch += 64) {
+    float o[N];
+#pragma unroll
+    for (int e4 = 0; e4 < N; e4 += 4) {
+      f32x4 a = *(const f32x4*)(src + ch * N + e4), p4 = *(const f32x4*)(pr + ch * N + e4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e4 + e] = a[e] + p4[e];
+    }
+    if (drop_scale != 0.f) keep_mask(seed, sid, (unsigned long long)row * C + ch * N, N, thresh, drop_scale, o);
+    V16<T>::st(out + row * C + ch * N, o);
+  }
+}
+
+// table_grad[v,:] (+)= sum over items j with item_idx[j]==v of keep(dX[row(j),:]),  row(j) = (j/ipb)*Ttot + off + j%ipb
+// one workgroup per table row; positions are visited in ascending order -> deterministic, no atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_table_kernel(const T* __restrict__ dx, const long long* __restrict__ item_idx,
+                                                              long long n_items, int ipb, int Ttot, int off, int C,
+                                                              float* __restrict__ grad, int accumulate, float drop_scale,
+                                                              unsigned thresh, unsigned long long seed, unsigned sid) {
+  __shared__ int list[256];
+  __shared__ int count;
+  const int v = blockIdx.x, t = threadIdx.x;
+  // thread owns 4 consecutive columns c = 4*(t + 256*i)
+  constexpr int MAXC4 = 8;  // C <= 8192
+  f32x4 acc[MAXC4];
+#pragma unroll
+  for (int i = 0; i < MAXC4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (long long base = 0; base < n_items; base += 256) {
+    if (t == 0) count = 0;
+    __syncthreads();
+    const long long j = base + t;
+    const bool hit = j < n_items && item_idx[j] == v;
+    // ordered compaction: ballot per wave, waves in order
+    unsigned long long bal = __ballot(hit);
+    __shared__ int wcount[4];
+    if ((t & 63) == 0) wcount[t >> 6] = __popcll(bal);
+    __syncthreads();
+    int wbase = 0;
+    for (int ww = 0; ww < (t >> 6); ++ww) wbase += wcount[ww];
+    if (hit) list[wbase + __popcll(bal & ((1ull << (t & 63)) - 1ull))] = (int)(j - base);
+    if (t == 0) count = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    __syncthreads();
+    const int cnt = count;
+    for (int s = 0; s < cnt; ++s) {
+      const long long jj = base + list[s];
+      const long long row = (jj / ipb) * Ttot + off + (jj % ipb);
+#pragma unroll
+      for (int i = 0; i < MAXC4; ++i) {
+        const int c = 4 * (t + 256 * i);
+        if (c < C) {
+          float d[4];
+          if constexpr (sizeof(T) == 4) {
+            f32x4 q = *(const f32x4*)((const float*)dx + row * C + c);
+            d[0] = q[0]; d[1] = q[1]; d[2] = q[2]; d[3] = q[3];
+          } else {
+            u32x2 q = *(const u32x2*)((const bf16_t*)dx + row * C + c);
+            d[0] = __uint_as_float(q[0] << 16); d[1] = __uint_as_float(q[0] & 0xFFFF0000u);
+            d[2] = __uint_as_float(q[1] << 16); d[3] = __uint_as_float(q[1] & 0xFFFF0000u);
+          }
+          if (drop_scale != 0.f) keep_mask(seed, sid, (unsigned long long)row * C + c, 4, thresh, drop_scale, d);
+          acc[i] += f32x4{d[0], d[1], d[2], d[3]};
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < MAXC4; ++i) {
+    const int c = 4 * (t + 256 * i);
+    if (c < C) {
+      f32x4* g = (f32x4*)(grad + (long long)v * C + c);
+      *g = accumulate ? *g + acc[i] : acc[i];
+    }
+  }
+}
+
+// pos_grad[t,:] (+)= sum_b keep(dX[b,t,:])   and   (optional) pre_vals_grad[b,t,:] = keep(dX[b,t,:]) for t < n_pre
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const T* __restrict__ dx, int B, int Ttot, int C,
+                                                            float* __restrict__ pos_grad, int accumulate,
+                                                            float* __restrict__ pre_grad, int n_pre, float drop_scale,
+                                                            unsigned thresh, unsigned long long seed, unsigned sid) {
+  constexpr int N = V16<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int tt = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tt >= Ttot) return;
+  for (int ch = lane; ch < C / N; ch += 64) {
+    float acc[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[e] = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const long long row = (long long)b * Ttot + tt;
+      float d[N];
+      V16<T>::ld(dx + row * C + ch * N, d);
+      if (drop_scale != 0.f) keep_mask(seed, sid, (unsigned long long)row * C + ch * N, N, thresh, drop_scale, d);
+#pragma unroll
+      for (int e = 0; e < N; ++e) acc[e] += d[e];
+      if (pre_grad && tt < n_pre) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) pre_grad[((long long)b * n_pre + tt) * C + ch * N + e] = d[e];
+      }
+    }
+    float* g = pos_grad + (long long)tt * C + ch * N;
+#pragma unroll
+    for (int e = 0; e < N; ++e) g[e] = accumulate ? g[e] + acc[e] : acc[e];
+  }
+}
+
+// ================================================================================== cross entropy
+// logits (M,V) f32 with row stride ld.  loss_rows[m] = lse - logit[target]; lse saved for the backward.
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, long long ld,
+                                                     const long long* __restrict__ target, long long M, int V,
+                                                     float* __restrict__ loss_rows, float* __restrict__ lse) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* lr = logits + row * ld;
+  float mx = -__builtin_inff();
+  for (int c = lane; c < V; c += 64) mx = fmaxf(mx, lr[c]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int c = lane; c < V; c += 64) s += __expf(lr[c] - mx);
+  s = wave_sum(s);
+  const float l = mx + __logf(s);
+  if (lane == 0) {
+    long long tg = target[row];
+    tg = tg < 0 ? 0 : (tg >= V ? V - 1 : tg);
+    loss_rows[row] = l - lr[tg];
+    lse[row] = l;
+  }
+}
+
+// dlogits[m,v] = (exp(logit - lse) - [v == target]) * g_rows[m] * g_scale
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, long long ld,
+                                                     const long long* __restrict__ target,
+                                                     const float* __restrict__ lse, const float* __restrict__ g_rows,
+                                                     const float* __restrict__ g_scalar, float g_scale, long long M,
+                                                     int V, T* __restrict__ dlogits, long long ldd) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* lr = logits + row * ld;
+  const float l = lse[row];
+  const float g = (g_rows ? g_rows[row] : 1.f) * (g_scalar ? *g_scalar : 1.f) * g_scale;
+  const long long tg = target[row];
+  for (int c = lane; c < V; c += 64) {
+    float p = __expf(lr[c] - l) - (c == tg ? 1.f : 0.f);
+    Elem<T>::st(dlogits + row * ldd + c, p * g);
+  }
+}
+
+// out[0] (+)= scale * sum(in[0..n))   single workgroup, fixed order
+__global__ void sum_kernel(const float* __restrict__ in, long long n, float scale, float* __restrict__ out,
+                           int accumulate) {
+  __shared__ float sh[256];
+  float s = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 256) s += in[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + sh[0] * scale : sh[0] * scale;
+}
+
+// ================================================================================== elementwise
+// y = keep(x) * scale  (dropout replay for a backward pass), element index = linear index in a contiguous tensor
+template <typename T>
+__global__ void dropout_apply_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, float scale,
+                                     unsigned thresh, unsigned long long seed, unsigned sid) {
+  constexpr int N = V16<T>::N;
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * N;
+  const long long step = (long long)gridDim.x * blockDim.x * N;
+  for (; i < n; i += step) {
+    float v[N];
+    V16<T>::ld(x + i, v);
+    keep_mask(seed, sid, (unsigned long long)i, N, thresh, scale, v);
+    V16<T>::st(y + i, v);
+  }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long long n) {
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  const long long step = (long long)gridDim.x * blockDim.x * 8;
+  for (; i + 7 < n; i += step) {
+    f32x4 a = *(const f32x4*)(x + i), b = *(const f32x4*)(x + i + 4);
+    *(u32x4*)(y + i) =
+        u32x4{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+  }
+  if (i < n && i + 7 >= n)
+    for (long long j = i; j < n; ++j) y[j] = f32_to_bf16(x[j]);
+}
+
+template <typename TI, typename TO>
+__global__ void cast_strided_kernel(const TI* __restrict__ x, TO* __restrict__ y, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (long long)gridDim.x * blockDim.x) Elem<TO>::st(y + i, Elem<TI>::ld(x + i));
+}
+
+// torch.optim.AdamW semantics (decoupled decay first, bias-corrected step), fused over a flat f32 buffer
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, bf16_t* __restrict__ p_bf16, long long n, float lr, float beta1,
+                             float beta2, float eps, float wd, float bc1, float bc2_sqrt, float grad_scale) {
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long long step = (long long)gridDim.x * blockDim.x * 4;
+  const float step_size = lr / bc1;
+  for (; i < n; i += step) {
+    if (i + 3 < n) {
+      f32x4 pp = *(f32x4*)(p + i), gg = *(const f32x4*)(g + i) * grad_scale, mm = *(f32x4*)(m + i), vv = *(f32x4*)(v + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pp[e] *= (1.f - lr * wd);
+        mm[e] = beta1 * mm[e] + (1.f - beta1) * gg[e];
+        vv[e] = beta2 * vv[e] + (1.f - beta2) * gg[e] * gg[e];
+        const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+        pp[e] -= step_size * (mm[e] / denom);
+      }
+      *(f32x4*)(p + i) = pp; *(f32x4*)(m + i) = mm; *(f32x4*)(v + i) = vv;
+      if (p_bf16) *(u32x2*)(p_bf16 + i) = u32x2{pack_bf16x2(pp[0], pp[1]), pack_bf16x2(pp[2], pp[3])};
+    } else {
+      for (long long j = i; j < n; ++j) {
+        float pp = p[j] * (1.f - lr * wd), gg = g[j] * grad_scale;
+        float mm = beta1 * m[j] + (1.f - beta1) * gg, vv = beta2 * v[j] + (1.f - beta2) * gg * gg;
+        pp -= step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+        p[j] = pp; m[j] = mm; v[j] = vv;
+        if (p_bf16) p_bf16[j] = f32_to_bf16(pp);
+      }
+    }
+  }
+}
+
+inline int grid_for(long long work_items, int per_block, int cap = 8192) {
+  long long g = (work_items + per_block - 1) / per_block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+inline unsigned thresh_of(float p) {
+  double th = (double)p * 4294967296.0;
+  return th >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)th;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                                  \
+  if ((dtype) == MELGPT_F32) {                                  \
+    using T = float;                                            \
+    __VA_ARGS__;                                                \
+  } else if ((dtype) == MELGPT_BF16) {                          \
+    using T = bf16_t;                                           \
+    __VA_ARGS__;                                                \
+  } else                                                        \
+    return MELGPT_ERR_UNSUPPORTED;
+
+extern "C" int melgpt_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                    float* rstd, long long M, int C, float eps, int dtype, void* stream) {
+  MELGPT_CHECK(x && gamma && beta && y && M > 0 && C > 0, MELGPT_ERR_BAD_ARG);
+  const int vec = dtype == MELGPT_F32 ? 4 : 8;
+  MELGPT_CHECK(C % vec == 0 && C / vec <= 64 * LN_MAXCH, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, MELGPT_ERR_ALIGN);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0,
+                                       (hipStream_t)stream, (const T*)x, gamma, beta, (T*)y, mean, rstd, M, C, eps));
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_layernorm_bwd_nwaves(long long M) {
+  long long w = (M + 7) / 8;  // >= 8 rows per wave where possible
+  if (w < 4) w = 4;
+  if (w > 2048) w = 2048;
+  return (int)((w + 3) / 4 * 4);
+}
+
+extern "C" int melgpt_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                    const float* rstd, const void* add_in, void* dx, float* dgamma, float* dbeta,
+                                    int accumulate, float* workspace, long long M, int C, int dtype, void* stream) {
+  MELGPT_CHECK(dy && x && gamma && mean && rstd && dx && M > 0 && C > 0, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK((dgamma == nullptr) == (dbeta == nullptr), MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(!dgamma || workspace, MELGPT_ERR_BAD_ARG);
+  const int vec = dtype == MELGPT_F32 ? 4 : 8;
+  MELGPT_CHECK(C % vec == 0 && C / vec <= 64 * LN_MAXCH, MELGPT_ERR_UNSUPPORTED);
+  const int nwaves = melgpt_layernorm_bwd_nwaves(M);
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(nwaves / 4), dim3(256), 0, s, (const T*)dy,
+                                       (const T*)x, gamma, mean, rstd, (const T*)add_in, (T*)dx,
+                                       dgamma ? workspace : nullptr, M, C));
+  if (dgamma) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace, nwaves, 2LL * C, C,
+                       dgamma, accumulate, 1.0f);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace + C, nwaves, 2LL * C, C,
+                       dbeta, accumulate, 1.0f);
+  }
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_colsum_rows(void) { return 256; }
+
+extern "C" int melgpt_colsum(const void* a, long long M, int N, long long lda, float* out, int accumulate,
+                             float* workspace, int dtype, void* stream) {
+  MELGPT_CHECK(a && out && workspace && M > 0 && N > 0, MELGPT_ERR_BAD_ARG);
+  const int vec = dtype == MELGPT_F32 ? 4 : 8;
+  MELGPT_CHECK(N % vec == 0 && lda % vec == 0 && ((uintptr_t)a & 15) == 0, MELGPT_ERR_ALIGN);
+  long long rows = (M + 3) / 4;
+  const int gy = (int)(rows < 256 ? rows : 256);
+  const int nch = N / vec;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3((nch + 63) / 64, gy), dim3(256), 0, s,
+                                       (const T*)a, M, N, lda, workspace));
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, s, workspace, gy, (long long)N, N, out,
+                     accumulate, 1.0f);
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_embed_fwd(const long long* idx, const float* tok_emb, const float* pos_emb,
+                                const long long* pre_idx, const float* pre_table, const float* pre_vals, int n_pre,
+                                int B, int Tt, int C, int V, void* out, int dtype, float drop_p,
+                                unsigned long long seed, unsigned stream_id, void* stream) {
+  MELGPT_CHECK(tok_emb && pos_emb && out && B > 0 && Tt >= 0 && C > 0 && V > 0 && n_pre >= 0, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(Tt == 0 || idx, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(n_pre == 0 || (pre_idx && pre_table) || pre_vals, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(C % 8 == 0 && drop_p >= 0.f && drop_p < 1.f, MELGPT_ERR_UNSUPPORTED);
+  const long long rows = (long long)B * (Tt + n_pre);
+  const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 0.f;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(embed_fwd_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                                       (hipStream_t)stream, idx, tok_emb, pos_emb, pre_idx, pre_table, pre_vals, n_pre,
+                                       B, Tt, C, V, (T*)out, sc, thresh_of(drop_p), seed, stream_id));
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_embed_bwd(const void* dx, const long long* idx, const long long* pre_idx, int n_pre, int B,
+                                int Tt, int C, int V, int n_pre_rows, float* tok_grad, float* pos_grad,
+                                float* pre_table_grad, float* pre_vals_grad, int accumulate, int dtype, float drop_p,
+                                unsigned long long seed, unsigned stream_id, void* stream) {
+  MELGPT_CHECK(dx && B > 0 && C > 0 && V > 0 && n_pre >= 0 && Tt >= 0, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(C % 8 == 0 && C <= 8192, MELGPT_ERR_UNSUPPORTED);
+  const int Ttot = Tt + n_pre;
+  const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 0.f;
+  const unsigned th = thresh_of(drop_p);
+  hipStream_t s = (hipStream_t)stream;
+  if (tok_grad && Tt > 0) {
+    MELGPT_CHECK(idx, MELGPT_ERR_BAD_ARG);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(embed_bwd_table_kernel<T>, dim3(V), dim3(256), 0, s, (const T*)dx, idx,
+                                         (long long)B * Tt, Tt, Ttot, n_pre, C, tok_grad, accumulate, sc, th, seed,
+                                         stream_id));
+  }
+  if (pre_table_grad && n_pre > 0) {
+    MELGPT_CHECK(pre_idx && n_pre_rows > 0, MELGPT_ERR_BAD_ARG);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(embed_bwd_table_kernel<T>, dim3(n_pre_rows), dim3(256), 0, s, (const T*)dx,
+                                         pre_idx, (long long)B * n_pre, n_pre, Ttot, 0, C, pre_table_grad, accumulate,
+                                         sc, th, seed, stream_id));
+  }
+  if (pos_grad) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(embed_bwd_pos_kernel<T>, dim3((Ttot + 3) / 4), dim3(256), 0, s, (const T*)dx, B,
+                                         Ttot, C, pos_grad, accumulate, pre_vals_grad, n_pre, sc, th, seed, stream_id));
+  }
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_cross_entropy_fwd(const float* logits, long long ld, const long long* target, long long M, int V,
+                                        float* loss_rows, float* lse, void* stream) {
+  MELGPT_CHECK(logits && target && loss_rows && lse && M > 0 && V > 0 && ld >= V, MELGPT_ERR_BAD_ARG);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, ld,
+                     target, M, V, loss_rows, lse);
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_cross_entropy_bwd(const float* logits, long long ld, const long long* target, const float* lse,
+                                        const float* g_rows, const float* g_scalar, float g_scale, long long M, int V,
+                                        void* dlogits, long long ldd, int dtype, void* stream) {
+  MELGPT_CHECK(logits && target && lse && dlogits && M > 0 && V > 0, MELGPT_ERR_BAD_ARG);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(ce_bwd_kernel<T>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0,
+                                       (hipStream_t)stream, logits, ld, target, lse, g_rows, g_scalar, g_scale, M, V,
+                                       (T*)dlogits, ldd));
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_sum_f32(const float* in, long long n, float scale, float* out, int accumulate, void* stream) {
+  MELGPT_CHECK(in && out && n > 0, MELGPT_ERR_BAD_ARG);
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in, n, scale, out, accumulate);
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_dropout_apply(const void* x, void* y, long long n, float drop_p, unsigned long long seed,
+                                    unsigned stream_id, int dtype, void* stream) {
+  MELGPT_CHECK(x && y && n > 0 && drop_p > 0.f && drop_p < 1.f, MELGPT_ERR_BAD_ARG);
+  const int vec = dtype == MELGPT_F32 ? 4 : 8;
+  MELGPT_CHECK(n % vec == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, MELGPT_ERR_ALIGN);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(dropout_apply_kernel<T>, dim3(grid_for(n / vec, 256)), dim3(256), 0,
+                                       (hipStream_t)stream, (const T*)x, (T*)y, n, 1.f / (1.f - drop_p),
+                                       thresh_of(drop_p), seed, stream_id));
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_cast(const void* x, int src_dtype, void* y, int dst_dtype, long long n, void* stream) {
+  MELGPT_CHECK(x && y && n > 0, MELGPT_ERR_BAD_ARG);
+  hipStream_t s = (hipStream_t)stream;
+  if (src_dtype == MELGPT_F32 && dst_dtype == MELGPT_BF16 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for((n + 7) / 8, 256)), dim3(256), 0, s, (const float*)x,
+                       (bf16_t*)y, n);
+  } else if (src_dtype == MELGPT_F32 && dst_dtype == MELGPT_BF16) {
+    hipLaunchKernelGGL((cast_strided_kernel<float, bf16_t>), dim3(grid_for(n, 256)), dim3(256), 0, s, (const float*)x,
+                       (bf16_t*)y, n);
+  } else if (src_dtype == MELGPT_BF16 && dst_dtype == MELGPT_F32) {
+    hipLaunchKernelGGL((cast_strided_kernel<bf16_t, float>), dim3(grid_for(n, 256)), dim3(256), 0, s,
+                       (const bf16_t*)x, (float*)y, n);
+  } else if (src_dtype == MELGPT_F32 && dst_dtype == MELGPT_F32) {
+    hipLaunchKernelGGL((cast_strided_kernel<float, float>), dim3(grid_for(n, 256)), dim3(256), 0, s, (const float*)x,
+                       (float*)y, n);
+  } else {
+    return MELGPT_ERR_UNSUPPORTED;
+  }
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16,
+                            long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                            float grad_scale, void* stream) {
+  MELGPT_CHECK(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0 &&
+                   ((uintptr_t)param_bf16 & 7) == 0,
+               MELGPT_ERR_ALIGN);
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, param,
+                     grad, exp_avg, exp_avg_sq, (bf16_t*)param_bf16, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
+                     (float)sqrt(bc2), grad_scale);
+  return melgpt_launch_status();
+}

@@ -1,0 +1,168 @@
+"""GPU parity of the MFMA GEMM / implicit-GEMM convolution (csrc/gemm.hip) against plain fp32 PyTorch on CPU.
+Tolerances: f32 lane 1e-5 relative-to-max (exact f32 FMA chains, only the summation order differs);
+bf16 lane: inputs are pre-rounded to bf16 on both sides, products exact, f32 accumulate -> 1e-5 before the
+output rounding, 2^-8 relative after it."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import synth
+from util import rel_err, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+
+
+def _rand(seed, shape, dt, scale=1.0):
+    x = t(synth.normal(seed, shape) * np.float32(scale)).to(dt)
+    return x.to(DEV), x.float()
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (530, 128, 256), (265, 384, 96), (77, 20, 40), (1, 4, 8),
+                                    (300, 1024, 512)])
+def test_nt_plain(dt, M, N, K):
+    from melspec_gpt_vqvae_amd import ops
+
+    a, ac = _rand(1, (M, K), DT[dt])
+    b, bc = _rand(2, (N, K), DT[dt])
+    out = ops.gemm(a, b, out_dtype=torch.float32)
+    assert rel_err(out.cpu().numpy(), (ac @ bc.t()).numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("form", ["nn", "tn", "tt"])
+def test_transposed_operands(dt, form):
+    """nn: dX = dY W (B k-major);  tn: dW = dY^T X (both k-major);  tt: A k-major, B row."""
+    from melspec_gpt_vqvae_amd import ops
+
+    M, N, K = 200, 136, 328
+    if form == "nn":
+        a, ac = _rand(3, (M, K), DT[dt])
+        b, bc = _rand(4, (K, N), DT[dt])
+        out = ops.gemm(a, b, b_kmajor=True, out_dtype=torch.float32)
+        ref = ac @ bc
+    elif form == "tn":
+        a, ac = _rand(5, (K, M), DT[dt])
+        b, bc = _rand(6, (K, N), DT[dt])
+        out = ops.gemm(a, b, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+        ref = ac.t() @ bc
+    else:
+        a, ac = _rand(7, (K, M), DT[dt])
+        b, bc = _rand(8, (N, K), DT[dt])
+        out = ops.gemm(a, b, a_kmajor=True, out_dtype=torch.float32)
+        ref = ac.t() @ bc.t()
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_asymmetric_identity_layout_check(dt):
+    """A = I with an asymmetric B catches a transposed C write (guide §3)."""
+    from melspec_gpt_vqvae_amd import ops
+
+    n = 128
+    a = torch.eye(n, dtype=DT[dt], device=DEV)
+    bc = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 61) - 30 + torch.arange(n)[:, None] * 0.5
+    out = ops.gemm(a, bc.to(DT[dt]).to(DEV), out_dtype=torch.float32)
+    assert torch.equal(out.cpu(), bc.to(DT[dt]).float().t().contiguous())
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_epilogues(dt):
+    from melspec_gpt_vqvae_amd import ops
+
+    M, N, K = 265, 256, 128
+    a, ac = _rand(10, (M, K), DT[dt], 0.5)
+    b, bc = _rand(11, (N, K), DT[dt], 0.5)
+    bias = t(synth.normal(12, (N,)), DEV)
+    r, rc = _rand(13, (M, N), DT[dt])
+    lin = ac @ bc.t() * 0.37 + bias.cpu()
+    tol = 1e-5 if dt == "f32" else 6e-3
+    # bias + GELU, with pre-activation copy
+    pre = torch.empty(M, N, dtype=DT[dt], device=DEV)
+    out = ops.gemm(a, b, alpha=0.37, bias=bias, act=ops.ACT_GELU, pre_out=pre)
+    assert rel_err(pre.float().cpu().numpy(), lin.numpy()) < tol
+    assert rel_err(out.float().cpu().numpy(), F.gelu(lin).numpy()) < tol
+    # bias + residual
+    out = ops.gemm(a, b, alpha=0.37, bias=bias, residual=r)
+    assert rel_err(out.float().cpu().numpy(), (lin + rc).numpy()) < tol
+    # gelu-grad epilogue: v * gelu'(R)
+    x = rc.clone().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    out = ops.gemm(a, b, alpha=0.37, act=ops.ACT_GELU_GRAD, residual=r, out_dtype=torch.float32)
+    assert rel_err(out.cpu().numpy(), ((ac @ bc.t() * 0.37) * x.grad).numpy()) < 2e-5
+    # accumulate into f32
+    acc = t(synth.normal(14, (M, N)), DEV)
+    acc0 = acc.cpu().clone()
+    ops.gemm(a, b, out=acc, accumulate=True)
+    assert rel_err(acc.cpu().numpy(), (acc0 + ac @ bc.t()).numpy()) < 1e-5
+    # strided views (q inside a packed qkv buffer) and batched
+    big, bigc = _rand(15, (M, 3 * K), DT[dt], 0.5)
+    out = ops.gemm(big[:, K:2 * K], b, out_dtype=torch.float32)
+    assert rel_err(out.cpu().numpy(), (bigc[:, K:2 * K] @ bc.t()).numpy()) < 1e-5
+    a3, a3c = _rand(16, (3, 70, K), DT[dt], 0.5)
+    b3, b3c = _rand(17, (3, 52, K), DT[dt], 0.5)
+    out = ops.gemm(a3, b3, out_dtype=torch.float32)
+    assert rel_err(out.cpu().numpy(), torch.bmm(a3c, b3c.transpose(1, 2)).numpy()) < 1e-5
+
+
+def test_dropout_epilogue_statistics_and_replay():
+    from melspec_gpt_vqvae_amd import ops
+
+    M, N, K = 512, 512, 64
+    a, ac = _rand(20, (M, K), torch.float32, 0.5)
+    b, bc = _rand(21, (N, K), torch.float32, 0.5)
+    ref = (ac @ bc.t()).numpy()
+    o1 = ops.gemm(a, b, drop_p=0.5, seed=1234, stream_id=7).cpu().numpy()
+    o2 = ops.gemm(a, b, drop_p=0.5, seed=1234, stream_id=7).cpu().numpy()
+    o3 = ops.gemm(a, b, drop_p=0.5, seed=1234, stream_id=8).cpu().numpy()
+    assert np.array_equal(o1, o2), "counter-based mask must replay exactly"
+    keep = o1 != 0
+    assert abs(keep.mean() - 0.5) < 0.01
+    assert rel_err(o1[keep], 2.0 * ref[keep]) < 1e-5
+    assert (keep != (o3 != 0)).mean() > 0.4, "different stream id -> independent mask"
+    o4 = ops.gemm(a, b, drop_p=0.3, seed=99, stream_id=1).cpu().numpy()
+    assert abs((o4 != 0).mean() - 0.7) < 0.01
+    # rows / columns are not correlated
+    k2 = (o4 != 0).astype(np.float64)
+    assert abs(np.corrcoef(k2[:, 0], k2[:, 4])[0, 1]) < 0.2 and abs(np.corrcoef(k2[0], k2[1])[0, 1]) < 0.2
+
+
+def _conv_ref(xc, wc, bias, stride, pad, ups, res):
+    x = xc.permute(0, 3, 1, 2)
+    if ups:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    if stride == 2:
+        x = F.pad(x, (0, 1, 0, 1))
+        y = F.conv2d(x, wc, bias, stride=2, padding=0)
+    else:
+        y = F.conv2d(x, wc, bias, stride=1, padding=pad)
+    y = y.permute(0, 2, 3, 1)
+    return y + res if res is not None else y
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", ["3x3", "3x3_res", "down", "up", "1x1"])
+def test_conv_implicit_gemm(dt, case):
+    from melspec_gpt_vqvae_amd import ops
+
+    B, H, W, Cin, Cout = 2, 10, 53, 128, 64
+    k = 1 if case == "1x1" else 3
+    x, xc = _rand(30, (B, H, W, Cin), DT[dt])
+    w, wc = _rand(31, (Cout, Cin, k, k), DT[dt], 0.05)
+    bias = t(synth.normal(32, (Cout,)), DEV)
+    wpack = w.permute(0, 2, 3, 1).contiguous()
+    stride, pad, ups, res, resc = 1, (k // 2, k // 2), False, None, None
+    if case == "down":
+        stride, pad = 2, (0, 0)
+    if case == "up":
+        ups = True
+    oh = {"down": (5, 26), "up": (20, 106)}.get(case, (H, W))
+    if case == "3x3_res":
+        res, resc = _rand(33, (B, H, W, Cout), DT[dt])
+    y = ops.conv2d_nhwc(x, wpack, bias, stride=stride, pad=pad, out_hw=oh, upsample=ups, residual=res)
+    ref = _conv_ref(xc, wc, bias.cpu(), stride, k // 2, ups, resc)
+    assert y.shape == ref.shape
+    assert rel_err(y.float().cpu().numpy(), ref.numpy()) < (1e-5 if dt == "f32" else 6e-3)
