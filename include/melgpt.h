@@ -130,6 +130,67 @@ int melgpt_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, const void* 
                        int KW, int stride, int pad_t, int pad_l, int OH, int OW, int upsample,
                        const float* bias, const void* residual, void* y, int dtype, void* stream);
 
+/* ===================================================================== attention (minGPT.py:72-90)
+ * q/k/v: (B*T, >= H*64) matrices with row stride ld (elements), head h in columns [64h, 64h+64) - i.e. the
+ * three column blocks of a packed QKV projection; no (B,H,T,hs) transposes are ever materialised.
+ * mask: key <= query, plus the fully visible n_unmasked x n_unmasked corner (minGPT.py:65-69).
+ * out (B*T, H*64) row stride ldo = softmax(mask(q k^T / sqrt(hs))) -> dropout(p) -> @ v, heads merged (:85).
+ * lse (B,H,T) f32 is saved for the backward.  att: optional (B,H,T,T) f32 = post-softmax PRE-dropout
+ * probabilities, the tensor CausalSelfAttention.forward returns (:90); NULL skips it.
+ * Built for head_size 64 (all reference configs: 1024/16, 1472/23) and T <= 288 (block_size 265/266). */
+int melgpt_attn_fwd(const void* q, const void* k, const void* v, long long ld, void* out, long long ldo,
+                    float* lse, float* att, int B, int H, int T, int head_size, int n_unmasked, float drop_p,
+                    unsigned long long seed, unsigned stream_id, int dtype, void* stream);
+
+/* backward: dq/dk/dv (row stride ldg) from dout; probabilities are recomputed from lse, the dropout mask is
+ * regenerated from (seed, stream_id).  delta (B,H,T) f32 is workspace (rowsum(dout*out)). Deterministic. */
+int melgpt_attn_bwd(const void* q, const void* k, const void* v, long long ld, const void* out,
+                    const void* dout, long long ldo, const float* lse, float* delta, void* dq, void* dk,
+                    void* dv, long long ldg, int B, int H, int T, int head_size, int n_unmasked, float drop_p,
+                    unsigned long long seed, unsigned stream_id, int dtype, void* stream);
+
+/* ===================================================================== row kernels
+ * nn.LayerNorm(C, eps) (minGPT.py:97-98,141): y = (x-mean)*rstd*gamma+beta; mean/rstd (M,) f32 saved. */
+int melgpt_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                         float* rstd, long long M, int C, float eps, int dtype, void* stream);
+/* dx = add_in + LN'(dy); dgamma/dbeta (+)= column sums (two-stage, deterministic).  workspace: f32
+ * [melgpt_layernorm_bwd_nwaves(M) * 2 * C].  dgamma/dbeta may both be NULL. */
+int melgpt_layernorm_bwd_nwaves(long long M);
+int melgpt_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                         const float* rstd, const void* add_in, void* dx, float* dgamma, float* dbeta,
+                         int accumulate, float* workspace, long long M, int C, int dtype, void* stream);
+/* out[n] (+)= sum_m a[m,n] (bias gradients).  workspace: f32 [melgpt_colsum_rows() * N]. */
+int melgpt_colsum_rows(void);
+int melgpt_colsum(const void* a, long long M, int N, long long lda, float* out, int accumulate,
+                  float* workspace, int dtype, void* stream);
+/* embedding stem (minGPT.py:170-180, 207-212): out[b,t,:] = drop((t < n_pre ? PRE : tok_emb[idx]) + pos_emb[t]);
+ * PRE = pre_table[pre_idx[b*n_pre+t]] (GPTClass.embedder) or pre_vals[b,t,:] (explicit embeddings, f32). */
+int melgpt_embed_fwd(const long long* idx, const float* tok_emb, const float* pos_emb,
+                     const long long* pre_idx, const float* pre_table, const float* pre_vals, int n_pre, int B,
+                     int Tt, int C, int V, void* out, int dtype, float drop_p, unsigned long long seed,
+                     unsigned stream_id, void* stream);
+/* gradients of the stem; every table row is reduced by one workgroup in ascending position order (no atomics) */
+int melgpt_embed_bwd(const void* dx, const long long* idx, const long long* pre_idx, int n_pre, int B, int Tt,
+                     int C, int V, int n_pre_rows, float* tok_grad, float* pos_grad, float* pre_table_grad,
+                     float* pre_vals_grad, int accumulate, int dtype, float drop_p, unsigned long long seed,
+                     unsigned stream_id, void* stream);
+/* F.cross_entropy pieces (minGPT.py:197,416; decoders.py:64-68): loss_rows[m] = lse[m] - logits[m,target[m]] */
+int melgpt_cross_entropy_fwd(const float* logits, long long ld, const long long* target, long long M, int V,
+                             float* loss_rows, float* lse, void* stream);
+/* dlogits[m,v] = (softmax - onehot) * g_rows[m] * (*g_scalar) * g_scale   (g_rows / g_scalar may be NULL = 1) */
+int melgpt_cross_entropy_bwd(const float* logits, long long ld, const long long* target, const float* lse,
+                             const float* g_rows, const float* g_scalar, float g_scale, long long M, int V,
+                             void* dlogits, long long ldd, int dtype, void* stream);
+int melgpt_sum_f32(const float* in, long long n, float scale, float* out, int accumulate, void* stream);
+/* y = keep(x)/(1-p) with the same Philox mask an epilogue used for element i of a contiguous tensor */
+int melgpt_dropout_apply(const void* x, void* y, long long n, float drop_p, unsigned long long seed,
+                         unsigned stream_id, int dtype, void* stream);
+int melgpt_cast(const void* x, int src_dtype, void* y, int dst_dtype, long long n, void* stream);
+/* torch.optim.AdamW step (minGPT.py:660-664) fused over a flat f32 buffer; optional bf16 shadow copy. */
+int melgpt_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16,
+                 long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                 float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

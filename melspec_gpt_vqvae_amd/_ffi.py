@@ -36,6 +36,22 @@ _PROTOS = {
     "melgpt_gemm": [_p, _i, _l, _l, _p, _i, _l, _l, _p, _l, _l, _i, _i, _i, _i, _i, _i, _i, _f, _p, _i, _p, _l, _l,
                     _p, _f, _u64, C.c_uint, _p],
     "melgpt_conv2d_nhwc": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],
+    "melgpt_attn_fwd": [_p, _p, _p, _l, _p, _l, _p, _p, _i, _i, _i, _i, _i, _f, _u64, C.c_uint, _i, _p],
+    "melgpt_attn_bwd": [_p, _p, _p, _l, _p, _p, _l, _p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _f, _u64, C.c_uint,
+                        _i, _p],
+    "melgpt_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _l, _i, _f, _i, _p],
+    "melgpt_layernorm_bwd_nwaves": [_l],
+    "melgpt_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _l, _i, _i, _p],
+    "melgpt_colsum_rows": [],
+    "melgpt_colsum": [_p, _l, _i, _l, _p, _i, _p, _i, _p],
+    "melgpt_embed_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _f, _u64, C.c_uint, _p],
+    "melgpt_embed_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _f, _u64, C.c_uint, _p],
+    "melgpt_cross_entropy_fwd": [_p, _l, _p, _l, _i, _p, _p, _p],
+    "melgpt_cross_entropy_bwd": [_p, _l, _p, _p, _p, _p, _f, _l, _i, _p, _l, _i, _p],
+    "melgpt_sum_f32": [_p, _l, _f, _p, _i, _p],
+    "melgpt_dropout_apply": [_p, _p, _l, _f, _u64, C.c_uint, _i, _p],
+    "melgpt_cast": [_p, _i, _p, _i, _l, _p],
+    "melgpt_adamw": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _f, _p],
 }
 _RESTYPE = {"melgpt_strerror": C.c_char_p}
 

@@ -21,7 +21,7 @@
 //   * T = bf16 : v_mfma_f32_16x16x32_bf16, f32 accumulate.   T = f32 : v_mfma_f32_16x16x4_f32 (exact f32
 //     FMA chain) - the parity lane.  Fragment addressing is identical for both.
 //   * workgroup -> tile mapping is XCD-aware (consecutive tiles of one A row-panel share an L2).
-#include "common.h"
+#include "mma.h"
 
 namespace {
 
@@ -46,17 +46,6 @@ struct GemmParams {
   unsigned stream_id;
   // implicit-GEMM convolution (A = NHWC input)
   int cH, cW, cC, OH, OW, cstride, pad_t, pad_l, ups, KW;
-};
-
-template <typename T>
-struct Tr;
-template <>
-struct Tr<bf16_t> {
-  static constexpr int ES = 2, KSTEP = 64;
-};
-template <>
-struct Tr<float> {
-  static constexpr int ES = 4, KSTEP = 32;
 };
 
 constexpr int BM = 128, BN = 128, TILE_BYTES = 16384;
@@ -105,18 +94,6 @@ __device__ __forceinline__ u32x4 load_frag(const char* tile, int st, int ks, int
       f[e] = *(const unsigned*)(tile + kmaj_off<T>(krow, mn >> 2) + (mn & 3) * 4);
     }
     return f;
-  }
-}
-
-template <typename T>
-__device__ __forceinline__ void mma(f32x4& acc, u32x4 a, u32x4 b) {
-  if constexpr (Tr<T>::ES == 2) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), acc,
-                                                  0, 0, 0);
-  } else {
-    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], acc, 0, 0, 0);
   }
 }
 
@@ -363,7 +340,9 @@ extern "C" int melgpt_gemm(const void* A, int a_kmajor, long long lda, long long
   MELGPT_CHECK(act != MELGPT_ACT_GELU_GRAD || R, MELGPT_ERR_BAD_ARG);
   MELGPT_CHECK(drop_p >= 0.f && drop_p < 1.f, MELGPT_ERR_BAD_ARG);
   // 16-byte vector accesses everywhere
-  MELGPT_CHECK(N % 4 == 0 && K % vec == 0 && lda % vec == 0 && ldb % vec == 0 && ldc % 4 == 0 &&
+  // K only has to be a whole number of 16-byte chunks for operands whose reduction index is contiguous
+  MELGPT_CHECK((a_kmajor && b_kmajor) || K % vec == 0, MELGPT_ERR_ALIGN);
+  MELGPT_CHECK(N % 4 == 0 && lda % vec == 0 && ldb % vec == 0 && ldc % 4 == 0 &&
                    strideA % vec == 0 && strideB % vec == 0 && strideC % 4 == 0,
                MELGPT_ERR_ALIGN);
   MELGPT_CHECK(!a_kmajor || M % vec == 0, MELGPT_ERR_ALIGN);

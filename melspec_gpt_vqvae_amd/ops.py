@@ -74,3 +74,173 @@ def conv2d_nhwc(x, wpack, bias=None, *, stride=1, pad=(1, 1), out_hw=None, upsam
     call("melgpt_conv2d_nhwc", ptr(x), B, H, W, Cin, ptr(wpack), Cout, KH, KW, stride, pad[0], pad[1], OH, OW,
          int(upsample), ptr(bias), ptr(residual), ptr(out), dtype_code(x.dtype), stream())
     return out
+
+
+# --------------------------------------------------------------------------------- workspace
+_WS = {}
+
+
+def workspace(nfloats, device):
+    """A cached f32 scratch buffer (grown on demand).  All kernels run on the current stream in program
+    order, so one buffer per device is enough for the two-stage reductions."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream())
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# --------------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x, gamma, beta, eps=1e-5, want_stats=True):
+    """x (M,C) contiguous -> (y, mean, rstd)."""
+    M, C = x.shape
+    assert x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    y = torch.empty_like(x)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device) if want_stats else None
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device) if want_stats else None
+    call("melgpt_layernorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), M, C, float(eps),
+         dtype_code(x.dtype), stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, *, add_in=None, dgamma=None, dbeta=None, accumulate=False):
+    """returns dx (= add_in + LN'(dy)); writes dgamma/dbeta (f32, (+)= if accumulate) when given."""
+    M, C = x.shape
+    assert dy.is_contiguous() and x.is_contiguous() and dy.dtype == x.dtype
+    dx = torch.empty_like(x)
+    ws = None
+    if dgamma is not None:
+        nw = _ffi.lib().melgpt_layernorm_bwd_nwaves(M)
+        ws = workspace(nw * 2 * C, x.device)
+    call("melgpt_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(add_in), ptr(dx),
+         ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), M, C, dtype_code(x.dtype), stream())
+    return dx
+
+
+def colsum(a, out, accumulate=False):
+    """out[n] (+)= sum_m a[m,n]; a (M,N) with unit inner stride, out f32 (N,)."""
+    M, N = a.shape
+    assert a.stride(1) == 1 and out.dtype == torch.float32 and out.numel() == N
+    ws = workspace(_ffi.lib().melgpt_colsum_rows() * N, a.device)
+    call("melgpt_colsum", ptr(a), M, N, a.stride(0), ptr(out), int(accumulate), ptr(ws), dtype_code(a.dtype), stream())
+    return out
+
+
+# --------------------------------------------------------------------------------- embedding stem
+def embed_fwd(idx, tok_emb, pos_emb, *, pre_idx=None, pre_table=None, pre_vals=None, n_pre=0, dtype=torch.float32,
+              drop_p=0.0, seed=0, stream_id=0):
+    """idx (B,Tt) int64; tok_emb (V,C) f32; pos_emb (>=Tt+n_pre, C) f32 -> (B, Tt+n_pre, C) in `dtype`."""
+    B, Tt = idx.shape
+    V, C = tok_emb.shape
+    assert tok_emb.dtype == torch.float32 and tok_emb.is_contiguous() and pos_emb.is_contiguous()
+    assert pos_emb.shape[-1] == C and pos_emb.shape[-2] >= Tt + n_pre
+    idx = idx.contiguous()
+    out = torch.empty(B, Tt + n_pre, C, dtype=dtype, device=tok_emb.device)
+    if pre_idx is not None:
+        pre_idx = pre_idx.reshape(-1).contiguous()
+        assert pre_idx.numel() == B * n_pre and pre_table.is_contiguous() and pre_table.dtype == torch.float32
+    if pre_vals is not None:
+        assert pre_vals.shape == (B, n_pre, C) and pre_vals.dtype == torch.float32 and pre_vals.is_contiguous()
+    call("melgpt_embed_fwd", ptr(idx) if Tt > 0 else None, ptr(tok_emb), ptr(pos_emb), ptr(pre_idx), ptr(pre_table),
+         ptr(pre_vals), n_pre, B, Tt, C, V, ptr(out), dtype_code(dtype), float(drop_p), int(seed), int(stream_id), stream())
+    return out
+
+
+def embed_bwd(dx, idx, *, tok_grad=None, pos_grad=None, pre_idx=None, pre_table_grad=None, pre_vals_grad=None,
+              n_pre=0, accumulate=False, drop_p=0.0, seed=0, stream_id=0):
+    B, Ttot, C = dx.shape
+    Tt = Ttot - n_pre
+    assert dx.is_contiguous()
+    V = tok_grad.shape[0] if tok_grad is not None else 1
+    n_rows = pre_table_grad.shape[0] if pre_table_grad is not None else 0
+    if pre_idx is not None:
+        pre_idx = pre_idx.reshape(-1).contiguous()
+    call("melgpt_embed_bwd", ptr(dx), ptr(idx.contiguous()) if Tt > 0 else None, ptr(pre_idx), n_pre, B, Tt, C, V,
+         n_rows, ptr(tok_grad), ptr(pos_grad), ptr(pre_table_grad), ptr(pre_vals_grad), int(accumulate),
+         dtype_code(dx.dtype), float(drop_p), int(seed), int(stream_id), stream())
+
+
+# --------------------------------------------------------------------------------- cross entropy
+def cross_entropy_fwd(logits, target):
+    """logits (M,V) f32 (unit inner stride), target (M,) int64 -> (loss_rows (M,), lse (M,))."""
+    M, V = logits.shape
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    target = target.reshape(-1).contiguous()
+    loss = torch.empty(M, dtype=torch.float32, device=logits.device)
+    lse = torch.empty(M, dtype=torch.float32, device=logits.device)
+    call("melgpt_cross_entropy_fwd", ptr(logits), logits.stride(0), ptr(target), M, V, ptr(loss), ptr(lse), stream())
+    return loss, lse
+
+
+def cross_entropy_bwd(logits, target, lse, *, g_rows=None, g_scalar=None, g_scale=1.0, dtype=torch.float32):
+    M, V = logits.shape
+    target = target.reshape(-1).contiguous()
+    d = torch.empty(M, V, dtype=dtype, device=logits.device)
+    call("melgpt_cross_entropy_bwd", ptr(logits), logits.stride(0), ptr(target), ptr(lse), ptr(g_rows), ptr(g_scalar),
+         float(g_scale), M, V, ptr(d), V, dtype_code(dtype), stream())
+    return d
+
+
+def sum_f32(x, scale=1.0, out=None, accumulate=False):
+    x = x.reshape(-1)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+    call("melgpt_sum_f32", ptr(x), x.numel(), float(scale), ptr(out), int(accumulate), stream())
+    return out
+
+
+def dropout_apply(x, drop_p, seed, stream_id):
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    call("melgpt_dropout_apply", ptr(x), ptr(y), x.numel(), float(drop_p), int(seed), int(stream_id),
+         dtype_code(x.dtype), stream())
+    return y
+
+
+def cast(x, dtype, out=None):
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    assert out.is_contiguous() and out.numel() == x.numel()
+    call("melgpt_cast", ptr(x), dtype_code(x.dtype), ptr(out), dtype_code(out.dtype), x.numel(), stream())
+    return out
+
+
+def adamw(param, grad, exp_avg, exp_avg_sq, *, lr, betas, eps, weight_decay, step, param_bf16=None, grad_scale=1.0):
+    n = param.numel()
+    for t_ in (param, grad, exp_avg, exp_avg_sq):
+        assert t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == n
+    call("melgpt_adamw", ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), ptr(param_bf16), n, float(lr),
+         float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_scale), stream())
+
+
+# --------------------------------------------------------------------------------- attention
+def attn_fwd(q, k, v, n_head, *, B, T, n_unmasked=0, drop_p=0.0, seed=0, stream_id=0, want_att=False):
+    """q,k,v: (B*T, C) views with a common row stride (e.g. column blocks of the packed QKV matrix)."""
+    M, C = q.shape
+    assert M == B * T and C == n_head * 64 and q.stride(1) == 1
+    assert q.stride(0) == k.stride(0) == v.stride(0) and q.dtype == k.dtype == v.dtype
+    out = torch.empty(M, C, dtype=q.dtype, device=q.device)
+    lse = torch.empty(B, n_head, T, dtype=torch.float32, device=q.device)
+    att = torch.empty(B, n_head, T, T, dtype=torch.float32, device=q.device) if want_att else None
+    call("melgpt_attn_fwd", ptr(q), ptr(k), ptr(v), q.stride(0), ptr(out), C, ptr(lse), ptr(att), B, n_head, T, 64,
+         int(n_unmasked), float(drop_p), int(seed), int(stream_id), dtype_code(q.dtype), stream())
+    return out, lse, att
+
+
+def attn_bwd(q, k, v, out, dout, lse, n_head, *, B, T, dqkv=None, n_unmasked=0, drop_p=0.0, seed=0, stream_id=0):
+    """-> (dq, dk, dv) as column blocks [q | k | v] of one (B*T, 3C) buffer unless dqkv views are given."""
+    M, C = q.shape
+    assert out.is_contiguous() and dout.is_contiguous() and dout.dtype == q.dtype
+    if dqkv is None:
+        buf = torch.empty(M, 3 * C, dtype=q.dtype, device=q.device)
+        dqkv = (buf[:, :C], buf[:, C:2 * C], buf[:, 2 * C:])
+    dq, dk, dv = dqkv
+    assert dq.stride(0) == dk.stride(0) == dv.stride(0)
+    delta = torch.empty(B, n_head, T, dtype=torch.float32, device=q.device)
+    call("melgpt_attn_bwd", ptr(q), ptr(k), ptr(v), q.stride(0), ptr(out), ptr(dout), C, ptr(lse), ptr(delta), ptr(dq),
+         ptr(dk), ptr(dv), dq.stride(0), B, n_head, T, 64, int(n_unmasked), float(drop_p), int(seed), int(stream_id),
+         dtype_code(q.dtype), stream())
+    return dq, dk, dv

@@ -1,0 +1,506 @@
+"""minGPT on the MI355X HIP kernels - host-side mirror of the reference's transformer/minGPT.py.
+
+Same class names, constructor/forward signatures, return tuples, assertions and `state_dict` keys as the
+reference (GPTConfig :30-40, CausalSelfAttention :45-90, Block :93-119, GPT :121-199, GPTClass :203-212,
+Lit_minGPT :216-665), so it drops in under the reference's training scripts; every tensor op of the forward and
+backward pass is a launch through the C ABI (include/melgpt.h).  nn.Linear / nn.LayerNorm / nn.Embedding /
+nn.Dropout / nn.GELU children exist only as PARAMETER CONTAINERS that keep the checkpoint ABI - they are never
+called.  There is no eager fallback: CPU tensors raise.
+
+Numerics lanes (module attribute `compute_dtype`, see set_compute_dtype):
+  torch.float32  - parity lane: exact-f32 MFMA, matches the reference's CPU path to ~1e-6 (gate: 1e-4)
+  torch.bfloat16 - throughput lane: bf16 operands/activations, f32 accumulation, f32 master weights & grads
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _ffi, ops
+from ..flat import ensure_flat
+
+try:  # Lightning is optional: the model classes are plain nn.Modules
+    import pytorch_lightning as pl
+
+    _LitBase = pl.LightningModule
+except Exception:  # pragma: no cover - not installed in the build container
+    pl = None
+    _LitBase = nn.Module
+
+
+class GPTConfig:
+    """base GPT config, params common to all GPT versions (reference :30-40)"""
+    embd_pdrop = 0.1
+    resid_pdrop = 0.1
+    attn_pdrop = 0.1
+
+    def __init__(self, vocab_size, block_size, **kwargs):
+        self.vocab_size = vocab_size
+        self.block_size = block_size
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+
+# ------------------------------------------------------------------------------------------ dropout seeds
+class _Seeds:
+    """Counter-based dropout: every forward call draws a fresh 64-bit key from (torch.initial_seed(), a
+    host-side call counter); kernels derive per-element masks from (key, site id, element index), so the
+    backward pass regenerates masks instead of storing them.  No device sync, no generator state on the GPU."""
+    counter = 0
+
+    @classmethod
+    def next(cls):
+        cls.counter += 1
+        x = (torch.initial_seed() * 0x9E3779B97F4A7C15 + cls.counter * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        x ^= x >> 31
+        return x & 0x7FFFFFFFFFFFFFFF
+
+
+def _require_cuda(x):
+    if not x.is_cuda:
+        raise _ffi.MelgptError("melspec_gpt_vqvae_amd runs on the GPU only: move the module and its inputs to "
+                               "'cuda' (there is no CPU / eager fallback)")
+
+
+def _compute_dtype(module):
+    return getattr(module, "compute_dtype", torch.float32)
+
+
+def set_compute_dtype(module, dtype):
+    """torch.float32 (parity lane) or torch.bfloat16 (throughput lane) for `module` and all its children."""
+    assert dtype in (torch.float32, torch.bfloat16)
+    for m in module.modules():
+        object.__setattr__(m, "compute_dtype", dtype)
+    return module
+
+
+class _BlockWeights:
+    """Views into the flat compute buffer / grad buffer for one Block (packed K|Q|V first)."""
+
+    def __init__(self, blk, fp, dtype):
+        a, m = blk.attn, blk.mlp
+        buf = fp.compute_buffer(dtype)
+        self.fp = fp
+        self.qkv_p = [a.key.weight, a.query.weight, a.value.weight]
+        self.qkvb_p = [a.key.bias, a.query.bias, a.value.bias]
+        self.w_qkv = fp.packed(buf, self.qkv_p)
+        self.b_qkv = fp.packed(fp.data, self.qkvb_p)
+        v = lambda p: fp._slice(buf, p).view(p.shape)
+        self.w_proj, self.w_fc1, self.w_fc2 = v(a.proj.weight), v(m[0].weight), v(m[2].weight)
+        self.blk = blk
+
+
+# ========================================================================================== functional core
+def _attention_core(x2d, w_qkv, b_qkv, w_proj, b_proj, *, B, T, n_head, n_unmasked, attn_p, resid_p, seed, site,
+                    residual, want_att):
+    """qkv projection -> fused attention -> output projection (+bias, dropout, residual).  x2d (B*T, C)."""
+    C = x2d.shape[1]
+    qkv = ops.gemm(x2d, w_qkv, bias=b_qkv)                                   # columns [key | query | value]
+    k, q, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    a, lse, att = ops.attn_fwd(q, k, v, n_head, B=B, T=T, n_unmasked=n_unmasked, drop_p=attn_p, seed=seed,
+                               stream_id=site, want_att=want_att)
+    y = ops.gemm(a, w_proj, bias=b_proj, drop_p=resid_p, seed=seed, stream_id=site + 1, residual=residual)
+    return y, att, (qkv, a, lse)
+
+
+def _attention_core_bwd(dy, x2d, saved, w_qkv, w_proj, fp, blkw_params, *, B, T, n_head, n_unmasked, attn_p, resid_p,
+                        seed, site, need_dx=True):
+    """backward of _attention_core w.r.t. its input (without the residual path) and its parameters."""
+    qkv, a, lse = saved
+    C = x2d.shape[1]
+    (qkv_p, qkvb_p, proj_w, proj_b) = blkw_params
+    d = ops.dropout_apply(dy, resid_p, seed, site + 1) if resid_p > 0 else dy
+    gw, acc = fp.grad_target(proj_w)
+    ops.gemm(d, a, a_kmajor=True, b_kmajor=True, out=gw, accumulate=acc)         # dW_proj = d^T a
+    gb, acc = fp.grad_target(proj_b)
+    ops.colsum(d, gb, accumulate=acc)
+    da = ops.gemm(d, w_proj, b_kmajor=True)
+    dqkv = torch.empty_like(qkv)
+    k, q, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    ops.attn_bwd(q, k, v, a, da, lse, n_head, B=B, T=T, dqkv=(dqkv[:, C:2 * C], dqkv[:, :C], dqkv[:, 2 * C:]),
+                 n_unmasked=n_unmasked, drop_p=attn_p, seed=seed, stream_id=site)
+    gw, acc = fp.packed_grad_target(qkv_p)
+    ops.gemm(dqkv, x2d, a_kmajor=True, b_kmajor=True, out=gw, accumulate=acc)    # dW_qkv = dqkv^T x
+    gb, acc = fp.packed_grad_target(qkvb_p)
+    ops.colsum(dqkv, gb, accumulate=acc)
+    return ops.gemm(dqkv, w_qkv, b_kmajor=True) if need_dx else None
+
+
+class _BlockFn(torch.autograd.Function):
+    """One pre-LN transformer block (reference Block.forward :107-119) = 10 launches forward, 19 backward."""
+
+    @staticmethod
+    def forward(ctx, x, blk, want_att, seed, *params):
+        B, T, C = x.shape
+        dt = _compute_dtype(blk)
+        fp = ensure_flat(blk)
+        W = _BlockWeights(blk, fp, dt)
+        x2 = x.reshape(B * T, C)
+        if x2.dtype != dt or not x2.is_contiguous():
+            x2 = ops.cast(x2.contiguous(), dt)
+        a, m = blk.attn, blk.mlp
+        train = blk.training
+        attn_p = a.attn_drop.p if train else 0.0
+        resid_p = a.resid_drop.p if train else 0.0
+        mlp_p = m[3].p if train else 0.0
+        site = 16 * getattr(blk, "_layer_index", 0)
+        h1, mu1, rs1 = ops.layernorm_fwd(x2, blk.ln1.weight, blk.ln1.bias, blk.ln1.eps)
+        x1, att, sav = _attention_core(h1, W.w_qkv, W.b_qkv, W.w_proj, a.proj.bias, B=B, T=T, n_head=a.n_head,
+                                       n_unmasked=a.n_unmasked, attn_p=attn_p, resid_p=resid_p, seed=seed, site=site,
+                                       residual=x2, want_att=want_att)
+        h2, mu2, rs2 = ops.layernorm_fwd(x1, blk.ln2.weight, blk.ln2.bias, blk.ln2.eps)
+        pre = torch.empty(B * T, 4 * C, dtype=dt, device=x.device)
+        act = ops.gemm(h2, W.w_fc1, bias=m[0].bias, act=ops.ACT_GELU, pre_out=pre)
+        y = ops.gemm(act, W.w_fc2, bias=m[2].bias, drop_p=mlp_p, seed=seed, stream_id=site + 2, residual=x1)
+        ctx.blk, ctx.seed, ctx.site = blk, seed, site
+        ctx.cfg = (B, T, C, attn_p, resid_p, mlp_p, dt)
+        ctx.save_for_backward(x2, mu1, rs1, h1, sav[0], sav[1], sav[2], x1, mu2, rs2, h2, pre, act)
+        if att is None:
+            att = x.new_zeros(0)
+        ctx.mark_non_differentiable(att)
+        return y.view(B, T, C), att
+
+    @staticmethod
+    def backward(ctx, dy, _datt):
+        blk = ctx.blk
+        B, T, C, attn_p, resid_p, mlp_p, dt = ctx.cfg
+        x2, mu1, rs1, h1, qkv, a_out, lse, x1, mu2, rs2, h2, pre, act = ctx.saved_tensors
+        fp = ensure_flat(blk)
+        W = _BlockWeights(blk, fp, dt)
+        a, m = blk.attn, blk.mlp
+        seed, site = ctx.seed, ctx.site
+        dy2 = dy.reshape(B * T, C)
+        if dy2.dtype != dt or not dy2.is_contiguous():
+            dy2 = ops.cast(dy2.contiguous(), dt)
+        # ---- MLP branch: y = x1 + drop(fc2(gelu(fc1(ln2(x1)))))
+        d = ops.dropout_apply(dy2, mlp_p, seed, site + 2) if mlp_p > 0 else dy2
+        gw, acc = fp.grad_target(m[2].weight)
+        ops.gemm(d, act, a_kmajor=True, b_kmajor=True, out=gw, accumulate=acc)
+        gb, acc = fp.grad_target(m[2].bias)
+        ops.colsum(d, gb, accumulate=acc)
+        dpre = ops.gemm(d, W.w_fc2, b_kmajor=True, act=ops.ACT_GELU_GRAD, residual=pre)
+        gw, acc = fp.grad_target(m[0].weight)
+        ops.gemm(dpre, h2, a_kmajor=True, b_kmajor=True, out=gw, accumulate=acc)
+        gb, acc = fp.grad_target(m[0].bias)
+        ops.colsum(dpre, gb, accumulate=acc)
+        dh2 = ops.gemm(dpre, W.w_fc1, b_kmajor=True)
+        g2, accg = fp.grad_target(blk.ln2.weight)
+        b2, accb = fp.grad_target(blk.ln2.bias)
+        assert accg == accb
+        dx1 = ops.layernorm_bwd(dh2, x1, blk.ln2.weight, mu2, rs2, add_in=dy2, dgamma=g2, dbeta=b2, accumulate=accg)
+        # ---- attention branch: x1 = x + drop(proj(attn(ln1(x))))
+        dh1 = _attention_core_bwd(dx1, h1, (qkv, a_out, lse), W.w_qkv, W.w_proj, fp,
+                                  (W.qkv_p, W.qkvb_p, a.proj.weight, a.proj.bias), B=B, T=T, n_head=a.n_head,
+                                  n_unmasked=a.n_unmasked, attn_p=attn_p, resid_p=resid_p, seed=seed, site=site)
+        g1, accg = fp.grad_target(blk.ln1.weight)
+        b1, accb = fp.grad_target(blk.ln1.bias)
+        dx = ops.layernorm_bwd(dh1, x2, blk.ln1.weight, mu1, rs1, add_in=dx1, dgamma=g1, dbeta=b1, accumulate=accg)
+        hook = getattr(blk, "_grad_ready_hook", None)
+        if hook is not None:
+            hook(blk)
+        return (dx.view(B, T, C), None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+class _AttnFn(torch.autograd.Function):
+    """Stand-alone CausalSelfAttention.forward (reference :72-90)."""
+
+    @staticmethod
+    def forward(ctx, x, mod, seed, *params):
+        B, T, C = x.shape
+        dt = _compute_dtype(mod)
+        fp = ensure_flat(mod)
+        buf = fp.compute_buffer(dt)
+        qkv_p = [mod.key.weight, mod.query.weight, mod.value.weight]
+        qkvb_p = [mod.key.bias, mod.query.bias, mod.value.bias]
+        w_qkv, b_qkv = fp.packed(buf, qkv_p), fp.packed(fp.data, qkvb_p)
+        w_proj = fp._slice(buf, mod.proj.weight).view(C, C)
+        x2 = x.reshape(B * T, C)
+        if x2.dtype != dt or not x2.is_contiguous():
+            x2 = ops.cast(x2.contiguous(), dt)
+        attn_p = mod.attn_drop.p if mod.training else 0.0
+        resid_p = mod.resid_drop.p if mod.training else 0.0
+        y, att, sav = _attention_core(x2, w_qkv, b_qkv, w_proj, mod.proj.bias, B=B, T=T, n_head=mod.n_head,
+                                      n_unmasked=mod.n_unmasked, attn_p=attn_p, resid_p=resid_p, seed=seed, site=0,
+                                      residual=None, want_att=True)
+        ctx.mod, ctx.seed, ctx.cfg = mod, seed, (B, T, C, attn_p, resid_p, dt)
+        ctx.save_for_backward(x2, *sav)
+        ctx.mark_non_differentiable(att)
+        return y.view(B, T, C), att
+
+    @staticmethod
+    def backward(ctx, dy, _datt):
+        mod = ctx.mod
+        B, T, C, attn_p, resid_p, dt = ctx.cfg
+        x2, qkv, a_out, lse = ctx.saved_tensors
+        fp = ensure_flat(mod)
+        buf = fp.compute_buffer(dt)
+        qkv_p = [mod.key.weight, mod.query.weight, mod.value.weight]
+        qkvb_p = [mod.key.bias, mod.query.bias, mod.value.bias]
+        w_qkv = fp.packed(buf, qkv_p)
+        w_proj = fp._slice(buf, mod.proj.weight).view(C, C)
+        dy2 = dy.reshape(B * T, C)
+        if dy2.dtype != dt or not dy2.is_contiguous():
+            dy2 = ops.cast(dy2.contiguous(), dt)
+        dx = _attention_core_bwd(dy2, x2, (qkv, a_out, lse), w_qkv, w_proj, fp,
+                                 (qkv_p, qkvb_p, mod.proj.weight, mod.proj.bias), B=B, T=T, n_head=mod.n_head,
+                                 n_unmasked=mod.n_unmasked, attn_p=attn_p, resid_p=resid_p, seed=ctx.seed, site=0)
+        return (dx.view(B, T, C), None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+class CausalSelfAttention(nn.Module):
+    """Multi-head masked self-attention with an output projection (reference :45-90).  forward -> (y, att)."""
+
+    def __init__(self, config):
+        super().__init__()
+        assert config.n_embd % config.n_head == 0
+        self.key = nn.Linear(config.n_embd, config.n_embd)
+        self.query = nn.Linear(config.n_embd, config.n_embd)
+        self.value = nn.Linear(config.n_embd, config.n_embd)
+        self.attn_drop = nn.Dropout(config.attn_pdrop)
+        self.resid_drop = nn.Dropout(config.resid_pdrop)
+        self.proj = nn.Linear(config.n_embd, config.n_embd)
+        # checkpoint ABI only: the kernels derive the mask from (row, col, n_unmasked) and never read this buffer
+        mask = torch.tril(torch.ones(config.block_size, config.block_size))
+        self.n_unmasked = int(getattr(config, "n_unmasked", 0) or 0)
+        mask[:self.n_unmasked, :self.n_unmasked] = 1
+        self.register_buffer("mask", mask.view(1, 1, config.block_size, config.block_size))
+        self.n_head = config.n_head
+
+    def forward(self, x, layer_past=None):
+        _require_cuda(x)
+        return _AttnFn.apply(x, self, _Seeds.next(), *self.parameters())
+
+
+class Block(nn.Module):
+    """Transformer block; tuple in / tuple out like the reference (:93-119)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.ln1 = nn.LayerNorm(config.n_embd)
+        self.ln2 = nn.LayerNorm(config.n_embd)
+        self.attn = CausalSelfAttention(config)
+        self.mlp = nn.Sequential(
+            nn.Linear(config.n_embd, 4 * config.n_embd),
+            nn.GELU(),
+            nn.Linear(4 * config.n_embd, config.n_embd),
+            nn.Dropout(config.resid_pdrop),
+        )
+        self._want_att = True
+
+    def forward(self, x):
+        x, _ = x
+        _require_cuda(x)
+        y, att = _BlockFn.apply(x, self, self._want_att, getattr(self, "_fwd_seed", None) or _Seeds.next(),
+                                *self.parameters())
+        return y, (att if att.numel() else None)
+
+
+class _StemFn(torch.autograd.Function):
+    """tok_emb(idx) [+ prepended embeddings] + pos_emb -> dropout   (reference GPT.forward :170-180)."""
+
+    @staticmethod
+    def forward(ctx, gpt, idx, embeddings, pre_idx, seed, *params):
+        dt = _compute_dtype(gpt)
+        fp = ensure_flat(gpt)
+        B, Tt = idx.shape
+        n_pre = 0
+        kw = {}
+        if pre_idx is not None:
+            n_pre = pre_idx.shape[1]
+            kw = dict(pre_idx=pre_idx, pre_table=gpt.embedder.weight, n_pre=n_pre)
+        elif embeddings is not None:
+            n_pre = embeddings.shape[1]
+            ev = embeddings
+            if ev.dtype != torch.float32 or not ev.is_contiguous():
+                ev = ops.cast(ev.contiguous(), torch.float32)
+            kw = dict(pre_vals=ev, n_pre=n_pre)
+        p = gpt.drop.p if gpt.training else 0.0
+        x = ops.embed_fwd(idx, gpt.tok_emb.weight, gpt.pos_emb[0], dtype=dt, drop_p=p, seed=seed, stream_id=0xFFFF0000, **kw)
+        ctx.gpt, ctx.cfg = gpt, (n_pre, p, seed, pre_idx is not None, embeddings is not None)
+        ctx.save_for_backward(idx, pre_idx if pre_idx is not None else idx.new_zeros(0))
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        gpt = ctx.gpt
+        n_pre, p, seed, is_cls, is_vals = ctx.cfg
+        idx, pre_idx = ctx.saved_tensors
+        fp = ensure_flat(gpt)
+        dt = _compute_dtype(gpt)
+        if dx.dtype != dt or not dx.is_contiguous():
+            dx = ops.cast(dx.contiguous(), dt)
+        B, Ttot, C = dx.shape
+        tg, acc_t = fp.grad_target(gpt.tok_emb.weight)
+        pg_full, acc_p = fp.grad_target(gpt.pos_emb)
+        pg = pg_full.view(-1, C)
+        if not acc_p:
+            pg[Ttot:].zero_()
+        assert acc_t == acc_p
+        kw = {}
+        dvals = None
+        if is_cls:
+            cg, acc_c = fp.grad_target(gpt.embedder.weight)
+            assert acc_c == acc_t
+            kw = dict(pre_idx=pre_idx, pre_table_grad=cg)
+        elif is_vals:
+            dvals = torch.empty(B, n_pre, C, dtype=torch.float32, device=dx.device)
+            kw = dict(pre_vals_grad=dvals)
+        ops.embed_bwd(dx, idx, tok_grad=tg, pos_grad=pg[:Ttot], n_pre=n_pre, accumulate=acc_t, drop_p=p, seed=seed,
+                      stream_id=0xFFFF0000, **kw)
+        return (None, None, dvals, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
+
+
+class _HeadFn(torch.autograd.Function):
+    """ln_f -> head (no bias) -> f32 logits   (reference GPT.forward :186-188)."""
+
+    @staticmethod
+    def forward(ctx, x, gpt, *params):
+        B, T, C = x.shape
+        dt = _compute_dtype(gpt)
+        fp = ensure_flat(gpt)
+        buf = fp.compute_buffer(dt)
+        w = fp._slice(buf, gpt.head.weight).view(gpt.head.weight.shape)
+        x2 = x.reshape(B * T, C)
+        if x2.dtype != dt or not x2.is_contiguous():
+            x2 = ops.cast(x2.contiguous(), dt)
+        h, mu, rs = ops.layernorm_fwd(x2, gpt.ln_f.weight, gpt.ln_f.bias, gpt.ln_f.eps)
+        logits = ops.gemm(h, w, out_dtype=torch.float32)
+        ctx.gpt, ctx.cfg = gpt, (B, T, C, dt)
+        ctx.save_for_backward(x2, mu, rs, h)
+        return logits.view(B, T, -1)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        gpt = ctx.gpt
+        B, T, C, dt = ctx.cfg
+        x2, mu, rs, h = ctx.saved_tensors
+        fp = ensure_flat(gpt)
+        buf = fp.compute_buffer(dt)
+        w = fp._slice(buf, gpt.head.weight).view(gpt.head.weight.shape)
+        d = dlogits.reshape(B * T, -1)
+        if d.dtype != dt or not d.is_contiguous():
+            d = ops.cast(d.contiguous(), dt)
+        gw, acc = fp.grad_target(gpt.head.weight)
+        ops.gemm(d, h, a_kmajor=True, b_kmajor=True, out=gw, accumulate=acc)
+        dh = ops.gemm(d, w, b_kmajor=True)
+        g, accg = fp.grad_target(gpt.ln_f.weight)
+        b, accb = fp.grad_target(gpt.ln_f.bias)
+        dx = ops.layernorm_bwd(dh, x2, gpt.ln_f.weight, mu, rs, dgamma=g, dbeta=b, accumulate=accg)
+        return (dx.view(B, T, C), None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    """F.cross_entropy on f32 logits: reduction 'mean' (reference :197, :416) or 'none' (decoders.py:64-68)."""
+
+    @staticmethod
+    def forward(ctx, logits2d, target, reduction):
+        if not logits2d.is_contiguous():
+            logits2d = logits2d.contiguous()
+        loss_rows, lse = ops.cross_entropy_fwd(logits2d, target)
+        ctx.save_for_backward(logits2d, target, lse)
+        ctx.reduction = reduction
+        if reduction == "mean":
+            return ops.sum_f32(loss_rows, 1.0 / loss_rows.numel()).reshape(())
+        return loss_rows
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, lse = ctx.saved_tensors
+        g = g.float().contiguous()
+        if ctx.reduction == "mean":
+            d = ops.cross_entropy_bwd(logits, target, lse, g_scalar=g.reshape(1), g_scale=1.0 / logits.shape[0])
+        else:
+            d = ops.cross_entropy_bwd(logits, target, lse, g_rows=g.reshape(-1))
+        return d, None, None
+
+
+def cross_entropy(logits, target, reduction="mean"):
+    """drop-in for F.cross_entropy(logits (M,V) f32, target (M,)) on the HIP kernels."""
+    _require_cuda(logits)
+    assert reduction in ("mean", "none")
+    return _CrossEntropyFn.apply(logits.float() if logits.dtype != torch.float32 else logits, target, reduction)
+
+
+class GPT(nn.Module):
+    """the full GPT language model, with a context size of block_size (reference :121-199)"""
+
+    def __init__(self, args, embd_pdrop=0., resid_pdrop=0., attn_pdrop=0., n_unmasked=0, last_linear=None,
+                 block_size=None):
+        super().__init__()
+        config = GPTConfig(vocab_size=args.vocab_size, block_size=args.block_size, embd_pdrop=embd_pdrop,
+                           resid_pdrop=resid_pdrop, attn_pdrop=attn_pdrop, n_layer=args.n_layer, n_head=args.n_head,
+                           n_embd=args.n_embd, n_unmasked=n_unmasked, last_linear=last_linear)
+        if block_size is not None:
+            config.block_size = block_size
+        self.tok_emb = nn.Embedding(config.vocab_size, config.n_embd)
+        self.pos_emb = nn.Parameter(torch.zeros(1, config.block_size, config.n_embd))
+        self.drop = nn.Dropout(config.embd_pdrop)
+        self.blocks = nn.Sequential(*[Block(config) for _ in range(config.n_layer)])
+        self.ln_f = nn.LayerNorm(config.n_embd)
+        output_size = last_linear if config.last_linear is not None else config.vocab_size
+        self.head = nn.Linear(config.n_embd, output_size, bias=False)
+        self.block_size = config.block_size
+        self.apply(self._init_weights)
+        self.config = config
+        for i, blk in enumerate(self.blocks):
+            object.__setattr__(blk, "_layer_index", i)
+        self.compute_dtype = torch.float32
+
+    def get_block_size(self):
+        return self.block_size
+
+    def _init_weights(self, module):
+        # reference :159-166
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=0.02)
+            if isinstance(module, nn.Linear) and module.bias is not None:
+                module.bias.data.zero_()
+        elif isinstance(module, nn.LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+
+    def _trunk(self, idx, embeddings=None, pre_idx=None, want_att=True):
+        _require_cuda(idx)
+        ensure_flat(self)
+        n_pre = embeddings.shape[1] if embeddings is not None else (pre_idx.shape[1] if pre_idx is not None else 0)
+        t = idx.shape[1] + n_pre
+        assert t <= self.block_size, "Cannot forward, model block size is exhausted."
+        seed = _Seeds.next()
+        x = _StemFn.apply(self, idx, embeddings, pre_idx, seed, *self._stem_params())
+        last = len(self.blocks) - 1
+        for i, blk in enumerate(self.blocks):  # only the last block's attention is part of the API (:182-185)
+            blk._want_att = want_att and i == last
+            object.__setattr__(blk, "_fwd_seed", seed)
+        x, att = self.blocks((x, None))
+        logits = _HeadFn.apply(x, self, self.ln_f.weight, self.ln_f.bias, self.head.weight)
+        return logits, att
+
+    def _stem_params(self):
+        ps = [self.tok_emb.weight, self.pos_emb]
+        if hasattr(self, "embedder"):
+            ps.append(self.embedder.weight)
+        return ps
+
+    def forward(self, idx, embeddings=None, targets=None):
+        logits, att = self._trunk(idx, embeddings=embeddings)
+        loss = None
+        if targets is not None:
+            loss = cross_entropy(logits.view(-1, logits.size(-1)), targets.view(-1))
+        return logits, loss, att
+
+
+class GPTClass(GPT):
+    """class-conditioned GPT: embedder(token) is prepended (reference :203-212).  The embedder is created AFTER
+    apply(_init_weights), so it keeps nn.Embedding's N(0,1) init, as in the reference."""
+
+    def __init__(self, args):
+        super().__init__(args, embd_pdrop=args.embd_pdrop, resid_pdrop=args.resid_pdrop, attn_pdrop=args.attn_pdrop,
+                         n_unmasked=args.n_unmasked, last_linear=args.last_linear, block_size=args.block_size)
+        self.embedder = nn.Embedding(args.class_size, args.n_embd)
+
+    def forward(self, idx, token):
+        logits, att = self._trunk(idx, pre_idx=token)
+        return logits, None, att

@@ -39,3 +39,22 @@ def check_indices_with_tie_policy(got, want, gap_ulps, top2, ulp_thresh=8.0):
     for n in nt:
         assert got[n] in (int(top2[n][0]), int(top2[n][1])), (n, got[n], top2[n])
     return int(near.sum())
+
+
+def grad_check(name, got, ref, tol, zero_floor=2e-5):
+    """Compare a parameter gradient.  `attn.key.bias` gradients are mathematically ZERO (adding a constant to
+    every key's score leaves the softmax unchanged), so both sides hold only rounding noise: require them tiny."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    if name.endswith("key.bias"):
+        assert np.abs(got).max() < zero_floor and np.abs(ref).max() < zero_floor, (name, np.abs(got).max())
+        return
+    err = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)
+    assert err < tol, (name, err)
+
+
+def gnorm_check(name, got_norm, ref_norm, tol, zero_floor=1e-3):
+    if name.endswith("key.bias"):
+        assert got_norm < zero_floor and ref_norm < zero_floor, (name, got_norm, ref_norm)
+        return
+    assert abs(got_norm - ref_norm) <= tol * ref_norm + 1e-8, (name, got_norm, ref_norm)
