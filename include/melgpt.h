@@ -191,6 +191,33 @@ int melgpt_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg
                  long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                  float grad_scale, void* stream);
 
+/* ===================================================================== VQ-VAE encoder / decoder pieces
+ * All activations are NHWC ((B, H*W, C) row-major) in `dtype`.
+ * GroupNorm(32, C, eps) (big_model_attn_gan.py:139-140): statistics per (batch, group) in two deterministic
+ * stages (f32 partials per 512-pixel chunk, combined in f64); workspace f32 [B * nchunks(HW) * 32 * 2].   */
+int melgpt_groupnorm_nchunks(int HW);
+int melgpt_groupnorm_stats(const void* x, int B, int HW, int C, float eps, float* mean, float* rstd,
+                           float* workspace, int dtype, void* stream);
+/* y = act((x - mean)*rstd*gamma + beta), act = swish x*sigmoid(x) (:164-166) when swish != 0 */
+int melgpt_groupnorm_apply(const void* x, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, void* y, int B, int HW, int C, int swish, int dtype, void* stream);
+/* Encoder.conv_in (:203-207): 3x3, pad 1, ONE input channel; x (B,H,W) x_dtype; w (Cout,1,3,3) f32 as stored. */
+int melgpt_conv_in_c1(const void* x, int x_dtype, const float* w, const float* bias, void* y, int dtype, int B,
+                      int H, int W, int Cout, void* stream);
+/* Decoder.conv_out (:355-359): 3x3, pad 1, ONE output channel; w tap-major (9, C) f32; y (B,H,W). */
+int melgpt_conv_out_c1(const void* x, int dtype, const float* w_tap_major, const float* bias, void* y,
+                       int y_dtype, int B, int H, int W, int C, void* stream);
+/* AttnBlock softmax (:438-440): probs[r,c] = softmax_c(scale*scores[r,c]), c < n; columns n..ld_probs-1 = 0 */
+int melgpt_softmax_rows(const float* scores, long long ld_scores, int n, long long rows, float scale,
+                        void* probs, long long ld_probs, int dtype, void* stream);
+/* torch Conv2d weight (O,I,KH,KW) f32 -> (O,KH,KW,I) in out_dtype: the B operand of melgpt_conv2d_nhwc */
+int melgpt_repack_conv_weight(const float* w_oihw, void* out_ohwi, int out_dtype, int O, int I, int KH, int KW,
+                              void* stream);
+
+/* (B,C,HW) <-> (B,HW,C) copy with dtype conversion, for callers that hand over contiguous NCHW tensors */
+int melgpt_permute_nchw_nhwc(const void* x, int x_dtype, void* y, int y_dtype, int B, int C, int HW,
+                             int to_nhwc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,14 @@ _PROTOS = {
     "melgpt_dropout_apply": [_p, _p, _l, _f, _u64, C.c_uint, _i, _p],
     "melgpt_cast": [_p, _i, _p, _i, _l, _p],
     "melgpt_adamw": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _f, _p],
+    "melgpt_groupnorm_nchunks": [_i],
+    "melgpt_groupnorm_stats": [_p, _i, _i, _i, _f, _p, _p, _p, _i, _p],
+    "melgpt_groupnorm_apply": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "melgpt_conv_in_c1": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "melgpt_conv_out_c1": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "melgpt_softmax_rows": [_p, _l, _i, _l, _f, _p, _l, _i, _p],
+    "melgpt_repack_conv_weight": [_p, _p, _i, _i, _i, _i, _i, _p],
+    "melgpt_permute_nchw_nhwc": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
 }
 _RESTYPE = {"melgpt_strerror": C.c_char_p}
 

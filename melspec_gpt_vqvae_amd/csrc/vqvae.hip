@@ -1,0 +1,382 @@
+// VQ-VAE encoder/decoder support kernels for gfx950 (NHWC activations, reference vqvae/big_model_attn_gan.py):
+//   GroupNorm(32, C, eps=1e-6) statistics + normalise(+swish)      (:139-140, :164-166, :117-126)
+//   conv_in  3x3, Cin = 1  (mel tile -> 128 channels)               (:203-207)  - HBM-bound on its output
+//   conv_out 3x3, Cout = 1 (128 channels -> mel tile)               (:355-359)
+//   row softmax of the 265x265 single-head spatial attention        (:438-440)
+//   OIHW f32 -> O,KH,KW,I repack of conv weights into the implicit-GEMM operand layout
+// The 3x3 / 1x1 convolutions themselves are csrc/gemm.hip (implicit GEMM on MFMA).
+#include "common.h"
+
+namespace {
+
+template <typename T>
+struct V16;
+template <>
+struct V16<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void ld(const float* p, float* o) {
+    f32x4 v = *(const f32x4*)p;
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  }
+  static __device__ __forceinline__ void st(float* p, const float* o) { *(f32x4*)p = f32x4{o[0], o[1], o[2], o[3]}; }
+};
+template <>
+struct V16<bf16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void ld(const bf16_t* p, float* o) {
+    u32x4 v = *(const u32x4*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[2 * i] = __uint_as_float(v[i] << 16);
+      o[2 * i + 1] = __uint_as_float(v[i] & 0xFFFF0000u);
+    }
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float* o) {
+    *(u32x4*)p = u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
+                       pack_bf16x2(o[6], o[7])};
+  }
+};
+
+constexpr int GN_GROUPS = 32;
+constexpr int GN_CHUNK = 512;  // pixels per stage-1 workgroup
+
+// stage 1: per (batch, pixel chunk) partial sum / sum of squares for each of the 32 groups
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, int HW, int C,
+                                                         float* __restrict__ partial) {
+  constexpr int N = V16<T>::N;
+  extern __shared__ float sh[];  // [nrows][C][2]
+  const int t = threadIdx.x, ncols = C / N, nrows = 256 / ncols;
+  const int col = t % ncols, prow = t / ncols;
+  const int chunk = blockIdx.x, b = blockIdx.y, nchunks = gridDim.x;
+  const int p0 = chunk * GN_CHUNK, p1 = min(p0 + GN_CHUNK, HW);
+  float s[N], ss[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) s[e] = ss[e] = 0.f;
+  if (prow < nrows) {
+    const T* xb = x + ((long long)b * HW) * C + col * N;
+    for (int p = p0 + prow; p < p1; p += nrows) {
+      float v[N];
+      V16<T>::ld(xb + (long long)p * C, v);
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        s[e] += v[e];
+        ss[e] = fmaf(v[e], v[e], ss[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      sh[(prow * C + col * N + e) * 2] = s[e];
+      sh[(prow * C + col * N + e) * 2 + 1] = ss[e];
+    }
+  }
+  __syncthreads();
+  if (t < GN_GROUPS) {
+    const int cg = C / GN_GROUPS;
+    float a = 0.f, q = 0.f;
+    for (int r = 0; r < nrows; ++r)
+      for (int c = t * cg; c < (t + 1) * cg; ++c) {
+        a += sh[(r * C + c) * 2];
+        q += sh[(r * C + c) * 2 + 1];
+      }
+    float* o = partial + (((long long)b * nchunks + chunk) * GN_GROUPS + t) * 2;
+    o[0] = a;
+    o[1] = q;
+  }
+}
+
+// stage 2: chunks are combined in double, var = E[x^2] - mean^2 (biased), rstd = 1/sqrt(var + eps)
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunks, int B, double count, float eps,
+                                   float* __restrict__ mean, float* __restrict__ rstd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (b, g)
+  if (i >= B * GN_GROUPS) return;
+  const int b = i / GN_GROUPS, g = i % GN_GROUPS;
+  double a = 0.0, q = 0.0;
+  for (int c = 0; c < nchunks; ++c) {
+    const float* o = partial + (((long long)b * nchunks + c) * GN_GROUPS + g) * 2;
+    a += (double)o[0];
+    q += (double)o[1];
+  }
+  const double m = a / count;
+  double var = q / count - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[i] = (float)m;
+  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+template <typename T>
+__global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
+                                long long total_vec, int HW, int C, int swish) {
+  constexpr int N = V16<T>::N;
+  const int ncols = C / N, cg = C / GN_GROUPS;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < total_vec; i += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % ncols);
+    const long long pix = i / ncols;
+    const int b = (int)(pix / HW);
+    float v[N];
+    V16<T>::ld(x + i * N, v);
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const int c = col * N + e, g = b * GN_GROUPS + c / cg;
+      float o = (v[e] - mean[g]) * rstd[g] * gamma[c] + beta[c];
+      if (swish) o = o / (1.0f + __expf(-o));
+      v[e] = o;
+    }
+    V16<T>::st(y + i * N, v);
+  }
+}
+
+// 3x3 convolution of a single-channel image into COUT channels (NHWC out).  16 threads per pixel x 8 channels.
+template <typename TI, typename T>
+__global__ __launch_bounds__(256) void conv_in_c1_kernel(const TI* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, T* __restrict__ y, int B, int H,
+                                                         int W, int COUT) {
+  extern __shared__ float wsh[];  // [COUT][9] + [COUT]
+  for (int i = threadIdx.x; i < COUT * 9; i += 256) wsh[i] = w[i];
+  for (int i = threadIdx.x; i < COUT; i += 256) wsh[COUT * 9 + i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  const int groups = COUT / 8, ppb = 256 / groups;
+  const int cgp = threadIdx.x % groups, pl = threadIdx.x / groups;
+  const long long total = (long long)B * H * W;
+  for (long long pix = (long long)blockIdx.x * ppb + pl; pix < total; pix += (long long)gridDim.x * ppb) {
+    if (pl >= ppb) break;
+    const int xw = (int)(pix % W), yh = (int)((pix / W) % H);
+    const long long b = pix / ((long long)W * H);
+    float in[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = yh + ky - 1, ix = xw + kx - 1;
+        in[ky * 3 + kx] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? Elem<TI>::ld(x + (b * H + iy) * W + ix) : 0.f;
+      }
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cgp * 8 + e;
+      float a = wsh[COUT * 9 + c];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a = fmaf(in[k], wsh[c * 9 + k], a);
+      o[e] = a;
+    }
+    T* dst = y + pix * COUT + cgp * 8;
+    if constexpr (sizeof(T) == 2) {
+      V16<bf16_t>::st((bf16_t*)dst, o);
+    } else {
+      V16<float>::st((float*)dst, o);
+      V16<float>::st((float*)dst + 4, o + 4);
+    }
+  }
+}
+
+// 3x3 convolution of a C-channel NHWC tensor into ONE channel: 16 lanes per pixel, shuffle reduction.
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void conv_out_c1_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, TO* __restrict__ y, int B,
+                                                          int H, int W, int C) {
+  // w: (9, C) f32 (tap-major)
+  const int lane16 = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const long long total = (long long)B * H * W;
+  for (long long pix0 = (long long)blockIdx.x * 16; pix0 < total; pix0 += (long long)gridDim.x * 16) {
+    const long long pix = pix0 + pl;
+    float acc = 0.f;
+    if (pix < total) {
+      const int xw = (int)(pix % W), yh = (int)((pix / W) % H);
+      const long long b = pix / ((long long)W * H);
+      for (int k = 0; k < 9; ++k) {
+        const int iy = yh + k / 3 - 1, ix = xw + k % 3 - 1;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        const T* src = x + ((b * H + iy) * W + ix) * C;
+        for (int c = lane16; c < C; c += 16) acc = fmaf(Elem<T>::ld(src + c), w[k * C + c], acc);
+      }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane16 == 0 && pix < total) Elem<TO>::st(y + pix, acc + (bias ? bias[0] : 0.f));
+  }
+}
+
+// P[r, c] = softmax_c(scale * S[r, c]) for c < n; zero for n <= c < ldp (the padding feeds a K-padded GEMM)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, long long lds_, int n,
+                                                           long long rows, float scale, T* __restrict__ P,
+                                                           long long ldp) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* s = S + row * lds_;
+  float mx = -__builtin_inff();
+  for (int c = lane; c < n; c += 64) mx = fmaxf(mx, s[c] * scale);
+  mx = wave_max(mx);
+  float l = 0.f;
+  for (int c = lane; c < n; c += 64) l += __expf(s[c] * scale - mx);
+  l = wave_sum(l);
+  const float inv = 1.f / l;
+  for (int c = lane; c < ldp; c += 64) Elem<T>::st(P + row * ldp + c, c < n ? __expf(s[c] * scale - mx) * inv : 0.f);
+}
+
+template <typename T>
+__global__ void repack_oihw_kernel(const float* __restrict__ w, T* __restrict__ out, int O, int I, int KH, int KW) {
+  const long long total = (long long)O * I * KH * KW;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < total; i += (long long)gridDim.x * blockDim.x) {  // i indexes the OUTPUT (o, kh, kw, ci)
+    const int ci = (int)(i % I);
+    const int kw = (int)((i / I) % KW);
+    const int kh = (int)((i / ((long long)I * KW)) % KH);
+    const int o = (int)(i / ((long long)I * KW * KH));
+    Elem<T>::st(out + i, w[(((long long)o * I + ci) * KH + kh) * KW + kw]);
+  }
+}
+
+// logical (B,C,HW) <-> (B,HW,C) permute with dtype conversion (API boundary only; the pipeline itself stays NHWC)
+template <typename TI, typename TO>
+__global__ void permute_kernel(const TI* __restrict__ x, TO* __restrict__ y, int B, int C, int HW, int to_nhwc) {
+  const long long total = (long long)B * C * HW;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < total; i += (long long)gridDim.x * blockDim.x) {  // i indexes the OUTPUT
+    long long src;
+    if (to_nhwc) {
+      const int c = (int)(i % C);
+      const long long p = (i / C) % HW, b = i / ((long long)C * HW);
+      src = (b * C + c) * HW + p;
+    } else {
+      const long long p = i % HW;
+      const int c = (int)((i / HW) % C);
+      const long long b = i / ((long long)C * HW);
+      src = (b * HW + p) * C + c;
+    }
+    Elem<TO>::st(y + i, Elem<TI>::ld(x + src));
+  }
+}
+
+inline int cap_grid(long long n, int per, int cap = 16384) {
+  long long g = (n + per - 1) / per;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int melgpt_groupnorm_nchunks(int HW) { return (HW + GN_CHUNK - 1) / GN_CHUNK; }
+
+extern "C" int melgpt_groupnorm_stats(const void* x, int B, int HW, int C, float eps, float* mean, float* rstd,
+                                      float* workspace, int dtype, void* stream) {
+  MELGPT_CHECK(x && mean && rstd && workspace && B > 0 && HW > 0 && C > 0, MELGPT_ERR_BAD_ARG);
+  const int vec = dtype == MELGPT_F32 ? 4 : 8;
+  MELGPT_CHECK(dtype == MELGPT_F32 || dtype == MELGPT_BF16, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK(C % GN_GROUPS == 0 && C % vec == 0 && C / vec <= 256 && 256 % (C / vec) == 0, MELGPT_ERR_UNSUPPORTED);
+  const int nchunks = melgpt_groupnorm_nchunks(HW);
+  const int nrows = 256 / (C / vec);
+  const size_t lds = (size_t)nrows * C * 2 * sizeof(float);
+  MELGPT_CHECK(lds <= 64 * 1024, MELGPT_ERR_UNSUPPORTED);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MELGPT_F32)
+    hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nchunks, B), dim3(256), lds, s, (const float*)x, HW, C, workspace);
+  else
+    hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, dim3(nchunks, B), dim3(256), lds, s, (const bf16_t*)x, HW, C,
+                       workspace);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * GN_GROUPS + 255) / 256), dim3(256), 0, s, workspace, nchunks, B,
+                     (double)HW * (C / GN_GROUPS), eps, mean, rstd);
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_groupnorm_apply(const void* x, const float* mean, const float* rstd, const float* gamma,
+                                      const float* beta, void* y, int B, int HW, int C, int swish, int dtype,
+                                      void* stream) {
+  MELGPT_CHECK(x && mean && rstd && gamma && beta && y && B > 0 && HW > 0 && C > 0, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(dtype == MELGPT_F32 || dtype == MELGPT_BF16, MELGPT_ERR_UNSUPPORTED);
+  const int vec = dtype == MELGPT_F32 ? 4 : 8;
+  MELGPT_CHECK(C % GN_GROUPS == 0 && C % vec == 0, MELGPT_ERR_UNSUPPORTED);
+  const long long total = (long long)B * HW * (C / vec);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MELGPT_F32)
+    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(cap_grid(total, 256)), dim3(256), 0, s, (const float*)x, mean, rstd,
+                       gamma, beta, (float*)y, total, HW, C, swish);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(cap_grid(total, 256)), dim3(256), 0, s, (const bf16_t*)x, mean,
+                       rstd, gamma, beta, (bf16_t*)y, total, HW, C, swish);
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_conv_in_c1(const void* x, int x_dtype, const float* w, const float* bias, void* y, int dtype,
+                                 int B, int H, int W, int Cout, void* stream) {
+  MELGPT_CHECK(x && w && y && B > 0 && H > 0 && W > 0 && Cout > 0, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(Cout % 8 == 0 && Cout <= 2048 && 256 % (Cout / 8) == 0, MELGPT_ERR_UNSUPPORTED);
+  const size_t lds = (size_t)Cout * 10 * sizeof(float);
+  const int ppb = 256 / (Cout / 8);
+  const int grid = cap_grid((long long)B * H * W, ppb, 65536);
+  hipStream_t s = (hipStream_t)stream;
+#define CI_LAUNCH(TI, T) \
+  hipLaunchKernelGGL((conv_in_c1_kernel<TI, T>), dim3(grid), dim3(256), lds, s, (const TI*)x, w, bias, (T*)y, B, H, W, Cout)
+  if (x_dtype == MELGPT_F32 && dtype == MELGPT_F32) CI_LAUNCH(float, float);
+  else if (x_dtype == MELGPT_F32 && dtype == MELGPT_BF16) CI_LAUNCH(float, bf16_t);
+  else if (x_dtype == MELGPT_BF16 && dtype == MELGPT_BF16) CI_LAUNCH(bf16_t, bf16_t);
+  else if (x_dtype == MELGPT_BF16 && dtype == MELGPT_F32) CI_LAUNCH(bf16_t, float);
+  else return MELGPT_ERR_UNSUPPORTED;
+#undef CI_LAUNCH
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_conv_out_c1(const void* x, int dtype, const float* w_tap_major, const float* bias, void* y,
+                                  int y_dtype, int B, int H, int W, int C, void* stream) {
+  MELGPT_CHECK(x && w_tap_major && y && B > 0 && H > 0 && W > 0 && C > 0, MELGPT_ERR_BAD_ARG);
+  const int grid = cap_grid((long long)B * H * W, 16, 65536);
+  hipStream_t s = (hipStream_t)stream;
+#define CO_LAUNCH(T, TO) \
+  hipLaunchKernelGGL((conv_out_c1_kernel<T, TO>), dim3(grid), dim3(256), 0, s, (const T*)x, w_tap_major, bias, (TO*)y, B, H, W, C)
+  if (dtype == MELGPT_F32 && y_dtype == MELGPT_F32) CO_LAUNCH(float, float);
+  else if (dtype == MELGPT_BF16 && y_dtype == MELGPT_F32) CO_LAUNCH(bf16_t, float);
+  else if (dtype == MELGPT_BF16 && y_dtype == MELGPT_BF16) CO_LAUNCH(bf16_t, bf16_t);
+  else return MELGPT_ERR_UNSUPPORTED;
+#undef CO_LAUNCH
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_softmax_rows(const float* scores, long long ld_scores, int n, long long rows, float scale,
+                                   void* probs, long long ld_probs, int dtype, void* stream) {
+  MELGPT_CHECK(scores && probs && n > 0 && rows > 0 && ld_scores >= n && ld_probs >= n, MELGPT_ERR_BAD_ARG);
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  if (dtype == MELGPT_F32)
+    hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3(grid), dim3(256), 0, s, scores, ld_scores, n, rows, scale,
+                       (float*)probs, ld_probs);
+  else if (dtype == MELGPT_BF16)
+    hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, scores, ld_scores, n, rows, scale,
+                       (bf16_t*)probs, ld_probs);
+  else
+    return MELGPT_ERR_UNSUPPORTED;
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_repack_conv_weight(const float* w_oihw, void* out_ohwi, int out_dtype, int O, int I, int KH,
+                                         int KW, void* stream) {
+  MELGPT_CHECK(w_oihw && out_ohwi && O > 0 && I > 0 && KH > 0 && KW > 0, MELGPT_ERR_BAD_ARG);
+  const long long total = (long long)O * I * KH * KW;
+  hipStream_t s = (hipStream_t)stream;
+  if (out_dtype == MELGPT_F32)
+    hipLaunchKernelGGL(repack_oihw_kernel<float>, dim3(cap_grid(total, 256, 4096)), dim3(256), 0, s, w_oihw,
+                       (float*)out_ohwi, O, I, KH, KW);
+  else if (out_dtype == MELGPT_BF16)
+    hipLaunchKernelGGL(repack_oihw_kernel<bf16_t>, dim3(cap_grid(total, 256, 4096)), dim3(256), 0, s, w_oihw,
+                       (bf16_t*)out_ohwi, O, I, KH, KW);
+  else
+    return MELGPT_ERR_UNSUPPORTED;
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_permute_nchw_nhwc(const void* x, int x_dtype, void* y, int y_dtype, int B, int C, int HW,
+                                        int to_nhwc, void* stream) {
+  MELGPT_CHECK(x && y && B > 0 && C > 0 && HW > 0, MELGPT_ERR_BAD_ARG);
+  const long long total = (long long)B * C * HW;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = cap_grid(total, 256, 16384);
+#define PM(TI, TO) hipLaunchKernelGGL((permute_kernel<TI, TO>), dim3(grid), dim3(256), 0, s, (const TI*)x, (TO*)y, B, C, HW, to_nhwc)
+  if (x_dtype == MELGPT_F32 && y_dtype == MELGPT_F32) PM(float, float);
+  else if (x_dtype == MELGPT_F32 && y_dtype == MELGPT_BF16) PM(float, bf16_t);
+  else if (x_dtype == MELGPT_BF16 && y_dtype == MELGPT_F32) PM(bf16_t, float);
+  else if (x_dtype == MELGPT_BF16 && y_dtype == MELGPT_BF16) PM(bf16_t, bf16_t);
+  else return MELGPT_ERR_UNSUPPORTED;
+#undef PM
+  return melgpt_launch_status();
+}

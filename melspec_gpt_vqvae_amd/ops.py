@@ -244,3 +244,84 @@ def attn_bwd(q, k, v, out, dout, lse, n_head, *, B, T, dqkv=None, n_unmasked=0, 
          ptr(dk), ptr(dv), dq.stride(0), B, n_head, T, 64, int(n_unmasked), float(drop_p), int(seed), int(stream_id),
          dtype_code(q.dtype), stream())
     return dq, dk, dv
+
+
+# --------------------------------------------------------------------------------- VQ-VAE pieces (NHWC)
+def groupnorm(x, gamma, beta, eps=1e-6, swish=True):
+    """x (B,H,W,C) contiguous -> GroupNorm(32) [+ swish]."""
+    B, H, W, C = x.shape
+    assert x.is_contiguous()
+    L = _ffi.lib()
+    nch = L.melgpt_groupnorm_nchunks(H * W)
+    ws = workspace(B * nch * 64 + 2 * B * 32, x.device)
+    mean = torch.empty(B * 32, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B * 32, dtype=torch.float32, device=x.device)
+    call("melgpt_groupnorm_stats", ptr(x), B, H * W, C, float(eps), ptr(mean), ptr(rstd), ptr(ws), dtype_code(x.dtype),
+         stream())
+    y = torch.empty_like(x)
+    call("melgpt_groupnorm_apply", ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(y), B, H * W, C, int(swish),
+         dtype_code(x.dtype), stream())
+    return y
+
+
+def conv_in_c1(x, w, bias, dtype):
+    """x (B,H,W) f32/bf16 single-channel image; w (Cout,1,3,3) f32 -> (B,H,W,Cout) in dtype."""
+    B, H, W = x.shape
+    Cout = w.shape[0]
+    assert x.is_contiguous() and w.is_contiguous() and w.dtype == torch.float32
+    y = torch.empty(B, H, W, Cout, dtype=dtype, device=x.device)
+    call("melgpt_conv_in_c1", ptr(x), dtype_code(x.dtype), ptr(w), ptr(bias), ptr(y), dtype_code(dtype), B, H, W, Cout,
+         stream())
+    return y
+
+
+def conv_out_c1(x, w_tap_major, bias, out_dtype=torch.float32):
+    B, H, W, C = x.shape
+    assert x.is_contiguous() and w_tap_major.dtype == torch.float32 and w_tap_major.numel() == 9 * C
+    y = torch.empty(B, H, W, dtype=out_dtype, device=x.device)
+    call("melgpt_conv_out_c1", ptr(x), dtype_code(x.dtype), ptr(w_tap_major), ptr(bias), ptr(y), dtype_code(out_dtype),
+         B, H, W, C, stream())
+    return y
+
+
+def softmax_rows(scores, n, scale, out_dtype, ld_out):
+    """scores (..., rows, ld) f32 -> probs (..., rows, ld_out) with columns >= n zeroed."""
+    assert scores.dtype == torch.float32 and scores.is_contiguous()
+    rows = scores.numel() // scores.shape[-1]
+    probs = torch.empty(scores.shape[:-1] + (ld_out,), dtype=out_dtype, device=scores.device)
+    call("melgpt_softmax_rows", ptr(scores), scores.shape[-1], n, rows, float(scale), ptr(probs), ld_out,
+         dtype_code(out_dtype), stream())
+    return probs
+
+
+def repack_conv_weight(w, dtype):
+    """(O,I,KH,KW) f32 -> (O,KH,KW,I) in dtype."""
+    O, I, KH, KW = w.shape
+    w = w.detach()
+    assert w.dtype == torch.float32 and w.is_contiguous()
+    out = torch.empty(O, KH, KW, I, dtype=dtype, device=w.device)
+    call("melgpt_repack_conv_weight", ptr(w), ptr(out), dtype_code(dtype), O, I, KH, KW, stream())
+    return out
+
+
+def to_nhwc(x, dtype):
+    """logical (B,C,H,W) tensor (any strides) -> contiguous (B,H,W,C) in dtype; free when it already is."""
+    B, C, H, W = x.shape
+    v = x.permute(0, 2, 3, 1)
+    if v.is_contiguous() and x.dtype == dtype:
+        return v
+    if not x.is_contiguous():
+        if v.is_contiguous():  # channels-last, wrong dtype
+            return cast(v, dtype)
+        x = x.contiguous()
+    y = torch.empty(B, H, W, C, dtype=dtype, device=x.device)
+    call("melgpt_permute_nchw_nhwc", ptr(x), dtype_code(x.dtype), ptr(y), dtype_code(dtype), B, C, H * W, 1, stream())
+    return y
+
+
+def to_nchw_contiguous(x_nhwc, dtype):
+    B, H, W, C = x_nhwc.shape
+    y = torch.empty(B, C, H, W, dtype=dtype, device=x_nhwc.device)
+    call("melgpt_permute_nchw_nhwc", ptr(x_nhwc), dtype_code(x_nhwc.dtype), ptr(y), dtype_code(dtype), B, C, H * W, 0,
+         stream())
+    return y

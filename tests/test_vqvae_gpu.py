@@ -1,0 +1,150 @@
+"""GPU parity of the VQ-VAE encoder / decoder modules (melspec_gpt_vqvae_amd/vqvae/big_model_attn_gan.py on the
+HIP kernels) against golden vectors recorded from the real reference (tests/golden/vqvae_*.npz) and plain
+fp32 PyTorch on CPU.  f32 lane gate 1e-4; codes bit-exact under the SURVEY §8a tie policy."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import synth
+from util import check_indices_with_tie_policy, golden, rel_err, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+
+
+def _load(module, sd_np, allow_missing_prefix=None):
+    res = module.load_state_dict({k: t(v) for k, v in sd_np.items()}, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys[:4]
+    if allow_missing_prefix is None:
+        assert not res.missing_keys, res.missing_keys[:4]
+    else:
+        assert all(k.startswith(allow_missing_prefix) for k in res.missing_keys), res.missing_keys[:4]
+    return module
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("C,HW", [(128, (80, 848)), (512, (5, 53)), (256, (20, 212))])
+def test_groupnorm_swish(dt, C, HW):
+    from melspec_gpt_vqvae_amd import ops
+
+    B = 2
+    x = t(synth.normal(1, (B, HW[0], HW[1], C), 1.5, 0.7)).to(DT[dt])
+    gm, bt = t(synth.normal(2, (C,), 0.1, 1.0)), t(synth.normal(3, (C,), 0.1))
+    for swish in (True, False):
+        y = ops.groupnorm(x.to(DEV), gm.to(DEV), bt.to(DEV), 1e-6, swish=swish)
+        ref = F.group_norm(x.float().permute(0, 3, 1, 2), 32, gm, bt, eps=1e-6)
+        if swish:
+            ref = ref * torch.sigmoid(ref)
+        ref = ref.permute(0, 2, 3, 1)
+        assert rel_err(y.float().cpu().numpy(), ref.numpy()) < (2e-5 if dt == "f32" else 8e-3)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv_in_out_single_channel_and_permute(dt):
+    from melspec_gpt_vqvae_amd import ops
+
+    B, H, W, C = 2, 80, 848, 128
+    x = t(2 * synth.mel_tiles(5, B)[:, :, 6:854] - 1)
+    w = t(synth.uniform(6, (C, 1, 3, 3), -0.3, 0.3))
+    b = t(synth.uniform(7, (C,), -0.3, 0.3))
+    y = ops.conv_in_c1(x.to(DEV), w.to(DEV), b.to(DEV), DT[dt])
+    ref = F.conv2d(x[:, None], w, b, padding=1).permute(0, 2, 3, 1)
+    assert rel_err(y.float().cpu().numpy(), ref.numpy()) < (1e-6 if dt == "f32" else 8e-3)
+    # 128 -> 1
+    h = t(synth.normal(8, (B, 20, 53, C))).to(DT[dt])
+    wo = t(synth.uniform(9, (1, C, 3, 3), -0.05, 0.05))
+    bo = t(synth.uniform(10, (1,), -0.1, 0.1))
+    wt = ops.repack_conv_weight(wo.to(DEV), torch.float32).reshape(9, C)
+    yo = ops.conv_out_c1(h.to(DEV), wt, bo.to(DEV))
+    refo = F.conv2d(h.float().permute(0, 3, 1, 2), wo, bo, padding=1)[:, 0]
+    assert rel_err(yo.cpu().numpy(), refo.numpy()) < 2e-5
+    # NCHW <-> NHWC boundary copies
+    z = t(synth.normal(11, (2, 256, 5, 53)))
+    zn = ops.to_nhwc(z.to(DEV), DT[dt])
+    assert torch.equal(zn.cpu(), z.permute(0, 2, 3, 1).contiguous().to(DT[dt]))
+    back = ops.to_nchw_contiguous(zn, torch.float32)
+    assert torch.equal(back.cpu(), z.to(DT[dt]).float())
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_attn_block_vs_oracle(dt):
+    from melspec_gpt_vqvae_amd.vqvae.big_model_attn_gan import AttnBlock, set_compute_dtype
+    from oracle import vqvae as ovq
+
+    C = 512
+    sd = {}
+    synth._attn(sd, "a", C, 77)
+    sd = {k[2:]: v for k, v in sd.items()}
+    blk = _load(AttnBlock(C), sd).to(DEV)
+    set_compute_dtype(blk, DT[dt])
+    x = t(synth.normal(78, (2, C, 5, 53)))
+    y = blk(x.to(DEV))
+    assert y.shape == (2, C, 5, 53)
+    ref = ovq.attn_block({("a." + k): t(v) for k, v in sd.items()}, "a", x)
+    assert rel_err(y.float().cpu().numpy(), ref.numpy()) < (1e-5 if dt == "f32" else 2e-2)
+
+
+def test_narrow_encoder_decoder_vs_reference_golden():
+    from melspec_gpt_vqvae_amd.vqvae.big_model_attn_gan import Decoder, Encoder
+
+    g = golden("vqvae_narrow")
+    hp = dict(ch=32, ch_mult=(1, 1, 2, 2, 4), num_res_blocks=2, z_channels=64)
+    kw = dict(ch=32, out_ch=1, ch_mult=(1, 1, 2, 2, 4), num_res_blocks=2, attn_resolutions=[53], in_channels=1,
+              resolution=848, z_channels=64, double_z=False)
+    enc = _load(Encoder(**kw), synth.encoder_state_dict(int(g["seed"]), **hp)).to(DEV)
+    dec = _load(Decoder(**kw), synth.decoder_state_dict(int(g["seed"]), **hp)).to(DEV)
+    with torch.no_grad():
+        h = enc(t(g["x"], DEV))
+        y = dec(t(g["dec_in"], DEV))
+    assert h.shape == (1, 64, 5, 53) and y.shape == (1, 1, 80, 848)
+    assert rel_err(h.float().cpu().numpy(), g["enc_out"]) < 1e-4
+    assert rel_err(y.float().cpu().numpy(), g["dec_out"]) < 1e-4
+
+
+def test_full_vqvae_tile_to_codes_vs_reference_golden():
+    """full-size LitVQVAE (ch=128): mel tile -> encode -> VQ -> codes, and decode of the quantised latent."""
+    from melspec_gpt_vqvae_amd.vqvae.big_model_attn_gan import LitVQVAE
+
+    g = golden("vqvae_full")
+    m = LitVQVAE(num_embeddings=128, embedding_dim=256)
+    assert [k for k in m.state_dict().keys()] == [str(k) for k in g["sd_keys"]], "checkpoint ABI: key names and order"
+    _load(m, synth.vqvae_state_dict(int(g["seed"])), allow_missing_prefix="discriminator.")
+    m.to(DEV).eval()
+    x = t(g["x"], DEV)
+    with torch.no_grad():
+        z = m.encode(x)
+        assert z.shape == (2, 256, 5, 53)
+        assert rel_err(z.float().cpu().numpy(), g["z"]) < 1e-4
+        codes = m.encode_to_codes(x)
+        assert codes.shape == (2, 5, 53) and codes.dtype == torch.int64
+        # the encoder's own 1e-6-level differences can move a distance by a few hundred ulp: ties within 2048 ulp
+        # may resolve to either of the two nearest codes, everything else must be bit-identical
+        n_near = check_indices_with_tie_policy(codes.cpu().numpy(), g["indices"], g["gap_ulps"], g["top2"],
+                                               ulp_thresh=2048.0)
+        print("near-tie vectors (<2048 ulp):", n_near)
+        loss, q, (perp, enc1h, idx) = m._vq_vae(z)
+        assert abs(loss.item() - float(g["vq_loss"])) <= 1e-4 * abs(float(g["vq_loss"]))
+        assert abs(perp.item() - float(g["perplexity"])) <= 1e-3 * float(g["perplexity"])
+        rec = m.decode(q[:1])
+    assert rec.shape == (1, 1, 80, 848)
+    assert rel_err(rec.float().cpu().numpy(), g["rec"]) < 1e-4
+
+
+def test_full_vqvae_bf16_lane_reports_code_agreement():
+    """bf16 throughput lane of the encoder: reported (not gated at 1e-4) - latent error and code agreement."""
+    from melspec_gpt_vqvae_amd.vqvae.big_model_attn_gan import LitVQVAE, set_compute_dtype
+
+    g = golden("vqvae_full")
+    m = LitVQVAE(num_embeddings=128, embedding_dim=256)
+    _load(m, synth.vqvae_state_dict(int(g["seed"])), allow_missing_prefix="discriminator.")
+    m.to(DEV).eval()
+    set_compute_dtype(m, torch.bfloat16)
+    with torch.no_grad():
+        z = m.encode(t(g["x"], DEV))
+        codes = m.encode_to_codes(t(g["x"], DEV))
+    err = rel_err(z.float().cpu().numpy(), g["z"])
+    agree = float((codes.cpu().numpy().ravel() == g["indices"].astype(np.int64)).mean())
+    print(f"bf16 encoder: latent rel-to-max err {err:.3e}, code agreement {agree:.3f}")
+    assert err < 5e-2 and agree > 0.9
