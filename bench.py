@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py - mel-token sequences / second for one training step of the hot path
+(VQ-encode + class-conditioned minGPT forward/backward + AdamW), BASELINE.json's metric.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+  mel tiles (B,1,80,848) in [-1,1]  --LitVQVAE.encode + 128-code L2 argmin-->  codes (B,5,53)
+  --time-major permute-->  (B,265) tokens  --GPTClass (VAS: 24 L, 1024, 16 H, block 266, dropout 0.5)-->
+  logits -> cross entropy -> backward -> [N>1: RCCL all-reduce of the flat gradient] -> fused AdamW.
+Every tensor op is a hand-written HIP kernel behind the C ABI (include/melgpt.h); bf16 storage / MFMA operands,
+f32 accumulation, f32 master weights and gradients.  Random-init weights of the real architecture, synthetic data.
+Prints ONE JSON line on rank 0 (contract in the task statement), including `roofline` for the dominant kernel
+(the bf16 MFMA GEMM / implicit-GEMM conv, timed live with HIP events on the launch stream) and `cpu_baseline`
+(the CPU oracle's restatement of the same step timed on this box's host cores, bounded sample, rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+SEED = 783435              # the reference's fixed seed (GPT_train.py:56-61)
+
+
+def vas_args(**kw):
+    from types import SimpleNamespace
+
+    d = dict(vocab_size=128, block_size=266, n_layer=24, n_head=16, n_embd=1024, class_size=8, embd_pdrop=0.5,
+             resid_pdrop=0.5, attn_pdrop=0.5, n_unmasked=0, last_linear=None, learning_rate=1e-6)
+    d.update(kw)
+    return SimpleNamespace(**d)  # config/config_GPT_vas.py:1-18
+
+
+def build_models(device, dtype, args):
+    from melspec_gpt_vqvae_amd.transformer import minGPT
+    from melspec_gpt_vqvae_amd.vqvae import big_model_attn_gan as vq
+
+    torch.manual_seed(SEED)  # identical initial weights on every rank (no start-up broadcast needed)
+    gpt = minGPT.GPTClass(args)
+    vqvae = vq.LitVQVAE(num_embeddings=128, embedding_dim=256)
+    with torch.no_grad():  # spread the codebook so that codes are not degenerate with a random encoder
+        vqvae._vq_vae._embedding.weight.normal_(0.0, 1.0)
+    gpt.to(device).train()
+    vqvae.to(device).eval()
+    minGPT.set_compute_dtype(gpt, dtype)
+    vq.set_compute_dtype(vqvae, dtype)
+    return gpt, vqvae
+
+
+def synthetic_batch(batch, rank, device):
+    import synth
+
+    mel = torch.from_numpy(synth.mel_tiles(SEED + 17 * rank, batch))          # (B,80,860) in [0,1]
+    x = (2 * mel[:, :, 6:854] - 1).unsqueeze(1).contiguous().to(device)       # CenterCrop 848, 2x-1
+    c = torch.from_numpy(synth.randint(SEED + 1 + rank, 0, 8, (batch, 1))).to(device)
+    return x, c
+
+
+def cpu_baseline(batch=4, reps=2):
+    """The CPU oracle (kind "port": torch-CPU fp32 restatement pinned to the reference by tests/golden) running the
+    same step - VQ-encode + class-GPT fwd/bwd + AdamW - on a bounded sample."""
+    import synth
+    from oracle import gpt as ogpt
+    from oracle import vqvae as ovq
+
+    threads = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(1)
+    a = vas_args()
+    C, L, V = a.n_embd, a.n_layer, a.vocab_size
+
+    def rn(*s, std=0.02):
+        return (torch.randn(*s, generator=g) * std).requires_grad_(True)
+
+    sd = {"pos_emb": rn(1, 266, C), "tok_emb.weight": rn(V, C), "ln_f.weight": torch.ones(C, requires_grad=True),
+          "ln_f.bias": torch.zeros(C, requires_grad=True), "head.weight": rn(V, C), "embedder.weight": rn(8, C, std=1.0)}
+    for i in range(L):
+        p = f"blocks.{i}."
+        for ln in ("ln1", "ln2"):
+            sd[p + ln + ".weight"] = torch.ones(C, requires_grad=True)
+            sd[p + ln + ".bias"] = torch.zeros(C, requires_grad=True)
+        for nm in ("key", "query", "value", "proj"):
+            sd[p + f"attn.{nm}.weight"] = rn(C, C)
+            sd[p + f"attn.{nm}.bias"] = torch.zeros(C, requires_grad=True)
+        sd[p + "mlp.0.weight"], sd[p + "mlp.0.bias"] = rn(4 * C, C), torch.zeros(4 * C, requires_grad=True)
+        sd[p + "mlp.2.weight"], sd[p + "mlp.2.bias"] = rn(C, 4 * C), torch.zeros(C, requires_grad=True)
+    vsd = {k: torch.from_numpy(v) for k, v in synth.vqvae_state_dict(50).items()}
+    mel = torch.from_numpy(synth.mel_tiles(3, batch))
+    c = torch.from_numpy(synth.randint(4, 0, 8, (batch, 1)))
+    opt = torch.optim.AdamW(list(sd.values()), lr=1e-6, betas=(0.9, 0.95))
+
+    def step():
+        with torch.no_grad():
+            codes, _ = ovq.mel_to_codes(vsd, mel)
+        x = ogpt.codes_to_sequence(codes)
+        loss, _, _ = ogpt.class_gpt_loss(sd, x, c, L, a.n_head, pdrop=(0.5, 0.5, 0.5), train=True)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(batch / dt, 4), "unit": "seq/s", "cores": threads, "kind": "port",
+            "sample": f"batch {batch}, {reps} steps after 1 warm-up: oracle VQ-encode + class-GPT VAS fwd/bwd + AdamW, "
+                      f"fp32, {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=128, help="sequences per GPU per step (BASELINE config 3: 128)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--layers", type=int, default=24, help="debug only; anything but 24 is flagged in config")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print per-phase timings to stderr")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from melspec_gpt_vqvae_amd import ops
+    from melspec_gpt_vqvae_amd.dp import DataParallel
+    from melspec_gpt_vqvae_amd.optim import FusedAdamW
+    from melspec_gpt_vqvae_amd.transformer.minGPT import cross_entropy
+
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    gargs = vas_args(n_layer=a.layers)
+    gpt, vqvae = build_models(device, dtype, gargs)
+    x_mel, c = synthetic_batch(a.batch, rank, device)
+    opt = FusedAdamW(gpt, lr=gargs.learning_rate, betas=(0.9, 0.95), weight_decay=0.01)
+    opt.grad_scale = 1.0 / world
+    dp = DataParallel(gpt) if world > 1 else None
+
+    phases = {"encode": 0.0, "fwd": 0.0, "bwd": 0.0, "opt": 0.0}
+
+    def mark():
+        if a.breakdown:
+            torch.cuda.synchronize()
+        return time.perf_counter()
+
+    def step():
+        t0 = mark()
+        with torch.no_grad():
+            codes = vqvae.encode_to_codes(x_mel)                 # (B,5,53) int64
+            seq = ops.codes_permute(codes, 5, 53)                # (B,265) time-major (get_x)
+        t1 = mark()
+        logits, _, _ = gpt(seq[:, :-1], c)                       # Lit_minGPT.forward: transformer(z[:, :-1], c)
+        loss = cross_entropy(logits.reshape(-1, logits.size(-1)), seq.reshape(-1))
+        t2 = mark()
+        opt.zero_grad()
+        loss.backward()
+        if dp is not None:
+            dp.finish()
+        t3 = mark()
+        opt.step()
+        t4 = mark()
+        if a.breakdown:
+            for k, v in zip(phases, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                phases[k] += v
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    for k in phases:
+        phases[k] = 0.0
+    ops.TIMER = ops.KernelTimer()
+    fence()
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timer, ops.TIMER = ops.TIMER, None
+    loss_val = float(loss)
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    ms_per_step = 1e3 * elapsed / a.steps
+    value = world * a.batch * a.steps / elapsed
+
+    ks = timer.summary()
+    achieved = ks["flops"] / (ks["total_ms"] * 1e-3) / 1e12 if ks["total_ms"] > 0 else 0.0
+    if rank == 0:
+        out = {
+            "metric": "mel-token seqs/sec training step (VQ-encode + GPT fwd/bwd)",
+            "value": round(value, 3), "unit": "seq/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
+            "config": {
+                "workload": "VQ-encode (LitVQVAE encoder + 128-code L2 argmin on 80x848 mel tiles) + class-GPT VAS "
+                            f"({a.layers} L, 1024, 16 H, T=265, V=128, dropout 0.5) fwd/bwd + AdamW",
+                "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": 265,
+                "parallelism": f"dp{world}" if world > 1 else "single",
+                "final_loss": round(loss_val, 4),
+            },
+            "roofline": {
+                "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "kernel": "gemm_kernel<bf16> (MFMA GEMM + implicit-GEMM conv), all launches of the timed region",
+                "launches_per_step": ks["launches"] // max(a.steps, 1),
+                "kernel_ms_per_step": round(ks["total_ms"] / max(a.steps, 1), 3),
+                "algorithmic_tflop_per_step": round(ks["flops"] / max(a.steps, 1) / 1e12, 3),
+            },
+        }
+        if a.layers != 24:
+            out["config"]["INVALID_debug_layers"] = a.layers
+        if a.breakdown:
+            print({k: round(1e3 * v / a.steps, 2) for k, v in phases.items()}, file=sys.stderr)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -164,14 +164,15 @@ int melgpt_colsum_rows(void);
 int melgpt_colsum(const void* a, long long M, int N, long long lda, float* out, int accumulate,
                   float* workspace, int dtype, void* stream);
 /* embedding stem (minGPT.py:170-180, 207-212): out[b,t,:] = drop((t < n_pre ? PRE : tok_emb[idx]) + pos_emb[t]);
+ * idx is (B,Tt) int64 with row stride idx_ld (so z_indices[:, :-1] of :279 needs no copy);
  * PRE = pre_table[pre_idx[b*n_pre+t]] (GPTClass.embedder) or pre_vals[b,t,:] (explicit embeddings, f32). */
 int melgpt_embed_fwd(const long long* idx, const float* tok_emb, const float* pos_emb,
                      const long long* pre_idx, const float* pre_table, const float* pre_vals, int n_pre, int B,
-                     int Tt, int C, int V, void* out, int dtype, float drop_p, unsigned long long seed,
-                     unsigned stream_id, void* stream);
+                     int Tt, long long idx_ld, int C, int V, void* out, int dtype, float drop_p,
+                     unsigned long long seed, unsigned stream_id, void* stream);
 /* gradients of the stem; every table row is reduced by one workgroup in ascending position order (no atomics) */
-int melgpt_embed_bwd(const void* dx, const long long* idx, const long long* pre_idx, int n_pre, int B, int Tt,
-                     int C, int V, int n_pre_rows, float* tok_grad, float* pos_grad, float* pre_table_grad,
+int melgpt_embed_bwd(const void* dx, const long long* idx, long long idx_ld, const long long* pre_idx, int n_pre,
+                     int B, int Tt, int C, int V, int n_pre_rows, float* tok_grad, float* pos_grad, float* pre_table_grad,
                      float* pre_vals_grad, int accumulate, int dtype, float drop_p, unsigned long long seed,
                      unsigned stream_id, void* stream);
 /* F.cross_entropy pieces (minGPT.py:197,416; decoders.py:64-68): loss_rows[m] = lse[m] - logits[m,target[m]] */
@@ -190,6 +191,10 @@ int melgpt_cast(const void* x, int src_dtype, void* y, int dst_dtype, long long 
 int melgpt_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16,
                  long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                  float grad_scale, void* stream);
+
+/* VQ code ordering (minGPT.py:387-394 get_x, :431-456 make_idx/code_reader): (B,H,W) row-major <-> (B, W*H)
+ * time-major sequence, position p = w*H + h.  reverse = 1 is code_reader(reverse=True). int64 in/out. */
+int melgpt_codes_permute(const long long* in, long long* out, int B, int H, int W, int reverse, void* stream);
 
 /* ===================================================================== VQ-VAE encoder / decoder pieces
  * All activations are NHWC ((B, H*W, C) row-major) in `dtype`.

@@ -44,8 +44,8 @@ _PROTOS = {
     "melgpt_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _l, _i, _i, _p],
     "melgpt_colsum_rows": [],
     "melgpt_colsum": [_p, _l, _i, _l, _p, _i, _p, _i, _p],
-    "melgpt_embed_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _f, _u64, C.c_uint, _p],
-    "melgpt_embed_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _f, _u64, C.c_uint, _p],
+    "melgpt_embed_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _l, _i, _i, _p, _i, _f, _u64, C.c_uint, _p],
+    "melgpt_embed_bwd": [_p, _p, _l, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _f, _u64, C.c_uint, _p],
     "melgpt_cross_entropy_fwd": [_p, _l, _p, _l, _i, _p, _p, _p],
     "melgpt_cross_entropy_bwd": [_p, _l, _p, _p, _p, _p, _f, _l, _i, _p, _l, _i, _p],
     "melgpt_sum_f32": [_p, _l, _f, _p, _i, _p],
@@ -60,6 +60,7 @@ _PROTOS = {
     "melgpt_softmax_rows": [_p, _l, _i, _l, _f, _p, _l, _i, _p],
     "melgpt_repack_conv_weight": [_p, _p, _i, _i, _i, _i, _i, _p],
     "melgpt_permute_nchw_nhwc": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
+    "melgpt_codes_permute": [_p, _p, _i, _i, _i, _i, _p],
 }
 _RESTYPE = {"melgpt_strerror": C.c_char_p}
 

@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
                                                         const long long* __restrict__ pre_idx,
                                                         const float* __restrict__ pre_table,
                                                         const float* __restrict__ pre_vals, int n_pre, int B, int Tt,
-                                                        int C, int V, T* __restrict__ out, float drop_scale,
+                                                        long long idx_ld, int C, int V, T* __restrict__ out,
+                                                        float drop_scale,
                                                         unsigned thresh, unsigned long long seed, unsigned sid) {
   constexpr int N = V16<T>::N;
   const int lane = threadIdx.x & 63;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
   if (tt < n_pre) {
     src = pre_idx ? pre_table + pre_idx[(long long)b * n_pre + tt] * C : pre_vals + ((long long)b * n_pre + tt) * C;
   } else {
-    long long k = idx[(long long)b * Tt + (tt - n_pre)];
+    long long k = idx[(long long)b * idx_ld + (tt - n_pre)];
     k = k < 0 ? 0 : (k >= V ? V - 1 : k);
     src = tok + k * C;
   }
@@ -278,7 +279,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
 // one workgroup per table row; positions are visited in ascending order -> deterministic, no atomics.
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_table_kernel(const T* __restrict__ dx, const long long* __restrict__ item_idx,
-                                                              long long n_items, int ipb, int Ttot, int off, int C,
+                                                              long long n_items, int ipb, long long idx_ld, int Ttot,
+                                                              int off, int C,
                                                               float* __restrict__ grad, int accumulate, float drop_scale,
                                                               unsigned thresh, unsigned long long seed, unsigned sid) {
   __shared__ int list[256];
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(256) void embed_bwd_table_kernel(const T* __restric
     if (t == 0) count = 0;
     __syncthreads();
     const long long j = base + t;
-    const bool hit = j < n_items && item_idx[j] == v;
+    const bool hit = j < n_items && item_idx[(j / ipb) * idx_ld + (j % ipb)] == v;
     // ordered compaction: ballot per wave, waves in order
     unsigned long long bal = __ballot(hit);
     __shared__ int wcount[4];
@@ -495,6 +497,25 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// (B,H,W) row-major codes -> (B, W*H) time-major sequence p = w*H + h  (Lit_minGPT.get_x, minGPT.py:387-394;
+// make_idx/code_reader :431-456) and its inverse
+__global__ void codes_permute_kernel(const long long* __restrict__ in, long long* __restrict__ out, int B, int H, int W,
+                                     int reverse) {
+  const long long total = (long long)B * H * W;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / (H * W);
+    const int r = (int)(i % (H * W));
+    if (!reverse) {  // out[b, w*H + h] = in[b, h*W + w]
+      const int w = r / H, h = r % H;
+      out[i] = in[b * H * W + h * W + w];
+    } else {         // out[b, h*W + w] = in[b, w*H + h]
+      const int h = r / W, w = r % W;
+      out[i] = in[b * H * W + w * H + h];
+    }
+  }
+}
+
 inline int grid_for(long long work_items, int per_block, int cap = 8192) {
   long long g = (work_items + per_block - 1) / per_block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -576,22 +597,22 @@ extern "C" int melgpt_colsum(const void* a, long long M, int N, long long lda, f
 
 extern "C" int melgpt_embed_fwd(const long long* idx, const float* tok_emb, const float* pos_emb,
                                 const long long* pre_idx, const float* pre_table, const float* pre_vals, int n_pre,
-                                int B, int Tt, int C, int V, void* out, int dtype, float drop_p,
+                                int B, int Tt, long long idx_ld, int C, int V, void* out, int dtype, float drop_p,
                                 unsigned long long seed, unsigned stream_id, void* stream) {
   MELGPT_CHECK(tok_emb && pos_emb && out && B > 0 && Tt >= 0 && C > 0 && V > 0 && n_pre >= 0, MELGPT_ERR_BAD_ARG);
-  MELGPT_CHECK(Tt == 0 || idx, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(Tt == 0 || (idx && idx_ld >= Tt), MELGPT_ERR_BAD_ARG);
   MELGPT_CHECK(n_pre == 0 || (pre_idx && pre_table) || pre_vals, MELGPT_ERR_BAD_ARG);
   MELGPT_CHECK(C % 8 == 0 && drop_p >= 0.f && drop_p < 1.f, MELGPT_ERR_UNSUPPORTED);
   const long long rows = (long long)B * (Tt + n_pre);
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 0.f;
   DISPATCH_T(dtype, hipLaunchKernelGGL(embed_fwd_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                                        (hipStream_t)stream, idx, tok_emb, pos_emb, pre_idx, pre_table, pre_vals, n_pre,
-                                       B, Tt, C, V, (T*)out, sc, thresh_of(drop_p), seed, stream_id));
+                                       B, Tt, idx_ld, C, V, (T*)out, sc, thresh_of(drop_p), seed, stream_id));
   return melgpt_launch_status();
 }
 
-extern "C" int melgpt_embed_bwd(const void* dx, const long long* idx, const long long* pre_idx, int n_pre, int B,
-                                int Tt, int C, int V, int n_pre_rows, float* tok_grad, float* pos_grad,
+extern "C" int melgpt_embed_bwd(const void* dx, const long long* idx, long long idx_ld, const long long* pre_idx,
+                                int n_pre, int B, int Tt, int C, int V, int n_pre_rows, float* tok_grad, float* pos_grad,
                                 float* pre_table_grad, float* pre_vals_grad, int accumulate, int dtype, float drop_p,
                                 unsigned long long seed, unsigned stream_id, void* stream) {
   MELGPT_CHECK(dx && B > 0 && C > 0 && V > 0 && n_pre >= 0 && Tt >= 0, MELGPT_ERR_BAD_ARG);
@@ -601,15 +622,16 @@ extern "C" int melgpt_embed_bwd(const void* dx, const long long* idx, const long
   const unsigned th = thresh_of(drop_p);
   hipStream_t s = (hipStream_t)stream;
   if (tok_grad && Tt > 0) {
-    MELGPT_CHECK(idx, MELGPT_ERR_BAD_ARG);
+    MELGPT_CHECK(idx && idx_ld >= Tt, MELGPT_ERR_BAD_ARG);
     DISPATCH_T(dtype, hipLaunchKernelGGL(embed_bwd_table_kernel<T>, dim3(V), dim3(256), 0, s, (const T*)dx, idx,
-                                         (long long)B * Tt, Tt, Ttot, n_pre, C, tok_grad, accumulate, sc, th, seed,
+                                         (long long)B * Tt, Tt, idx_ld, Ttot, n_pre, C, tok_grad, accumulate, sc, th, seed,
                                          stream_id));
   }
   if (pre_table_grad && n_pre > 0) {
     MELGPT_CHECK(pre_idx && n_pre_rows > 0, MELGPT_ERR_BAD_ARG);
     DISPATCH_T(dtype, hipLaunchKernelGGL(embed_bwd_table_kernel<T>, dim3(n_pre_rows), dim3(256), 0, s, (const T*)dx,
-                                         pre_idx, (long long)B * n_pre, n_pre, Ttot, 0, C, pre_table_grad, accumulate,
+                                         pre_idx, (long long)B * n_pre, n_pre, (long long)n_pre, Ttot, 0, C,
+                                         pre_table_grad, accumulate,
                                          sc, th, seed, stream_id));
   }
   if (pos_grad) {
@@ -686,5 +708,13 @@ extern "C" int melgpt_adamw(float* param, const float* grad, float* exp_avg, flo
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, param,
                      grad, exp_avg, exp_avg_sq, (bf16_t*)param_bf16, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
                      (float)sqrt(bc2), grad_scale);
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_codes_permute(const long long* in, long long* out, int B, int H, int W, int reverse,
+                                    void* stream) {
+  MELGPT_CHECK(in && out && in != out && B > 0 && H > 0 && W > 0, MELGPT_ERR_BAD_ARG);
+  hipLaunchKernelGGL(codes_permute_kernel, dim3(grid_for((long long)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                     in, out, B, H, W, reverse);
   return melgpt_launch_status();
 }

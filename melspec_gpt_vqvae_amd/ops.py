@@ -11,6 +11,40 @@ from ._ffi import call, dtype_code, ptr, stream
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
 
 
+class KernelTimer:
+    """Live per-launch timing of the MFMA GEMM / conv kernel with HIP events recorded on the launch stream
+    (used by bench.py for the roofline figure; off by default - two event records per launch)."""
+
+    def __init__(self):
+        self.records = []  # (start_event, end_event, flops, tag)
+
+    def summary(self):
+        tot_ms = sum(s.elapsed_time(e) for s, e, _, _ in self.records)
+        flops = sum(f for _, _, f, _ in self.records)
+        return dict(launches=len(self.records), total_ms=tot_ms, flops=flops)
+
+
+TIMER = None  # set to a KernelTimer() to record
+
+
+class _timed:
+    def __init__(self, flops, tag):
+        self.flops, self.tag = flops, tag
+
+    def __enter__(self):
+        if TIMER is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if TIMER is not None:
+            self.e.record()
+            TIMER.records.append((self.s, self.e, self.flops, self.tag))
+        return False
+
+
 def _mat(x):
     """(rows, cols) or (batch, rows, cols) tensor with unit inner stride -> (x, batch, rows, cols, ld, batch_stride)."""
     if x.dim() == 2:
@@ -51,9 +85,11 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=None, accu
         assert pre_out.shape == out.shape and pre_out.stride() == out.stride() and pre_out.dtype == out.dtype
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
-    call("melgpt_gemm", ptr(a), int(a_kmajor), lda, sa, ptr(b), int(b_kmajor), ldb, sb, ptr(out), ldc, sc, M, N, K,
-         batch, dtype_code(dt), int(odt == torch.float32 and dt != torch.float32), int(accumulate), float(alpha),
-         ptr(bias), int(act), ptr(residual), ldr, sr, ptr(pre_out), float(drop_p), int(seed), int(stream_id), stream())
+    with _timed(2.0 * M * N * K * batch, "gemm"):
+        call("melgpt_gemm", ptr(a), int(a_kmajor), lda, sa, ptr(b), int(b_kmajor), ldb, sb, ptr(out), ldc, sc, M, N, K,
+             batch, dtype_code(dt), int(odt == torch.float32 and dt != torch.float32), int(accumulate), float(alpha),
+             ptr(bias), int(act), ptr(residual), ldr, sr, ptr(pre_out), float(drop_p), int(seed), int(stream_id),
+             stream())
     return out
 
 
@@ -71,8 +107,9 @@ def conv2d_nhwc(x, wpack, bias=None, *, stride=1, pad=(1, 1), out_hw=None, upsam
     assert out.shape == (B, OH, OW, Cout) and out.is_contiguous()
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype
-    call("melgpt_conv2d_nhwc", ptr(x), B, H, W, Cin, ptr(wpack), Cout, KH, KW, stride, pad[0], pad[1], OH, OW,
-         int(upsample), ptr(bias), ptr(residual), ptr(out), dtype_code(x.dtype), stream())
+    with _timed(2.0 * B * OH * OW * Cout * KH * KW * Cin, "conv"):
+        call("melgpt_conv2d_nhwc", ptr(x), B, H, W, Cin, ptr(wpack), Cout, KH, KW, stride, pad[0], pad[1], OH, OW,
+             int(upsample), ptr(bias), ptr(residual), ptr(out), dtype_code(x.dtype), stream())
     return out
 
 
@@ -135,7 +172,8 @@ def embed_fwd(idx, tok_emb, pos_emb, *, pre_idx=None, pre_table=None, pre_vals=N
     V, C = tok_emb.shape
     assert tok_emb.dtype == torch.float32 and tok_emb.is_contiguous() and pos_emb.is_contiguous()
     assert pos_emb.shape[-1] == C and pos_emb.shape[-2] >= Tt + n_pre
-    idx = idx.contiguous()
+    if idx.stride(-1) != 1:
+        idx = idx.contiguous()
     out = torch.empty(B, Tt + n_pre, C, dtype=dtype, device=tok_emb.device)
     if pre_idx is not None:
         pre_idx = pre_idx.reshape(-1).contiguous()
@@ -143,7 +181,7 @@ def embed_fwd(idx, tok_emb, pos_emb, *, pre_idx=None, pre_table=None, pre_vals=N
     if pre_vals is not None:
         assert pre_vals.shape == (B, n_pre, C) and pre_vals.dtype == torch.float32 and pre_vals.is_contiguous()
     call("melgpt_embed_fwd", ptr(idx) if Tt > 0 else None, ptr(tok_emb), ptr(pos_emb), ptr(pre_idx), ptr(pre_table),
-         ptr(pre_vals), n_pre, B, Tt, C, V, ptr(out), dtype_code(dtype), float(drop_p), int(seed), int(stream_id), stream())
+         ptr(pre_vals), n_pre, B, Tt, idx.stride(0) if Tt > 0 else 0, C, V, ptr(out), dtype_code(dtype), float(drop_p), int(seed), int(stream_id), stream())
     return out
 
 
@@ -156,7 +194,10 @@ def embed_bwd(dx, idx, *, tok_grad=None, pos_grad=None, pre_idx=None, pre_table_
     n_rows = pre_table_grad.shape[0] if pre_table_grad is not None else 0
     if pre_idx is not None:
         pre_idx = pre_idx.reshape(-1).contiguous()
-    call("melgpt_embed_bwd", ptr(dx), ptr(idx.contiguous()) if Tt > 0 else None, ptr(pre_idx), n_pre, B, Tt, C, V,
+    if idx.stride(-1) != 1:
+        idx = idx.contiguous()
+    call("melgpt_embed_bwd", ptr(dx), ptr(idx) if Tt > 0 else None, idx.stride(0) if Tt > 0 else 0, ptr(pre_idx), n_pre,
+         B, Tt, C, V,
          n_rows, ptr(tok_grad), ptr(pos_grad), ptr(pre_table_grad), ptr(pre_vals_grad), int(accumulate),
          dtype_code(dx.dtype), float(drop_p), int(seed), int(stream_id), stream())
 
@@ -325,3 +366,13 @@ def to_nchw_contiguous(x_nhwc, dtype):
     call("melgpt_permute_nchw_nhwc", ptr(x_nhwc), dtype_code(x_nhwc.dtype), ptr(y), dtype_code(dtype), B, C, H * W, 0,
          stream())
     return y
+
+
+def codes_permute(codes, H, W, reverse=False):
+    """(B,H,W) or (B,H*W) int64 codes -> (B, H*W) in the other ordering (time-major <-> row-major)."""
+    B = codes.shape[0]
+    src = codes.reshape(B, H * W).contiguous()
+    assert src.dtype == torch.int64
+    out = torch.empty_like(src)
+    call("melgpt_codes_permute", ptr(src), ptr(out), B, H, W, int(reverse), stream())
+    return out
