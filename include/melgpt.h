@@ -175,6 +175,12 @@ int melgpt_embed_bwd(const void* dx, const long long* idx, long long idx_ld, con
                      int B, int Tt, int C, int V, int n_pre_rows, float* tok_grad, float* pos_grad, float* pre_table_grad,
                      float* pre_vals_grad, int accumulate, int dtype, float drop_p, unsigned long long seed,
                      unsigned stream_id, void* stream);
+/* rows of the one-hot matrix behind  d tok_emb = OneHot^T @ dX  (zero rows for the n_pre prepended positions) */
+int melgpt_onehot_rows(const long long* idx, long long idx_ld, int B, int Tt, int n_pre, int V, void* out,
+                       int dtype, void* stream);
+/* out[c] (+)= scale * sum_{r<R} partials[r*ld + c], fixed summation order (split-K / two-stage reductions) */
+int melgpt_reduce_rows(const float* partials, int R, long long ld, long long ncols, float* out, int accumulate,
+                       float scale, void* stream);
 /* F.cross_entropy pieces (minGPT.py:197,416; decoders.py:64-68): loss_rows[m] = lse[m] - logits[m,target[m]] */
 int melgpt_cross_entropy_fwd(const float* logits, long long ld, const long long* target, long long M, int V,
                              float* loss_rows, float* lse, void* stream);

@@ -61,6 +61,8 @@ _PROTOS = {
     "melgpt_repack_conv_weight": [_p, _p, _i, _i, _i, _i, _i, _p],
     "melgpt_permute_nchw_nhwc": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
     "melgpt_codes_permute": [_p, _p, _i, _i, _i, _i, _p],
+    "melgpt_onehot_rows": [_p, _l, _i, _i, _i, _i, _p, _i, _p],
+    "melgpt_reduce_rows": [_p, _i, _l, _l, _p, _i, _f, _p],
 }
 _RESTYPE = {"melgpt_strerror": C.c_char_p}
 

@@ -21,44 +21,18 @@
 //   * T = bf16 : v_mfma_f32_16x16x32_bf16, f32 accumulate.   T = f32 : v_mfma_f32_16x16x4_f32 (exact f32
 //     FMA chain) - the parity lane.  Fragment addressing is identical for both.
 //   * workgroup -> tile mapping is XCD-aware (consecutive tiles of one A row-panel share an L2).
-#include "mma.h"
+#include <math.h>
+#include <stdlib.h>
+
+#include "gemm_common.h"
+
+using namespace gemmk;
 
 namespace {
 
-enum { LAY_ROW = 0, LAY_KMAJ = 1, LAY_CONV = 2 };
-
-struct GemmParams {
-  const void* A;
-  const void* B;
-  void* C;
-  void* C2;           // optional second output (pre-activation), same dtype/ld as C
-  const float* bias;  // (N,) f32 or null
-  const void* R;      // residual (ACT none/gelu) or pre-activation (MELGPT_ACT_GELU_GRAD); dtype T
-  int M, N, K;
-  long long lda, ldb, ldc, ldr;
-  long long sA, sB, sC, sR;  // batch strides (elements)
-  unsigned a_bytes, b_bytes;  // addressable bytes of ONE batch of A / B (loads beyond return 0)
-  int out_f32, accumulate, act;
-  float alpha;
-  float drop_scale;  // 1/(1-p), or 0 when dropout is off
-  unsigned drop_thresh;
-  unsigned long long seed;
-  unsigned stream_id;
-  // implicit-GEMM convolution (A = NHWC input)
-  int cH, cW, cC, OH, OW, cstride, pad_t, pad_l, ups, KW;
-};
-
 constexpr int BM = 128, BN = 128, TILE_BYTES = 16384;
 
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad(float x) {
-  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
-}
-
 // ------------------------------------------------------------------------------- LDS addressing
-__device__ __forceinline__ int row_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
 template <typename T>
 __device__ __forceinline__ int kmaj_off(int krow, int lc) {
   if constexpr (Tr<T>::ES == 2) {
@@ -97,7 +71,6 @@ __device__ __forceinline__ u32x4 load_frag(const char* tile, int st, int ks, int
   }
 }
 
-constexpr unsigned OOB = 0xFFFFFFF0u;
 
 // ---------------------------------------------------------------------------------- the kernel
 template <typename T, int ALAY, int BLAY>
@@ -108,13 +81,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wm = w >> 1, wn = w & 1;
 
-  // XCD-aware tile order (bijective for any grid size)
   const int tilesN = (p.N + BN - 1) / BN;
-  int wg;
-  {
-    const int nwg = gridDim.x, b = blockIdx.x, qd = nwg >> 3, rm = nwg & 7, xcd = b & 7;
-    wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (b >> 3);
-  }
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (wg / tilesN) * BM, n0 = (wg % tilesN) * BN;
   const int bz = blockIdx.z;
 
@@ -238,65 +206,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  // ------------------------------------------------------------------------------ epilogue
-  const int i16 = lane & 15, g = lane >> 4;
-  char* Cb = (char*)p.C + (long long)bz * p.sC * (p.out_f32 ? 4 : ES);
-  char* C2b = p.C2 ? (char*)p.C2 + (long long)bz * p.sC * (p.out_f32 ? 4 : ES) : nullptr;
-  const char* Rb = p.R ? (const char*)p.R + (long long)bz * p.sR * ES : nullptr;
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const int n = n0 + wn * 64 + nt * 16 + g * 4;
-    if (n >= p.N) continue;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bv = *(const f32x4*)(p.bias + n);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int m = m0 + wm * 64 + mt * 16 + i16;
-      if (m >= p.M) continue;
-      f32x4 v = acc[mt][nt] * p.alpha + bv;
-      if (C2b) {
-        if (p.out_f32 || ES == 4) *(f32x4*)(C2b + ((long long)m * p.ldc + n) * 4) = v;
-        else *(u32x2*)(C2b + ((long long)m * p.ldc + n) * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-      }
-      f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-      if (Rb) {
-        if constexpr (ES == 4) {
-          rv = *(const f32x4*)(Rb + ((long long)m * p.ldr + n) * 4);
-        } else {
-          u32x2 r = *(const u32x2*)(Rb + ((long long)m * p.ldr + n) * 2);
-          rv = f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xFFFF0000u),
-                     __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xFFFF0000u)};
-        }
-      }
-      if (p.act == MELGPT_ACT_GELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
-      } else if (p.act == MELGPT_ACT_GELU_GRAD) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad(rv[e]);
-      }
-      if (p.drop_scale != 0.f) {
-        const unsigned long long e0 = ((unsigned long long)bz * p.M + m) * (unsigned long long)p.N + n;
-        const unsigned keep = dropout_keep4(p.seed, p.stream_id, e0 >> 2, p.drop_thresh);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (keep >> e & 1) ? v[e] * p.drop_scale : 0.f;
-      }
-      if (Rb && p.act != MELGPT_ACT_GELU_GRAD) v += rv;
-      if (p.out_f32 || ES == 4) {
-        float* dst = (float*)(Cb + ((long long)m * p.ldc + n) * 4);
-        if (p.accumulate) v += *(const f32x4*)dst;
-        *(f32x4*)dst = v;
-      } else {
-        u32x2* dst = (u32x2*)(Cb + ((long long)m * p.ldc + n) * 2);
-        if (p.accumulate) {
-          u32x2 o = *dst;
-          v += f32x4{__uint_as_float(o[0] << 16), __uint_as_float(o[0] & 0xFFFF0000u),
-                     __uint_as_float(o[1] << 16), __uint_as_float(o[1] & 0xFFFF0000u)};
-        }
-        *dst = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-      }
-    }
-  }
+  epilogue<T, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, bz, lane);
 }
 
 template <typename T, int ALAY, int BLAY>
@@ -323,7 +233,24 @@ int dispatch(const GemmParams& p, int alay, int blay, int batch, hipStream_t s) 
   return MELGPT_ERR_UNSUPPORTED;
 }
 
-bool fits32(long long rows, long long ld, int es) { return (rows + 130) * ld * es < 0xFFFFFF00LL; }
+bool fits32(long long rows, long long ld, int es) { return (rows + 260) * ld * es < 0xFFFFFF00LL; }
+
+// tile configuration for the bf16 lane: 1 = 128x128 (this file), 2 = 256x128, 3 = 256x256 (gemm256.hip).
+// MELGPT_GEMM_TILE=1|2|3 forces one (development / A-B timing).
+int pick_tile(const GemmParams& p, int batch) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("MELGPT_GEMM_TILE");
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced >= 1 && forced <= 3) return forced;
+  // measured on MI355X (profiles/r01_gemm_tiles.log): with its 2-stage pipeline the wide-tile kernel only wins on
+  // large, deep problems (4096^3: 837 vs 713 TFLOP/s); the skinny M=33920 / K=1024 shapes of the GPT step and
+  // the split-K weight gradients are faster on the 128x128 kernel, which runs two workgroups per CU.
+  const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
+  if (p.K >= 2048 && p.M >= 2048 && p.N >= 2048 && p.M % 256 == 0 && p.N % 256 == 0 && tiles128 >= 1024) return 3;
+  return 1;
+}
 
 }  // namespace
 
@@ -370,7 +297,13 @@ extern "C" int melgpt_gemm(const void* A, int a_kmajor, long long lda, long long
   p.seed = seed; p.stream_id = stream_id;
   hipStream_t s = (hipStream_t)stream;
   const int alay = a_kmajor ? LAY_KMAJ : LAY_ROW, blay = b_kmajor ? LAY_KMAJ : LAY_ROW;
-  return dtype == MELGPT_F32 ? dispatch<float>(p, alay, blay, batch, s) : dispatch<bf16_t>(p, alay, blay, batch, s);
+  if (dtype == MELGPT_F32) return dispatch<float>(p, alay, blay, batch, s);
+  const int cfg = pick_tile(p, batch);
+  if (cfg != 1) {
+    int st = launch_gemm256(p, alay, blay, batch, cfg, s);
+    if (st != MELGPT_ERR_UNSUPPORTED) return st;
+  }
+  return dispatch<bf16_t>(p, alay, blay, batch, s);
 }
 
 extern "C" int melgpt_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, const void* wpack, int Cout, int KH,
@@ -399,6 +332,11 @@ extern "C" int melgpt_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, c
   p.cH = H; p.cW = W; p.cC = Cin; p.OH = OH; p.OW = OW; p.cstride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
   p.ups = upsample; p.KW = KW;
   hipStream_t s = (hipStream_t)stream;
-  return dtype == MELGPT_F32 ? dispatch<float>(p, LAY_CONV, LAY_ROW, 1, s)
-                             : dispatch<bf16_t>(p, LAY_CONV, LAY_ROW, 1, s);
+  if (dtype == MELGPT_F32) return dispatch<float>(p, LAY_CONV, LAY_ROW, 1, s);
+  const int cfg = pick_tile(p, 1);
+  if (cfg != 1) {
+    int st = launch_gemm256(p, LAY_CONV, LAY_ROW, 1, cfg, s);
+    if (st != MELGPT_ERR_UNSUPPORTED) return st;
+  }
+  return dispatch<bf16_t>(p, LAY_CONV, LAY_ROW, 1, s);
 }

@@ -186,22 +186,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
-// out[c] (+)= scale * sum_{r<R} part[r*ld + c]  - fixed order => deterministic
-__global__ void reduce_rows_kernel(const float* __restrict__ part, int R, long long ld, int ncols,
-                                   float* __restrict__ out, int accumulate, float scale) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncols) return;
+// out[c] (+)= scale * sum_{r<R} part[r*ld + c]  - fixed order => deterministic.
+// block = 64 columns x 4 row phases (each phase sums rows r = phase, phase+4, ... with 4 independent chains)
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int R, long long ld,
+                                                          long long ncols, float* __restrict__ out, int accumulate,
+                                                          float scale) {
+  __shared__ float sh[4][64];
+  const int lc = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const long long c = (long long)blockIdx.x * 64 + lc;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int r = 0;
-  for (; r + 3 < R; r += 4) {
-    s0 += part[(long long)r * ld + c];
-    s1 += part[(long long)(r + 1) * ld + c];
-    s2 += part[(long long)(r + 2) * ld + c];
-    s3 += part[(long long)(r + 3) * ld + c];
+  if (c < ncols) {
+    int r = ph;
+    for (; r + 12 < R; r += 16) {
+      s0 += part[(long long)r * ld + c];
+      s1 += part[(long long)(r + 4) * ld + c];
+      s2 += part[(long long)(r + 8) * ld + c];
+      s3 += part[(long long)(r + 12) * ld + c];
+    }
+    for (; r < R; r += 4) s0 += part[(long long)r * ld + c];
   }
-  for (; r < R; ++r) s0 += part[(long long)r * ld + c];
-  float s = ((s0 + s1) + (s2 + s3)) * scale;
-  out[c] = accumulate ? out[c] + s : s;
+  sh[ph][lc] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ph == 0 && c < ncols) {
+    const float s = ((sh[0][lc] + sh[1][lc]) + (sh[2][lc] + sh[3][lc])) * scale;
+    out[c] = accumulate ? out[c] + s : s;
+  }
 }
 
 // column sums of a (M,N) matrix in dtype T into partials[(gridDim.y)][N]; second stage = reduce_rows_kernel
@@ -516,6 +525,23 @@ __global__ void codes_permute_kernel(const long long* __restrict__ in, long long
   }
 }
 
+// one-hot rows of the embedding-gradient GEMM: row (b,t) = e_{idx[b,t-n_pre]} (zero row for the n_pre prepended
+// positions), so that  d tok_emb = OneHot^T (V x M) @ dX (M x C)  runs on the MFMA GEMM, split over K as a batch
+template <typename T>
+__global__ void onehot_rows_kernel(const long long* __restrict__ idx, long long idx_ld, int B, int Tt, int n_pre, int V,
+                                   T* __restrict__ out) {
+  const long long total = (long long)B * (Tt + n_pre) * V;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % V);
+    const long long row = i / V;
+    const int tt = (int)(row % (Tt + n_pre));
+    const long long b = row / (Tt + n_pre);
+    const bool one = tt >= n_pre && idx[b * idx_ld + (tt - n_pre)] == v;
+    Elem<T>::st(out + i, one ? 1.f : 0.f);
+  }
+}
+
 inline int grid_for(long long work_items, int per_block, int cap = 8192) {
   long long g = (work_items + per_block - 1) / per_block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -551,7 +577,7 @@ extern "C" int melgpt_layernorm_fwd(const void* x, const float* gamma, const flo
 extern "C" int melgpt_layernorm_bwd_nwaves(long long M) {
   long long w = (M + 7) / 8;  // >= 8 rows per wave where possible
   if (w < 4) w = 4;
-  if (w > 2048) w = 2048;
+  if (w > 1024) w = 1024;
   return (int)((w + 3) / 4 * 4);
 }
 
@@ -569,15 +595,15 @@ extern "C" int melgpt_layernorm_bwd(const void* dy, const void* x, const float* 
                                        (const T*)x, gamma, mean, rstd, (const T*)add_in, (T*)dx,
                                        dgamma ? workspace : nullptr, M, C));
   if (dgamma) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace, nwaves, 2LL * C, C,
-                       dgamma, accumulate, 1.0f);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace + C, nwaves, 2LL * C, C,
-                       dbeta, accumulate, 1.0f);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 63) / 64), dim3(256), 0, s, workspace, nwaves, 2LL * C,
+                       (long long)C, dgamma, accumulate, 1.0f);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 63) / 64), dim3(256), 0, s, workspace + C, nwaves, 2LL * C,
+                       (long long)C, dbeta, accumulate, 1.0f);
   }
   return melgpt_launch_status();
 }
 
-extern "C" int melgpt_colsum_rows(void) { return 256; }
+extern "C" int melgpt_colsum_rows(void) { return 64; }
 
 extern "C" int melgpt_colsum(const void* a, long long M, int N, long long lda, float* out, int accumulate,
                              float* workspace, int dtype, void* stream) {
@@ -585,13 +611,13 @@ extern "C" int melgpt_colsum(const void* a, long long M, int N, long long lda, f
   const int vec = dtype == MELGPT_F32 ? 4 : 8;
   MELGPT_CHECK(N % vec == 0 && lda % vec == 0 && ((uintptr_t)a & 15) == 0, MELGPT_ERR_ALIGN);
   long long rows = (M + 3) / 4;
-  const int gy = (int)(rows < 256 ? rows : 256);
+  const int gy = (int)(rows < 64 ? rows : 64);
   const int nch = N / vec;
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3((nch + 63) / 64, gy), dim3(256), 0, s,
                                        (const T*)a, M, N, lda, workspace));
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, s, workspace, gy, (long long)N, N, out,
-                     accumulate, 1.0f);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 63) / 64), dim3(256), 0, s, workspace, gy, (long long)N,
+                     (long long)N, out, accumulate, 1.0f);
   return melgpt_launch_status();
 }
 
@@ -716,5 +742,22 @@ extern "C" int melgpt_codes_permute(const long long* in, long long* out, int B, 
   MELGPT_CHECK(in && out && in != out && B > 0 && H > 0 && W > 0, MELGPT_ERR_BAD_ARG);
   hipLaunchKernelGGL(codes_permute_kernel, dim3(grid_for((long long)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream,
                      in, out, B, H, W, reverse);
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_onehot_rows(const long long* idx, long long idx_ld, int B, int Tt, int n_pre, int V, void* out,
+                                  int dtype, void* stream) {
+  MELGPT_CHECK(idx && out && B > 0 && Tt > 0 && n_pre >= 0 && V > 0 && idx_ld >= Tt, MELGPT_ERR_BAD_ARG);
+  const long long total = (long long)B * (Tt + n_pre) * V;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(onehot_rows_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0,
+                                       (hipStream_t)stream, idx, idx_ld, B, Tt, n_pre, V, (T*)out));
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_reduce_rows(const float* partials, int R, long long ld, long long ncols, float* out,
+                                  int accumulate, float scale, void* stream) {
+  MELGPT_CHECK(partials && out && R > 0 && ncols > 0 && ld >= ncols, MELGPT_ERR_BAD_ARG);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                     partials, R, ld, ncols, out, accumulate, scale);
   return melgpt_launch_status();
 }

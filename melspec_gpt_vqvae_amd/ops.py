@@ -202,6 +202,52 @@ def embed_bwd(dx, idx, *, tok_grad=None, pos_grad=None, pre_idx=None, pre_table_
          dtype_code(dx.dtype), float(drop_p), int(seed), int(stream_id), stream())
 
 
+def _split_count(rows, target=32):
+    """largest divisor of `rows` that is <= target (split-K factor for the embedding-gradient GEMM)."""
+    for d in range(min(target, rows), 0, -1):
+        if rows % d == 0:
+            return d
+    return 1
+
+
+def wgrad(dy, x, out, accumulate):
+    """out (N,K) f32 (+)= dy^T (N x M) @ x (M x K): the weight gradient of y = x W^T.  The reduction runs over
+    M = B*T rows (tens of thousands) while the output has only a few hundred 128x128 tiles, so the rows are split
+    into batches until ~3 workgroups per CU exist; partial products are summed in fixed order (deterministic)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    want = max(1, min(16, 768 // max(tiles, 1)))
+    ns = _split_count(M, want) if want > 1 else 1
+    if ns == 1 or dy.stride(1) != 1 or x.stride(1) != 1 or (M // ns) < 512:
+        return gemm(dy, x, a_kmajor=True, b_kmajor=True, out=out, accumulate=accumulate)
+    rows = M // ns
+    a3 = torch.as_strided(dy, (ns, rows, N), (rows * dy.stride(0), dy.stride(0), 1), dy.storage_offset())
+    b3 = torch.as_strided(x, (ns, rows, K), (rows * x.stride(0), x.stride(0), 1), x.storage_offset())
+    part = gemm(a3, b3, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)     # (ns, N, K)
+    call("melgpt_reduce_rows", ptr(part), ns, N * K, N * K, ptr(out), int(accumulate), 1.0, stream())
+    return out
+
+
+def embed_table_grad(dx, idx, tok_grad, *, n_pre=0, accumulate=False, drop_p=0.0, seed=0, stream_id=0):
+    """d tok_emb (V,C) (+)= OneHot^T (V x M) @ keep(dX) (M x C) on the MFMA GEMM: K = B*T rows are split into
+    batches (deterministic split-K: partial tables are summed in fixed order by melgpt_reduce_rows)."""
+    B, Ttot, C = dx.shape
+    V = tok_grad.shape[0]
+    Tt = Ttot - n_pre
+    if idx.stride(-1) != 1:
+        idx = idx.contiguous()
+    M = B * Ttot
+    dxm = dropout_apply(dx, drop_p, seed, stream_id) if drop_p > 0 else dx
+    oh = torch.empty(M, V, dtype=dx.dtype, device=dx.device)
+    call("melgpt_onehot_rows", ptr(idx), idx.stride(0), B, Tt, n_pre, V, ptr(oh), dtype_code(dx.dtype), stream())
+    ns = _split_count(M)
+    part = gemm(oh.view(ns, M // ns, V), dxm.view(ns, M // ns, C), a_kmajor=True, b_kmajor=True,
+                out_dtype=torch.float32)                                            # (ns, V, C)
+    call("melgpt_reduce_rows", ptr(part), ns, V * C, V * C, ptr(tok_grad), int(accumulate), 1.0, stream())
+    return dxm
+
+
 # --------------------------------------------------------------------------------- cross entropy
 def cross_entropy_fwd(logits, target):
     """logits (M,V) f32 (unit inner stride), target (M,) int64 -> (loss_rows (M,), lse (M,))."""

@@ -114,7 +114,7 @@ def _attention_core_bwd(dy, x2d, saved, w_qkv, w_proj, fp, blkw_params, *, B, T,
     (qkv_p, qkvb_p, proj_w, proj_b) = blkw_params
     d = ops.dropout_apply(dy, resid_p, seed, site + 1) if resid_p > 0 else dy
     gw, acc = fp.grad_target(proj_w)
-    ops.gemm(d, a, a_kmajor=True, b_kmajor=True, out=gw, accumulate=acc)         # dW_proj = d^T a
+    ops.wgrad(d, a, gw, acc)         # dW_proj = d^T a
     gb, acc = fp.grad_target(proj_b)
     ops.colsum(d, gb, accumulate=acc)
     da = ops.gemm(d, w_proj, b_kmajor=True)
@@ -123,7 +123,7 @@ def _attention_core_bwd(dy, x2d, saved, w_qkv, w_proj, fp, blkw_params, *, B, T,
     ops.attn_bwd(q, k, v, a, da, lse, n_head, B=B, T=T, dqkv=(dqkv[:, C:2 * C], dqkv[:, :C], dqkv[:, 2 * C:]),
                  n_unmasked=n_unmasked, drop_p=attn_p, seed=seed, stream_id=site)
     gw, acc = fp.packed_grad_target(qkv_p)
-    ops.gemm(dqkv, x2d, a_kmajor=True, b_kmajor=True, out=gw, accumulate=acc)    # dW_qkv = dqkv^T x
+    ops.wgrad(dqkv, x2d, gw, acc)    # dW_qkv = dqkv^T x
     gb, acc = fp.packed_grad_target(qkvb_p)
     ops.colsum(dqkv, gb, accumulate=acc)
     return ops.gemm(dqkv, w_qkv, b_kmajor=True) if need_dx else None
@@ -178,12 +178,12 @@ class _BlockFn(torch.autograd.Function):
         # ---- MLP branch: y = x1 + drop(fc2(gelu(fc1(ln2(x1)))))
         d = ops.dropout_apply(dy2, mlp_p, seed, site + 2) if mlp_p > 0 else dy2
         gw, acc = fp.grad_target(m[2].weight)
-        ops.gemm(d, act, a_kmajor=True, b_kmajor=True, out=gw, accumulate=acc)
+        ops.wgrad(d, act, gw, acc)
         gb, acc = fp.grad_target(m[2].bias)
         ops.colsum(d, gb, accumulate=acc)
         dpre = ops.gemm(d, W.w_fc2, b_kmajor=True, act=ops.ACT_GELU_GRAD, residual=pre)
         gw, acc = fp.grad_target(m[0].weight)
-        ops.gemm(dpre, h2, a_kmajor=True, b_kmajor=True, out=gw, accumulate=acc)
+        ops.wgrad(dpre, h2, gw, acc)
         gb, acc = fp.grad_target(m[0].bias)
         ops.colsum(dpre, gb, accumulate=acc)
         dh2 = ops.gemm(dpre, W.w_fc1, b_kmajor=True)
@@ -348,7 +348,10 @@ class _StemFn(torch.autograd.Function):
         elif is_vals:
             dvals = torch.empty(B, n_pre, C, dtype=torch.float32, device=dx.device)
             kw = dict(pre_vals_grad=dvals)
-        ops.embed_bwd(dx, idx, tok_grad=tg, pos_grad=pg[:Ttot], n_pre=n_pre, accumulate=acc_t, drop_p=p, seed=seed,
+        # token table on the MFMA GEMM (one-hot^T @ dX, split-K); positions / class table / explicit embeddings
+        # by the row kernels.  All of them replay the stem's dropout mask.
+        ops.embed_table_grad(dx, idx, tg, n_pre=n_pre, accumulate=acc_t, drop_p=p, seed=seed, stream_id=0xFFFF0000)
+        ops.embed_bwd(dx, idx, tok_grad=None, pos_grad=pg[:Ttot], n_pre=n_pre, accumulate=acc_t, drop_p=p, seed=seed,
                       stream_id=0xFFFF0000, **kw)
         return (None, None, dvals, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
 
@@ -384,7 +387,7 @@ class _HeadFn(torch.autograd.Function):
         if d.dtype != dt or not d.is_contiguous():
             d = ops.cast(d.contiguous(), dt)
         gw, acc = fp.grad_target(gpt.head.weight)
-        ops.gemm(d, h, a_kmajor=True, b_kmajor=True, out=gw, accumulate=acc)
+        ops.wgrad(d, h, gw, acc)
         dh = ops.gemm(d, w, b_kmajor=True)
         g, accg = fp.grad_target(gpt.ln_f.weight)
         b, accb = fp.grad_target(gpt.ln_f.bias)
