@@ -39,6 +39,22 @@ enum {
 int melgpt_abi_version(void);
 const char* melgpt_strerror(int code);
 
+/* ===================================================================== mel frontend
+ * wav -> log-mel in one kernel = MelSpectrogram.__call__ + TRANSFORMS
+ * (feature_extraction/extract_mel_spectrogram.py:36-38, 141-151) and, optionally, the CenterCrop + 2x-1 of
+ * feature_extraction/extract_codes.py:42-43.  librosa-0.8.1 STFT semantics: n_fft = win_length = 1024, periodic Hann,
+ * center=True with reflect padding, frames = 1 + n_samples/hop.
+ *   wav        (n_clips, n_samples) f32, already padded/truncated to its final length (get_spectrogram :169-173)
+ *   mel_basis  (n_mels, 513) f32 = librosa.filters.mel(...) (:26); band_lo/band_hi (n_mels,) first/last non-zero bin
+ *   value      clip((log10(max(min_val, m)) * mult - sub + add) / div, clip_lo, clip_hi)     (:143-149)
+ *   mel_out    optional (n_clips, n_mels, n_keep) f32, frames [0, n_keep)                      (TrimSpec :150)
+ *   tile_out   optional (n_clips, n_mels, crop_len) f32|bf16 = 2*value - 1 of frames [crop0, crop0+crop_len)  */
+int melgpt_mel_frontend_fwd(const float* wav, int n_clips, long long n_samples, int n_fft, int hop,
+                            const float* mel_basis, const int* band_lo, const int* band_hi, int n_mels,
+                            float min_val, float mult, float sub, float add, float div, float clip_lo,
+                            float clip_hi, float* mel_out, int n_keep, void* tile_out, int tile_dtype, int crop0,
+                            int crop_len, void* stream);
+
 /* ===================================================================== VQ codebook
  * Nearest-neighbour lookup = VectorQuantizer.forward, vqvae/big_model_attn_gan.py:19-54
  * (distances :28-30, argmin :33 first-index tie-break, gather :36-40, MSE terms :43-45,
@@ -184,10 +200,26 @@ int melgpt_reduce_rows(const float* partials, int R, long long ld, long long nco
 /* F.cross_entropy pieces (minGPT.py:197,416; decoders.py:64-68): loss_rows[m] = lse[m] - logits[m,target[m]] */
 int melgpt_cross_entropy_fwd(const float* logits, long long ld, const long long* target, long long M, int V,
                              float* loss_rows, float* lse, void* stream);
-/* dlogits[m,v] = (softmax - onehot) * g_rows[m] * (*g_scalar) * g_scale   (g_rows / g_scalar may be NULL = 1) */
+/* dlogits[m,v] = (softmax - onehot) * g_rows[m / g_group] * (*g_scalar) * g_scale  (g_rows / g_scalar may be NULL = 1;
+ * g_group = tokens per sequence when the upstream gradient is per sequence, decoders.py:68) */
 int melgpt_cross_entropy_bwd(const float* logits, long long ld, const long long* target, const float* lse,
-                             const float* g_rows, const float* g_scalar, float g_scale, long long M, int V,
-                             void* dlogits, long long ldd, int dtype, void* stream);
+                             const float* g_rows, int g_group, const float* g_scalar, float g_scale, long long M,
+                             int V, void* dlogits, long long ldd, int dtype, void* stream);
+/* out[r] = scale * sum_{j<n} in[r*n+j]: per-sequence sums of per-token losses (decoders.py:68 `.sum(-1)`) */
+int melgpt_group_sum_f32(const float* in, long long groups, int n, float scale, float* out, void* stream);
+/* one autoregressive decoding step (minGPT.py:345-358, decoders.py:108-121): logits (rows,V<=1024) f32 ->
+ * /temperature -> top-k filter (top_k <= 0: off) -> softmax -> argmax (do_sample = 0) or one multinomial draw
+ * (Philox uniform keyed by seed, step, row).  out (rows,) int64; probs_out optional (rows,V). */
+int melgpt_sample_logits(const float* logits, long long ld, int rows, int V, float temperature, int top_k,
+                         int do_sample, unsigned long long seed, unsigned step, long long* out, float* probs_out,
+                         void* stream);
+/* GPTEncoder.reparameterize + KL (encoders.py:62-104): stats (B,2nz) = [mu | logvar]; z = mu + eps*exp(logvar/2);
+ * KL[b] = 0.5*sum(mu^2 + exp(logvar) - logvar - 1).  gen_eps != 0: eps (B,ns,nz) is DRAWN in-kernel (N(0,1) from
+ * Philox + Box-Muller) and written; gen_eps == 0: eps is an input. */
+int melgpt_vae_reparam_fwd(const float* stats, float* eps, int gen_eps, unsigned long long seed, int B, int ns,
+                           int nz, float* z, float* kl, void* stream);
+int melgpt_vae_reparam_bwd(const float* stats, const float* eps, const float* dz, const float* dkl, int B, int ns,
+                           int nz, float* dstats, void* stream);
 int melgpt_sum_f32(const float* in, long long n, float scale, float* out, int accumulate, void* stream);
 /* y = keep(x)/(1-p) with the same Philox mask an epilogue used for element i of a contiguous tensor */
 int melgpt_dropout_apply(const void* x, void* y, long long n, float drop_p, unsigned long long seed,

@@ -47,7 +47,11 @@ _PROTOS = {
     "melgpt_embed_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _l, _i, _i, _p, _i, _f, _u64, C.c_uint, _p],
     "melgpt_embed_bwd": [_p, _p, _l, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _f, _u64, C.c_uint, _p],
     "melgpt_cross_entropy_fwd": [_p, _l, _p, _l, _i, _p, _p, _p],
-    "melgpt_cross_entropy_bwd": [_p, _l, _p, _p, _p, _p, _f, _l, _i, _p, _l, _i, _p],
+    "melgpt_cross_entropy_bwd": [_p, _l, _p, _p, _p, _i, _p, _f, _l, _i, _p, _l, _i, _p],
+    "melgpt_group_sum_f32": [_p, _l, _i, _f, _p, _p],
+    "melgpt_sample_logits": [_p, _l, _i, _i, _f, _i, _i, _u64, C.c_uint, _p, _p, _p],
+    "melgpt_vae_reparam_fwd": [_p, _p, _i, _u64, _i, _i, _i, _p, _p, _p],
+    "melgpt_vae_reparam_bwd": [_p, _p, _p, _p, _i, _i, _i, _p, _p],
     "melgpt_sum_f32": [_p, _l, _f, _p, _i, _p],
     "melgpt_dropout_apply": [_p, _p, _l, _f, _u64, C.c_uint, _i, _p],
     "melgpt_cast": [_p, _i, _p, _i, _l, _p],
@@ -63,6 +67,8 @@ _PROTOS = {
     "melgpt_codes_permute": [_p, _p, _i, _i, _i, _i, _p],
     "melgpt_onehot_rows": [_p, _l, _i, _i, _i, _i, _p, _i, _p],
     "melgpt_reduce_rows": [_p, _i, _l, _l, _p, _i, _f, _p],
+    "melgpt_mel_frontend_fwd": [_p, _i, _l, _i, _i, _p, _p, _p, _i, _f, _f, _f, _f, _f, _f, _f, _p, _i, _p, _i, _i, _i,
+                                _p],
 }
 _RESTYPE = {"melgpt_strerror": C.c_char_p}
 

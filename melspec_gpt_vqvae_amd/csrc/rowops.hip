@@ -410,14 +410,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, long long ld,
                                                      const long long* __restrict__ target,
                                                      const float* __restrict__ lse, const float* __restrict__ g_rows,
-                                                     const float* __restrict__ g_scalar, float g_scale, long long M,
-                                                     int V, T* __restrict__ dlogits, long long ldd) {
+                                                     int g_group, const float* __restrict__ g_scalar, float g_scale,
+                                                     long long M, int V, T* __restrict__ dlogits, long long ldd) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const float* lr = logits + row * ld;
   const float l = lse[row];
-  const float g = (g_rows ? g_rows[row] : 1.f) * (g_scalar ? *g_scalar : 1.f) * g_scale;
+  const float g = (g_rows ? g_rows[row / g_group] : 1.f) * (g_scalar ? *g_scalar : 1.f) * g_scale;
   const long long tg = target[row];
   for (int c = lane; c < V; c += 64) {
     float p = __expf(lr[c] - l) - (c == tg ? 1.f : 0.f);
@@ -540,6 +540,157 @@ __global__ void onehot_rows_kernel(const long long* __restrict__ idx, long long 
     const bool one = tt >= n_pre && idx[b * idx_ld + (tt - n_pre)] == v;
     Elem<T>::st(out + i, one ? 1.f : 0.f);
   }
+}
+
+// out[r] = scale * sum_{j<n} in[r*n + j]   (one wave per group; per-sequence sums of the per-token losses)
+__global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict__ in, long long R, int n, float scale,
+                                                        float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  float s = 0.f;
+  for (int j = lane; j < n; j += 64) s += in[r * n + j];
+  s = wave_sum(s);
+  if (lane == 0) out[r] = s * scale;
+}
+
+// one decoding step of Lit_minGPT.sample / GPTDecoder.sample (minGPT.py:345-358, decoders.py:108-121):
+// logits/temperature -> optional top-k filter (values below the k-th largest -> -inf, ties kept) -> softmax ->
+// argmax (sample = 0) or one multinomial draw by inverse CDF with a Philox uniform.  One workgroup per row, V <= 1024.
+__global__ __launch_bounds__(256) void sample_logits_kernel(const float* __restrict__ logits, long long ld, int V,
+                                                            float temperature, int top_k, int do_sample,
+                                                            unsigned long long seed, unsigned step,
+                                                            long long* __restrict__ out, float* __restrict__ probs_out) {
+  __shared__ float v[1024], srt[1024], red[256];
+  __shared__ int redi[256];
+  const int t = threadIdx.x, row = blockIdx.x;
+  const float NEG = -__builtin_inff();
+  for (int i = t; i < 1024; i += 256) {
+    float x = i < V ? logits[(long long)row * ld + i] / temperature : NEG;
+    v[i] = x;
+    srt[i] = x;
+  }
+  __syncthreads();
+  if (top_k > 0 && top_k < V) {
+    for (int k = 2; k <= 1024; k <<= 1)          // bitonic sort, descending
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = t; i < 1024; i += 256) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const bool up = (i & k) == 0;
+            const float a = srt[i], b = srt[ixj];
+            if (up ? (a < b) : (a > b)) { srt[i] = b; srt[ixj] = a; }
+          }
+        }
+        __syncthreads();
+      }
+    const float thr = srt[top_k - 1];
+    for (int i = t; i < V; i += 256)
+      if (v[i] < thr) v[i] = NEG;
+    __syncthreads();
+  }
+  // max / argmax (lowest index on ties)
+  float m = NEG;
+  int mi = 0x7fffffff;
+  for (int i = t; i < V; i += 256)
+    if (v[i] > m) { m = v[i]; mi = i; }
+  red[t] = m; redi[t] = mi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) {
+      if (red[t + o] > red[t] || (red[t + o] == red[t] && redi[t + o] < redi[t])) { red[t] = red[t + o]; redi[t] = redi[t + o]; }
+    }
+    __syncthreads();
+  }
+  const float mx = red[0];
+  const int amax = redi[0];
+  __syncthreads();
+  float l = 0.f;
+  for (int i = t; i < V; i += 256) {
+    const float e = __expf(v[i] - mx);
+    v[i] = e;
+    l += e;
+  }
+  red[t] = l;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] += red[t + o];
+    __syncthreads();
+  }
+  const float total = red[0];
+  if (probs_out)
+    for (int i = t; i < V; i += 256) probs_out[(long long)row * V + i] = v[i] / total;
+  if (t == 0) {
+    int pick = amax;
+    if (do_sample) {
+      Philox4 r = philox4x32_10(seed, ((unsigned long long)step << 32) | (unsigned)row, 0x5A3Du);
+      const float u = ((r.x >> 8) + 0.5f) * (1.0f / 16777216.0f) * total;
+      float c = 0.f;
+      pick = V - 1;
+      for (int i = 0; i < V; ++i) {
+        c += v[i];
+        if (c >= u && v[i] > 0.f) { pick = i; break; }
+      }
+    }
+    out[row] = pick;
+  }
+}
+
+// GPTEncoder.reparameterize + KL (encoders.py:62-104): stats (B, 2*nz) f32 = [mu | logvar] (the last position's
+// logits); z[b,s,:] = mu + eps[b,s,:]*exp(logvar/2); KL[b] = 0.5*sum(mu^2 + exp(logvar) - logvar - 1).
+// eps is given (tests) or drawn in-kernel from Philox + Box-Muller (and written out for the backward).
+__global__ __launch_bounds__(256) void vae_reparam_fwd_kernel(const float* __restrict__ stats, float* __restrict__ eps,
+                                                              int gen_eps, unsigned long long seed, int B, int ns,
+                                                              int nz, float* __restrict__ z, float* __restrict__ kl) {
+  __shared__ float sh[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* mu = stats + (long long)b * 2 * nz;
+  const float* lv = mu + nz;
+  float acc = 0.f;
+  for (int c = t; c < nz; c += 256) {
+    const float m = mu[c], l = lv[c], sd = __expf(0.5f * l);
+    acc += m * m + __expf(l) - l - 1.0f;
+    for (int s = 0; s < ns; ++s) {
+      const long long o = ((long long)b * ns + s) * nz + c;
+      float e;
+      if (gen_eps) {
+        Philox4 r = philox4x32_10(seed, (unsigned long long)o, 0x7AE5u);
+        const float u1 = ((r.x >> 8) + 1.0f) * (1.0f / 16777217.0f), u2 = (r.y >> 8) * (1.0f / 16777216.0f);
+        e = sqrtf(-2.0f * __logf(u1)) * cospif(2.0f * u2);
+        eps[o] = e;
+      } else {
+        e = eps[o];
+      }
+      z[o] = m + e * sd;
+    }
+  }
+  sh[t] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) sh[t] += sh[t + o];
+    __syncthreads();
+  }
+  if (t == 0) kl[b] = 0.5f * sh[0];
+}
+
+// d stats from dz (B,ns,nz) and dKL (B):  dmu = sum_s dz + dKL*mu ;  dlogvar = sum_s dz*eps*sd/2 + dKL*(exp(lv)-1)/2
+__global__ void vae_reparam_bwd_kernel(const float* __restrict__ stats, const float* __restrict__ eps,
+                                       const float* __restrict__ dz, const float* __restrict__ dkl, int B, int ns, int nz,
+                                       float* __restrict__ dstats) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * nz) return;
+  const int b = (int)(i / nz), c = (int)(i % nz);
+  const float m = stats[(long long)b * 2 * nz + c], l = stats[(long long)b * 2 * nz + nz + c];
+  const float sd = __expf(0.5f * l), g = dkl ? dkl[b] : 0.f;
+  float dm = g * m, dl = g * 0.5f * (__expf(l) - 1.0f);
+  if (dz)
+    for (int s = 0; s < ns; ++s) {
+      const long long o = ((long long)b * ns + s) * nz + c;
+      dm += dz[o];
+      dl += dz[o] * eps[o] * sd * 0.5f;
+    }
+  dstats[(long long)b * 2 * nz + c] = dm;
+  dstats[(long long)b * 2 * nz + nz + c] = dl;
 }
 
 inline int grid_for(long long work_items, int per_block, int cap = 8192) {
@@ -676,12 +827,12 @@ extern "C" int melgpt_cross_entropy_fwd(const float* logits, long long ld, const
 }
 
 extern "C" int melgpt_cross_entropy_bwd(const float* logits, long long ld, const long long* target, const float* lse,
-                                        const float* g_rows, const float* g_scalar, float g_scale, long long M, int V,
-                                        void* dlogits, long long ldd, int dtype, void* stream) {
-  MELGPT_CHECK(logits && target && lse && dlogits && M > 0 && V > 0, MELGPT_ERR_BAD_ARG);
+                                        const float* g_rows, int g_group, const float* g_scalar, float g_scale,
+                                        long long M, int V, void* dlogits, long long ldd, int dtype, void* stream) {
+  MELGPT_CHECK(logits && target && lse && dlogits && M > 0 && V > 0 && g_group >= 1, MELGPT_ERR_BAD_ARG);
   DISPATCH_T(dtype, hipLaunchKernelGGL(ce_bwd_kernel<T>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0,
-                                       (hipStream_t)stream, logits, ld, target, lse, g_rows, g_scalar, g_scale, M, V,
-                                       (T*)dlogits, ldd));
+                                       (hipStream_t)stream, logits, ld, target, lse, g_rows, g_group, g_scalar, g_scale,
+                                       M, V, (T*)dlogits, ldd));
   return melgpt_launch_status();
 }
 
@@ -759,5 +910,39 @@ extern "C" int melgpt_reduce_rows(const float* partials, int R, long long ld, lo
   MELGPT_CHECK(partials && out && R > 0 && ncols > 0 && ld >= ncols, MELGPT_ERR_BAD_ARG);
   hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
                      partials, R, ld, ncols, out, accumulate, scale);
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_group_sum_f32(const float* in, long long groups, int n, float scale, float* out, void* stream) {
+  MELGPT_CHECK(in && out && groups > 0 && n > 0, MELGPT_ERR_BAD_ARG);
+  hipLaunchKernelGGL(group_sum_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, groups,
+                     n, scale, out);
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_sample_logits(const float* logits, long long ld, int rows, int V, float temperature, int top_k,
+                                    int do_sample, unsigned long long seed, unsigned step, long long* out,
+                                    float* probs_out, void* stream) {
+  MELGPT_CHECK(logits && out && rows > 0 && V > 0 && ld >= V && temperature > 0.f, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(V <= 1024, MELGPT_ERR_UNSUPPORTED);
+  hipLaunchKernelGGL(sample_logits_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ld, V, temperature,
+                     top_k, do_sample, seed, step, out, probs_out);
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_vae_reparam_fwd(const float* stats, float* eps, int gen_eps, unsigned long long seed, int B, int ns,
+                                      int nz, float* z, float* kl, void* stream) {
+  MELGPT_CHECK(stats && eps && z && kl && B > 0 && ns > 0 && nz > 0, MELGPT_ERR_BAD_ARG);
+  hipLaunchKernelGGL(vae_reparam_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, stats, eps, gen_eps, seed, B, ns,
+                     nz, z, kl);
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_vae_reparam_bwd(const float* stats, const float* eps, const float* dz, const float* dkl, int B,
+                                      int ns, int nz, float* dstats, void* stream) {
+  MELGPT_CHECK(stats && eps && dstats && B > 0 && ns > 0 && nz > 0, MELGPT_ERR_BAD_ARG);
+  const long long n = (long long)B * nz;
+  hipLaunchKernelGGL(vae_reparam_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, stats,
+                     eps, dz, dkl, B, ns, nz, dstats);
   return melgpt_launch_status();
 }

@@ -260,13 +260,33 @@ def cross_entropy_fwd(logits, target):
     return loss, lse
 
 
-def cross_entropy_bwd(logits, target, lse, *, g_rows=None, g_scalar=None, g_scale=1.0, dtype=torch.float32):
+def cross_entropy_bwd(logits, target, lse, *, g_rows=None, g_group=1, g_scalar=None, g_scale=1.0, dtype=torch.float32):
     M, V = logits.shape
     target = target.reshape(-1).contiguous()
     d = torch.empty(M, V, dtype=dtype, device=logits.device)
-    call("melgpt_cross_entropy_bwd", ptr(logits), logits.stride(0), ptr(target), ptr(lse), ptr(g_rows), ptr(g_scalar),
-         float(g_scale), M, V, ptr(d), V, dtype_code(dtype), stream())
+    call("melgpt_cross_entropy_bwd", ptr(logits), logits.stride(0), ptr(target), ptr(lse), ptr(g_rows), int(g_group),
+         ptr(g_scalar), float(g_scale), M, V, ptr(d), V, dtype_code(dtype), stream())
     return d
+
+
+def group_sum(x, n, scale=1.0):
+    """x (groups*n,) f32 -> (groups,) sums of consecutive runs of n."""
+    x = x.reshape(-1)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() % n == 0
+    out = torch.empty(x.numel() // n, dtype=torch.float32, device=x.device)
+    call("melgpt_group_sum_f32", ptr(x), x.numel() // n, n, float(scale), ptr(out), stream())
+    return out
+
+
+def sample_logits(logits, temperature=1.0, top_k=None, sample=False, seed=0, step=0, want_probs=False):
+    """logits (rows, V) f32 -> next-token ids (rows, 1) int64 (one step of the reference's sampling loops)."""
+    assert logits.dim() == 2 and logits.dtype == torch.float32 and logits.stride(1) == 1
+    rows, V = logits.shape
+    out = torch.empty(rows, 1, dtype=torch.int64, device=logits.device)
+    probs = torch.empty(rows, V, dtype=torch.float32, device=logits.device) if want_probs else None
+    call("melgpt_sample_logits", ptr(logits), logits.stride(0), rows, V, float(temperature), int(top_k or 0), int(sample),
+         int(seed), int(step), ptr(out), ptr(probs), stream())
+    return (out, probs) if want_probs else out
 
 
 def sum_f32(x, scale=1.0, out=None, accumulate=False):

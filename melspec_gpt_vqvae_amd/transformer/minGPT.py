@@ -507,3 +507,196 @@ class GPTClass(GPT):
     def forward(self, idx, token):
         logits, att = self._trunk(idx, pre_idx=token)
         return logits, None, att
+
+
+# ================================================================================================= per-sequence CE
+class _SequenceCEFn(torch.autograd.Function):
+    """per-token cross entropy summed per sequence = CrossEntropyLoss(reduction='none') + view + sum(-1)
+    (reference decoders.py:64-68).  logits (R*T, V) f32, target (R*T,) -> (R,)"""
+
+    @staticmethod
+    def forward(ctx, logits2d, target, T):
+        if not logits2d.is_contiguous():
+            logits2d = logits2d.contiguous()
+        loss_rows, lse = ops.cross_entropy_fwd(logits2d, target)
+        ctx.save_for_backward(logits2d, target, lse)
+        ctx.T = T
+        return ops.group_sum(loss_rows, T)
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, lse = ctx.saved_tensors
+        d = ops.cross_entropy_bwd(logits, target, lse, g_rows=g.float().contiguous().reshape(-1), g_group=ctx.T)
+        return d, None, None
+
+
+def sequence_cross_entropy(logits, target):
+    """logits (R, T, V), target (R, T) -> (R,) summed token NLL."""
+    _require_cuda(logits)
+    R, T, V = logits.shape
+    lg = logits.float() if logits.dtype != torch.float32 else logits
+    return _SequenceCEFn.apply(lg.reshape(R * T, V), target.reshape(-1), T)
+
+
+def decay_groups(module):
+    """The reference's AdamW grouping (minGPT.py:618-665, Lit_GPT_VAE.py:895-943): weights of nn.Linear decay,
+    every bias / LayerNorm weight / Embedding weight / pos_emb does not.  Returns (decay names, no_decay names),
+    sorted, and asserts the reference's partition invariants (:653-657)."""
+    decay, no_decay = set(), set()
+    for mn, m in module.named_modules():
+        for pn, p in m.named_parameters(recurse=False):
+            fpn = "%s.%s" % (mn, pn) if mn else pn
+            if pn.endswith("bias"):
+                no_decay.add(fpn)
+            elif pn.endswith("weight") and isinstance(m, nn.Linear):
+                decay.add(fpn)
+            elif pn.endswith("weight") and isinstance(m, (nn.LayerNorm, nn.Embedding)):
+                no_decay.add(fpn)
+            elif pn == "pos_emb":
+                no_decay.add(fpn)
+    param_dict = {pn: p for pn, p in module.named_parameters()}
+    inter, union = decay & no_decay, decay | no_decay
+    assert len(inter) == 0, "parameters %s made it into both decay/no_decay sets!" % (str(inter),)
+    assert len(param_dict.keys() - union) == 0, "parameters %s were not separated into either decay/no_decay set!" \
+        % (str(param_dict.keys() - union),)
+    return sorted(decay), sorted(no_decay)
+
+
+def make_adamw(module, learning_rate, weight_decay=0.01, betas=(0.9, 0.95)):
+    decay, no_decay = decay_groups(module)
+    pd = {pn: p for pn, p in module.named_parameters()}
+    groups = [{"params": [pd[pn] for pn in decay], "weight_decay": weight_decay},
+              {"params": [pd[pn] for pn in no_decay], "weight_decay": 0.0}]
+    return torch.optim.AdamW(groups, lr=learning_rate, betas=betas)
+
+
+# ================================================================================================== Lit_minGPT
+class Lit_minGPT(_LitBase):
+    """Host logic of the reference's LightningModule (minGPT.py:216-665): teacher-forced step, autoregressive
+    sampling, VQ-code ordering, optimizer grouping.  A pytorch_lightning.LightningModule when Lightning is
+    installed, else a plain nn.Module with the same methods.  Data loading (datasets/, :461-505) and the
+    TensorBoard image logging (:530-612) are outside the hot path; `datamodule_loader` is a hook."""
+
+    def __init__(self, args, ckpt_path=None, ignore_keys=[], first_stage_key="image", cond_stage_key="depth",
+                 downsample_cond_size=-1, pkeep=1.0):
+        super().__init__()
+        self.args = args
+        self.transformer = GPTClass(args)
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
+        self.first_stage_key = first_stage_key
+        self.cond_stage_key = cond_stage_key
+        self.downsample_cond_size = downsample_cond_size
+        self.pkeep = pkeep
+        self.datamodule_loader()
+        self.forward_shuffle_idx, self.backward_shuffle_idx = self.make_idx(5, 53)
+        if getattr(self.args, "reconstruct_spec", "") != "":
+            from ..vqvae.big_model_attn_gan import LitVQVAE
+
+            self.first_stage_model = LitVQVAE(num_embeddings=128, embedding_dim=256)
+            self.first_stage_model.load_state_dict(torch.load(self.args.reconstruct_spec))
+            self.first_stage_model.eval().to(self.args.device)
+
+    def datamodule_loader(self):
+        self.data = None
+
+    def init_from_ckpt(self, path, ignore_keys=list()):
+        sd = torch.load(path, map_location="cpu")["state_dict"]
+        for k in list(sd.keys()):
+            for ik in ignore_keys:
+                if k.startswith(ik):
+                    del sd[k]
+        self.load_state_dict(sd, strict=False)
+
+    def forward(self, x, c=None):
+        """reference :260-285: logits for p(z_i | z_<i, c); the target is the full sequence."""
+        logits, _, _ = self.transformer(x[:, :-1], c)
+        cond_size = c.size(-1)
+        return logits[:, cond_size - 1:], x
+
+    def top_k_logits(self, logits, k):
+        v, ix = torch.topk(logits, k)
+        out = logits.clone()
+        out[out < v[..., [-1]]] = -float('Inf')
+        return out
+
+    @torch.no_grad()
+    def sample(self, x, c, steps, temperature=1.0, sample=False, top_k=None, callback=lambda k: None):
+        """reference :293-360 (GPTClass branch): full re-forward per step; temperature / top-k / softmax /
+        multinomial-or-argmax run in one kernel (melgpt_sample_logits).  Returns (x, last attention on CPU)."""
+        block_size = self.transformer.get_block_size()
+        assert not self.transformer.training
+        if self.pkeep <= 0.0:
+            raise NotImplementedError('Implement for GPTClass')
+        seed = _Seeds.next()
+        att = None
+        for k in range(steps):
+            callback(k)
+            cond_size = c.size(-1)
+            assert x.size(1) + cond_size <= block_size
+            logits, _, att = self.transformer(x, c)
+            last = logits[:, -1, :]
+            ix = ops.sample_logits(last, temperature=temperature, top_k=top_k, sample=sample, seed=seed, step=k)
+            x = torch.cat((x, ix), dim=1)
+        return x, att.detach().cpu()
+
+    def get_x(self, batch):
+        """(B,5,53) codes -> (B,265) time-major (:387-394)."""
+        x = batch['codes'].to(self.args.device)
+        return ops.codes_permute(x, x.shape[1], x.shape[2])
+
+    def get_c(self, batch):
+        return batch["target"].unsqueeze(1).to(self.args.device)
+
+    def get_xc(self, batch, N=None):
+        x, c = self.get_x(batch), self.get_c(batch)
+        if N is not None:
+            x, c = x[:N], c[:N]
+        return x, c
+
+    def shared_step(self, batch, batch_idx):
+        x, c = self.get_xc(batch)
+        logits, target = self(x, c)
+        return cross_entropy(logits.reshape(-1, logits.size(-1)), target.reshape(-1))
+
+    def training_step(self, batch, batch_idx):
+        loss = self.shared_step(batch, batch_idx)
+        if pl is not None:
+            self.log("train/loss", loss, prog_bar=True, logger=True, on_step=True, on_epoch=True)
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        loss = self.shared_step(batch, batch_idx)
+        if pl is not None:
+            self.log("val/loss", loss, prog_bar=True, logger=True, on_step=True, on_epoch=True)
+        return loss
+
+    def make_idx(self, H, W):
+        idx = np.arange(H * W).reshape(H, W).T
+        idx = torch.tensor(idx.ravel())
+        return idx, torch.argsort(idx)
+
+    def code_reader(self, x, reverse=False):
+        """reference :438-456 for L == H*W: x (B,265) permuted by the forward / backward shuffle index."""
+        B, L = x.shape
+        assert L == len(self.forward_shuffle_idx), "only the 5x53 code grid is supported"
+        if x.is_cuda:
+            return ops.codes_permute(x, 5, 53, reverse=reverse)
+        return x[:, self.backward_shuffle_idx if reverse else self.forward_shuffle_idx]
+
+    @torch.no_grad()
+    def decode_to_img(self, index, zshape):
+        """reference :515-528: codes -> codebook entries -> VQ-VAE decoder."""
+        index = self.code_reader(index, reverse=True)
+        bhwc = (zshape[0], zshape[2], zshape[3], zshape[1])
+        quant_z = self.first_stage_model._vq_vae.get_codebook_entry(index.reshape(-1), shape=bhwc)
+        return self.first_stage_model.decode(quant_z)
+
+    def configure_optimizers(self):
+        return make_adamw(self, self.args.learning_rate)
+
+    def configure_fused_optimizer(self):
+        """MI355X-native alternative: one fused AdamW launch per weight-decay group over the flat store."""
+        from ..optim import FusedAdamW
+
+        return FusedAdamW(self.transformer, lr=self.args.learning_rate, betas=(0.9, 0.95), weight_decay=0.01)

@@ -1,0 +1,124 @@
+"""CPU-side checks of the host logic: checkpoint ABI (state_dict keys), initialisation, optimizer grouping, the
+no-CPU-fallback rule, and the data-parallel engine on 2 gloo processes.  No GPU, no compute through the C ABI."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import synth
+from util import golden
+
+
+def test_gptclass_checkpoint_abi_init_and_optimizer_groups():
+    from melspec_gpt_vqvae_amd._ffi import MelgptError
+    from melspec_gpt_vqvae_amd.transformer.minGPT import GPTClass, decay_groups
+
+    g = golden("gpt_optim_groups")
+    torch.manual_seed(0)
+    m = GPTClass(synth.gpt_args(n_layer=24, n_head=16, n_embd=1024))
+    assert list(m.state_dict().keys()) == [str(k) for k in g["keys"]], "state_dict keys / order are the checkpoint ABI"
+    assert sum(p.numel() for p in m.parameters()) == int(g["n_params"]) == 302854144
+    assert m.blocks[0].attn.mask.shape == (1, 1, 266, 266) and m.get_block_size() == 266
+    decay, no_decay = decay_groups(m)
+    assert decay == [str(s) for s in g["decay"]] and no_decay == [str(s) for s in g["no_decay"]]
+    assert len(decay) == 145 and len(no_decay) == 245
+    # reference init: N(0, 0.02) Linear/Embedding, zero biases, unit LayerNorm; embedder keeps N(0, 1)
+    assert abs(float(m.tok_emb.weight.std()) - 0.02) < 1e-3 and abs(float(m.embedder.weight.std()) - 1.0) < 0.05
+    assert float(m.blocks[3].mlp[0].bias.abs().max()) == 0.0 and float(m.ln_f.weight.min()) == 1.0
+    assert float(m.pos_emb.abs().max()) == 0.0
+    with pytest.raises(MelgptError):
+        m(torch.zeros(1, 264, dtype=torch.int64), torch.zeros(1, 1, dtype=torch.int64))
+    with pytest.raises(AssertionError):
+        from melspec_gpt_vqvae_amd.transformer.minGPT import CausalSelfAttention, GPTConfig
+
+        CausalSelfAttention(GPTConfig(128, 266, n_embd=100, n_head=16, attn_pdrop=0, resid_pdrop=0))
+
+
+def test_vqvae_checkpoint_abi():
+    from melspec_gpt_vqvae_amd.vqvae.big_model_attn_gan import LitVQVAE
+
+    g = golden("vqvae_full")
+    m = LitVQVAE(num_embeddings=128, embedding_dim=256)
+    keys = list(m.state_dict().keys())
+    assert keys == [str(k) for k in g["sd_keys"]]
+    assert sum(1 for k in keys if k.startswith("discriminator.")) == 22
+    assert m._vq_vae._embedding.weight.shape == (128, 256)
+    assert float(m._vq_vae._embedding.weight.abs().max()) <= 1.0 / 128 + 1e-9
+    assert sum(p.numel() for p in m._encoder.parameters()) > 29000000
+
+
+def test_gpt_vae_structure():
+    from melspec_gpt_vqvae_amd.transformer.Lit_GPT_VAE import GPT_VAE
+
+    a = synth.gpt_args(n_layer=2, n_head=4, n_embd=256, block_size=265, fix_var=0, kl_start=0.1, warm_up=10,
+                       batch_size=4, target_kl=8.0, beta=1.0, nsamples=1, fb=0, device="cpu", learning_rate=1e-6,
+                       len_train_data=400)
+    v = GPT_VAE(a)
+    assert v.encoder.transformer.head.weight.shape == (512, 256)           # last_linear = 2C
+    assert v.encoder.transformer.blocks[0].attn.n_unmasked == 265          # fully visible
+    assert v.decoder.transformer.get_block_size() == 266                   # block_size + 1
+    assert abs(v.anneal_rate - (1 - 0.1) / (10 * 100)) < 1e-12
+    keys = list(v.state_dict().keys())
+    assert "encoder.transformer.blocks.1.attn.key.weight" in keys and "decoder.transformer.pos_emb" in keys
+    opt = v.GPT_configure_optimizers()
+    assert len(opt.param_groups) == 2
+
+
+def test_distributed_shard_is_the_distributed_sampler_rule():
+    from torch.utils.data.distributed import DistributedSampler
+
+    from melspec_gpt_vqvae_amd.dp import distributed_shard
+
+    for n, world in ((11773, 8), (768, 8), (10, 4), (7, 2)):
+        for rank in range(world):
+            for epoch in (0, 3):
+                s = DistributedSampler(range(n), num_replicas=world, rank=rank, shuffle=True, seed=5)
+                s.set_epoch(epoch)
+                assert list(s) == distributed_shard(n, rank, world, seed=5, epoch=epoch)
+            s = DistributedSampler(range(n), num_replicas=world, rank=rank, shuffle=False, drop_last=True)
+            assert list(s) == distributed_shard(n, rank, world, shuffle=False, drop_last=True)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from melspec_gpt_vqvae_amd.dp import GradientExchange
+
+    n = 100_003
+    g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    ex = GradientExchange(g, max_bucket_elems=4096)
+    # two "blocks" announce their slices early and out of order; finish() covers the rest exactly once
+    ex.launch(50_000, 70_000)
+    ex.launch(1_000, 9_000)
+    ex.finish()
+    expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    ok = torch.equal(g, expect)
+    # a second step reuses the engine
+    g.copy_(torch.ones(n) * (rank + 1))
+    ex.finish()
+    ok = ok and torch.equal(g, torch.ones(n) * sum(r + 1 for r in range(world)))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_two_process_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
