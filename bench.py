@@ -206,7 +206,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -243,6 +243,9 @@ def main():
             out["config"]["INVALID_debug_layers"] = a.layers
         if a.breakdown:
             print({k: round(1e3 * v / a.steps, 2) for k, v in phases.items()}, file=sys.stderr)
+            for tag, n, ms, fl in timer.by_tag()[:40]:
+                print(f"  {tag:44s} n/step={n / a.steps:6.1f} ms/step={ms / a.steps:8.3f} "
+                      f"TFLOP/s={fl / ms / 1e9 if ms > 0 else 0:7.1f}", file=sys.stderr)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -71,7 +71,42 @@ __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned b
   return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
 
-// ---------------------------------------------------------------- Philox4x32-10 (counter-based dropout masks)
+// ---------------------------------------------------------------- counter-based dropout masks
+// Stateless: the keep decision of an element is a pure function of (seed, stream id, counter), so the backward
+// kernels regenerate the forward's mask instead of storing it.  One call yields FOUR 16-bit uniforms (for 4
+// consecutive elements) from two rounds of a 3-multiply avalanche hash ("triple32", bias < 2^-30 per output bit)
+// over the 64-bit counter mixed with the key - ~25 integer ops per 4 decisions.  (A Philox4x32-10 call costs ~100;
+// at one call per 4 attention probabilities / GEMM outputs it was the largest VALU cost of both kernels.)
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+  x ^= x >> 17; x *= 0xed5ad4bbu;
+  x ^= x >> 11; x *= 0xac4c1b51u;
+  x ^= x >> 15; x *= 0x31848babu;
+  x ^= x >> 14;
+  return x;
+}
+struct Rand4x16 {
+  unsigned a, b;  // four 16-bit lanes: a.lo, a.hi, b.lo, b.hi
+};
+__device__ __forceinline__ Rand4x16 rand4x16(unsigned long long seed, unsigned stream_id, unsigned long long ctr) {
+  const unsigned k0 = (unsigned)seed ^ (stream_id * 0x9E3779B9u), k1 = (unsigned)(seed >> 32) + stream_id;
+  const unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32);
+  const unsigned h = hash32(c0 ^ k0) + c1 * 0x85EBCA6Bu;
+  Rand4x16 r;
+  r.a = hash32(h ^ k1);
+  r.b = hash32(r.a + 0x6A09E667u + k0);
+  return r;
+}
+// keep-mask for 4 consecutive elements whose first linear index is 4*q: bit i set = element kept.
+// `thresh` = round(p_drop * 2^32) (kept for ABI stability); compared on its top 16 bits: p is honoured to 2^-16.
+__device__ __forceinline__ unsigned dropout_keep4(unsigned long long seed, unsigned stream_id,
+                                                  unsigned long long q, unsigned thresh) {
+  const Rand4x16 r = rand4x16(seed, stream_id, q);
+  const unsigned t16 = thresh >> 16;
+  return ((r.a & 0xFFFFu) >= t16 ? 1u : 0u) | ((r.a >> 16) >= t16 ? 2u : 0u) | ((r.b & 0xFFFFu) >= t16 ? 4u : 0u) |
+         ((r.b >> 16) >= t16 ? 8u : 0u);
+}
+
+// ---------------------------------------------------------------- Philox4x32-10 (sampling / reparameterisation draws)
 struct Philox4 {
   unsigned x, y, z, w;
 };
@@ -91,12 +126,4 @@ __device__ __forceinline__ Philox4 philox4x32_10(unsigned long long seed, unsign
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
   return Philox4{c0, c1, c2, c3};
-}
-// keep-mask for 4 consecutive elements whose first linear index is 4*q: bit i set = element kept.
-// `thresh` = round(p_drop * 2^32) clamped; element kept iff random >= thresh.
-__device__ __forceinline__ unsigned dropout_keep4(unsigned long long seed, unsigned stream_id,
-                                                  unsigned long long q, unsigned thresh) {
-  Philox4 r = philox4x32_10(seed, q, stream_id);
-  return (r.x >= thresh ? 1u : 0u) | (r.y >= thresh ? 2u : 0u) | (r.z >= thresh ? 4u : 0u) |
-         (r.w >= thresh ? 8u : 0u);
 }

@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  epilogue<T, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, bz, lane);
+  // the last K step ended with a barrier: every wave is done with the operand tiles, LDS can be reused
+  epilogue<T, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, bz, lane, smem + w * 4096);
 }
 
 template <typename T, int ALAY, int BLAY>
@@ -289,6 +290,12 @@ extern "C" int melgpt_gemm(const void* A, int a_kmajor, long long lda, long long
   p.a_bytes = (unsigned)(((a_rows - 1) * lda + a_cols) * es);
   p.b_bytes = (unsigned)(((b_rows - 1) * ldb + b_cols) * es);
   p.out_f32 = out_f32; p.accumulate = accumulate; p.act = act; p.alpha = alpha;
+  {
+    const int oes = (out_f32 || dtype == MELGPT_F32) ? 4 : 2;
+    const bool c_ok = (ldc * oes) % 16 == 0 && (strideC * oes) % 16 == 0 && N % (16 / oes) == 0;
+    const bool r_ok = !R || ((ldr * es) % 16 == 0 && (strideR * es) % 16 == 0 && N % vec == 0);
+    p.vec_io = c_ok && r_ok;
+  }
   if (drop_p > 0.f) {
     p.drop_scale = 1.0f / (1.0f - drop_p);
     double th = (double)drop_p * 4294967296.0;
@@ -329,6 +336,7 @@ extern "C" int melgpt_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, c
   p.a_bytes = (unsigned)in_bytes;
   p.b_bytes = (unsigned)((long long)Cout * p.K * es);
   p.alpha = 1.0f;
+  p.vec_io = (Cout * es) % 16 == 0;
   p.cH = H; p.cW = W; p.cC = Cin; p.OH = OH; p.OW = OW; p.cstride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
   p.ups = upsample; p.KW = KW;
   hipStream_t s = (hipStream_t)stream;

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm256_kernel(GemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  epilogue<bf16_t, TM, TN>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, bz, lane);
+  epilogue<bf16_t, TM, TN>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, bz, lane, smem + w * 4096);
 }
 
 template <int ALAY, int BLAY, int WM, int WN, int TM, int TN>

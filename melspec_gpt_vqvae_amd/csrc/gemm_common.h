@@ -1,6 +1,8 @@
 // Shared between the two MFMA GEMM kernels (gemm.hip: 128x128 register-staged, both numerics lanes;
 // gemm256.hip: 256-wide LDS-DMA staged, bf16 lane): parameters, LDS swizzles, fused epilogue.
 #pragma once
+#include <type_traits>
+
 #include "mma.h"
 
 namespace gemmk {
@@ -19,6 +21,7 @@ struct GemmParams {
   long long sA, sB, sC, sR;  // batch strides (elements)
   unsigned a_bytes, b_bytes;  // addressable bytes of ONE batch of A / B (loads beyond return 0)
   int out_f32, accumulate, act;
+  int vec_io;  // C / C2 / R rows are 16-byte aligned -> staged row-contiguous epilogue
   float alpha;
   float drop_scale;  // 1/(1-p), or 0 when dropout is off
   unsigned drop_thresh;
@@ -30,11 +33,31 @@ struct GemmParams {
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (nn.GELU(), minGPT.py:102) and its derivative.  erf by Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7, i.e. below f32 rounding of the result) sharing ONE exponential between the cdf and the pdf:
+//   erf(u) = 1 - (a1 t + ... + a5 t^5) exp(-u^2),  t = 1/(1 + p|u|),  u = x/sqrt(2)  =>  exp(-u^2) = exp(-x^2/2)
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf_times_x) {
+  const float u = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+  const float e = __expf(-0.5f * x * x);
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float erf_abs = 1.0f - poly * t * e;            // erf(|u|)
+  const float half_erf = 0.5f * erf_abs;
+  cdf = x >= 0.f ? 0.5f + half_erf : 0.5f - half_erf;   // Phi(x)
+  pdf_times_x = x * 0.39894228040143267794f * e;        // x * phi(x)
+}
+__device__ __forceinline__ float gelu_exact(float x) {
+  float cdf, xp;
+  gelu_parts(x, cdf, xp);
+  return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad(float x) {
-  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float cdf, xp;
+  gelu_parts(x, cdf, xp);
+  return cdf + xp;
 }
 
 // 128-byte rows, 16-byte chunk index XOR-ed with (row>>1)&7: conflict-free ds_read_b128 fragment reads
@@ -48,53 +71,161 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 
 // Fused epilogue for a wave that owns TM x TN accumulator tiles of 16x16 (rows = n, cols = m, see gemm.hip):
 // lane (i16, g) holds C[m_base + 16 mt + i16][n_base + 16 nt + 4 g + 0..3].
+//
+// Global traffic goes through a 4 KiB per-wave LDS staging block, one 16-row slab (one `mt`) at a time, so that
+// every global access is a 16-byte piece of a full, contiguous output row (128..256 B per row per instruction)
+// instead of 8-byte pieces scattered over 16 rows:
+//   R / old C : coalesced 16-byte loads (all issued up front) -> LDS -> read back in accumulator layout
+//   C2, C     : accumulator layout -> LDS -> 16-byte row pieces -> global
+// LDS rows are XOR-swizzled by (row & 7) on the 16-byte chunk index.  Requires 16-byte aligned rows (host flag
+// p.vec_io); otherwise the direct per-lane path below is used.
+template <int ROWB>
+__device__ __forceinline__ int stage_off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
+
 template <typename T, int TM, int TN>
 __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[TM][TN], int m_base, int n_base, int bz,
-                                         int lane) {
+                                         int lane, char* stage) {
   constexpr int ES = Tr<T>::ES;
+  using RV = typename std::conditional<ES == 4, f32x4, u32x2>::type;  // one 4-element group of R / C in dtype T
   const int i16 = lane & 15, g = lane >> 4;
-  char* Cb = (char*)p.C + (long long)bz * p.sC * (p.out_f32 ? 4 : ES);
-  char* C2b = p.C2 ? (char*)p.C2 + (long long)bz * p.sC * (p.out_f32 ? 4 : ES) : nullptr;
+  const bool f32out = p.out_f32 || ES == 4;
+  char* Cb = (char*)p.C + (long long)bz * p.sC * (f32out ? 4 : ES);
+  char* C2b = p.C2 ? (char*)p.C2 + (long long)bz * p.sC * (f32out ? 4 : ES) : nullptr;
   const char* Rb = p.R ? (const char*)p.R + (long long)bz * p.sR * ES : nullptr;
+
+  f32x4 bv[TN];
+#pragma clang loop unroll(full)
+  for (int nt = 0; nt < TN; ++nt) {
+    const int n = n_base + nt * 16 + g * 4;
+    bv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n < p.N) bv[nt] = *(const f32x4*)(p.bias + n);
+  }
+  auto unpack = [](RV r) -> f32x4 {
+    if constexpr (ES == 4) return r;
+    else return f32x4{bf16lo(r[0]), bf16hi(r[0]), bf16lo(r[1]), bf16hi(r[1])};
+  };
+  auto math = [&](f32x4 v, f32x4 r4, int m, int n, bool has_r) -> f32x4 {
+    if (p.act == MELGPT_ACT_GELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
+    } else if (p.act == MELGPT_ACT_GELU_GRAD) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= gelu_grad(r4[e]);
+    }
+    if (p.drop_scale != 0.f) {
+      const unsigned long long e0 = ((unsigned long long)bz * p.M + m) * (unsigned long long)p.N + n;
+      const unsigned keep = dropout_keep4(p.seed, p.stream_id, e0 >> 2, p.drop_thresh);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (keep >> e & 1) ? v[e] * p.drop_scale : 0.f;
+    }
+    if (has_r && p.act != MELGPT_ACT_GELU_GRAD) v += r4;
+    return v;
+  };
+
+  if (p.vec_io) {
+    // ------------------------------------------------------------------ staged, row-contiguous path
+    constexpr int IN_ROWB = TN * 16 * ES, IN_CPR = IN_ROWB / 16, IN_PER = (16 * IN_CPR) / 64;  // chunks / lane / slab
+    u32x4 rin[TM][IN_PER > 0 ? IN_PER : 1];
+    if (Rb) {
+#pragma clang loop unroll(full)
+      for (int mt = 0; mt < TM; ++mt)
+#pragma clang loop unroll(full)
+        for (int j = 0; j < IN_PER; ++j) {
+          const int q = lane + 64 * j, row = q / IN_CPR, ch = q % IN_CPR;
+          const int m = m_base + mt * 16 + row, n = n_base + ch * (16 / ES);
+          rin[mt][j] = u32x4{0u, 0u, 0u, 0u};
+          if (m < p.M && n < p.N) rin[mt][j] = *(const u32x4*)(Rb + ((long long)m * p.ldr + n) * ES);
+        }
+    }
+#pragma clang loop unroll(full)
+    for (int mt = 0; mt < TM; ++mt) {
+      const int m = m_base + mt * 16 + i16;
+      f32x4 r4[TN];
+      if (Rb) {
+#pragma clang loop unroll(full)
+        for (int j = 0; j < IN_PER; ++j) {
+          const int q = lane + 64 * j;
+          *(u32x4*)(stage + stage_off<IN_ROWB>(q / IN_CPR, q % IN_CPR)) = rin[mt][j];
+        }
+#pragma clang loop unroll(full)
+        for (int nt = 0; nt < TN; ++nt) {
+          if constexpr (ES == 4) r4[nt] = *(const f32x4*)(stage + stage_off<IN_ROWB>(i16, 4 * nt + g));
+          else r4[nt] = unpack(*(const u32x2*)(stage + stage_off<IN_ROWB>(i16, 2 * nt + (g >> 1)) + (g & 1) * 8));
+        }
+      }
+      // one or two outputs, each staged and written as full rows
+#pragma clang loop unroll(full)
+      for (int pass = 0; pass < 2; ++pass) {
+        char* Ob = pass == 0 ? C2b : Cb;
+        if (!Ob) continue;
+        if (f32out) {
+          constexpr int ROWB = TN * 64, CPR = ROWB / 16, PER = (16 * CPR) / 64;
+#pragma clang loop unroll(full)
+          for (int nt = 0; nt < TN; ++nt) {
+            f32x4 v = acc[mt][nt] * p.alpha + bv[nt];
+            if (pass == 1) v = math(v, Rb ? r4[nt] : v, m, n_base + nt * 16 + g * 4, Rb != nullptr);
+            *(f32x4*)(stage + stage_off<ROWB>(i16, 4 * nt + g)) = v;
+          }
+#pragma clang loop unroll(full)
+          for (int j = 0; j < PER; ++j) {
+            const int q = lane + 64 * j, row = q / CPR, ch = q % CPR;
+            const int mm = m_base + mt * 16 + row, nn = n_base + ch * 4;
+            if (mm < p.M && nn < p.N) {
+              f32x4 o = *(const f32x4*)(stage + stage_off<ROWB>(row, ch));
+              float* dst = (float*)(Ob + ((long long)mm * p.ldc + nn) * 4);
+              if (pass == 1 && p.accumulate) o += *(const f32x4*)dst;
+              *(f32x4*)dst = o;
+            }
+          }
+        } else {
+          constexpr int ROWB = TN * 32, CPR = ROWB / 16, PER = (16 * CPR) / 64;
+#pragma clang loop unroll(full)
+          for (int nt = 0; nt < TN; ++nt) {
+            f32x4 v = acc[mt][nt] * p.alpha + bv[nt];
+            if (pass == 1) v = math(v, Rb ? r4[nt] : v, m, n_base + nt * 16 + g * 4, Rb != nullptr);
+            *(u32x2*)(stage + stage_off<ROWB>(i16, 2 * nt + (g >> 1)) + (g & 1) * 8) =
+                u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          }
+#pragma clang loop unroll(full)
+          for (int j = 0; j < PER; ++j) {
+            const int q = lane + 64 * j, row = q / CPR, ch = q % CPR;
+            const int mm = m_base + mt * 16 + row, nn = n_base + ch * 8;
+            if (mm < p.M && nn < p.N) {
+              u32x4 o = *(const u32x4*)(stage + stage_off<ROWB>(row, ch));
+              u32x4* dst = (u32x4*)(Ob + ((long long)mm * p.ldc + nn) * 2);
+              if (pass == 1 && p.accumulate) {
+                const u32x4 c = *dst;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  o[e] = pack_bf16x2(bf16lo(o[e]) + bf16lo(c[e]), bf16hi(o[e]) + bf16hi(c[e]));
+              }
+              *dst = o;
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------------- direct per-lane path (unaligned rows)
 #pragma clang loop unroll(full)
   for (int nt = 0; nt < TN; ++nt) {
     const int n = n_base + nt * 16 + g * 4;
     if (n >= p.N) continue;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bv = *(const f32x4*)(p.bias + n);
 #pragma clang loop unroll(full)
     for (int mt = 0; mt < TM; ++mt) {
       const int m = m_base + mt * 16 + i16;
       if (m >= p.M) continue;
-      f32x4 v = acc[mt][nt] * p.alpha + bv;
+      f32x4 v = acc[mt][nt] * p.alpha + bv[nt];
       if (C2b) {
-        if (p.out_f32 || ES == 4) *(f32x4*)(C2b + ((long long)m * p.ldc + n) * 4) = v;
+        if (f32out) *(f32x4*)(C2b + ((long long)m * p.ldc + n) * 4) = v;
         else *(u32x2*)(C2b + ((long long)m * p.ldc + n) * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
       }
-      f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-      if (Rb) {
-        if constexpr (ES == 4) {
-          rv = *(const f32x4*)(Rb + ((long long)m * p.ldr + n) * 4);
-        } else {
-          u32x2 r = *(const u32x2*)(Rb + ((long long)m * p.ldr + n) * 2);
-          rv = f32x4{bf16lo(r[0]), bf16hi(r[0]), bf16lo(r[1]), bf16hi(r[1])};
-        }
-      }
-      if (p.act == MELGPT_ACT_GELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
-      } else if (p.act == MELGPT_ACT_GELU_GRAD) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad(rv[e]);
-      }
-      if (p.drop_scale != 0.f) {
-        const unsigned long long e0 = ((unsigned long long)bz * p.M + m) * (unsigned long long)p.N + n;
-        const unsigned keep = dropout_keep4(p.seed, p.stream_id, e0 >> 2, p.drop_thresh);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (keep >> e & 1) ? v[e] * p.drop_scale : 0.f;
-      }
-      if (Rb && p.act != MELGPT_ACT_GELU_GRAD) v += rv;
-      if (p.out_f32 || ES == 4) {
+      f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+      if (Rb) r4 = unpack(*(const RV*)(Rb + ((long long)m * p.ldr + n) * ES));
+      v = math(v, r4, m, n, Rb != nullptr);
+      if (f32out) {
         float* dst = (float*)(Cb + ((long long)m * p.ldc + n) * 4);
         if (p.accumulate) v += *(const f32x4*)dst;
         *(f32x4*)dst = v;

@@ -23,6 +23,16 @@ class KernelTimer:
         flops = sum(f for _, _, f, _ in self.records)
         return dict(launches=len(self.records), total_ms=tot_ms, flops=flops)
 
+    def by_tag(self):
+        agg = {}
+        for s, e, f, tag in self.records:
+            ms = s.elapsed_time(e)
+            a = agg.setdefault(tag, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += ms
+            a[2] += f
+        return sorted(((t, n, ms, fl) for t, (n, ms, fl) in agg.items()), key=lambda r: -r[2])
+
 
 TIMER = None  # set to a KernelTimer() to record
 
@@ -85,7 +95,9 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=None, accu
         assert pre_out.shape == out.shape and pre_out.stride() == out.stride() and pre_out.dtype == out.dtype
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
-    with _timed(2.0 * M * N * K * batch, "gemm"):
+    with _timed(2.0 * M * N * K * batch, f"gemm {'T' if a_kmajor else 'N'}{'N' if b_kmajor else 'T'} {M}x{N}x{K}"
+                + (f" b{batch}" if batch > 1 else "") + (" gelu" if act == ACT_GELU else " dgelu" if act else "")
+                + (" drop" if drop_p > 0 else "") + (" res" if residual is not None and act != ACT_GELU_GRAD else "")):
         call("melgpt_gemm", ptr(a), int(a_kmajor), lda, sa, ptr(b), int(b_kmajor), ldb, sb, ptr(out), ldc, sc, M, N, K,
              batch, dtype_code(dt), int(odt == torch.float32 and dt != torch.float32), int(accumulate), float(alpha),
              ptr(bias), int(act), ptr(residual), ldr, sr, ptr(pre_out), float(drop_p), int(seed), int(stream_id),
@@ -107,7 +119,7 @@ def conv2d_nhwc(x, wpack, bias=None, *, stride=1, pad=(1, 1), out_hw=None, upsam
     assert out.shape == (B, OH, OW, Cout) and out.is_contiguous()
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype
-    with _timed(2.0 * B * OH * OW * Cout * KH * KW * Cin, "conv"):
+    with _timed(2.0 * B * OH * OW * Cout * KH * KW * Cin, f"conv{KH}x{KW} s{stride} {H}x{W} {Cin}->{Cout}"):
         call("melgpt_conv2d_nhwc", ptr(x), B, H, W, Cin, ptr(wpack), Cout, KH, KW, stride, pad[0], pad[1], OH, OW,
              int(upsample), ptr(bias), ptr(residual), ptr(out), dtype_code(x.dtype), stream())
     return out
