@@ -257,6 +257,15 @@ int melgpt_softmax_rows(const float* scores, long long ld_scores, int n, long lo
 int melgpt_repack_conv_weight(const float* w_oihw, void* out_ohwi, int out_dtype, int O, int I, int KH, int KW,
                               void* stream);
 
+/* ResnetBlock's  norm -> swish -> conv3x3  (big_model_attn_gan.py:117-127) as ONE kernel: halo-tiled 3x3 conv
+ * (stride 1, pad 1) whose input patch is normalised (GroupNorm(32) statistics from melgpt_groupnorm_stats, affine
+ * gamma/beta) and swish-ed while it is staged into LDS; mean == NULL -> plain convolution.  residual/bias as in
+ * melgpt_conv2d_nhwc.  Supported when the patch fits LDS: Cin*elem_size in [256, ~680] bytes (Cin 128/256 bf16,
+ * 64/128 f32); otherwise MELGPT_ERR_UNSUPPORTED (callers fall back to groupnorm_apply + conv2d_nhwc). */
+int melgpt_conv3x3_gn_nhwc(const void* x, int B, int H, int W, int Cin, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, int swish, const void* wpack, int Cout,
+                           const float* bias, const void* residual, void* y, int dtype, void* stream);
+
 /* (B,C,HW) <-> (B,HW,C) copy with dtype conversion, for callers that hand over contiguous NCHW tensors */
 int melgpt_permute_nchw_nhwc(const void* x, int x_dtype, void* y, int y_dtype, int B, int C, int HW,
                              int to_nhwc, void* stream);

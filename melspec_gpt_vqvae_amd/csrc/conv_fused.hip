@@ -1,0 +1,217 @@
+// Halo-tiled 3x3 convolution (stride 1, pad 1) with GroupNorm(+swish) fused into its input staging, for the
+// ResnetBlocks of the VQ-VAE encoder/decoder on gfx950 (reference vqvae/big_model_attn_gan.py:114-135: norm -> swish
+// -> conv; Normalize :139-140; nonlinearity :164-166).
+//
+// The plain implicit-GEMM kernel (gemm.hip, LAY_CONV) re-gathers its A operand from L2 for each of the 9 taps and
+// needs the normalised activation to exist in HBM, i.e. a separate GroupNorm-apply pass that reads and writes the
+// whole (B, 80*848, 128) tensor.  Here a workgroup owns an 8 x 16 pixel output tile x 128 output channels and
+//   1. stages the (8+2) x (16+2) pixel input patch into LDS ONCE, applying y = swish((x - mean) * rstd * gamma + beta)
+//      on the way (zero padding is applied AFTER the normalisation, exactly like the reference); the raw activation
+//      is read 1.4x instead of 9x, and the normalised tensor never exists in HBM;
+//   2. runs the 9 taps x Cin/64 K steps reading A fragments straight from shifted windows of that patch
+//      (16 consecutive pixels of one row = one MFMA row block; pixel-index XOR swizzle keeps ds_read_b128
+//      conflict-free), while the weight tile of each K step is double-buffered through LDS like in gemm.hip;
+//   3. finishes with the shared fused epilogue (bias, residual x + h of the ResnetBlock, row-contiguous stores).
+// MFMA: v_mfma_f32_16x16x32_bf16 (bf16 lane) / v_mfma_f32_16x16x4_f32 (f32 parity lane), same fragment maps as gemm.hip.
+#include "gemm_common.h"
+
+using namespace gemmk;
+
+namespace {
+
+constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW;  // 180 patch pixels
+
+struct FusedConvParams {
+  GemmParams g;          // C, bias, R, ldc, ldr, M (= B*H*W), N (= Cout), B operand = packed weights (Cout, 9*Cin)
+  const void* x;         // (B, H, W, Cin) raw activation
+  const float* mean;     // (B*32) or null (no normalisation: plain conv)
+  const float* rstd;
+  const float* gamma;    // (Cin)
+  const float* beta;
+  int H, W, Cin, swish, tiles_x, tiles_y;
+};
+
+template <typename T>
+__device__ __forceinline__ int patch_off(int pix, int chunk, int pix_bytes) {
+  return pix * pix_bytes + ((chunk ^ (pix & 15)) << 4);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv3x3_gn_kernel(FusedConvParams q) {
+  constexpr int ES = Tr<T>::ES, KSTEP = Tr<T>::KSTEP, VEC = 16 / ES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const GemmParams& p = q.g;
+  const int Cin = q.Cin, pix_bytes = Cin * ES, cpp = pix_bytes / 16;  // chunks per pixel
+  char* patch = smem;                                     // [180][Cin] swizzled
+  char* wtile = smem + (size_t)NPIX * pix_bytes;          // [2][128 rows x 128 B]
+  float* ab = (float*)(wtile + 2 * 16384);                // [Cin][2]: scale, shift of this image's GroupNorm
+
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
+  const int i16 = lane & 15, g = lane >> 4;
+  int tile = blockIdx.x;
+  const int tx = tile % q.tiles_x;
+  tile /= q.tiles_x;
+  const int ty = tile % q.tiles_y, b = tile / q.tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = blockIdx.y * 128;
+
+  // ---- per-channel affine of the GroupNorm for image b
+  const bool norm = q.mean != nullptr;
+  if (norm) {
+    const int cg = Cin / 32;
+    for (int c = t; c < Cin; c += 256) {
+      const float a = q.rstd[b * 32 + c / cg] * q.gamma[c];
+      ab[2 * c] = a;
+      ab[2 * c + 1] = q.beta[c] - q.mean[b * 32 + c / cg] * a;
+    }
+  }
+  // ---- weight tile staging plan (ROW layout, K contiguous), identical to gemm.hip's B operand
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+  unsigned b_base[4];
+  int b_lds[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int qq = t + 256 * i, row = qq >> 3, ch = qq & 7;
+    b_base[i] = (unsigned)(((long long)(n0 + row) * p.ldb) * ES) + ch * 16;
+    b_lds[i] = row_off(row, ch);
+  }
+  u32x4 br[4];
+  auto issue_b = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) br[i] = buf_load16(rb, b_base[i] + kt * KSTEP * ES);
+  };
+  auto commit_b = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(u32x4*)(wtile + buf * 16384 + b_lds[i]) = br[i];
+  };
+  issue_b(0);
+  __syncthreads();  // ab[] visible
+
+  // ---- stage the input patch once (normalise + swish on the fly; out-of-image pixels are zeros)
+  const T* xb = (const T*)q.x + (long long)b * q.H * q.W * Cin;
+  for (int idx = t; idx < NPIX * cpp; idx += 256) {
+    const int pix = idx / cpp, ch = idx - pix * cpp;
+    const int py = pix / PW, px = pix - py * PW;
+    const int iy = y0 + py - 1, ix = x0 + px - 1;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (iy >= 0 && iy < q.H && ix >= 0 && ix < q.W) {
+      v = *(const u32x4*)(xb + ((long long)iy * q.W + ix) * Cin + ch * VEC);
+      if (norm) {
+        float f[VEC];
+        if constexpr (ES == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            f[2 * e] = bf16lo(v[e]);
+            f[2 * e + 1] = bf16hi(v[e]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[e] = __uint_as_float(v[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const int c = ch * VEC + e;
+          float o = fmaf(f[e], ab[2 * c], ab[2 * c + 1]);
+          if (q.swish) o = o * __builtin_amdgcn_rcpf(1.0f + __expf(-o));
+          f[e] = o;
+        }
+        if constexpr (ES == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = pack_bf16x2(f[2 * e], f[2 * e + 1]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(f[e]);
+        }
+      }
+    }
+    *(u32x4*)(patch + patch_off<T>(pix, ch, pix_bytes)) = v;
+  }
+  commit_b(0);
+  __syncthreads();
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int kpt = Cin / KSTEP;  // K steps per tap
+  const int nk = 9 * kpt;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) issue_b(kt + 1);
+    const int tap = kt / kpt, kc = kt - tap * kpt;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const char* sb = wtile + cur * 16384;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 fa[4], fb[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int pix = (wm * 4 + mt + ky) * PW + i16 + kx;  // output row (wm*4+mt), shifted by the tap
+        fa[mt] = *(const u32x4*)(patch + patch_off<T>(pix, kc * 8 + 4 * ks + g, pix_bytes));
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) fb[nt] = *(const u32x4*)(sb + row_off((wn * 4 + nt) * 16 + i16, 4 * ks + g));
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) mma<T>(acc[mt][nt], fb[nt], fa[mt]);
+    }
+    if (kt + 1 < nk) commit_b(cur ^ 1);
+    __syncthreads();
+  }
+
+  long long mrow[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int y = y0 + wm * 4 + mt;
+    mrow[mt] = (y < q.H) ? ((long long)b * q.H + y) * q.W + x0 : -1;
+  }
+  epilogue_rows<T, 4, 4>(p, acc, mrow, min(TW, q.W - x0), n0 + wn * 64, 0, lane, smem + w * 4096);
+}
+
+template <typename T>
+int launch_fused(const FusedConvParams& q, int B, hipStream_t s) {
+  const int ES = Tr<T>::ES;
+  const size_t lds = (size_t)NPIX * q.Cin * ES + 2 * 16384 + (size_t)q.Cin * 8;
+  if (lds > 160 * 1024) return MELGPT_ERR_UNSUPPORTED;
+  static size_t attr = 0;
+  if (lds > attr) {
+    if (hipFuncSetAttribute((const void*)conv3x3_gn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess)
+      return MELGPT_ERR_LAUNCH;
+    attr = 160 * 1024;
+  }
+  dim3 grid(q.tiles_x * q.tiles_y * B, (q.g.N + 127) / 128);
+  hipLaunchKernelGGL(conv3x3_gn_kernel<T>, grid, dim3(256), lds, s, q);
+  return melgpt_launch_status();
+}
+
+}  // namespace
+
+extern "C" int melgpt_conv3x3_gn_nhwc(const void* x, int B, int H, int W, int Cin, const float* mean, const float* rstd,
+                                      const float* gamma, const float* beta, int swish, const void* wpack, int Cout,
+                                      const float* bias, const void* residual, void* y, int dtype, void* stream) {
+  MELGPT_CHECK(x && wpack && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(dtype == MELGPT_F32 || dtype == MELGPT_BF16, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK((mean == nullptr) == (rstd == nullptr), MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(!mean || (gamma && beta), MELGPT_ERR_BAD_ARG);
+  const int es = dtype == MELGPT_F32 ? 4 : 2, kstep = dtype == MELGPT_F32 ? 32 : 64;
+  MELGPT_CHECK(Cin % kstep == 0 && Cin % 32 == 0 && (Cin * es) / 16 >= 16 && Cout % 8 == 0, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK((((uintptr_t)x | (uintptr_t)wpack | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)bias) & 15) == 0,
+               MELGPT_ERR_ALIGN);
+  const long long M = (long long)B * H * W;
+  MELGPT_CHECK(M < 0x7FFFFF00LL && (long long)Cout * 9 * Cin * es < 0xFFFFFF00LL, MELGPT_ERR_UNSUPPORTED);
+  FusedConvParams q{};
+  q.g.B = wpack; q.g.C = y; q.g.bias = bias; q.g.R = residual;
+  q.g.M = (int)M; q.g.N = Cout; q.g.K = 9 * Cin;
+  q.g.ldb = 9LL * Cin; q.g.ldc = Cout; q.g.ldr = Cout;
+  q.g.b_bytes = (unsigned)((long long)Cout * 9 * Cin * es);
+  q.g.alpha = 1.0f;
+  q.g.vec_io = (Cout * es) % 16 == 0;
+  q.x = x; q.mean = mean; q.rstd = rstd; q.gamma = gamma; q.beta = beta;
+  q.H = H; q.W = W; q.Cin = Cin; q.swish = swish;
+  q.tiles_x = (W + TW - 1) / TW; q.tiles_y = (H + TH - 1) / TH;
+  hipStream_t s = (hipStream_t)stream;
+  return dtype == MELGPT_F32 ? launch_fused<float>(q, B, s) : launch_fused<bf16_t>(q, B, s);
+}

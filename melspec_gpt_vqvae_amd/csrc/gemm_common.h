@@ -83,8 +83,23 @@ template <int ROWB>
 __device__ __forceinline__ int stage_off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
 
 template <typename T, int TM, int TN>
+__device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[TM][TN], const long long (&mrow)[TM],
+                                              int row_limit, int n_base, int bz, int lane, char* stage);
+
+template <typename T, int TM, int TN>
 __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[TM][TN], int m_base, int n_base, int bz,
                                          int lane, char* stage) {
+  long long mrow[TM];
+#pragma unroll
+  for (int mt = 0; mt < TM; ++mt) mrow[mt] = m_base + mt * 16;
+  epilogue_rows<T, TM, TN>(p, acc, mrow, 16, n_base, bz, lane, stage);
+}
+
+// mrow[mt] = output row (in C) of the first of the 16 consecutive rows held by accumulator slab mt, or < 0 when the
+// slab is entirely out of range; rows mrow[mt] + r with r >= row_limit (or >= p.M) are skipped.
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[TM][TN], const long long (&mrow)[TM],
+                                              int row_limit, int n_base, int bz, int lane, char* stage) {
   constexpr int ES = Tr<T>::ES;
   using RV = typename std::conditional<ES == 4, f32x4, u32x2>::type;  // one 4-element group of R / C in dtype T
   const int i16 = lane & 15, g = lane >> 4;
@@ -104,7 +119,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[TM][T
     if constexpr (ES == 4) return r;
     else return f32x4{bf16lo(r[0]), bf16hi(r[0]), bf16lo(r[1]), bf16hi(r[1])};
   };
-  auto math = [&](f32x4 v, f32x4 r4, int m, int n, bool has_r) -> f32x4 {
+  auto math = [&](f32x4 v, f32x4 r4, long long m, int n, bool has_r) -> f32x4 {
     if (p.act == MELGPT_ACT_GELU) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
@@ -132,14 +147,16 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[TM][T
 #pragma clang loop unroll(full)
         for (int j = 0; j < IN_PER; ++j) {
           const int q = lane + 64 * j, row = q / IN_CPR, ch = q % IN_CPR;
-          const int m = m_base + mt * 16 + row, n = n_base + ch * (16 / ES);
+          const long long m = mrow[mt] + row;
+          const int n = n_base + ch * (16 / ES);
           rin[mt][j] = u32x4{0u, 0u, 0u, 0u};
-          if (m < p.M && n < p.N) rin[mt][j] = *(const u32x4*)(Rb + ((long long)m * p.ldr + n) * ES);
+          if (mrow[mt] >= 0 && row < row_limit && m < p.M && n < p.N)
+            rin[mt][j] = *(const u32x4*)(Rb + (m * p.ldr + n) * ES);
         }
     }
 #pragma clang loop unroll(full)
     for (int mt = 0; mt < TM; ++mt) {
-      const int m = m_base + mt * 16 + i16;
+      const long long m = mrow[mt] + i16;
       f32x4 r4[TN];
       if (Rb) {
 #pragma clang loop unroll(full)
@@ -169,10 +186,11 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[TM][T
 #pragma clang loop unroll(full)
           for (int j = 0; j < PER; ++j) {
             const int q = lane + 64 * j, row = q / CPR, ch = q % CPR;
-            const int mm = m_base + mt * 16 + row, nn = n_base + ch * 4;
-            if (mm < p.M && nn < p.N) {
+            const long long mm = mrow[mt] + row;
+            const int nn = n_base + ch * 4;
+            if (mrow[mt] >= 0 && row < row_limit && mm < p.M && nn < p.N) {
               f32x4 o = *(const f32x4*)(stage + stage_off<ROWB>(row, ch));
-              float* dst = (float*)(Ob + ((long long)mm * p.ldc + nn) * 4);
+              float* dst = (float*)(Ob + (mm * p.ldc + nn) * 4);
               if (pass == 1 && p.accumulate) o += *(const f32x4*)dst;
               *(f32x4*)dst = o;
             }
@@ -189,10 +207,11 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[TM][T
 #pragma clang loop unroll(full)
           for (int j = 0; j < PER; ++j) {
             const int q = lane + 64 * j, row = q / CPR, ch = q % CPR;
-            const int mm = m_base + mt * 16 + row, nn = n_base + ch * 8;
-            if (mm < p.M && nn < p.N) {
+            const long long mm = mrow[mt] + row;
+            const int nn = n_base + ch * 8;
+            if (mrow[mt] >= 0 && row < row_limit && mm < p.M && nn < p.N) {
               u32x4 o = *(const u32x4*)(stage + stage_off<ROWB>(row, ch));
-              u32x4* dst = (u32x4*)(Ob + ((long long)mm * p.ldc + nn) * 2);
+              u32x4* dst = (u32x4*)(Ob + (mm * p.ldc + nn) * 2);
               if (pass == 1 && p.accumulate) {
                 const u32x4 c = *dst;
 #pragma unroll
@@ -215,8 +234,8 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[TM][T
     if (n >= p.N) continue;
 #pragma clang loop unroll(full)
     for (int mt = 0; mt < TM; ++mt) {
-      const int m = m_base + mt * 16 + i16;
-      if (m >= p.M) continue;
+      const long long m = mrow[mt] + i16;
+      if (mrow[mt] < 0 || i16 >= row_limit || m >= p.M) continue;
       f32x4 v = acc[mt][nt] * p.alpha + bv[nt];
       if (C2b) {
         if (f32out) *(f32x4*)(C2b + ((long long)m * p.ldc + n) * 4) = v;

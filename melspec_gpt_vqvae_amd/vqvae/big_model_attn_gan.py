@@ -95,6 +95,16 @@ def _gn(norm, h, swish):
     return ops.groupnorm(h, _f32(norm.weight), _f32(norm.bias), norm.eps, swish=swish)
 
 
+def _gn_swish_conv3x3(norm, conv, h, residual=None):
+    """norm -> swish -> 3x3 conv (reference :117-119 / :124-127).  One fused halo-tiled launch when the input patch
+    fits LDS (the normalised tensor then never exists in HBM), else GroupNorm-apply followed by the implicit-GEMM conv."""
+    if conv.kernel_size[0] == 3 and conv.stride[0] == 1 and ops.fused_conv_supported(h.shape[-1], h.dtype, occupancy=2):
+        stats = ops.groupnorm_stats(h, norm.eps)
+        return ops.conv3x3_gn(h, stats, _f32(norm.weight), _f32(norm.bias), _packed_weight(conv, h.dtype), _f32(conv.bias),
+                              swish=True, residual=residual)
+    return _conv(conv, _gn(norm, h, True), residual=residual)
+
+
 class ResnetBlock(nn.Module):
     def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout, temb_channels=512):
         super().__init__()
@@ -117,13 +127,12 @@ class ResnetBlock(nn.Module):
 
     def _nhwc(self, h):
         """reference :114-135 on an NHWC tensor (temb is None on this path, dropout p = 0)."""
-        t = _conv(self.conv1, _gn(self.norm1, h, True))
-        t = _gn(self.norm2, t, True)
+        t = _gn_swish_conv3x3(self.norm1, self.conv1, h)
         if self.in_channels != self.out_channels:
             sc = _conv(self.conv_shortcut if self.use_conv_shortcut else self.nin_shortcut, h)
         else:
             sc = h
-        return _conv(self.conv2, t, residual=sc)
+        return _gn_swish_conv3x3(self.norm2, self.conv2, t, residual=sc)
 
     def forward(self, x, temb):
         assert temb is None, "the mel VQ-VAE has no timestep embedding (temb_ch = 0, reference :196)"
@@ -288,7 +297,7 @@ class Encoder(nn.Module):
         h = self.mid.block_1._nhwc(h)
         h = self.mid.attn_1._nhwc(h)
         h = self.mid.block_2._nhwc(h)
-        return _conv(self.conv_out, _gn(self.norm_out, h, True))
+        return _gn_swish_conv3x3(self.norm_out, self.conv_out, h)
 
     def forward(self, x):
         _require_cuda(x)

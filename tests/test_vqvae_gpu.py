@@ -148,3 +148,33 @@ def test_full_vqvae_bf16_lane_reports_code_agreement():
     agree = float((codes.cpu().numpy().ravel() == g["indices"].astype(np.int64)).mean())
     print(f"bf16 encoder: latent rel-to-max err {err:.3e}, code agreement {agree:.3f}")
     assert err < 5e-2 and agree > 0.9
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("H,W,Cin,Cout,B", [(80, 848, 128, 128, 1), (20, 53, 128, 256, 2), (5, 7, 256, 128, 3),
+                                             (9, 33, 128, 64, 2)])
+def test_fused_groupnorm_swish_conv3x3(dt, H, W, Cin, Cout, B):
+    """halo-tiled conv with GroupNorm+swish applied while staging (csrc/conv_fused.hip) == GN -> swish -> conv2d."""
+    from melspec_gpt_vqvae_amd import ops
+
+    if not ops.fused_conv_supported(Cin, DT[dt]):
+        pytest.skip("patch does not fit LDS for this width/dtype: the module falls back to the unfused path")
+    x = t(synth.normal(1, (B, H, W, Cin), 1.3, 0.5)).to(DT[dt])
+    w = t(synth.normal(2, (Cout, Cin, 3, 3), 0.03)).to(DT[dt])
+    bias = t(synth.normal(3, (Cout,), 0.1))
+    gm, bt = t(synth.normal(4, (Cin,), 0.1, 1.0)), t(synth.normal(5, (Cin,), 0.1))
+    res = t(synth.normal(6, (B, H, W, Cout))).to(DT[dt])
+    xd = x.to(DEV)
+    stats = ops.groupnorm_stats(xd, 1e-6)
+    wp = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = ops.conv3x3_gn(xd, stats, gm.to(DEV), bt.to(DEV), wp, bias.to(DEV), swish=True, residual=res.to(DEV))
+    h = F.group_norm(x.float().permute(0, 3, 1, 2), 32, gm, bt, eps=1e-6)
+    h = h * torch.sigmoid(h)
+    if dt == "bf16":
+        h = h.to(torch.bfloat16).float()   # the kernel rounds the normalised patch to bf16 before the MFMAs
+    ref = F.conv2d(h, w.float(), bias, padding=1).permute(0, 2, 3, 1) + res.float()
+    assert rel_err(y.float().cpu().numpy(), ref.numpy()) < (2e-5 if dt == "f32" else 8e-3)
+    # plain (no norm) mode
+    y2 = ops.conv3x3_gn(xd, None, None, None, wp, bias.to(DEV), swish=False)
+    ref2 = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, padding=1).permute(0, 2, 3, 1)
+    assert rel_err(y2.float().cpu().numpy(), ref2.numpy()) < (2e-5 if dt == "f32" else 8e-3)
