@@ -5,8 +5,10 @@
 //
 // Shape regime: T <= 288 (block_size 265/266), head size 64.  The whole K and V (or Q and dO) of one
 // (batch, head) live in LDS, so softmax is a plain two-pass row softmax in registers - no online rescaling.
-//   forward / dQ kernel : workgroup = 64 query rows (4 waves x 16), keys beyond the causal frontier skipped
-//   dK/dV kernel        : workgroup = 64 keys (4 waves x 16), sweeps the query tiles that can see them
+//   forward / dQ kernel : one 512-thread workgroup per (batch, head): K and V staged into LDS ONCE, the 8 waves pull
+//                         16-query-row tiles from an LDS work counter, heaviest (latest causal rows) first; keys
+//                         beyond a tile's causal frontier are skipped
+//   dK/dV kernel        : same shape with Q and dO in LDS; waves pull 16-key tiles (key tile 0 sees every query)
 // MFMA orientation is chosen so that no probability tile ever crosses lanes or LDS:
 //   S^T = K Q^T puts the query on the lane -> row max/sum are in-register + 2 xor-shuffles, and the S^T
 //   accumulators are directly the B operand of O^T = V^T P^T (V^T via ds_read_b64_tr_b16 transposed reads);
@@ -20,6 +22,7 @@
 namespace {
 
 constexpr int HS = 64;
+constexpr int NTHREADS = 512;  // 8 waves per (batch, head)
 constexpr int MAXT = 288;
 constexpr int MAXKT = MAXT / 16;
 
@@ -75,7 +78,7 @@ __device__ __forceinline__ int off(int row, int c) {
 template <typename T, bool VSWZ>
 __device__ __forceinline__ void load_tile(char* tile, const T* base, long long ld, int nvalid, int nfill, int t) {
   constexpr int CP = AT<T>::CP, VEC = AT<T>::VEC;
-  for (int q = t; q < nfill * CP; q += 256) {
+  for (int q = t; q < nfill * CP; q += NTHREADS) {
     const int row = q / CP, c = q % CP;
     u32x4 v = {0u, 0u, 0u, 0u};
     if (row < nvalid) v = *(const u32x4*)(base + (long long)row * ld + c * VEC);
@@ -137,31 +140,35 @@ __device__ __forceinline__ int rup(int x, int m) { return (x + m - 1) / m * m; }
 
 // ================================================================================================ forward
 template <typename T, bool BWD>
-__global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
+__global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kernel(AttnParams p) {
   // BWD == false: forward (O, lse, optional att).   BWD == true: dQ (+ delta) from dO, recomputing P from lse.
   using A = AT<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, i16 = lane & 15, g = lane >> 4;
+  const int t = threadIdx.x, lane = t & 63, i16 = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z, Tn = p.T, nu = p.n_unmasked;
-  const int qb0 = 64 * blockIdx.x;
-  int kend = min(qb0 + 64, Tn);
-  if (nu > qb0) kend = max(kend, min(nu, Tn));
-  const int nfill = rup(kend, 32);
+  const int TP = rup(Tn, 32);
   char* Kt = smem;
-  char* Vt = smem + (size_t)rup(Tn, 32) * A::ROWB;
+  char* Vt = smem + (size_t)TP * A::ROWB;
+  int* ctr = (int*)(smem + 2 * (size_t)TP * A::ROWB);
   const T* Kg = (const T*)p.K + (long long)b * Tn * p.ld + h * HS;
   const T* Vg = (const T*)p.V + (long long)b * Tn * p.ld + h * HS;
-  load_tile<T, false>(Kt, Kg, p.ld, min(Tn, nfill), nfill, t);
-  load_tile<T, !BWD>(Vt, Vg, p.ld, min(Tn, nfill), nfill, t);  // fwd: V only via transposed reads
+  load_tile<T, false>(Kt, Kg, p.ld, Tn, TP, t);
+  load_tile<T, !BWD>(Vt, Vg, p.ld, Tn, TP, t);  // fwd: V only via transposed reads
+  if (t == 0) *ctr = 0;
   __syncthreads();
+  const long long bh = (long long)b * p.H + h;
+  const int ntiles = (Tn + 15) / 16;
 
-  const int q0 = qb0 + 16 * w;
-  if (q0 >= Tn) return;
+ for (;;) {  // ---- this wave's next 16-row query tile (heaviest first)
+  int job = 0;
+  if (lane == 0) job = atomicAdd(ctr, 1);
+  job = __shfl(job, 0, 64);
+  if (job >= ntiles) break;
+  const int q0 = 16 * (ntiles - 1 - job);
   const int q = q0 + i16, qc = min(q, Tn - 1);
   int kw = min(q0 + 16, Tn);
   if (nu > q0) kw = max(kw, min(nu, Tn));
   const int nkt = (kw + 15) / 16;
-  const long long bh = (long long)b * p.H + h;
 
   u32x4 qf[A::NKS];
   {
@@ -307,6 +314,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) store4<T>(op + 16 * dt + 4 * g, o[dt]);
   }
+ }  // tile loop
 }
 
 // ============================================================================================ dK / dV
@@ -314,27 +322,34 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
 // columns = this wave's 16 keys (K / V rows held in registers on the B port), so every lane owns one key column
 // and the S / dP accumulators are directly the B operands of  dV^T = dO^T P_drop  and  dK^T = Q^T dS.
 template <typename T>
-__global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_dkv_kernel(AttnParams p) {
   using A = AT<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, i16 = lane & 15, g = lane >> 4;
+  const int t = threadIdx.x, lane = t & 63, i16 = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z, Tn = p.T, nu = p.n_unmasked;
   const int TP = rup(Tn, 32);
   char* Qt = smem;
   char* Dt = smem + (size_t)TP * A::ROWB;
   float* lse_s = (float*)(smem + 2 * (size_t)TP * A::ROWB);
   float* del_s = lse_s + TP;
+  int* ctr = (int*)(del_s + TP);
   const long long bh = (long long)b * p.H + h;
   load_tile<T, false>(Qt, (const T*)p.Q + (long long)b * Tn * p.ld + h * HS, p.ld, Tn, TP, t);
   load_tile<T, false>(Dt, (const T*)p.dO + (long long)b * Tn * p.ldo + h * HS, p.ldo, Tn, TP, t);
-  for (int j = t; j < TP; j += 256) {
+  for (int j = t; j < TP; j += NTHREADS) {
     lse_s[j] = j < Tn ? p.lse[bh * Tn + j] : 0.f;
     del_s[j] = j < Tn ? p.delta[bh * Tn + j] : 0.f;
   }
+  if (t == 0) *ctr = 0;
   __syncthreads();
+  const int ntiles = (Tn + 15) / 16;
 
-  const int kt = 4 * blockIdx.x + w, key0 = 16 * kt;
-  if (key0 >= Tn) return;
+ for (;;) {  // ---- this wave's next 16-key tile (key tile 0 is seen by every query: heaviest first)
+  int job = 0;
+  if (lane == 0) job = atomicAdd(ctr, 1);
+  job = __shfl(job, 0, 64);
+  if (job >= ntiles) break;
+  const int kt = job, key0 = 16 * kt;
   const int key = key0 + i16, kc = min(key, Tn - 1);
   u32x4 kf[A::NKS], vf[A::NKS];
   {
@@ -400,12 +415,13 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
       store4<T>(vp + 16 * dt + 4 * g, dv[dt]);
     }
   }
+ }  // tile loop
 }
 
 template <typename T>
 size_t lds_bytes(int Tn, bool with_stats) {
   const int TP = (Tn + 31) / 32 * 32;
-  return 2 * (size_t)TP * AT<T>::ROWB + (with_stats ? 2 * (size_t)TP * 4 : 0);
+  return 2 * (size_t)TP * AT<T>::ROWB + (with_stats ? 2 * (size_t)TP * 4 : 0) + 16;
 }
 
 int validate(const AttnParams& p, int hs, int dtype) {
@@ -449,16 +465,16 @@ extern "C" int melgpt_attn_fwd(const void* q, const void* k, const void* v, long
   if (st != MELGPT_OK) return st;
   MELGPT_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0, MELGPT_ERR_ALIGN);
   set_dropout(p, drop_p, seed, stream_id);
-  dim3 grid((T + 63) / 64, H, B);
+  dim3 grid(1, H, B);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MELGPT_F32) {
     size_t lds = lds_bytes<float>(T, false);
     if (set_lds(attn_q_kernel<float, false>, lds_bytes<float>(MAXT, false)) != MELGPT_OK) return MELGPT_ERR_LAUNCH;
-    hipLaunchKernelGGL((attn_q_kernel<float, false>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((attn_q_kernel<float, false>), grid, dim3(NTHREADS), lds, s, p);
   } else {
     size_t lds = lds_bytes<bf16_t>(T, false);
     if (set_lds(attn_q_kernel<bf16_t, false>, lds_bytes<bf16_t>(MAXT, false)) != MELGPT_OK) return MELGPT_ERR_LAUNCH;
-    hipLaunchKernelGGL((attn_q_kernel<bf16_t, false>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((attn_q_kernel<bf16_t, false>), grid, dim3(NTHREADS), lds, s, p);
   }
   return melgpt_launch_status();
 }
@@ -481,19 +497,19 @@ extern "C" int melgpt_attn_bwd(const void* q, const void* k, const void* v, long
                MELGPT_ERR_ALIGN);
   set_dropout(p, drop_p, seed, stream_id);
   hipStream_t s = (hipStream_t)stream;
-  dim3 gq((T + 63) / 64, H, B), gk(((T + 15) / 16 + 3) / 4, H, B);
+  dim3 gq(1, H, B), gk(1, H, B);
   if (dtype == MELGPT_F32) {
     if (set_lds(attn_q_kernel<float, true>, lds_bytes<float>(MAXT, false)) != MELGPT_OK ||
         set_lds(attn_dkv_kernel<float>, lds_bytes<float>(MAXT, true)) != MELGPT_OK)
       return MELGPT_ERR_LAUNCH;
-    hipLaunchKernelGGL((attn_q_kernel<float, true>), gq, dim3(256), lds_bytes<float>(T, false), s, p);
-    hipLaunchKernelGGL((attn_dkv_kernel<float>), gk, dim3(256), lds_bytes<float>(T, true), s, p);
+    hipLaunchKernelGGL((attn_q_kernel<float, true>), gq, dim3(NTHREADS), lds_bytes<float>(T, false), s, p);
+    hipLaunchKernelGGL((attn_dkv_kernel<float>), gk, dim3(NTHREADS), lds_bytes<float>(T, true), s, p);
   } else {
     if (set_lds(attn_q_kernel<bf16_t, true>, lds_bytes<bf16_t>(MAXT, false)) != MELGPT_OK ||
         set_lds(attn_dkv_kernel<bf16_t>, lds_bytes<bf16_t>(MAXT, true)) != MELGPT_OK)
       return MELGPT_ERR_LAUNCH;
-    hipLaunchKernelGGL((attn_q_kernel<bf16_t, true>), gq, dim3(256), lds_bytes<bf16_t>(T, false), s, p);
-    hipLaunchKernelGGL((attn_dkv_kernel<bf16_t>), gk, dim3(256), lds_bytes<bf16_t>(T, true), s, p);
+    hipLaunchKernelGGL((attn_q_kernel<bf16_t, true>), gq, dim3(NTHREADS), lds_bytes<bf16_t>(T, false), s, p);
+    hipLaunchKernelGGL((attn_dkv_kernel<bf16_t>), gk, dim3(NTHREADS), lds_bytes<bf16_t>(T, true), s, p);
   }
   return melgpt_launch_status();
 }
