@@ -132,8 +132,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     }
   }
 
-  u32x4 ar[4], br[4];
-  auto issue = [&](int kt) {
+  // two register sets: while tile t is multiplied, tile t+1 waits in one set (landed during the previous step, it
+  // is written to LDS after the MFMAs) and the loads of tile t+2 are issued into the other - every global load
+  // gets a full K step + the MFMAs of the next one to land before anything waits on it
+  u32x4 ar[2][4], br[2][4];
+  auto issue = [&](int kt, auto setc) {
+    constexpr int S = decltype(setc)::value;
     const int k0 = kt * KSTEP;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         ix >>= p.ups;
         off = ok ? a_base[i] + (unsigned)((iy * p.cW + ix) * p.cC + ci0) * ES : OOB;
       }
-      ar[i] = buf_load16(ra, off);
+      ar[S][i] = buf_load16(ra, off);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -163,16 +167,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
       } else {
         off = (b_base[i] == OOB) ? OOB : b_base[i] + (unsigned)((long long)k0 * p.ldb * ES);
       }
-      br[i] = buf_load16(rb, off);
+      br[S][i] = buf_load16(rb, off);
     }
   };
-  auto commit = [&](int buf) {
+  auto commit = [&](int buf, auto setc) {
+    constexpr int S = decltype(setc)::value;
     char* sa = smem + buf * 2 * TILE_BYTES;
     char* sb = sa + TILE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(u32x4*)(sa + a_lds[i]) = ar[i];
+    for (int i = 0; i < 4; ++i) *(u32x4*)(sa + a_lds[i]) = ar[S][i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(u32x4*)(sb + b_lds[i]) = br[i];
+    for (int i = 0; i < 4; ++i) *(u32x4*)(sb + b_lds[i]) = br[S][i];
   };
 
   f32x4 acc[4][4];
@@ -181,13 +186,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + KSTEP - 1) / KSTEP;
-  issue(0);
-  commit(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) issue(kt + 1);
+  auto compute = [&](int cur) {
     const char* sa = smem + cur * 2 * TILE_BYTES;
     const char* sb = sa + TILE_BYTES;
 #pragma unroll
@@ -202,8 +201,43 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) mma<T>(acc[mt][nt], fb[nt], fa[mt]);  // rows = n, cols = m
     }
-    if (kt + 1 < nk) commit(cur ^ 1);
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  const int nk = (p.K + KSTEP - 1) / KSTEP;
+  // depth-2 prefetch only where the extra 32 staging VGPRs do not spill (measured on MI355X, profiles/: K-contiguous
+  // bf16 operands +8..14 %; the transposed-read variants need the registers for their fragment addressing)
+  constexpr bool DEEP = ES == 2 && ALAY != LAY_KMAJ && BLAY != LAY_KMAJ;
+  if constexpr (DEEP) {
+    issue(0, S0{});
+    commit(0, S0{});
+    if (nk > 1) issue(1, S1{});
     __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      // even step: tile kt in LDS buffer 0, tile kt+1 in register set 1
+      if (kt + 2 < nk) issue(kt + 2, S0{});
+      compute(0);
+      if (kt + 1 < nk) commit(1, S1{});
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      // odd step: tile kt+1 in LDS buffer 1, tile kt+2 in register set 0
+      if (kt + 3 < nk) issue(kt + 3, S1{});
+      compute(1);
+      if (kt + 2 < nk) commit(0, S0{});
+      __syncthreads();
+    }
+  } else {
+    issue(0, S0{});
+    commit(0, S0{});
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) issue(kt + 1, S0{});
+      compute(cur);
+      if (kt + 1 < nk) commit(cur ^ 1, S0{});
+      __syncthreads();
+    }
   }
 
   // the last K step ended with a barrier: every wave is done with the operand tiles, LDS can be reused

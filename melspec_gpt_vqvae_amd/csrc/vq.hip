@@ -5,8 +5,8 @@
 //   F32 lane  : codebook resident in LDS (128 x 258 f32, 2-float row skew => conflict-free b32 fragment
 //               reads), cross term on v_mfma_f32_16x16x4_f32 = exact k-ordered f32 FMA chain, so
 //               oracle/vq_argmin.c reproduces every distance bit for bit.
-//   BF16 lane : codebook fragments live in VGPRs for the whole (persistent) workgroup, latents staged
-//               through an XOR-swizzled LDS tile with 16-byte coalesced loads, v_mfma_f32_16x16x32_bf16.
+//   BF16 lane : codebook rounded to bf16 in LDS (XOR-swizzled), every wave owns 16 latent vectors end to end
+//               (fragments straight from global, v_mfma_f32_16x16x32_bf16, no barrier in the tile loop).
 // Both: rows of the MFMA tile = codes, columns = latent vectors, so every lane owns ONE vector column
 // and the argmin reduction is in-register + two xor-shuffles (first-index tie-break kept lexicographic).
 #include "common.h"
@@ -23,6 +23,9 @@ struct VqAddr {
 __device__ __forceinline__ long long vq_off(const VqAddr& a, long long n, int c) {
   return (n / a.inner) * a.s_outer + (n % a.inner) * a.s_inner + (long long)c * a.s_c;
 }
+
+__device__ __forceinline__ float bf16lo(unsigned v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bf16hi(unsigned v) { return __uint_as_float(v & 0xFFFF0000u); }
 
 // lexicographic (distance, code) minimum == torch.argmin's first-minimal-index rule
 __device__ __forceinline__ void lexmin(float& d, int& k, float d2, int k2) {
@@ -205,192 +208,173 @@ __global__ __launch_bounds__(256) void vq_f32_kernel(const float* __restrict__ z
 }
 
 // ============================================================================================== BF16
-constexpr int B16_TILE = 64;  // vectors per tile (4 MFMA column tiles)
-constexpr size_t B16_LDS_BYTES = (size_t)B16_TILE * 512 + (VQ_K + 4 * 16 + 4 * B16_TILE) * 4 +
-                                 (4 * B16_TILE + B16_TILE + VQ_K) * 4 + 16 * 4;
+// Codebook rounded to bf16 once per workgroup into LDS (128 x 512 B, 16-byte chunks XOR-swizzled by code&15 so
+// that ds_read_b128 fragment reads are conflict-free).  Every WAVE then owns 16 latent vectors end to end:
+//   x fragments (B operand: lane (v, g) holds x[v][32ks+8g .. +7]) are loaded straight from global memory,
+//   8 code tiles x 8 k-steps of v_mfma_f32_16x16x32_bf16 with the code fragments streamed from LDS,
+//   |x|^2 from the same registers, argmin in-lane + 2 xor-shuffles, optional gather / error / histogram.
+// No staging buffer, no barrier inside the tile loop: waves run independently and 16 of them (2 workgroups of 8)
+// share a CU, so HBM latency is hidden by occupancy.  Strided (NCHW) latents take a scalar gather path.
+constexpr int B16_WAVES = 8;
+constexpr size_t B16_LDS_BYTES = (size_t)VQ_K * 512 + VQ_K * 4 + VQ_K * 4;
 
-__device__ __forceinline__ int b16_swz(int row, int chunk) { return row * 512 + ((chunk ^ (row & 15)) << 4); }
+__device__ __forceinline__ int cb_off(int code, int chunk) { return code * 512 + ((chunk ^ (code & 15)) << 4); }
 
-__global__ __launch_bounds__(256) void vq_bf16_kernel(const bf16_t* __restrict__ z, VqAddr za, long long N,
-                                                      const float* __restrict__ codebook,
-                                                      long long* __restrict__ indices, bf16_t* __restrict__ qout,
-                                                      float* __restrict__ sq_err, int* __restrict__ hist,
-                                                      float* __restrict__ dist_out, int flat) {
+// FLAT: channel-contiguous latents (16-byte fragment loads).  EXTRAS: gather / squared error / distances wanted.
+// The lean <true,false> instantiation is the hot path of extract_codes (indices only).
+template <bool FLAT, bool EXTRAS>
+__global__ __launch_bounds__(64 * B16_WAVES, EXTRAS ? 2 : 4) void vq_bf16_kernel(const bf16_t* __restrict__ z, VqAddr za, long long N,
+                                                                   const float* __restrict__ codebook,
+                                                                   long long* __restrict__ indices,
+                                                                   bf16_t* __restrict__ qout, float* __restrict__ sq_err,
+                                                                   int* __restrict__ hist, float* __restrict__ dist_out) {
+  constexpr bool flat = FLAT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* xt = smem;                                        // [64][512 B], 16-B chunks XOR-swizzled by row&15
-  float* bsq = (float*)(smem + B16_TILE * 512);           // [128]
-  float* asq = bsq + VQ_K;                                // [4][16]
-  float* red_d = asq + 4 * 16;                            // [4][64]
-  int* red_k = (int*)(red_d + 4 * B16_TILE);              // [4][64]
-  int* idx_s = red_k + 4 * B16_TILE;                      // [64]
-  int* hist_s = idx_s + B16_TILE;                         // [128]
-  float* err_s = (float*)(hist_s + VQ_K);                 // [4]
-
+  char* cbs = smem;                                   // [128][512 B] bf16, swizzled
+  float* bsq = (float*)(smem + VQ_K * 512);           // [128] |e|^2 of the ROUNDED codes
+  int* hist_s = (int*)(bsq + VQ_K);                   // [128]
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int r16 = lane & 15, g = lane >> 4;
 
-  // ---- this wave's 32 codes as MFMA A fragments, rounded to bf16 once; |e|^2 of the ROUNDED codes
-  s16x8 cbf[2][8];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const float* e = codebook + (size_t)(32 * w + 16 * ct + r16) * VQ_D + 8 * g;
-    float p = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      f32x4 lo = *(const f32x4*)(e + 32 * ks), hi = *(const f32x4*)(e + 32 * ks + 4);
-      s16x8 f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f[j] = (short)f32_to_bf16(lo[j]);
-        f[4 + j] = (short)f32_to_bf16(hi[j]);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float v = bf16_to_f32((bf16_t)f[j]);
-        p = fmaf(v, v, p);
-      }
-      cbf[ct][ks] = f;
-    }
-    p += __shfl_xor(p, 16, 64);
-    p += __shfl_xor(p, 32, 64);
-    if (g == 0) bsq[32 * w + 16 * ct + r16] = p;
+  for (int q = t; q < VQ_K * 32; q += 64 * B16_WAVES) {  // 16-byte chunk q = (code, chunk)
+    const int code = q >> 5, ch = q & 31;
+    const float* e = codebook + (size_t)code * VQ_D + ch * 8;
+    f32x4 lo = *(const f32x4*)e, hi = *(const f32x4*)(e + 4);
+    *(u32x4*)(cbs + cb_off(code, ch)) =
+        u32x4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
   }
   if (t < VQ_K) hist_s[t] = 0;
-
-  const long long ntiles = (N + B16_TILE - 1) / B16_TILE;
-  u32x4 xr[8];
-  float err = 0.f;
-
-  auto load_tile = [&](long long tile) {
-    long long n0 = tile * B16_TILE;
+  __syncthreads();
+  if (t < VQ_K) {  // |e|^2: one FMA chain over the 256 rounded components (any fixed order is fine in this lane)
+    float p = 0.f;
+    for (int ch = 0; ch < 32; ++ch) {
+      u32x4 v = *(const u32x4*)(cbs + cb_off(t, ch));
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int q = t + 256 * i, row = q >> 5, ch = q & 31;
-      long long n = n0 + row;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (n < N) {
-        if (flat) {
-          v = *(const u32x4*)(z + vq_off(za, n, ch * 8));
-        } else {
-          unsigned e[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) e[j] = z[vq_off(za, n, ch * 8 + j)];
-          v = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
-        }
+      for (int e = 0; e < 4; ++e) {
+        p = fmaf(bf16lo(v[e]), bf16lo(v[e]), p);
+        p = fmaf(bf16hi(v[e]), bf16hi(v[e]), p);
       }
-      xr[i] = v;
+    }
+    bsq[t] = p;
+  }
+  __syncthreads();
+
+  const long long ntiles = (N + 15) / 16;
+  const long long stride = (long long)gridDim.x * B16_WAVES;
+  float err = 0.f;
+  // this lane's fragments of the 16 vectors of `tile` (clamped row for the ragged tail)
+  auto load_x = [&](long long tile, u32x4 (&dst)[8]) {
+    long long nn = tile * 16 + r16;
+    if (nn >= N) nn = N - 1;
+    if constexpr (FLAT) {
+      const bf16_t* xp = z + vq_off(za, nn, 8 * g);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) dst[ks] = *(const u32x4*)(xp + 32 * ks);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        unsigned e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = z[vq_off(za, nn, 32 * ks + 8 * g + j)];
+        dst[ks] = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+      }
     }
   };
+  u32x4 xf[8], xn[8];
+  long long tile = (long long)blockIdx.x * B16_WAVES + w;
+  if (tile < ntiles) load_x(tile, xf);
+  for (; tile < ntiles; tile += stride) {
+    const long long n = tile * 16 + r16;
+    const bool valid = n < N;
+    const bool more = tile + stride < ntiles;
+    if (FLAT && more) load_x(tile + stride, xn);  // next tile's loads fly under this tile's MFMAs
+    float A = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        A = fmaf(bf16lo(xf[ks][e]), bf16lo(xf[ks][e]), A);
+        A = fmaf(bf16hi(xf[ks][e]), bf16hi(xf[ks][e]), A);
+      }
+    A += __shfl_xor(A, 16, 64);
+    A += __shfl_xor(A, 32, 64);
 
-  long long tile = blockIdx.x;
-  if (tile < ntiles) load_tile(tile);
-  for (; tile < ntiles; tile += gridDim.x) {
-    const long long n0 = tile * B16_TILE;
-    __syncthreads();
+    float best = __builtin_inff();
+    int bk = 0x7fffffff;
+#pragma unroll 2
+    for (int ct = 0; ct < 8; ++ct) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int q = t + 256 * i, row = q >> 5, ch = q & 31;
-      *(u32x4*)(xt + b16_swz(row, ch)) = xr[i];
-    }
-    __syncthreads();
-    if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
-
-    f32x4 acc[2][4];
+      for (int ks = 0; ks < 8; ++ks) {
+        const u32x4 cf = *(const u32x4*)(cbs + cb_off(16 * ct + r16, 4 * ks + g));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, cf), __builtin_bit_cast(s16x8, xf[ks]),
+                                                      acc, 0, 0, 0);
+      }
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int vt = 0; vt < 4; ++vt) acc[ct][vt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float pa = 0.f;  // |x|^2 partial for column tile vt == w (each wave owns one)
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-#pragma unroll
-      for (int vt = 0; vt < 4; ++vt) {
-        s16x8 xb = *(const s16x8*)(xt + b16_swz(16 * vt + r16, 4 * ks + g));
-        acc[0][vt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cbf[0][ks], xb, acc[0][vt], 0, 0, 0);
-        acc[1][vt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cbf[1][ks], xb, acc[1][vt], 0, 0, 0);
-        if (vt == w) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float v = bf16_to_f32((bf16_t)xb[j]);
-            pa = fmaf(v, v, pa);
-          }
+      for (int rg = 0; rg < 4; ++rg) {
+        const int code = 16 * ct + 4 * g + rg;
+        const float d = (A + bsq[code]) - 2.0f * acc[rg];
+        if constexpr (EXTRAS) {
+          if (dist_out && valid) dist_out[n * VQ_K + code] = d;
         }
+        lexmin(best, bk, d, code);
       }
     }
-    pa += __shfl_xor(pa, 16, 64);
-    pa += __shfl_xor(pa, 32, 64);
-    if (g == 0) asq[w * 16 + r16] = pa;
-    __syncthreads();
-
-#pragma unroll
-    for (int vt = 0; vt < 4; ++vt) {
-      float A = asq[vt * 16 + r16];
-      float best = __builtin_inff();
-      int bk = 0x7fffffff;
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          int code = 32 * w + 16 * ct + 4 * g + rg;
-          float d = (A + bsq[code]) - 2.0f * acc[ct][vt][rg];
-          long long n = n0 + 16 * vt + r16;
-          if (dist_out && n < N) dist_out[n * VQ_K + code] = d;
-          lexmin(best, bk, d, code);
-        }
-      lexmin_xor(best, bk, 16);
-      lexmin_xor(best, bk, 32);
-      if (g == 0) {
-        red_d[w * B16_TILE + 16 * vt + r16] = best;
-        red_k[w * B16_TILE + 16 * vt + r16] = bk;
-      }
+    lexmin_xor(best, bk, 16);
+    lexmin_xor(best, bk, 32);
+    bk &= (VQ_K - 1);
+    if (g == 0 && valid) {
+      indices[n] = (long long)bk;
+      if (hist) atomicAdd(&hist_s[bk], 1);
     }
-    __syncthreads();
-    if (t < B16_TILE) {
-      float d = red_d[t];
-      int k = red_k[t];
+    if (EXTRAS && (qout || sq_err) && valid) {  // gather + straight-through value + squared error (64 components / lane)
 #pragma unroll
-      for (int ww = 1; ww < 4; ++ww) lexmin(d, k, red_d[ww * B16_TILE + t], red_k[ww * B16_TILE + t]);
-      k &= (VQ_K - 1);
-      idx_s[t] = k;
-      if (n0 + t < N) {
-        indices[n0 + t] = (long long)k;
-        atomicAdd(&hist_s[k], 1);
-      }
-    }
-    __syncthreads();
+      for (int ks = 0; ks < 8; ++ks) {
+        const u32x4 ev = *(const u32x4*)(cbs + cb_off(bk, 4 * ks + g));
+        u32x4 o;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int q = t + 256 * i, row = q >> 5, ch = q & 31;
-      long long n = n0 + row;
-      if (n < N) {
-        s16x8 xb = *(const s16x8*)(xt + b16_swz(row, ch));
-        const float* e = codebook + (size_t)idx_s[row] * VQ_D + ch * 8;
-        f32x4 lo = *(const f32x4*)e, hi = *(const f32x4*)(e + 4);
-        unsigned o[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float x = bf16_to_f32((bf16_t)xb[j]);
-          float ev = bf16_to_f32(f32_to_bf16(j < 4 ? lo[j] : hi[j - 4]));
-          float dq = ev - x;
-          err = fmaf(dq, dq, err);
-          o[j] = f32_to_bf16(x + dq);
+        for (int e = 0; e < 4; ++e) {
+          const float x0 = bf16lo(xf[ks][e]), x1 = bf16hi(xf[ks][e]);
+          const float d0 = bf16lo(ev[e]) - x0, d1 = bf16hi(ev[e]) - x1;
+          err = fmaf(d0, d0, err);
+          err = fmaf(d1, d1, err);
+          o[e] = pack_bf16x2(x0 + d0, x1 + d1);
         }
         if (qout) {
           if (flat) {
-            *(u32x4*)(qout + vq_off(za, n, ch * 8)) =
-                u32x4{o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16)};
+            *(u32x4*)(qout + vq_off(za, n, 32 * ks + 8 * g)) = o;
           } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) qout[vq_off(za, n, ch * 8 + j)] = (bf16_t)o[j];
+            for (int e = 0; e < 4; ++e) {
+              qout[vq_off(za, n, 32 * ks + 8 * g + 2 * e)] = (bf16_t)(o[e] & 0xFFFFu);
+              qout[vq_off(za, n, 32 * ks + 8 * g + 2 * e + 1)] = (bf16_t)(o[e] >> 16);
+            }
           }
         }
       }
     }
+    if (more) {
+      if constexpr (FLAT) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) xf[ks] = xn[ks];
+      } else {
+        load_x(tile + stride, xf);
+      }
+    }
   }
-  err = wave_sum(err);
-  if (lane == 0) err_s[w] = err;
-  __syncthreads();
-  if (t == 0 && sq_err) sq_err[blockIdx.x] = (err_s[0] + err_s[1]) + (err_s[2] + err_s[3]);
+  if (sq_err) {  // deterministic per-workgroup partial: wave sums combined in wave order
+    __shared__ float err_s[B16_WAVES];
+    err = wave_sum(err);
+    if (lane == 0) err_s[w] = err;
+    __syncthreads();
+    if (t == 0) {
+      float s = 0.f;
+      for (int i = 0; i < B16_WAVES; ++i) s += err_s[i];
+      sq_err[blockIdx.x] = s;
+    }
+  } else {
+    __syncthreads();
+  }
   if (hist && t < VQ_K && hist_s[t]) atomicAdd(&hist[t], hist_s[t]);
 }
 
@@ -511,11 +495,25 @@ extern "C" int melgpt_vq_argmin_fwd_ex(const void* z, int z_dtype, int64_t n_vec
   } else if (z_dtype == MELGPT_BF16) {
     int flat = (stride_c == 1 && (stride_inner % 8) == 0 && (stride_outer % 8) == 0 &&
                 ((uintptr_t)z & 15) == 0 && (!quantized || ((uintptr_t)quantized & 15) == 0));
-    long long ntiles = (n_vectors + B16_TILE - 1) / B16_TILE;
-    int grid = (int)(ntiles < 768 ? ntiles : 768);  // ~3 workgroups per CU
-    hipLaunchKernelGGL(vq_bf16_kernel, dim3(grid), dim3(256), B16_LDS_BYTES, s, (const bf16_t*)z, za,
-                       (long long)n_vectors, codebook, (long long*)indices, (bf16_t*)quantized, sq_err,
-                       (int*)histogram, distances, flat);
+    long long wg_tiles = ((n_vectors + 15) / 16 + B16_WAVES - 1) / B16_WAVES;  // 16 vectors per wave, 8 waves
+    int grid = (int)(wg_tiles < 512 ? wg_tiles : 512);                         // 2 persistent workgroups per CU
+    static bool attr16 = false;
+    if (!attr16) {
+      bool ok = hipFuncSetAttribute((const void*)vq_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B16_LDS_BYTES) == hipSuccess;
+      ok = ok && hipFuncSetAttribute((const void*)vq_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B16_LDS_BYTES) == hipSuccess;
+      ok = ok && hipFuncSetAttribute((const void*)vq_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B16_LDS_BYTES) == hipSuccess;
+      if (!ok) return MELGPT_ERR_LAUNCH;
+      attr16 = true;
+    }
+    const bool extras = quantized || sq_err || distances;
+#define VQ16_LAUNCH(F, E)                                                                                            \
+  hipLaunchKernelGGL((vq_bf16_kernel<F, E>), dim3(grid), dim3(64 * B16_WAVES), B16_LDS_BYTES, s, (const bf16_t*)z, za, \
+                     (long long)n_vectors, codebook, (long long*)indices, (bf16_t*)quantized, sq_err, (int*)histogram, \
+                     distances)
+    if (flat && !extras) VQ16_LAUNCH(true, false);
+    else if (flat) VQ16_LAUNCH(true, true);
+    else VQ16_LAUNCH(false, true);
+#undef VQ16_LAUNCH
     if (grid_out) *grid_out = grid;
   } else {
     return MELGPT_ERR_UNSUPPORTED;
