@@ -170,19 +170,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     }
   }
   if (partials) {
-    float* pg = partials + (long long)wave * 2 * C;
-    float* pb = pg + C;
+    // the block's 4 waves combine their column sums through LDS (fixed order) -> ONE partial row per block
+    extern __shared__ float lnsh[];  // [4][2C]
+    float* mine = lnsh + (threadIdx.x >> 6) * 2 * C;
 #pragma unroll
     for (int i = 0; i < LN_MAXCH; ++i) {
       const int ch = lane + 64 * i;
       if (ch < nch) {
 #pragma unroll
-        for (int e4 = 0; e4 < N; e4 += 4) {
-          *(f32x4*)(pg + ch * N + e4) = f32x4{dg[i][e4], dg[i][e4 + 1], dg[i][e4 + 2], dg[i][e4 + 3]};
-          *(f32x4*)(pb + ch * N + e4) = f32x4{db[i][e4], db[i][e4 + 1], db[i][e4 + 2], db[i][e4 + 3]};
+        for (int e = 0; e < N; ++e) {
+          mine[ch * N + e] = dg[i][e];
+          mine[C + ch * N + e] = db[i][e];
         }
       }
     }
+    __syncthreads();
+    float* out = partials + (long long)blockIdx.x * 2 * C;
+    for (int c = threadIdx.x; c < 2 * C; c += 256)
+      out[c] = (lnsh[c] + lnsh[2 * C + c]) + (lnsh[4 * C + c] + lnsh[6 * C + c]);
   }
 }
 
@@ -728,7 +733,7 @@ extern "C" int melgpt_layernorm_fwd(const void* x, const float* gamma, const flo
 extern "C" int melgpt_layernorm_bwd_nwaves(long long M) {
   long long w = (M + 7) / 8;  // >= 8 rows per wave where possible
   if (w < 4) w = 4;
-  if (w > 1024) w = 1024;
+  if (w > 4096) w = 4096;  // 16 waves per CU; partial rows are per BLOCK of 4 waves (<= 1024)
   return (int)((w + 3) / 4 * 4);
 }
 
@@ -742,13 +747,16 @@ extern "C" int melgpt_layernorm_bwd(const void* dy, const void* x, const float* 
   MELGPT_CHECK(C % vec == 0 && C / vec <= 64 * LN_MAXCH, MELGPT_ERR_UNSUPPORTED);
   const int nwaves = melgpt_layernorm_bwd_nwaves(M);
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(nwaves / 4), dim3(256), 0, s, (const T*)dy,
+  const size_t lds = dgamma ? (size_t)4 * 2 * C * sizeof(float) : 0;
+  MELGPT_CHECK(lds <= 64 * 1024, MELGPT_ERR_UNSUPPORTED);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(nwaves / 4), dim3(256), lds, s, (const T*)dy,
                                        (const T*)x, gamma, mean, rstd, (const T*)add_in, (T*)dx,
                                        dgamma ? workspace : nullptr, M, C));
   if (dgamma) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 63) / 64), dim3(256), 0, s, workspace, nwaves, 2LL * C,
+    const int nblocks = nwaves / 4;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 63) / 64), dim3(256), 0, s, workspace, nblocks, 2LL * C,
                        (long long)C, dgamma, accumulate, 1.0f);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 63) / 64), dim3(256), 0, s, workspace + C, nwaves, 2LL * C,
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 63) / 64), dim3(256), 0, s, workspace + C, nblocks, 2LL * C,
                        (long long)C, dbeta, accumulate, 1.0f);
   }
   return melgpt_launch_status();
