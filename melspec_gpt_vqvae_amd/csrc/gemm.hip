@@ -278,12 +278,12 @@ int pick_tile(const GemmParams& p, int batch) {
     const char* e = getenv("MELGPT_GEMM_TILE");
     forced = e ? atoi(e) : 0;
   }
-  if (forced >= 1 && forced <= 3) return forced;
-  // measured on MI355X (profiles/r01_gemm_tiles.log): with its 2-stage pipeline the wide-tile kernel only wins on
-  // large, deep problems (4096^3: 837 vs 713 TFLOP/s); the skinny M=33920 / K=1024 shapes of the GPT step and
-  // the split-K weight gradients are faster on the 128x128 kernel, which runs two workgroups per CU.
-  const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
-  if (p.K >= 2048 && p.M >= 2048 && p.N >= 2048 && p.M % 256 == 0 && p.N % 256 == 0 && tiles128 >= 1024) return 3;
+  if (forced == 1 || forced == 3) return forced;
+  // The persistent 256 x 256 kernel (gemm256.hip) wins once there are enough tiles to occupy the chip and the
+  // tile grid is not mostly padding; small or skinny problems stay on the 128 x 128 kernel (two workgroups per CU).
+  const long long tiles256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch;
+  const double fill = (double)p.M * p.N / ((double)((p.M + 255) / 256) * ((p.N + 255) / 256) * 65536.0);
+  if (tiles256 >= 192 && fill >= 0.8 && p.K >= 256) return 3;
   return 1;
 }
 

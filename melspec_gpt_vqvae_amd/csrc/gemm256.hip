@@ -1,26 +1,42 @@
-// Wide-tile bf16 MFMA GEMM for gfx950: 256x256 (or 256x128) output tile per 512-thread workgroup, operands
-// streamed HBM/L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`: no VGPR round trip, out-of-range lanes
-// deposit zeros), two 64 KiB (48 KiB) LDS stages, v_mfma_f32_16x16x32_bf16.
+// Wide-tile bf16 MFMA GEMM for gfx950: persistent 512-thread workgroups, 256x256 output tiles, operands streamed
+// L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`: no VGPR round trip, out-of-range lanes deposit zeros) into
+// a ring of five 32 KiB half-unit slots, v_mfma_f32_16x16x32_bf16.
 //
-// Why a second kernel: a 128x128 tile moves 64 FLOP per byte staged from L2, i.e. ~39 TB/s of L2->LDS traffic at
-// the 2.5 PFLOP/s MFMA peak - more than the ~34 TB/s the eight L2s deliver; 256x256 halves that (128 FLOP/B), and
-// LDS-DMA frees the 32 staging VGPRs so a wave can hold its 128x64 accumulator block (128 VGPRs).
-// Same operand layouts, swizzles, fragment maps and fused epilogue as gemm.hip (gemm_common.h); the f32 parity
-// lane stays on gemm.hip.
+// Why a second kernel: a 128x128 tile moves 64 FLOP per byte staged from L2 - at the 2.5 PFLOP/s MFMA peak that is
+// ~39 TB/s of L2->LDS traffic, and the measured ceiling of that path is ~30 TB/s with everything hitting in L2
+// (tools/lab/dma_lab.hip).  256x256 halves the traffic (128 FLOP/B); LDS-DMA frees the staging VGPRs so a wave
+// can hold its 128x64 accumulator block (128 VGPRs).
+//
+// Synchronisation: per K-unit ONE counted `s_waitcnt vmcnt(n)` (this wave's pieces of the unit have landed, the
+// younger half-unit keeps flying) and ONE raw `s_barrier` (everybody's pieces landed + everybody is done reading
+// the slots that are refilled next).  __syncthreads() is not used in the loop: its fence makes the compiler
+// drain vmcnt(0), which would serialise the ring.
+// Same operand layouts, fragment maps and fused epilogue as gemm.hip (gemm_common.h); the f32 parity lane stays
+// on gemm.hip.
 //   LDS-DMA writes are lane-linear (wave-uniform base + 16*lane), so the XOR swizzle is applied to the SOURCE
 //   address (which chunk a lane fetches) and again on the fragment read - both sides or neither.
 #include "gemm_common.h"
 
 using namespace gemmk;
 
+#ifndef G256_PLACE
+#define G256_PLACE 0
+#endif
+#ifndef G256_PRIO
+#define G256_PRIO 1
+#endif
+#ifndef G256_LAB
+#define G256_LAB 0  // tools/lab/gemm_lab.hip builds ablated variants; the library always builds 0
+#endif
+
 namespace {
 
-constexpr int KSTEP = 64;  // bf16 elements per K step = 128 bytes per ROW-layout tile row
+constexpr int KU = 64;  // bf16 elements of K per unit = 128 bytes per ROW-layout row (full L2 lines per request)
 
 template <int MN>
 __device__ __forceinline__ int kmaj_off(int krow, int lc) {
-  // K-major tile: 64 k-rows of MN bf16 (MN*2 bytes); 32-byte column blocks XOR-ed so that the 8 rows a half-wave
-  // touches in one ds_read_b64_tr_b16 land on 8 different 32-byte slots of the 256-byte bank row
+  // K-major half-unit: 64 k-rows of MN bf16 (MN*2 bytes); 32-byte column blocks XOR-ed so that the 8 rows a
+  // half-wave touches in one ds_read_b64_tr_b16 land on 8 different 32-byte slots of the 256-byte bank row
   const int s = (krow & 3) | (((krow >> 3) & 1) << 2);
   return krow * (MN * 2) + ((lc ^ (s << 1)) << 4);
 }
@@ -47,170 +63,295 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* lds_wave_b
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
 }
 
-// WM x WN waves, each TM x TN accumulator tiles of 16x16  ->  BM = 16*WM*TM, BN = 16*WN*TN
-template <int ALAY, int BLAY, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(64 * WM * WN) void gemm256_kernel(GemmParams p) {
-  constexpr int NW = WM * WN, BM = 16 * WM * TM, BN = 16 * WN * TN;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int A_INSTR = A_BYTES / 1024, B_INSTR = B_BYTES / 1024;  // 1 KiB LDS-DMA pieces per tile
-  constexpr int A_PER = A_INSTR / NW, B_PER = B_INSTR / NW;
-  static_assert(A_INSTR % NW == 0 && B_INSTR % NW == 0, "tile must split evenly over the waves");
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A | B]
+// wait until at most N of this wave's vector-memory operations are outstanding, then workgroup barrier
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// 256 x 256 output tile, 8 waves as 2 (M) x 4 (N), each wave 128 x 64 = 8 x 4 accumulator tiles of 16 x 16.
+//
+// LDS = five 32 KiB slots holding HALF-units: H(2u) = the A operand of K-unit u (256 rows x 128 B), H(2u+1) = its
+// B operand; H(j) lives in slot j mod 5.  While unit u is multiplied (two slots), H(2u+2..2u+4) - 96 KiB - are in
+// flight or landed; when unit u is done its two slots are refilled with H(2u+5), H(2u+6).  (Measured with
+// tools/lab/dma_lab.hip: the L2 -> LDS path needs ~96 KiB in flight per CU and full 128-byte lines per request to
+// reach ~30 TB/s; 64 KiB in flight gives ~20, 64-byte row slices ~17.)
+//
+// PERSISTENT: gridDim.x workgroups (one per CU) walk their tile lists; the ring does not stop at tile boundaries,
+// so the next tile's first three half-units land while this tile's accumulators go through the epilogue, and the
+// epilogue's stores drain under the next tile's MFMAs.  The epilogue stages through the slot that is refilled next.
+//
+// Tile order: the 32 workgroups of one XCD (blockIdx & 7, round-robin dispatch) take an RM x RN block of tiles, so
+// one L2 serves RM row panels of A and RN column panels of B instead of 1 + 32.
+template <int ALAY, int BLAY, int MODE>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m, int tiles_n, int batch, int RN) {
+  constexpr int WN = 4, TM = 8, TN = 4, NW = 8, BM = 256, BN = 256;
+  constexpr int HALF = 256 * 128, NSLOT = 5;
+  constexpr int PER = HALF / 1024 / NW;  // LDS-DMA pieces per wave per half-unit (4)
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [5][32 KiB]
 
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = w / WN, wn = w % WN;
-  const int tilesN = (p.N + BN - 1) / BN;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (wg / tilesN) * BM, n0 = (wg % tilesN) * BN;
-  const int bz = blockIdx.z;
+  const int G = gridDim.x;
+  const int nu = (p.K + KU - 1) / KU;
+  const int rows_m = tiles_m * batch;  // tile rows over all batches
+  const int total = rows_m * tiles_n;
 
-  const __amdgpu_buffer_rsrc_t ra = make_rsrc((const char*)p.A + (long long)bz * p.sA * 2, p.a_bytes);
-  const __amdgpu_buffer_rsrc_t rb = make_rsrc((const char*)p.B + (long long)bz * p.sB * 2, p.b_bytes);
-
-  // ---- per-lane source plan for this wave's LDS-DMA pieces (piece j of the wave = tile piece w + NW*j)
-  unsigned a_base[A_PER], b_base[B_PER];
-  int a_kc[A_PER], b_kc[B_PER];      // ROW: byte offset of the lane's chunk inside the 128-byte K slice
-  int cy[A_PER], cx[A_PER];          // CONV
-#pragma unroll
-  for (int j = 0; j < A_PER; ++j) {
-    const int piece = w + NW * j;
-    if constexpr (ALAY == LAY_KMAJ) {
-      constexpr int RB = BM * 2, RPP = 1024 / RB;  // rows per piece
-      const int krow = piece * RPP + (lane * 16) / RB, pch = ((lane * 16) % RB) >> 4;
-      const int s = (krow & 3) | (((krow >> 3) & 1) << 2);
-      const int lc = pch ^ (s << 1);
-      a_base[j] = (m0 + lc * 8 < p.M) ? (unsigned)(((long long)krow * p.lda + m0) * 2) + lc * 16 : OOB;
-      a_kc[j] = 0;
+  // ---- this workgroup's tile list: item r -> (batch, m0, n0) or "not a tile"
+  const int RM = RN > 0 ? (G >> 3) / RN : 0;
+  const int blocks_n = RN > 0 ? (tiles_n + RN - 1) / RN : 0;
+  const int nblocks = RN > 0 ? ((rows_m + RM - 1) / RM) * blocks_n : 0;
+  const int xcd = blockIdx.x & 7, jslot = blockIdx.x >> 3;
+  auto live = [&](int r) { return RN > 0 ? r * 8 + xcd < nblocks : r * G + (int)blockIdx.x < total; };
+  auto decode = [&](int r, int& bz, int& m0, int& n0) -> bool {
+    int tm, tn;
+    if (RN > 0) {
+      const int blk = r * 8 + xcd;
+      tm = (blk / blocks_n) * RM + jslot / RN;
+      tn = (blk % blocks_n) * RN + jslot % RN;
+      if (tm >= rows_m || tn >= tiles_n) return false;
     } else {
-      const int row = piece * 8 + (lane >> 3), pch = lane & 7;
-      const int c = pch ^ ((row >> 1) & 7);
-      a_kc[j] = c * 16;
-      if constexpr (ALAY == LAY_ROW) {
-        a_base[j] = (unsigned)(((long long)(m0 + row) * p.lda) * 2) + c * 16;
-      } else {
-        const int m = m0 + row, ohw = p.OH * p.OW;
-        const int bb = m / ohw, rem = m - bb * ohw;
-        const int oy = rem / p.OW, ox = rem - oy * p.OW;
-        cy[j] = (m < p.M) ? oy * p.cstride - p.pad_t : -100000;
-        cx[j] = ox * p.cstride - p.pad_l;
-        a_base[j] = (unsigned)((long long)bb * p.cH * p.cW * p.cC * 2) + c * 16;
-      }
+      const int gsz = min(G, total - r * G);
+      const int tl = r * G + xcd_remap(blockIdx.x, gsz);
+      tm = tl / tiles_n;
+      tn = tl - tm * tiles_n;
     }
-  }
-#pragma unroll
-  for (int j = 0; j < B_PER; ++j) {
-    const int piece = w + NW * j;
-    if constexpr (BLAY == LAY_KMAJ) {
-      constexpr int RB = BN * 2, RPP = 1024 / RB;
-      const int krow = piece * RPP + (lane * 16) / RB, pch = ((lane * 16) % RB) >> 4;
-      const int s = (krow & 3) | (((krow >> 3) & 1) << 2);
-      const int lc = pch ^ (s << 1);
-      b_base[j] = (n0 + lc * 8 < p.N) ? (unsigned)(((long long)krow * p.ldb + n0) * 2) + lc * 16 : OOB;
-      b_kc[j] = 0;
-    } else {
-      const int row = piece * 8 + (lane >> 3), pch = lane & 7;
-      const int c = pch ^ ((row >> 1) & 7);
-      b_kc[j] = c * 16;
-      b_base[j] = (unsigned)(((long long)(n0 + row) * p.ldb) * 2) + c * 16;
-    }
-  }
-
-  auto issue = [&](int kt, int buf) {
-    char* sa = smem + buf * STAGE;
-    char* sb = sa + A_BYTES;
-    const int k0 = kt * KSTEP;
-#pragma unroll
-    for (int j = 0; j < A_PER; ++j) {
-      unsigned off;
-      if constexpr (ALAY == LAY_ROW) {
-        off = (k0 * 2 + a_kc[j] < p.K * 2) ? a_base[j] + k0 * 2 : OOB;
-      } else if constexpr (ALAY == LAY_KMAJ) {
-        off = (a_base[j] == OOB) ? OOB : a_base[j] + (unsigned)((long long)k0 * p.lda * 2);
-      } else {
-        const int tap = k0 / p.cC, ci0 = k0 - tap * p.cC;
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        int iy = cy[j] + ky, ix = cx[j] + kx;
-        const bool ok = iy >= 0 && ix >= 0 && iy < (p.cH << p.ups) && ix < (p.cW << p.ups);
-        iy >>= p.ups;
-        ix >>= p.ups;
-        off = ok ? a_base[j] + (unsigned)((iy * p.cW + ix) * p.cC + ci0) * 2 : OOB;
-      }
-      dma16(ra, sa + (w + NW * j) * 1024, off);
-    }
-#pragma unroll
-    for (int j = 0; j < B_PER; ++j) {
-      unsigned off;
-      if constexpr (BLAY == LAY_ROW) {
-        off = (k0 * 2 + b_kc[j] < p.K * 2) ? b_base[j] + k0 * 2 : OOB;
-      } else {
-        off = (b_base[j] == OOB) ? OOB : b_base[j] + (unsigned)((long long)k0 * p.ldb * 2);
-      }
-      dma16(rb, sb + (w + NW * j) * 1024, off);
-    }
+    bz = tm / tiles_m;
+    m0 = (tm - bz * tiles_m) * BM;
+    n0 = tn * BN;
+    return true;
+  };
+  auto next_item = [&](int r) {  // first item after r that is a tile, or the first dead one
+    int bz, m0, n0;
+    do ++r;
+    while (live(r) && !decode(r, bz, m0, n0));
+    return r;
   };
 
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // ---- issue cursor: source plan of the tile whose half-units are being requested.  Piece j of a wave is piece
+  // w + 8 j of the half-unit; its rows are 64 j rows (ROW) / 16 j k-rows (K-major) below piece 0's, and the swizzled
+  // chunk a lane fetches is the same for every j, so one base offset per operand describes all four pieces.
+  __amdgpu_buffer_rsrc_t ra, rb;
+  unsigned a_base0, b_base0;  // byte offset of this lane's chunk in piece 0 at k = 0, or OOB when its column is out
+  int pm0 = 0, pn0 = 0;       // tile origin of the plan
+  bool pok = false;
+  // ROW: rows 8 w + 64 j + (lane >> 3), logical chunk = physical chunk ^ ((row >> 1) & 7)  (row_off's swizzle)
+  const int r_row0 = 8 * w + (lane >> 3), r_c = (lane & 7) ^ ((4 * w + (lane >> 4)) & 7);
+  // K-major: k-rows 2 w + 16 j + (lane >> 5), 32 column chunks, logical = physical ^ (s << 1)  (kmaj_off's swizzle)
+  const int k_row0 = 2 * w + (lane >> 5);
+  const int k_lc = (lane & 31) ^ (((k_row0 & 3) | (((k_row0 >> 3) & 1) << 2)) << 1);
+  auto plan = [&](int r) {
+    int bz = 0;
+    pm0 = pn0 = 0;
+    pok = live(r) && decode(r, bz, pm0, pn0);  // dead: every request is out of bounds (zero fills nobody reads)
+    ra = make_rsrc((const char*)p.A + (long long)bz * p.sA * 2, p.a_bytes);
+    rb = make_rsrc((const char*)p.B + (long long)bz * p.sB * 2, p.b_bytes);
+    if constexpr (ALAY == LAY_KMAJ)
+      a_base0 = (pok && pm0 + k_lc * 8 < p.M) ? (unsigned)(((long long)k_row0 * p.lda + pm0) * 2) + k_lc * 16 : OOB;
+    else
+      a_base0 = pok ? (unsigned)(((long long)(pm0 + r_row0) * p.lda) * 2) + r_c * 16 : OOB;
+    if constexpr (BLAY == LAY_KMAJ)
+      b_base0 = (pok && pn0 + k_lc * 8 < p.N) ? (unsigned)(((long long)k_row0 * p.ldb + pn0) * 2) + k_lc * 16 : OOB;
+    else
+      b_base0 = pok ? (unsigned)(((long long)(pn0 + r_row0) * p.ldb) * 2) + r_c * 16 : OOB;
+  };
+  // piece j (of PER) of one operand's half-unit u: `lay`-layout source with leading dimension ld, tile origin o0 of
+  // extent lim
+  auto issue_piece = [&](auto lay, __amdgpu_buffer_rsrc_t rs, unsigned base0, long long ld, int o0, int lim, int u,
+                         char* dst, int j) {
+    const int k0 = u * KU;
+    unsigned off;
+    if constexpr (decltype(lay)::value == LAY_KMAJ)
+      off = (base0 != OOB && k0 + k_row0 + 16 * j < p.K) ? base0 + (unsigned)((long long)(k0 + 16 * j) * ld * 2) : OOB;
+    else
+      off = (base0 != OOB && o0 + r_row0 + 64 * j < lim && k0 * 2 + r_c * 16 < p.K * 2)
+                ? base0 + (unsigned)((long long)(64 * j) * ld * 2) + k0 * 2
+                : OOB;
+    dma16(rs, dst + (w + NW * j) * 1024, off);
+  };
+  auto issue_a_piece = [&](int u, char* dst, int j) {
+    issue_piece(std::integral_constant<int, ALAY>{}, ra, a_base0, p.lda, pm0, p.M, u, dst, j);
+  };
+  auto issue_b_piece = [&](int u, char* dst, int j) {
+    issue_piece(std::integral_constant<int, BLAY>{}, rb, b_base0, p.ldb, pn0, p.N, u, dst, j);
+  };
 
-  const int nk = (p.K + KSTEP - 1) / KSTEP;
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);  // lands while this tile is being multiplied
-    const char* sa = smem + cur * STAGE;
-    const char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      u32x4 fa[TM], fb[TN];
-#pragma unroll
-      for (int nt = 0; nt < TN; ++nt) fb[nt] = load_frag<BLAY, BN>(sb, wn * TN + nt, ks, lane);
-#pragma unroll
-      for (int mt = 0; mt < TM; ++mt) fa[mt] = load_frag<ALAY, BM>(sa, wm * TM + mt, ks, lane);
-#pragma unroll
-      for (int mt = 0; mt < TM; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < TN; ++nt) mma<bf16_t>(acc[mt][nt], fb[nt], fa[mt]);  // rows = n, cols = m
+  int first_item = -1;
+  first_item = next_item(first_item);
+  // Issue cursor.  The stream of half-units is A(0) B(0) A(1) | B(1) A(2) | B(2) A(3) | ... : three up front, then
+  // every K-unit iteration requests the B half of unit `iu` and the A half of the unit after it.
+  int ir = first_item, iu = 0;  // item and K-unit of the next B half to request
+  int fill = 0;                 // slot of the next half-unit to request
+  plan(ir);
+  auto next_slot = [&]() { fill = fill + 1 == NSLOT ? 0 : fill + 1; };
+  auto next_unit = [&]() {      // the B half of unit iu is out: move on (possibly to the next tile)
+    if (++iu == nu) {
+      iu = 0;
+      ir = next_item(ir);
+      plan(ir);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  };
+#pragma unroll
+  for (int j = 0; j < PER; ++j) issue_a_piece(0, smem, j);             // A(0) -> slot 0
+#pragma unroll
+  for (int j = 0; j < PER; ++j) issue_b_piece(0, smem + HALF, j);      // B(0) -> slot 1
+  next_unit();
+#pragma unroll
+  for (int j = 0; j < PER; ++j) issue_a_piece(iu, smem + 2 * HALF, j);  // A(1) -> slot 2
+  fill = 3;
+  int slot = 0;  // slot of the A half of the unit being multiplied
+  bool first = true;
+  for (int r = first_item; live(r); r = next_item(r)) {
+    int bz, m0, n0;
+    decode(r, bz, m0, n0);
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if ((G256_LAB & 8)) ts0 = __builtin_amdgcn_s_memtime();
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int u = 0; u < nu; ++u) {
+      // H(2u), H(2u+1) must have landed for every wave and every wave must be past its reads of unit u-1, whose two
+      // slots are refilled now.  One younger half-unit (PER operations) may still be in flight.  The half-units
+      // requested before the previous tile's epilogue were drained there (vmcnt(0)): barrier only.
+      if (first || u > 0) wait_vm_barrier<PER>();
+      else asm volatile("s_barrier" ::: "memory");
+      // The eight LDS-DMA pieces of this iteration (B of unit iu, then A of the unit after) are issued ONE AT A TIME
+      // between groups of MFMAs: a piece occupies the issuing wave for 60-180 cycles, and all 64 of a workgroup's
+      // pieces issued together right after the barrier stall every wave for as long as the whole K-unit's MFMAs
+      // take (measured: K-unit time = MFMA time + DMA time).  Spread out, the SIMD's other wave keeps the matrix
+      // pipe busy meanwhile.
+      constexpr bool DMA_ON = G256_LAB != 1 && G256_LAB != 9;
+      char* dst_b = smem + fill * HALF;
+      next_slot();
+      char* dst_a = smem + fill * HALF;
+      next_slot();
+      const char* sa = smem + slot * HALF;
+      const char* sb = smem + (slot + 1 == NSLOT ? 0 : slot + 1) * HALF;
+#pragma unroll
+      for (int ks = 0; ks < (G256_LAB == 10 ? 0 : 2); ++ks) {
+        // all 12 fragment reads of this k-step go out back to back, then the MFMAs run at raised priority: the LDS
+        // sees a short read burst and is otherwise free for the LDS-DMA writes that are landing.  (Left to itself
+        // the compiler reads one A fragment at a time, each behind an lgkmcnt(0), to save registers.)
+        u32x4 fa[TM], fb[TN];
+        if (G256_LAB == 12) {  // MFMAs on whatever is in the registers: no LDS reads
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt) { fb[nt] = u32x4{(unsigned)lane, 1u, 2u, 3u}; asm volatile("" : "+v"(fb[nt])); }
+#pragma unroll
+          for (int mt = 0; mt < TM; ++mt) { fa[mt] = u32x4{(unsigned)lane, 1u, 2u, 3u}; asm volatile("" : "+v"(fa[mt])); }
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt) fb[nt] = load_frag<BLAY, BN>(sb, wn * TN + nt, ks, lane);
+#pragma unroll
+          for (int mt = 0; mt < TM; ++mt) fa[mt] = load_frag<ALAY, BM>(sa, wm * TM + mt, ks, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (G256_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt) mma<bf16_t>(acc[mt][nt], fb[nt], fa[mt]);  // rows = n, cols = m
+          if (DMA_ON && (mt & 1) == (G256_PLACE == 1 ? 0 : 1)) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0) issue_b_piece(iu, dst_b, mt >> 1);
+            else issue_a_piece(iu, dst_a, mt >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (DMA_ON && ks == 0) next_unit();
+      }
+      if (DMA_ON && G256_LAB == 10) {  // lab: DMA only
+#pragma unroll
+        for (int j = 0; j < PER; ++j) issue_b_piece(iu, dst_b, j);
+        next_unit();
+#pragma unroll
+        for (int j = 0; j < PER; ++j) issue_a_piece(iu, dst_a, j);
+      }
+      slot = slot + 2 >= NSLOT ? slot + 2 - NSLOT : slot + 2;
+    }
+    first = false;
+    if ((G256_LAB & 8)) ts1 = __builtin_amdgcn_s_memtime();
+    // this wave's pieces of the next three half-units have landed; every wave is past its reads of the last unit,
+    // whose A slot ( = `fill`, refilled at the next barrier) is the epilogue's staging block
+    wait_vm_barrier<0>();
+    // the epilogue's per-lane offsets are tile-invariant; hoisted out of the tile loop they would sit in scratch
+    // (the K loop owns the whole register file) and every reload is a memory round trip - recompute them per tile
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    if ((G256_LAB & 8)) ts2 = __builtin_amdgcn_s_memtime();
+    if (G256_LAB == 6) {  // no epilogue, accumulators kept alive
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) sum += acc[a][b];
+      if (sum[0] + sum[1] + sum[2] + sum[3] == 12345.f) *(float*)p.C = sum[0];
+      continue;
+    }
+    if (G256_LAB == 4) {  // full epilogue arithmetic + staging, stores predicated off at run time
+      GemmParams q = p;
+      q.N = p.alpha == 1.f ? 0 : p.N;
+      epilogue<bf16_t, TM, TN, MODE>(q, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, bz, lane_e, smem + fill * HALF + w * 4096);
+      continue;
+    }
+    epilogue<bf16_t, TM, TN, MODE>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, bz, lane_e, smem + fill * HALF + w * 4096);
+    if ((G256_LAB & 8) && blockIdx.x == 17 && t == 0) {
+      unsigned long long* dbg = (unsigned long long*)p.C2 + 4 * (r - first_item);
+      dbg[0] = ts0; dbg[1] = ts1; dbg[2] = ts2; dbg[3] = __builtin_amdgcn_s_memtime();
+    }
   }
-  epilogue<bf16_t, TM, TN>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, bz, lane, smem + w * 4096);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int ALAY, int BLAY, int WM, int WN, int TM, int TN>
-int launch_cfg(const GemmParams& p, int batch, hipStream_t s) {
-  constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN, LDS = 2 * (BM + BN) * 128;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)gemm256_kernel<ALAY, BLAY, WM, WN, TM, TN>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+template <int ALAY, int BLAY, int MODE>
+int launch_mode(const GemmParams& p, int batch, hipStream_t s) {
+  constexpr int LDS = 5 * 256 * 128;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
       return MELGPT_ERR_LAUNCH;
-    attr = true;
+    if (hipFuncSetAttribute((const void*)gemm256_kernel<ALAY, BLAY, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS) != hipSuccess)
+      return MELGPT_ERR_LAUNCH;
+    ncu = n;
   }
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm256_kernel<ALAY, BLAY, WM, WN, TM, TN>), dim3(tiles, 1, batch), dim3(64 * WM * WN), LDS, s, p);
+  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+  const long long total = (long long)tiles_m * tiles_n * batch;
+  if (total > 0x3FFFFFFF) return MELGPT_ERR_UNSUPPORTED;
+  int grid = (int)(total < ncu ? total : ncu);  // LDS footprint: exactly one workgroup per CU
+  // XCD blocks need every XCD to own the same number of workgroups; otherwise the linear order is used
+  int RN = 0;
+  if (grid == ncu && ncu % 8 == 0) {
+    const int per = ncu / 8;
+    for (int c = 1; c * c <= per; ++c)
+      if (per % c == 0 && c <= tiles_n) RN = c;  // most square block whose width fits the tile grid
+  }
+  hipLaunchKernelGGL((gemm256_kernel<ALAY, BLAY, MODE>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n, batch, RN);
   return melgpt_launch_status();
 }
 
 template <int ALAY, int BLAY>
-int launch_lay(const GemmParams& p, int batch, int cfg, hipStream_t s) {
-  if (cfg == 3) return launch_cfg<ALAY, BLAY, 2, 4, 8, 4>(p, batch, s);  // 256 x 256
-  return launch_cfg<ALAY, BLAY, 4, 2, 4, 4>(p, batch, s);                // 256 x 128
+int launch_lay(const GemmParams& p, int batch, hipStream_t s) {
+  if (!p.vec_io) return MELGPT_ERR_UNSUPPORTED;
+  const bool plain = p.act == MELGPT_ACT_NONE && p.drop_scale == 0.f && !p.C2;
+  if (p.out_f32) return plain ? launch_mode<ALAY, BLAY, EPI_PLAIN32>(p, batch, s) : MELGPT_ERR_UNSUPPORTED;
+  return plain ? launch_mode<ALAY, BLAY, EPI_PLAIN16>(p, batch, s) : launch_mode<ALAY, BLAY, EPI_FULL16>(p, batch, s);
 }
 
 }  // namespace
 
 int gemmk::launch_gemm256(const GemmParams& p, int alay, int blay, int batch, int tile_cfg, hipStream_t s) {
-  if (tile_cfg != 2 && tile_cfg != 3) return MELGPT_ERR_UNSUPPORTED;
-  if (alay == LAY_ROW && blay == LAY_ROW) return launch_lay<LAY_ROW, LAY_ROW>(p, batch, tile_cfg, s);
-  if (alay == LAY_ROW && blay == LAY_KMAJ) return launch_lay<LAY_ROW, LAY_KMAJ>(p, batch, tile_cfg, s);
-  if (alay == LAY_KMAJ && blay == LAY_KMAJ) return launch_lay<LAY_KMAJ, LAY_KMAJ>(p, batch, tile_cfg, s);
-  if (alay == LAY_CONV && blay == LAY_ROW) return launch_lay<LAY_CONV, LAY_ROW>(p, batch, tile_cfg, s);
-  return MELGPT_ERR_UNSUPPORTED;
+  if (tile_cfg != 3) return MELGPT_ERR_UNSUPPORTED;
+  if (alay == LAY_ROW && blay == LAY_ROW) return launch_lay<LAY_ROW, LAY_ROW>(p, batch, s);
+  if (alay == LAY_ROW && blay == LAY_KMAJ) return launch_lay<LAY_ROW, LAY_KMAJ>(p, batch, s);
+  if (alay == LAY_KMAJ && blay == LAY_KMAJ) return launch_lay<LAY_KMAJ, LAY_KMAJ>(p, batch, s);
+  return MELGPT_ERR_UNSUPPORTED;  // implicit-GEMM convolutions stay on the 128 x 128 kernel
 }

@@ -82,30 +82,44 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 template <int ROWB>
 __device__ __forceinline__ int stage_off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
 
-template <typename T, int TM, int TN>
+// MODE picks what is compiled in (the persistent 256-wide kernel instantiates one kernel per mode so that its
+// epilogue stays small enough for the instruction cache; the generic mode serves gemm.hip and conv_fused.hip):
+enum { EPI_GENERIC = 0, EPI_PLAIN16 = 1, EPI_PLAIN32 = 2, EPI_FULL16 = 3 };
+//   EPI_GENERIC  everything, decided at run time; slabs unrolled
+//   EPI_PLAIN16  alpha, bias, +R, accumulate; bf16 output; slabs unrolled (a few hundred instructions in all)
+//   EPI_PLAIN32  the same with f32 output (split-K weight gradients)
+//   EPI_FULL16   activation / dropout / second output as well, bf16 output; ONE copy of the slab body in a rolled
+//                loop (unrolled it is ~100 KiB of code, which a persistent kernel would re-fetch on every tile)
+// EPI_PLAIN* / EPI_FULL16 require p.vec_io.
+template <typename T, int TM, int TN, int MODE = EPI_GENERIC>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[TM][TN], const long long (&mrow)[TM],
                                               int row_limit, int n_base, int bz, int lane, char* stage);
 
-template <typename T, int TM, int TN>
+template <typename T, int TM, int TN, int MODE = EPI_GENERIC>
 __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[TM][TN], int m_base, int n_base, int bz,
                                          int lane, char* stage) {
   long long mrow[TM];
 #pragma unroll
   for (int mt = 0; mt < TM; ++mt) mrow[mt] = m_base + mt * 16;
-  epilogue_rows<T, TM, TN>(p, acc, mrow, 16, n_base, bz, lane, stage);
+  epilogue_rows<T, TM, TN, MODE>(p, acc, mrow, 16, n_base, bz, lane, stage);
 }
 
 // mrow[mt] = output row (in C) of the first of the 16 consecutive rows held by accumulator slab mt, or < 0 when the
 // slab is entirely out of range; rows mrow[mt] + r with r >= row_limit (or >= p.M) are skipped.
-template <typename T, int TM, int TN>
+template <typename T, int TM, int TN, int MODE>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[TM][TN], const long long (&mrow)[TM],
                                               int row_limit, int n_base, int bz, int lane, char* stage) {
   constexpr int ES = Tr<T>::ES;
+  constexpr bool ACT = MODE == EPI_GENERIC || MODE == EPI_FULL16;           // activation / dropout / C2 compiled in
+  constexpr bool CAN32 = MODE == EPI_GENERIC || MODE == EPI_PLAIN32;
+  constexpr bool CAN16 = MODE != EPI_PLAIN32 && ES == 2;
+  constexpr bool ROLLED = MODE == EPI_FULL16;
+  static_assert(CAN32 || CAN16, "no output type left");
   using RV = typename std::conditional<ES == 4, f32x4, u32x2>::type;  // one 4-element group of R / C in dtype T
   const int i16 = lane & 15, g = lane >> 4;
-  const bool f32out = p.out_f32 || ES == 4;
+  const bool f32out = CAN32 && (!CAN16 || p.out_f32);
   char* Cb = (char*)p.C + (long long)bz * p.sC * (f32out ? 4 : ES);
-  char* C2b = p.C2 ? (char*)p.C2 + (long long)bz * p.sC * (f32out ? 4 : ES) : nullptr;
+  char* C2b = (ACT && p.C2) ? (char*)p.C2 + (long long)bz * p.sC * (f32out ? 4 : ES) : nullptr;
   const char* Rb = p.R ? (const char*)p.R + (long long)bz * p.sR * ES : nullptr;
 
   f32x4 bv[TN];
@@ -120,141 +134,191 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
     else return f32x4{bf16lo(r[0]), bf16hi(r[0]), bf16lo(r[1]), bf16hi(r[1])};
   };
   auto math = [&](f32x4 v, f32x4 r4, long long m, int n, bool has_r) -> f32x4 {
-    if (p.act == MELGPT_ACT_GELU) {
+    if constexpr (ACT) {
+      if (p.act == MELGPT_ACT_GELU) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
-    } else if (p.act == MELGPT_ACT_GELU_GRAD) {
+        for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
+      } else if (p.act == MELGPT_ACT_GELU_GRAD) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= gelu_grad(r4[e]);
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad(r4[e]);
+      }
+      if (p.drop_scale != 0.f) {
+        const unsigned long long e0 = ((unsigned long long)bz * p.M + m) * (unsigned long long)p.N + n;
+        const unsigned keep = dropout_keep4(p.seed, p.stream_id, e0 >> 2, p.drop_thresh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (keep >> e & 1) ? v[e] * p.drop_scale : 0.f;
+      }
+      if (has_r && p.act != MELGPT_ACT_GELU_GRAD) v += r4;
+    } else {
+      if (has_r) v += r4;
     }
-    if (p.drop_scale != 0.f) {
-      const unsigned long long e0 = ((unsigned long long)bz * p.M + m) * (unsigned long long)p.N + n;
-      const unsigned keep = dropout_keep4(p.seed, p.stream_id, e0 >> 2, p.drop_thresh);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (keep >> e & 1) ? v[e] * p.drop_scale : 0.f;
-    }
-    if (has_r && p.act != MELGPT_ACT_GELU_GRAD) v += r4;
     return v;
   };
 
-  if (p.vec_io) {
+  if (MODE != EPI_GENERIC || p.vec_io) {
     // ------------------------------------------------------------------ staged, row-contiguous path
     constexpr int IN_ROWB = TN * 16 * ES, IN_CPR = IN_ROWB / 16, IN_PER = (16 * IN_CPR) / 64;  // chunks / lane / slab
-    u32x4 rin[TM][IN_PER > 0 ? IN_PER : 1];
-    if (Rb) {
+    constexpr int NR = IN_PER > 0 ? IN_PER : 1;
+    // R slabs are fetched one slab ahead of their use: rin[0] = current slab, rin[1] = next (rotated in at the end)
+    u32x4 rin[2][NR];
+    auto fetch_r = [&](long long mr, u32x4 (&dst)[NR]) {
 #pragma clang loop unroll(full)
-      for (int mt = 0; mt < TM; ++mt)
-#pragma clang loop unroll(full)
-        for (int j = 0; j < IN_PER; ++j) {
-          const int q = lane + 64 * j, row = q / IN_CPR, ch = q % IN_CPR;
-          const long long m = mrow[mt] + row;
-          const int n = n_base + ch * (16 / ES);
-          rin[mt][j] = u32x4{0u, 0u, 0u, 0u};
-          if (mrow[mt] >= 0 && row < row_limit && m < p.M && n < p.N)
-            rin[mt][j] = *(const u32x4*)(Rb + (m * p.ldr + n) * ES);
-        }
-    }
-#pragma clang loop unroll(full)
-    for (int mt = 0; mt < TM; ++mt) {
-      const long long m = mrow[mt] + i16;
+      for (int j = 0; j < IN_PER; ++j) {
+        const int q = lane + 64 * j, row = q / IN_CPR, ch = q % IN_CPR;
+        const long long m = mr + row;
+        const int n = n_base + ch * (16 / ES);
+        dst[j] = u32x4{0u, 0u, 0u, 0u};
+        if (mr >= 0 && row < row_limit && m < p.M && n < p.N) dst[j] = *(const u32x4*)(Rb + (m * p.ldr + n) * ES);
+      }
+    };
+    // one 16-row slab: accumulators av, first output row mr, first row of the NEXT slab mr_next (or -1)
+    auto slab = [&](const f32x4 (&av)[TN], long long mr, long long mr_next) {
+      const long long m = mr + i16;
       f32x4 r4[TN];
       if (Rb) {
+        fetch_r(mr_next, rin[1]);
 #pragma clang loop unroll(full)
         for (int j = 0; j < IN_PER; ++j) {
           const int q = lane + 64 * j;
-          *(u32x4*)(stage + stage_off<IN_ROWB>(q / IN_CPR, q % IN_CPR)) = rin[mt][j];
+          *(u32x4*)(stage + stage_off<IN_ROWB>(q / IN_CPR, q % IN_CPR)) = rin[0][j];
         }
 #pragma clang loop unroll(full)
         for (int nt = 0; nt < TN; ++nt) {
           if constexpr (ES == 4) r4[nt] = *(const f32x4*)(stage + stage_off<IN_ROWB>(i16, 4 * nt + g));
           else r4[nt] = unpack(*(const u32x2*)(stage + stage_off<IN_ROWB>(i16, 2 * nt + (g >> 1)) + (g & 1) * 8));
         }
+#pragma clang loop unroll(full)
+        for (int j = 0; j < IN_PER; ++j) rin[0][j] = rin[1][j];
       }
       // one or two outputs, each staged and written as full rows
 #pragma clang loop unroll(full)
-      for (int pass = 0; pass < 2; ++pass) {
+      for (int pass = ACT ? 0 : 1; pass < 2; ++pass) {
         char* Ob = pass == 0 ? C2b : Cb;
         if (!Ob) continue;
         if (f32out) {
-          constexpr int ROWB = TN * 64, CPR = ROWB / 16, PER = (16 * CPR) / 64;
+          if constexpr (CAN32) {
+            constexpr int ROWB = TN * 64, CPR = ROWB / 16, PER = (16 * CPR) / 64;
 #pragma clang loop unroll(full)
-          for (int nt = 0; nt < TN; ++nt) {
-            f32x4 v = acc[mt][nt] * p.alpha + bv[nt];
-            if (pass == 1) v = math(v, Rb ? r4[nt] : v, m, n_base + nt * 16 + g * 4, Rb != nullptr);
-            *(f32x4*)(stage + stage_off<ROWB>(i16, 4 * nt + g)) = v;
-          }
+            for (int nt = 0; nt < TN; ++nt) {
+              f32x4 v = av[nt] * p.alpha + bv[nt];
+              if (pass == 1) v = math(v, Rb ? r4[nt] : v, m, n_base + nt * 16 + g * 4, Rb != nullptr);
+              *(f32x4*)(stage + stage_off<ROWB>(i16, 4 * nt + g)) = v;
+            }
 #pragma clang loop unroll(full)
-          for (int j = 0; j < PER; ++j) {
-            const int q = lane + 64 * j, row = q / CPR, ch = q % CPR;
-            const long long mm = mrow[mt] + row;
-            const int nn = n_base + ch * 4;
-            if (mrow[mt] >= 0 && row < row_limit && mm < p.M && nn < p.N) {
-              f32x4 o = *(const f32x4*)(stage + stage_off<ROWB>(row, ch));
-              float* dst = (float*)(Ob + (mm * p.ldc + nn) * 4);
-              if (pass == 1 && p.accumulate) o += *(const f32x4*)dst;
-              *(f32x4*)dst = o;
+            for (int j = 0; j < PER; ++j) {
+              const int q = lane + 64 * j, row = q / CPR, ch = q % CPR;
+              const long long mm = mr + row;
+              const int nn = n_base + ch * 4;
+              if (mr >= 0 && row < row_limit && mm < p.M && nn < p.N) {
+                f32x4 o = *(const f32x4*)(stage + stage_off<ROWB>(row, ch));
+                float* dst = (float*)(Ob + (mm * p.ldc + nn) * 4);
+                if (pass == 1 && p.accumulate) o += *(const f32x4*)dst;
+                *(f32x4*)dst = o;
+              }
             }
           }
         } else {
-          constexpr int ROWB = TN * 32, CPR = ROWB / 16, PER = (16 * CPR) / 64;
+          if constexpr (CAN16) {
+            constexpr int ROWB = TN * 32, CPR = ROWB / 16, PER = (16 * CPR) / 64;
 #pragma clang loop unroll(full)
-          for (int nt = 0; nt < TN; ++nt) {
-            f32x4 v = acc[mt][nt] * p.alpha + bv[nt];
-            if (pass == 1) v = math(v, Rb ? r4[nt] : v, m, n_base + nt * 16 + g * 4, Rb != nullptr);
-            *(u32x2*)(stage + stage_off<ROWB>(i16, 2 * nt + (g >> 1)) + (g & 1) * 8) =
-                u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          }
+            for (int nt = 0; nt < TN; ++nt) {
+              f32x4 v = av[nt] * p.alpha + bv[nt];
+              if (pass == 1) v = math(v, Rb ? r4[nt] : v, m, n_base + nt * 16 + g * 4, Rb != nullptr);
+              *(u32x2*)(stage + stage_off<ROWB>(i16, 2 * nt + (g >> 1)) + (g & 1) * 8) =
+                  u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
 #pragma clang loop unroll(full)
-          for (int j = 0; j < PER; ++j) {
-            const int q = lane + 64 * j, row = q / CPR, ch = q % CPR;
-            const long long mm = mrow[mt] + row;
-            const int nn = n_base + ch * 8;
-            if (mrow[mt] >= 0 && row < row_limit && mm < p.M && nn < p.N) {
-              u32x4 o = *(const u32x4*)(stage + stage_off<ROWB>(row, ch));
-              u32x4* dst = (u32x4*)(Ob + (mm * p.ldc + nn) * 2);
-              if (pass == 1 && p.accumulate) {
-                const u32x4 c = *dst;
+            for (int j = 0; j < PER; ++j) {
+              const int q = lane + 64 * j, row = q / CPR, ch = q % CPR;
+              const long long mm = mr + row;
+              const int nn = n_base + ch * 8;
+              if (mr >= 0 && row < row_limit && mm < p.M && nn < p.N) {
+                u32x4 o = *(const u32x4*)(stage + stage_off<ROWB>(row, ch));
+                u32x4* dst = (u32x4*)(Ob + (mm * p.ldc + nn) * 2);
+                if (pass == 1 && p.accumulate) {
+                  const u32x4 c = *dst;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  o[e] = pack_bf16x2(bf16lo(o[e]) + bf16lo(c[e]), bf16hi(o[e]) + bf16hi(c[e]));
+                  for (int e = 0; e < 4; ++e)
+                    o[e] = pack_bf16x2(bf16lo(o[e]) + bf16lo(c[e]), bf16hi(o[e]) + bf16hi(c[e]));
+                }
+                *dst = o;
               }
-              *dst = o;
             }
           }
         }
+      }
+    };
+
+    if (Rb) fetch_r(mrow[0], rin[0]);
+    if constexpr (!ROLLED) {
+#pragma clang loop unroll(full)
+      for (int mt = 0; mt < TM; ++mt) {
+        // slabs strictly one after another: interleaving the unrolled slabs only raises register pressure (the
+        // accumulators already fill half the file) and ends in scratch spills, whose reloads are memory round trips
+        __builtin_amdgcn_sched_barrier(0);
+        slab(acc[mt], mrow[mt], mt + 1 < TM ? mrow[mt + 1] : -1);
+      }
+    } else {
+      static_assert(!ROLLED || TM <= 8, "switch below covers 8 slabs");
+#pragma clang loop unroll(disable)
+      for (int mt = 0; mt < TM; ++mt) {
+        f32x4 av[TN];
+        long long mr = -1, mr_next = -1;
+        auto take = [&](auto c) {
+          constexpr int MT = decltype(c)::value;
+          if constexpr (MT < TM) {
+#pragma clang loop unroll(full)
+            for (int nt = 0; nt < TN; ++nt) av[nt] = acc[MT][nt];
+            mr = mrow[MT];
+            mr_next = MT + 1 < TM ? mrow[MT + 1 < TM ? MT + 1 : MT] : -1;
+          }
+        };
+        switch (mt) {
+          case 0: take(std::integral_constant<int, 0>{}); break;
+          case 1: take(std::integral_constant<int, 1>{}); break;
+          case 2: take(std::integral_constant<int, 2>{}); break;
+          case 3: take(std::integral_constant<int, 3>{}); break;
+          case 4: take(std::integral_constant<int, 4>{}); break;
+          case 5: take(std::integral_constant<int, 5>{}); break;
+          case 6: take(std::integral_constant<int, 6>{}); break;
+          default: take(std::integral_constant<int, 7>{}); break;
+        }
+        slab(av, mr, mr_next);
       }
     }
     return;
   }
 
   // ---------------------------------------------------------------------- direct per-lane path (unaligned rows)
+  if constexpr (MODE == EPI_GENERIC) {
 #pragma clang loop unroll(full)
-  for (int nt = 0; nt < TN; ++nt) {
-    const int n = n_base + nt * 16 + g * 4;
-    if (n >= p.N) continue;
+    for (int nt = 0; nt < TN; ++nt) {
+      const int n = n_base + nt * 16 + g * 4;
+      if (n >= p.N) continue;
 #pragma clang loop unroll(full)
-    for (int mt = 0; mt < TM; ++mt) {
-      const long long m = mrow[mt] + i16;
-      if (mrow[mt] < 0 || i16 >= row_limit || m >= p.M) continue;
-      f32x4 v = acc[mt][nt] * p.alpha + bv[nt];
-      if (C2b) {
-        if (f32out) *(f32x4*)(C2b + ((long long)m * p.ldc + n) * 4) = v;
-        else *(u32x2*)(C2b + ((long long)m * p.ldc + n) * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-      }
-      f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
-      if (Rb) r4 = unpack(*(const RV*)(Rb + ((long long)m * p.ldr + n) * ES));
-      v = math(v, r4, m, n, Rb != nullptr);
-      if (f32out) {
-        float* dst = (float*)(Cb + ((long long)m * p.ldc + n) * 4);
-        if (p.accumulate) v += *(const f32x4*)dst;
-        *(f32x4*)dst = v;
-      } else {
-        u32x2* dst = (u32x2*)(Cb + ((long long)m * p.ldc + n) * 2);
-        if (p.accumulate) {
-          u32x2 o = *dst;
-          v += f32x4{bf16lo(o[0]), bf16hi(o[0]), bf16lo(o[1]), bf16hi(o[1])};
+      for (int mt = 0; mt < TM; ++mt) {
+        const long long m = mrow[mt] + i16;
+        if (mrow[mt] < 0 || i16 >= row_limit || m >= p.M) continue;
+        f32x4 v = acc[mt][nt] * p.alpha + bv[nt];
+        if (C2b) {
+          if (f32out) *(f32x4*)(C2b + ((long long)m * p.ldc + n) * 4) = v;
+          else *(u32x2*)(C2b + ((long long)m * p.ldc + n) * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         }
-        *dst = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+        if (Rb) r4 = unpack(*(const RV*)(Rb + ((long long)m * p.ldr + n) * ES));
+        v = math(v, r4, m, n, Rb != nullptr);
+        if (f32out) {
+          float* dst = (float*)(Cb + ((long long)m * p.ldc + n) * 4);
+          if (p.accumulate) v += *(const f32x4*)dst;
+          *(f32x4*)dst = v;
+        } else {
+          u32x2* dst = (u32x2*)(Cb + ((long long)m * p.ldc + n) * 2);
+          if (p.accumulate) {
+            u32x2 o = *dst;
+            v += f32x4{bf16lo(o[0]), bf16hi(o[0]), bf16lo(o[1]), bf16hi(o[1])};
+          }
+          *dst = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        }
       }
     }
   }

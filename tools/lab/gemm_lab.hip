@@ -1,0 +1,86 @@
+// Development harness: times gemm256_kernel variants (G256_LAB: 0 full, 1 no LDS-DMA refills in the loop,
+// 2 no fragment reads / MFMAs, 3 no epilogue) to separate the load path, the LDS+MFMA path and the epilogue.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DG256_LAB=n -I include -I melspec_gpt_vqvae_amd/csrc tools/lab/gemm_lab.hip
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../melspec_gpt_vqvae_amd/csrc/gemm256.hip"
+
+
+static float run(int alay, int blay, int M, int N, int K, int cfg, int iters, int full = 0) {
+  void *A, *B, *C;
+  hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&B, (size_t)N * K * 2); hipMalloc(&C, (size_t)M * N * 2);
+  hipMemset(A, 0x3c, (size_t)M * K * 2); hipMemset(B, 0x3c, (size_t)N * K * 2);
+  GemmParams p{};
+  p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
+  p.lda = alay == LAY_KMAJ ? M : K; p.ldb = blay == LAY_KMAJ ? N : K; p.ldc = N; p.ldr = N;
+  p.a_bytes = (unsigned)((size_t)M * K * 2); p.b_bytes = (unsigned)((size_t)N * K * 2);
+  p.alpha = 1.f; p.vec_io = 1;
+  void *C2 = nullptr, *R = nullptr; float* bias = nullptr;
+  if (full) {
+    hipMalloc(&C2, (size_t)M * N * 2); hipMalloc(&R, (size_t)M * N * 2); hipMalloc(&bias, (size_t)N * 4);
+    hipMemset(R, 0, (size_t)M * N * 2); hipMemset(bias, 0, (size_t)N * 4);
+    p.bias = bias;
+    if (full == 1) { p.act = MELGPT_ACT_GELU; p.C2 = C2; }
+    if (full == 2) { p.R = R; p.drop_scale = 2.f; p.drop_thresh = 32768; p.seed = 7; }
+    if (full == 3) { p.R = R; p.act = MELGPT_ACT_GELU_GRAD; p.drop_scale = 2.f; p.drop_thresh = 32768; p.seed = 7; }
+  }
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) launch_gemm256(p, alay, blay, 1, cfg, 0);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < iters; ++i) launch_gemm256(p, alay, blay, 1, cfg, 0);
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  hipFree(A); hipFree(B); hipFree(C); hipFree(C2); hipFree(R); hipFree(bias);
+  return ms / iters;
+}
+
+static void trace(int alay, int blay, int M, int N, int K) {
+  void *A, *B, *C; unsigned long long* dbg;
+  hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&B, (size_t)N * K * 2); hipMalloc(&C, (size_t)M * N * 2);
+  hipMalloc(&dbg, 4096); hipMemset(dbg, 0, 4096);
+  hipMemset(A, 0x3c, (size_t)M * K * 2); hipMemset(B, 0x3c, (size_t)N * K * 2);
+  GemmParams p{};
+  p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
+  p.lda = alay == LAY_KMAJ ? M : K; p.ldb = blay == LAY_KMAJ ? N : K; p.ldc = N; p.ldr = N;
+  p.a_bytes = (unsigned)((size_t)M * K * 2); p.b_bytes = (unsigned)((size_t)N * K * 2);
+  p.alpha = 1.f; p.vec_io = 1; p.C2 = dbg;
+  // the PLAIN16 kernel ignores C2 (ACT off); launch it directly
+  launch_mode<LAY_ROW, LAY_ROW, EPI_PLAIN16>(p, 1, 0);
+  launch_mode<LAY_ROW, LAY_ROW, EPI_PLAIN16>(p, 1, 0);
+  hipDeviceSynchronize();
+  unsigned long long h[64];
+  hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+  for (int i = 0; i < 10 && h[4 * i]; ++i)
+    printf("tile %d: loop %6llu  drain+barrier %6llu  epilogue %6llu   (gap to next start %6lld) [memtime ticks]\n", i,
+           h[4 * i + 1] - h[4 * i], h[4 * i + 2] - h[4 * i + 1], h[4 * i + 3] - h[4 * i + 2],
+           h[4 * i + 4] ? (long long)(h[4 * i + 4] - h[4 * i + 3]) : -1LL);
+  hipFree(A); hipFree(B); hipFree(C); hipFree(dbg);
+}
+
+int main(int argc, char** argv) {
+  if (G256_LAB & 8) {
+    printf("fc1\n"); trace(LAY_ROW, LAY_ROW, 33920, 4096, 1024);
+    printf("sq8k\n"); trace(LAY_ROW, LAY_ROW, 8192, 8192, 8192);
+    return 0;
+  }
+  struct S { const char* name; int al, bl, M, N, K; } shapes[] = {
+      {"nt fc1 ", LAY_ROW, LAY_ROW, 33920, 4096, 1024}, {"nt fc2 ", LAY_ROW, LAY_ROW, 33920, 1024, 4096},
+      {"nt qkv ", LAY_ROW, LAY_ROW, 33920, 3072, 1024}, {"nt proj", LAY_ROW, LAY_ROW, 33920, 1024, 1024},
+      {"nn fc2d", LAY_ROW, LAY_KMAJ, 33920, 4096, 1024}, {"nn fc1d", LAY_ROW, LAY_KMAJ, 33920, 1024, 4096},
+      {"tn wfc1", LAY_KMAJ, LAY_KMAJ, 4096, 4096, 8192},
+      {"nt sq8k", LAY_ROW, LAY_ROW, 8192, 8192, 8192}};
+  for (auto& s : shapes)
+    for (int cfg = 3; cfg <= 3; ++cfg) {
+      float ms = run(s.al, s.bl, s.M, s.N, s.K, cfg, 10);
+      printf("lab=%d %s cfg=%d  %8.3f ms  %7.1f TFLOP/s\n", G256_LAB, s.name, cfg, ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
+    }
+  if (G256_LAB == 0) {
+    printf("fc1 +bias+gelu+C2     %8.3f ms\n", run(LAY_ROW, LAY_ROW, 33920, 4096, 1024, 3, 10, 1));
+    printf("proj +bias+drop+R     %8.3f ms\n", run(LAY_ROW, LAY_ROW, 33920, 1024, 1024, 3, 10, 2));
+    printf("fc2 +bias+drop+R      %8.3f ms\n", run(LAY_ROW, LAY_ROW, 33920, 1024, 4096, 3, 10, 2));
+    printf("dfc2 nn +drop*gelu'   %8.3f ms\n", run(LAY_ROW, LAY_KMAJ, 33920, 4096, 1024, 3, 10, 3));
+  }
+  return 0;
+}
