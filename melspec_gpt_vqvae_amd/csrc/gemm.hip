@@ -282,7 +282,7 @@ int pick_tile(const GemmParams& p, int batch) {
   // The persistent 256 x 256 kernel (gemm256.hip) wins once there are enough tiles to occupy the chip and the
   // tile grid is not mostly padding; small or skinny problems stay on the 128 x 128 kernel (two workgroups per CU).
   const long long tiles256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch;
-  const double fill = (double)p.M * p.N / ((double)((p.M + 255) / 256) * ((p.N + 255) / 256) * 65536.0);
+  const double fill = (double)p.M * p.N / ((double)((p.M + 191) / 192) * 192.0 * ((p.N + 255) / 256) * 256.0);
   if (tiles256 >= 192 && fill >= 0.8 && p.K >= 256) return 3;
   return 1;
 }

@@ -15,6 +15,8 @@
 // on gemm.hip.
 //   LDS-DMA writes are lane-linear (wave-uniform base + 16*lane), so the XOR swizzle is applied to the SOURCE
 //   address (which chunk a lane fetches) and again on the fragment read - both sides or neither.
+#include <cstdlib>
+
 #include "gemm_common.h"
 
 using namespace gemmk;
@@ -84,11 +86,13 @@ __device__ __forceinline__ void wait_vm_barrier() {
 //
 // Tile order: the 32 workgroups of one XCD (blockIdx & 7, round-robin dispatch) take an RM x RN block of tiles, so
 // one L2 serves RM row panels of A and RN column panels of B instead of 1 + 32.
-template <int ALAY, int BLAY, int MODE>
+template <int ALAY, int BLAY, int MODE, int TM>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m, int tiles_n, int batch, int RN) {
-  constexpr int WN = 4, TM = 8, TN = 4, NW = 8, BM = 256, BN = 256;
+  constexpr int WN = 4, TN = 4, NW = 8, BM = 32 * TM, BN = 256;  // TM = 8: 256 x 256; TM = 6: 192 x 256 (A row-major only)
   constexpr int HALF = 256 * 128, NSLOT = 5;
-  constexpr int PER = HALF / 1024 / NW;  // LDS-DMA pieces per wave per half-unit (4)
+  constexpr int PER = HALF / 1024 / NW;   // LDS-DMA pieces per wave per B half-unit (4)
+  constexpr int PER_A = BM * 128 / 1024 / NW;  // ... per A half-unit (4 or 3)
+  static_assert(TM == 8 || (TM == 6 && ALAY != LAY_KMAJ), "the K-major A image assumes 512-byte k-rows");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [5][32 KiB]
 
   const int t = threadIdx.x, lane = t & 63;
@@ -194,12 +198,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
     }
   };
 #pragma unroll
-  for (int j = 0; j < PER; ++j) issue_a_piece(0, smem, j);             // A(0) -> slot 0
+  for (int j = 0; j < PER_A; ++j) issue_a_piece(0, smem, j);           // A(0) -> slot 0
 #pragma unroll
   for (int j = 0; j < PER; ++j) issue_b_piece(0, smem + HALF, j);      // B(0) -> slot 1
   next_unit();
 #pragma unroll
-  for (int j = 0; j < PER; ++j) issue_a_piece(iu, smem + 2 * HALF, j);  // A(1) -> slot 2
+  for (int j = 0; j < PER_A; ++j) issue_a_piece(iu, smem + 2 * HALF, j);  // A(1) -> slot 2
   fill = 3;
   int slot = 0;  // slot of the A half of the unit being multiplied
   bool first = true;
@@ -216,9 +220,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
 
     for (int u = 0; u < nu; ++u) {
       // H(2u), H(2u+1) must have landed for every wave and every wave must be past its reads of unit u-1, whose two
-      // slots are refilled now.  One younger half-unit (PER operations) may still be in flight.  The half-units
+      // slots are refilled now.  One younger half-unit (an A half: PER_A operations) may still be in flight.  The half-units
       // requested before the previous tile's epilogue were drained there (vmcnt(0)): barrier only.
-      if (first || u > 0) wait_vm_barrier<PER>();
+      if (first || u > 0) wait_vm_barrier<PER_A>();
       else asm volatile("s_barrier" ::: "memory");
       // The eight LDS-DMA pieces of this iteration (B of unit iu, then A of the unit after) are issued ONE AT A TIME
       // between groups of MFMAs: a piece occupies the issuing wave for 60-180 cycles, and all 64 of a workgroup's
@@ -255,10 +259,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
         for (int mt = 0; mt < TM; ++mt) {
 #pragma unroll
           for (int nt = 0; nt < TN; ++nt) mma<bf16_t>(acc[mt][nt], fb[nt], fa[mt]);  // rows = n, cols = m
-          if (DMA_ON && (mt & 1) == (G256_PLACE == 1 ? 0 : 1)) {
+          // piece k of NP goes out after MFMA row floor((k + 1) TM / NP) - 1
+          const int np = ks == 0 ? PER : PER_A;
+          const int k_here = ((mt + 1) * np) / TM - (mt * np) / TM;  // 0 or 1 pieces after this row
+          if (DMA_ON && k_here > 0) {
             __builtin_amdgcn_sched_barrier(0);
-            if (ks == 0) issue_b_piece(iu, dst_b, mt >> 1);
-            else issue_a_piece(iu, dst_a, mt >> 1);
+            if (ks == 0) issue_b_piece(iu, dst_b, (mt * np) / TM);
+            else issue_a_piece(iu, dst_a, (mt * np) / TM);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
         for (int j = 0; j < PER; ++j) issue_b_piece(iu, dst_b, j);
         next_unit();
 #pragma unroll
-        for (int j = 0; j < PER; ++j) issue_a_piece(iu, dst_a, j);
+        for (int j = 0; j < PER_A; ++j) issue_a_piece(iu, dst_a, j);
       }
       slot = slot + 2 >= NSLOT ? slot + 2 - NSLOT : slot + 2;
     }
@@ -309,21 +316,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int ALAY, int BLAY, int MODE>
-int launch_mode(const GemmParams& p, int batch, hipStream_t s) {
+static int device_cus();
+
+template <int ALAY, int BLAY, int MODE, int TM>
+int launch_tm(const GemmParams& p, int batch, int ncu, hipStream_t s) {
   constexpr int LDS = 5 * 256 * 128;
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      return MELGPT_ERR_LAUNCH;
-    if (hipFuncSetAttribute((const void*)gemm256_kernel<ALAY, BLAY, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)gemm256_kernel<ALAY, BLAY, MODE, TM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS) != hipSuccess)
       return MELGPT_ERR_LAUNCH;
-    ncu = n;
+    attr = true;
   }
-  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+  constexpr int BM = 32 * TM;
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + 255) / 256;
   const long long total = (long long)tiles_m * tiles_n * batch;
   if (total > 0x3FFFFFFF) return MELGPT_ERR_UNSUPPORTED;
   int grid = (int)(total < ncu ? total : ncu);  // LDS footprint: exactly one workgroup per CU
@@ -334,8 +340,40 @@ int launch_mode(const GemmParams& p, int batch, hipStream_t s) {
     for (int c = 1; c * c <= per; ++c)
       if (per % c == 0 && c <= tiles_n) RN = c;  // most square block whose width fits the tile grid
   }
-  hipLaunchKernelGGL((gemm256_kernel<ALAY, BLAY, MODE>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n, batch, RN);
+  hipLaunchKernelGGL((gemm256_kernel<ALAY, BLAY, MODE, TM>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n, batch, RN);
   return melgpt_launch_status();
+}
+
+static int device_cus() {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+      ncu = n;
+  }
+  return ncu;
+}
+
+// Tile height: 256 rows, or 192 when that leaves fewer padded tile-rounds (rounds x tile rows) on this many CUs -
+// e.g. M = 33920, N = 1024: 532 tiles of 256 x 256 are 3 rounds on 256 CUs (cost 3 x 8), 708 of 192 x 256 are 3 shorter
+// rounds (3 x 6).
+template <int ALAY, int BLAY, int MODE>
+int launch_mode(const GemmParams& p, int batch, hipStream_t s) {
+  const int ncu = device_cus();
+  if (ncu <= 0) return MELGPT_ERR_LAUNCH;
+  if constexpr (ALAY != LAY_KMAJ) {
+    auto cost = [&](int bm, int tm) {
+      const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + 255) / 256) * batch;
+      return ((tiles + ncu - 1) / ncu) * tm;
+    };
+    static int forced = -1;  // MELGPT_GEMM_TM=6|8 pins the tile height (tests cover both)
+    if (forced < 0) {
+      const char* e = getenv("MELGPT_GEMM_TM");
+      forced = e ? atoi(e) : 0;
+    }
+    if (forced == 6 || (forced != 8 && cost(192, 6) < cost(256, 8))) return launch_tm<ALAY, BLAY, MODE, 6>(p, batch, ncu, s);
+  }
+  return launch_tm<ALAY, BLAY, MODE, 8>(p, batch, ncu, s);
 }
 
 template <int ALAY, int BLAY>

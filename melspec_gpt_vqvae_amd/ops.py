@@ -222,15 +222,37 @@ def _split_count(rows, target=32):
     return 1
 
 
-def wgrad(dy, x, out, accumulate):
-    """out (N,K) f32 (+)= dy^T (N x M) @ x (M x K): the weight gradient of y = x W^T.  The reduction runs over
-    M = B*T rows (tens of thousands) while the output has only a few hundred 128x128 tiles, so the rows are split
-    into batches until ~3 workgroups per CU exist; partial products are summed in fixed order (deterministic)."""
-    M, N = dy.shape
-    K = x.shape[1]
+def _wgrad_split(M, N, K, dtype):
+    """split-K factor for the weight-gradient GEMM (a divisor of the M reduction rows).
+    bf16, big outputs: the persistent 256x256 kernel runs one workgroup per CU, so the factor is chosen to fill whole
+    rounds of 256 tiles (cost = rounds x rows per batch, plus the pass that sums the f32 partials);
+    otherwise: ~3 workgroups of the 128x128 kernel per CU."""
+    t256 = ((N + 255) // 256) * ((K + 255) // 256)
+    if dtype == torch.bfloat16 and t256 >= 12:
+        best, best_cost = 1, None
+        for ns in range(1, 33):
+            if M % ns or (M // ns) % 8 or (ns > 1 and M // ns < 512):
+                continue
+            rounds = -(-(t256 * ns) // 256)
+            if t256 * ns < 192:          # the dispatcher keeps such launches on the 128x128 kernel
+                continue
+            cost = rounds * (M // ns) * 33e-9 + (ns > 1) * (ns + 1) * N * K * 4 / 3e12
+            if best_cost is None or cost < best_cost:
+                best, best_cost = ns, cost
+        if best_cost is not None:
+            return best
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     want = max(1, min(16, 768 // max(tiles, 1)))
-    ns = _split_count(M, want) if want > 1 else 1
+    return _split_count(M, want) if want > 1 else 1
+
+
+def wgrad(dy, x, out, accumulate):
+    """out (N,K) f32 (+)= dy^T (N x M) @ x (M x K): the weight gradient of y = x W^T.  The reduction runs over
+    M = B*T rows (tens of thousands) while the output has only a few dozen to a few hundred tiles, so the rows are
+    split into batches (_wgrad_split); partial products are summed in fixed order (deterministic)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    ns = _wgrad_split(M, N, K, dy.dtype)
     if ns == 1 or dy.stride(1) != 1 or x.stride(1) != 1 or (M // ns) < 512:
         return gemm(dy, x, a_kmajor=True, b_kmajor=True, out=out, accumulate=accumulate)
     rows = M // ns
