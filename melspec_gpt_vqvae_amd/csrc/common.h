@@ -77,23 +77,27 @@ __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned b
 // consecutive elements) from two rounds of a 3-multiply avalanche hash ("triple32", bias < 2^-30 per output bit)
 // over the 64-bit counter mixed with the key - ~25 integer ops per 4 decisions.  (A Philox4x32-10 call costs ~100;
 // at one call per 4 attention probabilities / GEMM outputs it was the largest VALU cost of both kernels.)
+// 32-bit integer hash with two multiplies ("lowbias32", bias 0.17): a bijection of the counter, good avalanche.
+// Integer multiplies are quarter-rate on CDNA, so the mask generator is priced in multiplies: 4 per 4 elements.
 __device__ __forceinline__ unsigned hash32(unsigned x) {
-  x ^= x >> 17; x *= 0xed5ad4bbu;
-  x ^= x >> 11; x *= 0xac4c1b51u;
-  x ^= x >> 15; x *= 0x31848babu;
-  x ^= x >> 14;
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
   return x;
 }
 struct Rand4x16 {
   unsigned a, b;  // four 16-bit lanes: a.lo, a.hi, b.lo, b.hi
 };
+// Counter-based: a pure function of (seed, stream_id, ctr), so a backward pass regenerates the forward mask.
+// Two independent hash chains over the same counter under two keys; the keys fold in the (almost always zero,
+// wave-uniform) high counter word with shifts and adds only.
 __device__ __forceinline__ Rand4x16 rand4x16(unsigned long long seed, unsigned stream_id, unsigned long long ctr) {
-  const unsigned k0 = (unsigned)seed ^ (stream_id * 0x9E3779B9u), k1 = (unsigned)(seed >> 32) + stream_id;
   const unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32);
-  const unsigned h = hash32(c0 ^ k0) + c1 * 0x85EBCA6Bu;
+  const unsigned k0 = ((unsigned)seed ^ (stream_id * 0x9E3779B9u)) + ((c1 << 13) | (c1 >> 19));
+  const unsigned k1 = ((unsigned)(seed >> 32) + stream_id * 0x85EBCA6Bu + 0x6A09E667u) ^ c1;
   Rand4x16 r;
-  r.a = hash32(h ^ k1);
-  r.b = hash32(r.a + 0x6A09E667u + k0);
+  r.a = hash32(c0 + k0);
+  r.b = hash32((c0 ^ 0x5bd1e995u) + k1);
   return r;
 }
 // keep-mask for 4 consecutive elements whose first linear index is 4*q: bit i set = element kept.

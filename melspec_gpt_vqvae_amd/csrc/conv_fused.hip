@@ -37,7 +37,7 @@ __device__ __forceinline__ int patch_off(int pix, int chunk, int pix_bytes) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void conv3x3_gn_kernel(FusedConvParams q) {
+__global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(FusedConvParams q) {  // two workgroups per CU: VGPR + AGPR <= 256
   constexpr int ES = Tr<T>::ES, KSTEP = Tr<T>::KSTEP, VEC = 16 / ES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const GemmParams& p = q.g;

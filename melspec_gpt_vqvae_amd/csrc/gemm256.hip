@@ -33,6 +33,10 @@ using namespace gemmk;
 
 namespace {
 
+#if G256_LAB & 8
+__device__ unsigned long long* g256_dbg;  // lab build only: phase stamps of workgroup 17
+#endif
+
 constexpr int KU = 64;  // bf16 elements of K per unit = 128 bytes per ROW-layout row (full L2 lines per request)
 
 template <int MN>
@@ -308,10 +312,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
       continue;
     }
     epilogue<bf16_t, TM, TN, MODE>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, bz, lane_e, smem + fill * HALF + w * 4096);
-    if ((G256_LAB & 8) && blockIdx.x == 17 && t == 0) {
-      unsigned long long* dbg = (unsigned long long*)p.C2 + 4 * (r - first_item);
+#if G256_LAB & 8
+    if (blockIdx.x == 17 && t == 0) {
+      unsigned long long* dbg = g256_dbg + 4 * (r - first_item);
       dbg[0] = ts0; dbg[1] = ts1; dbg[2] = ts2; dbg[3] = __builtin_amdgcn_s_memtime();
     }
+#endif
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

@@ -59,6 +59,36 @@ __device__ __forceinline__ float gelu_grad(float x) {
   gelu_parts(x, cdf, xp);
   return cdf + xp;
 }
+// Two elements at a time: the polynomial runs as packed f32 FMAs (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of
+// work per issue slot); only the reciprocal and the exponential stay scalar.  Same arithmetic, same results.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_parts2(f32x2 x, f32x2& cdf, f32x2& pdf_times_x) {
+  const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+  const f32x2 u = ax * 0.70710678118654752440f;
+  const f32x2 d = u * 0.3275911f + 1.0f;
+  const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  const f32x2 h = x * x * -0.5f;
+  const f32x2 e = {__expf(h[0]), __expf(h[1])};
+  f32x2 poly = t * 1.061405429f + -1.453152027f;
+  poly = poly * t + 1.421413741f;
+  poly = poly * t + -0.284496736f;
+  poly = poly * t + 0.254829592f;
+  const f32x2 half_erf = (1.0f - poly * t * e) * 0.5f;
+  cdf = f32x2{x[0] >= 0.f ? 0.5f + half_erf[0] : 0.5f - half_erf[0], x[1] >= 0.f ? 0.5f + half_erf[1] : 0.5f - half_erf[1]};
+  pdf_times_x = x * 0.39894228040143267794f * e;
+}
+__device__ __forceinline__ f32x4 gelu_exact4(f32x4 v) {
+  f32x2 c0, p0, c1, p1;
+  gelu_parts2(f32x2{v[0], v[1]}, c0, p0);
+  gelu_parts2(f32x2{v[2], v[3]}, c1, p1);
+  return f32x4{v[0] * c0[0], v[1] * c0[1], v[2] * c1[0], v[3] * c1[1]};
+}
+__device__ __forceinline__ f32x4 gelu_grad4(f32x4 v) {
+  f32x2 c0, p0, c1, p1;
+  gelu_parts2(f32x2{v[0], v[1]}, c0, p0);
+  gelu_parts2(f32x2{v[2], v[3]}, c1, p1);
+  return f32x4{c0[0] + p0[0], c0[1] + p0[1], c1[0] + p1[0], c1[1] + p1[1]};
+}
 
 // 128-byte rows, 16-byte chunk index XOR-ed with (row>>1)&7: conflict-free ds_read_b128 fragment reads
 __device__ __forceinline__ int row_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
@@ -136,11 +166,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
   auto math = [&](f32x4 v, f32x4 r4, long long m, int n, bool has_r) -> f32x4 {
     if constexpr (ACT) {
       if (p.act == MELGPT_ACT_GELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
+        v = gelu_exact4(v);
       } else if (p.act == MELGPT_ACT_GELU_GRAD) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad(r4[e]);
+        v *= gelu_grad4(r4);
       }
       if (p.drop_scale != 0.f) {
         const unsigned long long e0 = ((unsigned long long)bz * p.M + m) * (unsigned long long)p.N + n;
@@ -159,7 +187,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
     // ------------------------------------------------------------------ staged, row-contiguous path
     constexpr int IN_ROWB = TN * 16 * ES, IN_CPR = IN_ROWB / 16, IN_PER = (16 * IN_CPR) / 64;  // chunks / lane / slab
     constexpr int NR = IN_PER > 0 ? IN_PER : 1;
-    // R slabs are fetched one slab ahead of their use: rin[0] = current slab, rin[1] = next (rotated in at the end)
+    // R slabs are fetched TWO slabs ahead of their use into two register sets used alternately (set = slab & 1):
+    // a slab's R goes to the LDS stage first thing, which frees its set for the fetch of slab + 2, so a fetch has
+    // two slab bodies to land (one is not enough: a slab body is shorter than a loaded memory system's latency,
+    // and moving a set to another register would wait for its load).
     u32x4 rin[2][NR];
     auto fetch_r = [&](long long mr, u32x4 (&dst)[NR]) {
 #pragma clang loop unroll(full)
@@ -171,24 +202,24 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
         if (mr >= 0 && row < row_limit && m < p.M && n < p.N) dst[j] = *(const u32x4*)(Rb + (m * p.ldr + n) * ES);
       }
     };
-    // one 16-row slab: accumulators av, first output row mr, first row of the NEXT slab mr_next (or -1)
-    auto slab = [&](const f32x4 (&av)[TN], long long mr, long long mr_next) {
+    // one 16-row slab: accumulators av, first output row mr, first row of the slab after next mr_fetch (or -1),
+    // register set SET
+    auto slab = [&](const f32x4 (&av)[TN], long long mr, long long mr_fetch, auto set_c) {
+      constexpr int SET = decltype(set_c)::value;
       const long long m = mr + i16;
       f32x4 r4[TN];
       if (Rb) {
-        fetch_r(mr_next, rin[1]);
 #pragma clang loop unroll(full)
         for (int j = 0; j < IN_PER; ++j) {
           const int q = lane + 64 * j;
-          *(u32x4*)(stage + stage_off<IN_ROWB>(q / IN_CPR, q % IN_CPR)) = rin[0][j];
+          *(u32x4*)(stage + stage_off<IN_ROWB>(q / IN_CPR, q % IN_CPR)) = rin[SET][j];
         }
+        fetch_r(mr_fetch, rin[SET]);
 #pragma clang loop unroll(full)
         for (int nt = 0; nt < TN; ++nt) {
           if constexpr (ES == 4) r4[nt] = *(const f32x4*)(stage + stage_off<IN_ROWB>(i16, 4 * nt + g));
           else r4[nt] = unpack(*(const u32x2*)(stage + stage_off<IN_ROWB>(i16, 2 * nt + (g >> 1)) + (g & 1) * 8));
         }
-#pragma clang loop unroll(full)
-        for (int j = 0; j < IN_PER; ++j) rin[0][j] = rin[1][j];
       }
       // one or two outputs, each staged and written as full rows
 #pragma clang loop unroll(full)
@@ -249,41 +280,49 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
       }
     };
 
-    if (Rb) fetch_r(mrow[0], rin[0]);
+    if (Rb) {
+      fetch_r(mrow[0], rin[0]);
+      if (TM > 1) fetch_r(mrow[TM > 1 ? 1 : 0], rin[1]);
+    }
     if constexpr (!ROLLED) {
 #pragma clang loop unroll(full)
       for (int mt = 0; mt < TM; ++mt) {
         // slabs strictly one after another: interleaving the unrolled slabs only raises register pressure (the
         // accumulators already fill half the file) and ends in scratch spills, whose reloads are memory round trips
         __builtin_amdgcn_sched_barrier(0);
-        slab(acc[mt], mrow[mt], mt + 1 < TM ? mrow[mt + 1] : -1);
+        const long long mr_fetch = mt + 2 < TM ? mrow[mt + 2 < TM ? mt + 2 : 0] : -1;
+        if (mt & 1) slab(acc[mt], mrow[mt], mr_fetch, std::integral_constant<int, 1>{});
+        else slab(acc[mt], mrow[mt], mr_fetch, std::integral_constant<int, 0>{});
       }
     } else {
-      static_assert(!ROLLED || TM <= 8, "switch below covers 8 slabs");
+      static_assert(!ROLLED || (TM <= 8 && TM % 2 == 0), "the rolled loop takes slab pairs, the switch covers 8 slabs");
 #pragma clang loop unroll(disable)
-      for (int mt = 0; mt < TM; ++mt) {
+      for (int mt = 0; mt < TM; mt += 2) {
         f32x4 av[TN];
-        long long mr = -1, mr_next = -1;
+        long long mr = -1, mr_fetch = -1;
         auto take = [&](auto c) {
           constexpr int MT = decltype(c)::value;
           if constexpr (MT < TM) {
 #pragma clang loop unroll(full)
             for (int nt = 0; nt < TN; ++nt) av[nt] = acc[MT][nt];
             mr = mrow[MT];
-            mr_next = MT + 1 < TM ? mrow[MT + 1 < TM ? MT + 1 : MT] : -1;
+            mr_fetch = MT + 2 < TM ? mrow[MT + 2 < TM ? MT + 2 : 0] : -1;
           }
         };
         switch (mt) {
           case 0: take(std::integral_constant<int, 0>{}); break;
-          case 1: take(std::integral_constant<int, 1>{}); break;
           case 2: take(std::integral_constant<int, 2>{}); break;
-          case 3: take(std::integral_constant<int, 3>{}); break;
           case 4: take(std::integral_constant<int, 4>{}); break;
-          case 5: take(std::integral_constant<int, 5>{}); break;
-          case 6: take(std::integral_constant<int, 6>{}); break;
+          default: take(std::integral_constant<int, 6>{}); break;
+        }
+        slab(av, mr, mr_fetch, std::integral_constant<int, 0>{});
+        switch (mt) {
+          case 0: take(std::integral_constant<int, 1>{}); break;
+          case 2: take(std::integral_constant<int, 3>{}); break;
+          case 4: take(std::integral_constant<int, 5>{}); break;
           default: take(std::integral_constant<int, 7>{}); break;
         }
-        slab(av, mr, mr_next);
+        slab(av, mr, mr_fetch, std::integral_constant<int, 1>{});
       }
     }
     return;

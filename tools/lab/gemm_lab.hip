@@ -36,7 +36,7 @@ static float run(int alay, int blay, int M, int N, int K, int cfg, int iters, in
   return ms / iters;
 }
 
-static void trace(int alay, int blay, int M, int N, int K) {
+static void trace(int alay, int blay, int M, int N, int K, int full = 0) {
   void *A, *B, *C; unsigned long long* dbg;
   hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&B, (size_t)N * K * 2); hipMalloc(&C, (size_t)M * N * 2);
   hipMalloc(&dbg, 4096); hipMemset(dbg, 0, 4096);
@@ -45,10 +45,25 @@ static void trace(int alay, int blay, int M, int N, int K) {
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
   p.lda = alay == LAY_KMAJ ? M : K; p.ldb = blay == LAY_KMAJ ? N : K; p.ldc = N; p.ldr = N;
   p.a_bytes = (unsigned)((size_t)M * K * 2); p.b_bytes = (unsigned)((size_t)N * K * 2);
-  p.alpha = 1.f; p.vec_io = 1; p.C2 = dbg;
-  // the PLAIN16 kernel ignores C2 (ACT off); launch it directly
-  launch_mode<LAY_ROW, LAY_ROW, EPI_PLAIN16>(p, 1, 0);
-  launch_mode<LAY_ROW, LAY_ROW, EPI_PLAIN16>(p, 1, 0);
+  p.alpha = 1.f; p.vec_io = 1;
+#if G256_LAB & 8
+  hipMemcpyToSymbol(HIP_SYMBOL(g256_dbg), &dbg, sizeof(dbg));
+#endif
+  void* R = nullptr; float* bias = nullptr;
+  if (full) {
+    hipMalloc(&R, (size_t)M * N * 2); hipMalloc(&bias, (size_t)N * 4);
+    hipMemset(R, 0, (size_t)M * N * 2); hipMemset(bias, 0, (size_t)N * 4);
+    p.bias = bias;
+    if (full == 1) p.act = MELGPT_ACT_GELU;
+    if (full == 2) { p.R = R; p.drop_scale = 2.f; p.drop_thresh = 32768; p.seed = 7; }
+    if (full == 3) { p.R = R; p.act = MELGPT_ACT_GELU_GRAD; p.drop_scale = 2.f; p.drop_thresh = 32768; p.seed = 7; }
+    if (full == 4 || full == 14) p.R = R;
+    if (full == 5) { p.drop_scale = 2.f; p.drop_thresh = 32768; p.seed = 7; }
+  }
+  for (int rep = 0; rep < 2; ++rep) {
+    if (full && full < 10) launch_mode<LAY_ROW, LAY_ROW, EPI_FULL16>(p, 1, 0);
+    else launch_mode<LAY_ROW, LAY_ROW, EPI_PLAIN16>(p, 1, 0);
+  }
   hipDeviceSynchronize();
   unsigned long long h[64];
   hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
@@ -62,6 +77,12 @@ static void trace(int alay, int blay, int M, int N, int K) {
 int main(int argc, char** argv) {
   if (G256_LAB & 8) {
     printf("fc1\n"); trace(LAY_ROW, LAY_ROW, 33920, 4096, 1024);
+    printf("fc1 drop+R\n"); trace(LAY_ROW, LAY_ROW, 33920, 4096, 1024, 2);
+    printf("fc1 drop*gelu'\n"); trace(LAY_ROW, LAY_ROW, 33920, 4096, 1024, 3);
+    printf("fc1 FULL16 bias only\n"); trace(LAY_ROW, LAY_ROW, 33920, 4096, 1024, 6);
+    printf("fc1 FULL16 +R\n"); trace(LAY_ROW, LAY_ROW, 33920, 4096, 1024, 4);
+    printf("fc1 FULL16 drop\n"); trace(LAY_ROW, LAY_ROW, 33920, 4096, 1024, 5);
+    printf("fc1 PLAIN16 +R\n"); trace(LAY_ROW, LAY_ROW, 33920, 4096, 1024, 14);
     printf("sq8k\n"); trace(LAY_ROW, LAY_ROW, 8192, 8192, 8192);
     return 0;
   }
