@@ -290,7 +290,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
     if ((G256_LAB & 8)) ts1 = __builtin_amdgcn_s_memtime();
     // this wave's pieces of the next three half-units have landed; every wave is past its reads of the last unit,
     // whose A slot ( = `fill`, refilled at the next barrier) is the epilogue's staging block
-    wait_vm_barrier<0>();
+    // (the drain is written with the builtin, not inline asm, so that the compiler's own wait-count bookkeeping
+    // knows that no vector-memory operation is outstanding here: with LDS-DMA pieces "possibly in flight" it would
+    // put a full vmcnt(0) in front of every use of an ordinary load in the epilogue - the residual slabs)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+    asm volatile("s_barrier" ::: "memory");
     // the epilogue's per-lane offsets are tile-invariant; hoisted out of the tile loop they would sit in scratch
     // (the K loop owns the whole register file) and every reload is a memory round trip - recompute them per tile
     int lane_e = lane;

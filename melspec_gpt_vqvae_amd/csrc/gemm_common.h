@@ -2,12 +2,23 @@
 // gemm256.hip: 256-wide LDS-DMA staged, bf16 lane): parameters, LDS swizzles, fused epilogue.
 #pragma once
 #include <type_traits>
+#include <utility>
 
 #include "mma.h"
 
 namespace gemmk {
 
 enum { LAY_ROW = 0, LAY_KMAJ = 1, LAY_CONV = 2 };
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant expression
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
 
 struct GemmParams {
   const void* A;
@@ -187,11 +198,14 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
     // ------------------------------------------------------------------ staged, row-contiguous path
     constexpr int IN_ROWB = TN * 16 * ES, IN_CPR = IN_ROWB / 16, IN_PER = (16 * IN_CPR) / 64;  // chunks / lane / slab
     constexpr int NR = IN_PER > 0 ? IN_PER : 1;
-    // R slabs are fetched TWO slabs ahead of their use into two register sets used alternately (set = slab & 1):
-    // a slab's R goes to the LDS stage first thing, which frees its set for the fetch of slab + 2, so a fetch has
-    // two slab bodies to land (one is not enough: a slab body is shorter than a loaded memory system's latency,
-    // and moving a set to another register would wait for its load).
-    u32x4 rin[2][NR];
+    // R is fetched for HALF the slabs at a time (NB register sets), consumed, then fetched for the other half.
+    // Finer-grained prefetching does not survive the compiler: with LDS-DMA pieces possibly in flight (the persistent
+    // kernel's ring) hipcc puts a full vmcnt(0) in front of every use of an ordinary load, so any fetch issued
+    // between two uses is waited for at once.  Two batches = two exposed latencies per tile instead of TM.
+    // (slabs per batch: half the tile where the registers allow it; the rolled full epilogue is at the 256-VGPR
+    // limit with two sets)
+    constexpr int NB = (MODE == EPI_GENERIC || MODE == EPI_FULL16) ? (TM < 2 ? 1 : 2) : (TM + 1) / 2;
+    u32x4 rin[NB][NR];
     auto fetch_r = [&](long long mr, u32x4 (&dst)[NR]) {
 #pragma clang loop unroll(full)
       for (int j = 0; j < IN_PER; ++j) {
@@ -202,9 +216,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
         if (mr >= 0 && row < row_limit && m < p.M && n < p.N) dst[j] = *(const u32x4*)(Rb + (m * p.ldr + n) * ES);
       }
     };
-    // one 16-row slab: accumulators av, first output row mr, first row of the slab after next mr_fetch (or -1),
-    // register set SET
-    auto slab = [&](const f32x4 (&av)[TN], long long mr, long long mr_fetch, auto set_c) {
+    // one 16-row slab: accumulators av, first output row mr, R in register set SET
+    auto slab = [&](const f32x4 (&av)[TN], long long mr, auto set_c) {
       constexpr int SET = decltype(set_c)::value;
       const long long m = mr + i16;
       f32x4 r4[TN];
@@ -214,7 +227,6 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
           const int q = lane + 64 * j;
           *(u32x4*)(stage + stage_off<IN_ROWB>(q / IN_CPR, q % IN_CPR)) = rin[SET][j];
         }
-        fetch_r(mr_fetch, rin[SET]);
 #pragma clang loop unroll(full)
         for (int nt = 0; nt < TN; ++nt) {
           if constexpr (ES == 4) r4[nt] = *(const f32x4*)(stage + stage_off<IN_ROWB>(i16, 4 * nt + g));
@@ -280,49 +292,65 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
       }
     };
 
-    if (Rb) {
-      fetch_r(mrow[0], rin[0]);
-      if (TM > 1) fetch_r(mrow[TM > 1 ? 1 : 0], rin[1]);
-    }
+    // batch b covers slabs b*NB .. b*NB + NB - 1
+    auto fetch_batch = [&](auto b_c) {
+      constexpr int B0 = decltype(b_c)::value * NB;
+#pragma clang loop unroll(full)
+      for (int k = 0; k < NB; ++k)
+        if (B0 + k < TM) fetch_r(mrow[B0 + k < TM ? B0 + k : 0], rin[k]);
+    };
+    auto run_batch = [&](auto b_c) {
+      constexpr int B0 = decltype(b_c)::value * NB;
+      if (Rb) fetch_batch(b_c);
+      static_for<NB>([&](auto k_c) {
+        constexpr int k = decltype(k_c)::value;
+        if constexpr (B0 + k < TM) {
+          // slabs strictly one after another: interleaving the unrolled slabs only raises register pressure (the
+          // accumulators already fill half the file) and ends in scratch spills, whose reloads are memory round trips
+          __builtin_amdgcn_sched_barrier(0);
+          slab(acc[B0 + k], mrow[B0 + k], k_c);
+        }
+      });
+    };
+    constexpr int NBATCH = (TM + NB - 1) / NB;
     if constexpr (!ROLLED) {
-#pragma clang loop unroll(full)
-      for (int mt = 0; mt < TM; ++mt) {
-        // slabs strictly one after another: interleaving the unrolled slabs only raises register pressure (the
-        // accumulators already fill half the file) and ends in scratch spills, whose reloads are memory round trips
-        __builtin_amdgcn_sched_barrier(0);
-        const long long mr_fetch = mt + 2 < TM ? mrow[mt + 2 < TM ? mt + 2 : 0] : -1;
-        if (mt & 1) slab(acc[mt], mrow[mt], mr_fetch, std::integral_constant<int, 1>{});
-        else slab(acc[mt], mrow[mt], mr_fetch, std::integral_constant<int, 0>{});
-      }
+      static_for<NBATCH>([&](auto b_c) { run_batch(b_c); });
     } else {
-      static_assert(!ROLLED || (TM <= 8 && TM % 2 == 0), "the rolled loop takes slab pairs, the switch covers 8 slabs");
+      // one copy of the batch body: a uniform switch copies the batch's accumulators and row origins out of the
+      // register arrays
+      static_assert(!ROLLED || (NB == 2 && TM % 2 == 0 && TM <= 8), "rolled epilogue: up to four batches of two slabs");
 #pragma clang loop unroll(disable)
-      for (int mt = 0; mt < TM; mt += 2) {
-        f32x4 av[TN];
-        long long mr = -1, mr_fetch = -1;
-        auto take = [&](auto c) {
-          constexpr int MT = decltype(c)::value;
-          if constexpr (MT < TM) {
+      for (int b = 0; b < NBATCH; ++b) {
+        long long mr[NB];
 #pragma clang loop unroll(full)
-            for (int nt = 0; nt < TN; ++nt) av[nt] = acc[MT][nt];
-            mr = mrow[MT];
-            mr_fetch = MT + 2 < TM ? mrow[MT + 2 < TM ? MT + 2 : 0] : -1;
+        for (int k = 0; k < NB; ++k) {
+          mr[k] = mrow[k];
+#pragma clang loop unroll(full)
+          for (int q = 1; q < NBATCH; ++q) mr[k] = b == q ? mrow[q * NB + k] : mr[k];
+        }
+        if (Rb) {
+#pragma clang loop unroll(full)
+          for (int k = 0; k < NB; ++k) fetch_r(mr[k], rin[k]);
+        }
+        static_for<NB>([&](auto k_c) {
+          constexpr int k = decltype(k_c)::value;
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4 av[TN];
+          auto take = [&](auto b_c) {
+            constexpr int MT = decltype(b_c)::value * NB + k;
+            if constexpr (MT < TM) {
+#pragma clang loop unroll(full)
+              for (int nt = 0; nt < TN; ++nt) av[nt] = acc[MT][nt];
+            }
+          };
+          switch (b) {
+            case 0: take(std::integral_constant<int, 0>{}); break;
+            case 1: take(std::integral_constant<int, 1>{}); break;
+            case 2: take(std::integral_constant<int, 2>{}); break;
+            default: take(std::integral_constant<int, 3>{}); break;
           }
-        };
-        switch (mt) {
-          case 0: take(std::integral_constant<int, 0>{}); break;
-          case 2: take(std::integral_constant<int, 2>{}); break;
-          case 4: take(std::integral_constant<int, 4>{}); break;
-          default: take(std::integral_constant<int, 6>{}); break;
-        }
-        slab(av, mr, mr_fetch, std::integral_constant<int, 0>{});
-        switch (mt) {
-          case 0: take(std::integral_constant<int, 1>{}); break;
-          case 2: take(std::integral_constant<int, 3>{}); break;
-          case 4: take(std::integral_constant<int, 5>{}); break;
-          default: take(std::integral_constant<int, 7>{}); break;
-        }
-        slab(av, mr, mr_fetch, std::integral_constant<int, 1>{});
+          slab(av, mr[k], k_c);
+        });
       }
     }
     return;
