@@ -68,6 +68,23 @@ def synthetic_batch(batch, rank, device):
     return x, c
 
 
+def pmc_traffic():
+    """HBM bytes per step of the GEMM-family kernels, from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_summary.json, written by tools/profile_round.sh; bench.py itself cannot collect PMC counters).
+    None when no summary is committed."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "*_summary.json")))
+    if not files:
+        return None, None
+    try:
+        j = json.load(open(files[-1]))
+        per_step = (j["gemm_family_hbm_read_MB"] + j["gemm_family_hbm_write_MB"]) * 1e6 / j["steps_profiled"]
+        return round(per_step), "profiles/" + os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(batch=4, reps=2):
     """The CPU oracle (kind "port": torch-CPU fp32 restatement pinned to the reference by tests/golden) running the
     same step - VQ-encode + class-GPT fwd/bwd + AdamW - on a bounded sample."""
@@ -217,6 +234,7 @@ def main():
 
     ks = timer.summary()
     achieved = ks["flops"] / (ks["total_ms"] * 1e-3) / 1e12 if ks["total_ms"] > 0 else 0.0
+    traffic, traffic_src = pmc_traffic()
     if rank == 0:
         out = {
             "metric": "mel-token seqs/sec training step (VQ-encode + GPT fwd/bwd)",
@@ -232,8 +250,10 @@ def main():
             },
             "roofline": {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                "kernel": "gemm_kernel<bf16> (MFMA GEMM + implicit-GEMM conv), all launches of the timed region",
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/step",
+                "traffic_source": traffic_src,
+                "kernel": "MFMA GEMM family (gemm256_kernel persistent 256x256 / gemm_kernel 128x128 + implicit-GEMM conv / "
+                          "conv3x3_gn_kernel), all launches of the timed region",
                 "launches_per_step": ks["launches"] // max(a.steps, 1),
                 "kernel_ms_per_step": round(ks["total_ms"] / max(a.steps, 1), 3),
                 "algorithmic_tflop_per_step": round(ks["flops"] / max(a.steps, 1) / 1e12, 3),
