@@ -3,6 +3,8 @@
 // is a 16-byte vector; reductions are xor-shuffles inside the wave (no LDS, no atomics -> deterministic).
 // Reference call sites: transformer/minGPT.py:97-98,141 (nn.LayerNorm), :170-180 (tok_emb/pos_emb/drop),
 // :197,:416 (F.cross_entropy), :660-664 (AdamW); transformer/decoders.py:20-21,64-68 (per-token CE).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -48,7 +50,9 @@ __device__ __forceinline__ void keep_mask(unsigned long long seed, unsigned sid,
 }
 
 // ================================================================================== LayerNorm
-template <typename T>
+// NCH = 16-byte chunks per lane held in registers (the row has C / N chunks, NCH = ceil(that / 64) rounded up to a
+// power of two): the kernels are instantiated per NCH so that a 1024-wide row costs 2 chunks of registers, not 8.
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
@@ -59,10 +63,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   if (row >= M) return;
   const int nch = C / N;
   const T* xr = x + row * C;
-  float v[LN_MAXCH][N];
+  float v[NCH][N];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int ch = lane + 64 * i;
     if (ch < nch) {
       V16<T>::ld(xr + ch * N, v[i]);
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   const float mu = wave_sum(s) / (float)C;
   float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     if (lane + 64 * i < nch) {
 #pragma unroll
       for (int e = 0; e < N; ++e) {
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   }
   T* yr = y + row * C;
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int ch = lane + 64 * i;
     if (ch < nch) {
       float o[N];
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma   [+ add_in]   [then optional dropout replay
 // into a second output `dx_drop` = keep(dx)*scale, which is the gradient of the dropout-ed branch input]
-template <typename T>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean,
@@ -114,59 +118,105 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             const T* __restrict__ add_in, T* __restrict__ dx,
                                                             float* __restrict__ partials, long long M, int C) {
   constexpr int N = V16<T>::N;
+  typedef typename std::conditional<sizeof(T) == 2, u32x4, f32x4>::type Raw;  // one 16-byte chunk as loaded
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
   const int nch = C / N;
-  float dg[LN_MAXCH][N], db[LN_MAXCH][N];
+  float dg[NCH][N], db[NCH][N];
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i)
+  for (int i = 0; i < NCH; ++i)
 #pragma unroll
     for (int e = 0; e < N; ++e) dg[i][e] = db[i][e] = 0.f;
-
-  for (long long row = wave; row < M; row += nwaves) {
-    const float mu = mean[row], rs = rstd[row];
-    float g[LN_MAXCH][N], xh[LN_MAXCH][N];
-    float s1 = 0.f, s2 = 0.f;
+  // gamma chunks of this lane (row-invariant)
+  float gm[NCH][N];
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+#pragma unroll
+    for (int e = 0; e < N; ++e) gm[i][e] = ch < nch ? gamma[ch * N + e] : 0.f;
+  }
+
+  // A row's three inputs (dy, x, add_in) are requested TOGETHER and one row ahead of their use: a wave handles its
+  // rows one after another, so without this every row pays two dependent memory latencies (inputs, then add_in).
+  struct RowIn {
+    Raw d[NCH], xv[NCH], a[NCH];
+    float mu, rs;
+  };
+  auto load_row = [&](long long row, RowIn& r) {
+    r.mu = mean[row];
+    r.rs = rstd[row];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
       const int ch = lane + 64 * i;
       if (ch < nch) {
+        r.d[i] = *(const Raw*)(dy + row * C + ch * N);
+        r.xv[i] = *(const Raw*)(x + row * C + ch * N);
+        if (add_in) r.a[i] = *(const Raw*)(add_in + row * C + ch * N);
+      }
+    }
+  };
+  auto unpack = [](const Raw& v, float* o) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o[2 * i] = __uint_as_float(v[i] << 16);
+        o[2 * i + 1] = __uint_as_float(v[i] & 0xFFFF0000u);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = v[i];
+    }
+  };
+  auto do_row = [&](long long row, const RowIn& r) {
+    float g[NCH][N], xh[NCH][N];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      if (lane + 64 * i < nch) {
         float d[N], xv[N];
-        V16<T>::ld(dy + row * C + ch * N, d);
-        V16<T>::ld(x + row * C + ch * N, xv);
+        unpack(r.d[i], d);
+        unpack(r.xv[i], xv);
 #pragma unroll
-        for (int e4 = 0; e4 < N; e4 += 4) {
-          f32x4 gm = *(const f32x4*)(gamma + ch * N + e4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float xhat = (xv[e4 + e] - mu) * rs;
-            const float gg = d[e4 + e] * gm[e];
-            xh[i][e4 + e] = xhat;
-            g[i][e4 + e] = gg;
-            s1 += gg;
-            s2 = fmaf(gg, xhat, s2);
-            dg[i][e4 + e] = fmaf(d[e4 + e], xhat, dg[i][e4 + e]);
-            db[i][e4 + e] += d[e4 + e];
-          }
+        for (int e = 0; e < N; ++e) {
+          const float xhat = (xv[e] - r.mu) * r.rs;
+          const float gg = d[e] * gm[i][e];
+          xh[i][e] = xhat;
+          g[i][e] = gg;
+          s1 += gg;
+          s2 = fmaf(gg, xhat, s2);
+          dg[i][e] = fmaf(d[e], xhat, dg[i][e]);
+          db[i][e] += d[e];
         }
       }
     }
     const float c1 = wave_sum(s1) / (float)C, c2 = wave_sum(s2) / (float)C;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int ch = lane + 64 * i;
       if (ch < nch) {
         float o[N];
-        if (add_in) V16<T>::ld(add_in + row * C + ch * N, o);
+        if (add_in) unpack(r.a[i], o);
         else {
 #pragma unroll
           for (int e = 0; e < N; ++e) o[e] = 0.f;
         }
 #pragma unroll
-        for (int e = 0; e < N; ++e) o[e] += rs * (g[i][e] - c1 - xh[i][e] * c2);
+        for (int e = 0; e < N; ++e) o[e] += r.rs * (g[i][e] - c1 - xh[i][e] * c2);
         V16<T>::st(dx + row * C + ch * N, o);
       }
+    }
+  };
+  RowIn ra, rb;
+  long long row = wave;
+  if (row < M) load_row(row, ra);
+  for (; row < M; row += 2LL * nwaves) {  // two rows per trip: the register sets swap roles without copies
+    const long long r1 = row + nwaves, r2 = r1 + nwaves;
+    if (r1 < M) load_row(r1, rb);
+    do_row(row, ra);
+    if (r1 < M) {
+      if (r2 < M) load_row(r2, ra);
+      do_row(r1, rb);
     }
   }
   if (partials) {
@@ -174,7 +224,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     extern __shared__ float lnsh[];  // [4][2C]
     float* mine = lnsh + (threadIdx.x >> 6) * 2 * C;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int ch = lane + 64 * i;
       if (ch < nch) {
 #pragma unroll
@@ -709,6 +759,34 @@ inline unsigned thresh_of(float p) {
 
 }  // namespace
 
+// LayerNorm kernels: element type x chunks-per-lane (C / (16 / sizeof(T)) chunks spread over 64 lanes)
+#define DISPATCH_LN_NCH(C_, VEC_, ...)                          \
+  {                                                             \
+    const int per_lane_ = ((C_) / (VEC_) + 63) / 64;            \
+    if (per_lane_ <= 1) {                                       \
+      constexpr int NCH = 1;                                    \
+      __VA_ARGS__;                                              \
+    } else if (per_lane_ <= 2) {                                \
+      constexpr int NCH = 2;                                    \
+      __VA_ARGS__;                                              \
+    } else if (per_lane_ <= 4) {                                \
+      constexpr int NCH = 4;                                    \
+      __VA_ARGS__;                                              \
+    } else {                                                    \
+      constexpr int NCH = LN_MAXCH;                             \
+      __VA_ARGS__;                                              \
+    }                                                           \
+  }
+#define DISPATCH_LN(dtype, C_, ...)                             \
+  if ((dtype) == MELGPT_F32) {                                  \
+    using T = float;                                            \
+    DISPATCH_LN_NCH(C_, 4, __VA_ARGS__)                         \
+  } else if ((dtype) == MELGPT_BF16) {                          \
+    using T = bf16_t;                                           \
+    DISPATCH_LN_NCH(C_, 8, __VA_ARGS__)                         \
+  } else                                                        \
+    return MELGPT_ERR_UNSUPPORTED;
+
 #define DISPATCH_T(dtype, ...)                                  \
   if ((dtype) == MELGPT_F32) {                                  \
     using T = float;                                            \
@@ -725,7 +803,7 @@ extern "C" int melgpt_layernorm_fwd(const void* x, const float* gamma, const flo
   const int vec = dtype == MELGPT_F32 ? 4 : 8;
   MELGPT_CHECK(C % vec == 0 && C / vec <= 64 * LN_MAXCH, MELGPT_ERR_UNSUPPORTED);
   MELGPT_CHECK((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, MELGPT_ERR_ALIGN);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0,
+  DISPATCH_LN(dtype, C, hipLaunchKernelGGL((layernorm_fwd_kernel<T, NCH>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0,
                                        (hipStream_t)stream, (const T*)x, gamma, beta, (T*)y, mean, rstd, M, C, eps));
   return melgpt_launch_status();
 }
@@ -749,7 +827,7 @@ extern "C" int melgpt_layernorm_bwd(const void* dy, const void* x, const float* 
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = dgamma ? (size_t)4 * 2 * C * sizeof(float) : 0;
   MELGPT_CHECK(lds <= 64 * 1024, MELGPT_ERR_UNSUPPORTED);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(nwaves / 4), dim3(256), lds, s, (const T*)dy,
+  DISPATCH_LN(dtype, C, hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH>), dim3(nwaves / 4), dim3(256), lds, s, (const T*)dy,
                                        (const T*)x, gamma, mean, rstd, (const T*)add_in, (T*)dx,
                                        dgamma ? workspace : nullptr, M, C));
   if (dgamma) {
