@@ -268,6 +268,63 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
   }
 }
 
+// The same reduction with 16-byte loads and 16 row phases per block (64 columns x 16 phases x 4 chains = 64 rows in
+// flight per column group): the partial tables of the LayerNorm / bias / split-K reductions have up to a thousand
+// rows, which a block of 4 phases walks latency-bound.  Optional second destination: columns >= split go to
+// out2[c - split] (LayerNorm's [dgamma | dbeta] partial rows are reduced by one launch).
+// Fixed summation order (phase-major, then the four chains, then the phases pairwise) => deterministic.
+__global__ __launch_bounds__(256) void reduce_rows4_kernel(const float* __restrict__ part, int R, long long ld,
+                                                           long long ncols, float* __restrict__ out,
+                                                           float* __restrict__ out2, long long split, int accumulate,
+                                                           float scale) {
+  __shared__ f32x4 sh[16][16];
+  const int lc = threadIdx.x & 15, ph = threadIdx.x >> 4;
+  const long long c = ((long long)blockIdx.x * 16 + lc) * 4;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  if (c < ncols) {
+    int r = ph;
+    for (; r + 48 < R; r += 64) {
+      s0 += *(const f32x4*)(part + (long long)r * ld + c);
+      s1 += *(const f32x4*)(part + (long long)(r + 16) * ld + c);
+      s2 += *(const f32x4*)(part + (long long)(r + 32) * ld + c);
+      s3 += *(const f32x4*)(part + (long long)(r + 48) * ld + c);
+    }
+    for (; r < R; r += 16) s0 += *(const f32x4*)(part + (long long)r * ld + c);
+  }
+  sh[ph][lc] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ph == 0 && c < ncols) {
+    f32x4 t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = sh[2 * i][lc] + sh[2 * i + 1][lc];
+    f32x4 v = (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) * scale;
+    float* dst = (out2 && c >= split) ? out2 + (c - split) : out + c;
+    if (accumulate) v += *(const f32x4*)dst;
+    *(f32x4*)dst = v;
+  }
+}
+
+// picks the vectorised form when columns, leading dimension, split and pointers allow 16-byte accesses
+static void launch_reduce_rows(const float* part, int R, long long ld, long long ncols, float* out, float* out2,
+                               long long split, int accumulate, float scale, hipStream_t s) {
+  const bool vec = ncols % 4 == 0 && ld % 4 == 0 && split % 4 == 0 &&
+                   ((((uintptr_t)part | (uintptr_t)out | (uintptr_t)out2) & 15) == 0);
+  if (vec) {
+    hipLaunchKernelGGL(reduce_rows4_kernel, dim3((unsigned)((ncols / 4 + 15) / 16)), dim3(256), 0, s, part, R, ld, ncols,
+                       out, out2, split, accumulate, scale);
+    return;
+  }
+  if (out2) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((split + 63) / 64)), dim3(256), 0, s, part, R, ld, split, out,
+                       accumulate, scale);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((ncols - split + 63) / 64)), dim3(256), 0, s, part + split, R,
+                       ld, ncols - split, out2, accumulate, scale);
+    return;
+  }
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(256), 0, s, part, R, ld, ncols, out,
+                     accumulate, scale);
+}
+
 // column sums of a (M,N) matrix in dtype T into partials[(gridDim.y)][N]; second stage = reduce_rows_kernel
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ a, long long M, int N, long long lda,
@@ -280,12 +337,35 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 #pragma unroll
   for (int e = 0; e < NV; ++e) acc[e] = 0.f;
   if (ch < nch) {
-    for (long long r = (long long)blockIdx.y * 4 + rsub; r < M; r += (long long)gridDim.y * 4) {
+    // four rows per trip with independent accumulators: four 16-byte loads in flight per lane (the sum order is
+    // fixed by the grid, so the result is reproducible)
+    const long long step = (long long)gridDim.y * 4;
+    long long r = (long long)blockIdx.y * 4 + rsub;
+    float a1[NV], a2[NV], a3[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) a1[e] = a2[e] = a3[e] = 0.f;
+    for (; r + 3 * step < M; r += 4 * step) {
+      float v0[NV], v1[NV], v2[NV], v3[NV];
+      V16<T>::ld(a + r * lda + ch * NV, v0);
+      V16<T>::ld(a + (r + step) * lda + ch * NV, v1);
+      V16<T>::ld(a + (r + 2 * step) * lda + ch * NV, v2);
+      V16<T>::ld(a + (r + 3 * step) * lda + ch * NV, v3);
+#pragma unroll
+      for (int e = 0; e < NV; ++e) {
+        acc[e] += v0[e];
+        a1[e] += v1[e];
+        a2[e] += v2[e];
+        a3[e] += v3[e];
+      }
+    }
+    for (; r < M; r += step) {
       float v[NV];
       V16<T>::ld(a + r * lda + ch * NV, v);
 #pragma unroll
       for (int e = 0; e < NV; ++e) acc[e] += v[e];
     }
+#pragma unroll
+    for (int e = 0; e < NV; ++e) acc[e] = (acc[e] + a1[e]) + (a2[e] + a3[e]);
   }
   __shared__ float sh[4][64][NV + 1];
 #pragma unroll
@@ -832,15 +912,12 @@ extern "C" int melgpt_layernorm_bwd(const void* dy, const void* x, const float* 
                                        dgamma ? workspace : nullptr, M, C));
   if (dgamma) {
     const int nblocks = nwaves / 4;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 63) / 64), dim3(256), 0, s, workspace, nblocks, 2LL * C,
-                       (long long)C, dgamma, accumulate, 1.0f);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 63) / 64), dim3(256), 0, s, workspace + C, nblocks, 2LL * C,
-                       (long long)C, dbeta, accumulate, 1.0f);
+    launch_reduce_rows(workspace, nblocks, 2LL * C, 2LL * C, dgamma, dbeta, (long long)C, accumulate, 1.0f, s);
   }
   return melgpt_launch_status();
 }
 
-extern "C" int melgpt_colsum_rows(void) { return 64; }
+extern "C" int melgpt_colsum_rows(void) { return 256; }
 
 extern "C" int melgpt_colsum(const void* a, long long M, int N, long long lda, float* out, int accumulate,
                              float* workspace, int dtype, void* stream) {
@@ -848,13 +925,15 @@ extern "C" int melgpt_colsum(const void* a, long long M, int N, long long lda, f
   const int vec = dtype == MELGPT_F32 ? 4 : 8;
   MELGPT_CHECK(N % vec == 0 && lda % vec == 0 && ((uintptr_t)a & 15) == 0, MELGPT_ERR_ALIGN);
   long long rows = (M + 3) / 4;
-  const int gy = (int)(rows < 64 ? rows : 64);
   const int nch = N / vec;
+  // enough row groups for ~2048 workgroups (<= melgpt_colsum_rows() partial rows)
+  int gy = 2048 / ((nch + 63) / 64);
+  gy = gy < 16 ? 16 : gy > 256 ? 256 : gy;
+  if (rows < gy) gy = (int)rows;
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3((nch + 63) / 64, gy), dim3(256), 0, s,
                                        (const T*)a, M, N, lda, workspace));
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 63) / 64), dim3(256), 0, s, workspace, gy, (long long)N,
-                     (long long)N, out, accumulate, 1.0f);
+  launch_reduce_rows(workspace, gy, (long long)N, (long long)N, out, nullptr, 0, accumulate, 1.0f, s);
   return melgpt_launch_status();
 }
 
@@ -994,8 +1073,7 @@ extern "C" int melgpt_onehot_rows(const long long* idx, long long idx_ld, int B,
 extern "C" int melgpt_reduce_rows(const float* partials, int R, long long ld, long long ncols, float* out,
                                   int accumulate, float scale, void* stream) {
   MELGPT_CHECK(partials && out && R > 0 && ncols > 0 && ld >= ncols, MELGPT_ERR_BAD_ARG);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
-                     partials, R, ld, ncols, out, accumulate, scale);
+  launch_reduce_rows(partials, R, ld, ncols, out, nullptr, 0, accumulate, scale, (hipStream_t)stream);
   return melgpt_launch_status();
 }
 
