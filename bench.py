@@ -154,13 +154,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # debug aid (1-GPU boxes): MELGPT_BENCH_SHARE_GPU=1 lets several ranks share cuda:0 over gloo to exercise the
+    # multi-rank control flow; the numbers of such a run mean nothing and the JSON line says so
+    share = os.environ.get("MELGPT_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from melspec_gpt_vqvae_amd import ops
@@ -261,6 +268,8 @@ def main():
         }
         if a.layers != 24:
             out["config"]["INVALID_debug_layers"] = a.layers
+        if share:
+            out["config"]["INVALID_debug_shared_gpu"] = True
         if a.breakdown:
             print({k: round(1e3 * v / a.steps, 2) for k, v in phases.items()}, file=sys.stderr)
             for tag, n, ms, fl in timer.by_tag()[:40]:
