@@ -158,6 +158,28 @@ int melgpt_attn_fwd(const void* q, const void* k, const void* v, long long ld, v
                     float* lse, float* att, int B, int H, int T, int head_size, int n_unmasked, float drop_p,
                     unsigned long long seed, unsigned stream_id, int dtype, void* stream);
 
+/* one KV-cached decoding step (replaces the full re-forward per sampled token of minGPT.py:293-360 /
+ * decoders.py:89-123): qkv = the new token's packed projection rows (B, 3C) [key|query|value], row stride ld.
+ * Appends its key / value at position `pos` of the (B, Tmax, C) caches and writes
+ * out (B, C) = softmax(q . K[0..pos] / sqrt(hs)) @ V[0..pos], heads merged.  att_row: optional (B, H, Tmax) f32
+ * probabilities of this row (entries > pos untouched).  head_size 64, Tmax <= 320, eval mode (no dropout).
+ * pos_dev: optional device int; when given the position is read from it (one captured HIP graph then serves every
+ * decoding step) and `pos` is ignored. */
+int melgpt_attn_decode(const void* qkv, long long ld, void* kcache, void* vcache, int B, int H, int head_size,
+                       int Tmax, int pos, const int* pos_dev, void* out, float* att_row, int dtype, void* stream);
+/* skinny-M linear layer of a decode step: y (M,N) = epi(x (M,K) @ W (N,K)^T + bias) (+ residual), W = nn.Linear.weight
+ * layout; act in {MELGPT_ACT_NONE, MELGPT_ACT_GELU (exact erf)}; y in `dtype`, or f32 when out_f32 (always f32 for
+ * dtype f32).  One wave per 4 output columns streams the weights once with every CU busy; M is walked 16 rows at a
+ * time (weights re-read from L2).  N % 4 == 0, K % (16 / sizeof(T)) == 0. */
+int melgpt_gemv_rows(const void* x, long long ldx, const void* W, long long ldw, const float* bias,
+                     const void* residual, long long ldr, void* y, long long ldy, int M, int N, int K, int act,
+                     int dtype, int out_f32, void* stream);
+/* graph-replayed decoding helpers: x[b,:] = tok_emb[idx[b]] + pos_emb[*pos_dev] (minGPT.py:170-180 for one position);
+ * *counter += 1 */
+int melgpt_embed_decode(const long long* idx, const float* tok_emb, const float* pos_emb, const int* pos_dev, int B,
+                        int C, int V, void* out, int dtype, void* stream);
+int melgpt_incr_i32(int* counter, void* stream);
+
 /* backward: dq/dk/dv (row stride ldg) from dout; probabilities are recomputed from lse, the dropout mask is
  * regenerated from (seed, stream_id).  delta (B,H,T) f32 is workspace (rowsum(dout*out)). Deterministic. */
 int melgpt_attn_bwd(const void* q, const void* k, const void* v, long long ld, const void* out,
@@ -213,6 +235,11 @@ int melgpt_group_sum_f32(const float* in, long long groups, int n, float scale, 
 int melgpt_sample_logits(const float* logits, long long ld, int rows, int V, float temperature, int top_k,
                          int do_sample, unsigned long long seed, unsigned step, long long* out, float* probs_out,
                          void* stream);
+/* the same step with its number read on the device (graph-replayed decoding): step = *pos_dev + step_offset; the
+ * picked token also goes to seq[row * seq_ld + *pos_dev] when seq is given. */
+int melgpt_sample_logits_dev(const float* logits, long long ld, int rows, int V, float temperature, int top_k,
+                             int do_sample, unsigned long long seed, const int* pos_dev, int step_offset,
+                             long long* out, long long* seq, long long seq_ld, void* stream);
 /* GPTEncoder.reparameterize + KL (encoders.py:62-104): stats (B,2nz) = [mu | logvar]; z = mu + eps*exp(logvar/2);
  * KL[b] = 0.5*sum(mu^2 + exp(logvar) - logvar - 1).  gen_eps != 0: eps (B,ns,nz) is DRAWN in-kernel (N(0,1) from
  * Philox + Box-Muller) and written; gen_eps == 0: eps is an input. */

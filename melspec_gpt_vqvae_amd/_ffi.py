@@ -37,6 +37,10 @@ _PROTOS = {
                     _p, _f, _u64, C.c_uint, _p],
     "melgpt_conv2d_nhwc": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],
     "melgpt_attn_fwd": [_p, _p, _p, _l, _p, _l, _p, _p, _i, _i, _i, _i, _i, _f, _u64, C.c_uint, _i, _p],
+    "melgpt_attn_decode": [_p, _l, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],
+    "melgpt_embed_decode": [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p],
+    "melgpt_incr_i32": [_p, _p],
+    "melgpt_gemv_rows": [_p, _l, _p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _p],
     "melgpt_attn_bwd": [_p, _p, _p, _l, _p, _p, _l, _p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _f, _u64, C.c_uint,
                         _i, _p],
     "melgpt_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _l, _i, _f, _i, _p],
@@ -50,6 +54,7 @@ _PROTOS = {
     "melgpt_cross_entropy_bwd": [_p, _l, _p, _p, _p, _i, _p, _f, _l, _i, _p, _l, _i, _p],
     "melgpt_group_sum_f32": [_p, _l, _i, _f, _p, _p],
     "melgpt_sample_logits": [_p, _l, _i, _i, _f, _i, _i, _u64, C.c_uint, _p, _p, _p],
+    "melgpt_sample_logits_dev": [_p, _l, _i, _i, _f, _i, _i, _u64, _p, _i, _p, _p, _l, _p],
     "melgpt_vae_reparam_fwd": [_p, _p, _i, _u64, _i, _i, _i, _p, _p, _p],
     "melgpt_vae_reparam_bwd": [_p, _p, _p, _p, _i, _i, _i, _p, _p],
     "melgpt_sum_f32": [_p, _l, _f, _p, _i, _p],

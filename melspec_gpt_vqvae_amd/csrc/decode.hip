@@ -1,0 +1,285 @@
+// Single-token (KV-cached) attention step for autoregressive sampling on gfx950 - SURVEY §8(f) rank 1.
+// Reference: the sampling loops re-run the whole GPT per generated token (transformer/minGPT.py:293-360,
+// transformer/decoders.py:89-123; CausalSelfAttention.forward(x, layer_past=None) at minGPT.py:72 never uses its
+// cache argument).  The last row of a causal attention only needs the new token's query against the keys / values of
+// the tokens before it, so a step is: append this token's k, v to a per-layer cache, then
+//   y[b, h, :] = softmax_t( q[b, h, :] . K[b, t, h, :] / sqrt(hs) ) @ V[b, t, h, :],   t = 0 .. pos
+// (every earlier token is visible to the newest one whatever n_unmasked is; eval mode, so no dropout).
+// One 64-lane wave per (batch, head): lanes own key positions for the scores and head dimensions for the output;
+// HBM-bound on the cache read (2 * (pos+1) * 64 * sizeof(T) bytes per wave).
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ float ldf(const T* p) {
+  if constexpr (sizeof(T) == 2) return bf16_to_f32(*p);
+  else return *p;
+}
+template <typename T>
+__device__ __forceinline__ void stf(T* p, float v) {
+  if constexpr (sizeof(T) == 2) *p = f32_to_bf16(v);
+  else *p = v;
+}
+
+// qkv: (B, 3C) rows [key | query | value] of the new token (row stride ld); caches: (B, Tmax, C)
+template <typename T>
+__global__ __launch_bounds__(64) void attn_decode_kernel(const T* __restrict__ qkv, long long ld, T* __restrict__ kc,
+                                                         T* __restrict__ vc, int Tmax, int C, int pos,
+                                                         const int* __restrict__ pos_dev, T* __restrict__ out,
+                                                         float* __restrict__ att_row, float scale) {
+  constexpr int HS = 64, MAXT = 320;  // <= 5 key positions per lane
+  if (pos_dev) pos = *pos_dev;  // graph-replayed decoding: the position lives on the device
+  if (pos >= Tmax) return;
+  const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  __shared__ float prob[MAXT];
+  __shared__ float qs[HS];
+  const T* row = qkv + (long long)b * ld;
+  T* kb = kc + ((long long)b * Tmax) * C + h * HS;
+  T* vb = vc + ((long long)b * Tmax) * C + h * HS;
+  // append this token's key / value (lane = head dimension), keep q in LDS
+  const float kn = ldf(row + h * HS + lane), qn = ldf(row + C + h * HS + lane), vn = ldf(row + 2 * C + h * HS + lane);
+  stf(kb + (long long)pos * C + lane, kn);
+  stf(vb + (long long)pos * C + lane, vn);
+  qs[lane] = qn;
+  __syncthreads();
+  const int len = pos + 1;
+  // scores: lane owns positions lane, lane + 64, ...  The newest key's score comes from registers (a wave reduction
+  // of k_new * q): its cache row was stored by all 64 lanes a moment ago and no other lane should have to read it
+  // back (the value row IS read back below, but each lane only re-reads the element it stored itself).
+  const float s_new = wave_sum(kn * qn);
+  float s[MAXT / 64];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < MAXT / 64; ++i) {
+    const int t = lane + 64 * i;
+    s[i] = -INFINITY;
+    if (t < len) {
+      const T* kr = kb + (long long)t * C;
+      float acc = 0.f;
+      if (t == pos) {
+        acc = s_new;
+      } else if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int c = 0; c < HS / 8; ++c) {
+          const u32x4 v = *(const u32x4*)(kr + 8 * c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc = fmaf(__uint_as_float(v[e] << 16), qs[8 * c + 2 * e], acc);
+            acc = fmaf(__uint_as_float(v[e] & 0xFFFF0000u), qs[8 * c + 2 * e + 1], acc);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < HS / 4; ++c) {
+          const f32x4 v = *(const f32x4*)(kr + 4 * c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = fmaf(v[e], qs[4 * c + e], acc);
+        }
+      }
+      s[i] = acc * scale;
+      mx = fmaxf(mx, s[i]);
+    }
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXT / 64; ++i) {
+    const int t = lane + 64 * i;
+    if (t < len) {
+      s[i] = __expf(s[i] - mx);
+      sum += s[i];
+    }
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int i = 0; i < MAXT / 64; ++i) {
+    const int t = lane + 64 * i;
+    if (t < len) {
+      prob[t] = s[i] * inv;
+      if (att_row) att_row[((long long)b * gridDim.x + h) * Tmax + t] = s[i] * inv;
+    }
+  }
+  __syncthreads();
+  // output: lane = head dimension, four independent chains over the positions
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+  int t = 0;
+  for (; t + 3 < len; t += 4) {
+    o0 = fmaf(prob[t], ldf(vb + (long long)t * C + lane), o0);
+    o1 = fmaf(prob[t + 1], ldf(vb + (long long)(t + 1) * C + lane), o1);
+    o2 = fmaf(prob[t + 2], ldf(vb + (long long)(t + 2) * C + lane), o2);
+    o3 = fmaf(prob[t + 3], ldf(vb + (long long)(t + 3) * C + lane), o3);
+  }
+  for (; t < len; ++t) o0 = fmaf(prob[t], ldf(vb + (long long)t * C + lane), o0);
+  stf(out + (long long)b * C + h * HS + lane, (o0 + o1) + (o2 + o3));
+}
+
+// x[b, :] = tok_emb[idx[b]] + pos_emb[*pos_dev]   (the stem of GPT.forward for one position, minGPT.py:170-180)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_decode_kernel(const long long* __restrict__ idx, const float* __restrict__ tok,
+                                                           const float* __restrict__ pos_emb,
+                                                           const int* __restrict__ pos_dev, int C, int V,
+                                                           T* __restrict__ out) {
+  const int b = blockIdx.x, p = *pos_dev;
+  long long tkn = idx[b];
+  tkn = tkn < 0 ? 0 : tkn >= V ? V - 1 : tkn;
+  for (int c = threadIdx.x; c < C; c += 256) stf(out + (long long)b * C + c, tok[tkn * C + c] + pos_emb[(long long)p * C + c]);
+}
+
+__global__ void incr_i32_kernel(int* p) { *p += 1; }
+
+}  // namespace
+
+extern "C" int melgpt_embed_decode(const long long* idx, const float* tok_emb, const float* pos_emb, const int* pos_dev,
+                                   int B, int C, int V, void* out, int dtype, void* stream) {
+  MELGPT_CHECK(idx && tok_emb && pos_emb && pos_dev && out && B > 0 && C > 0 && V > 0, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(dtype == MELGPT_F32 || dtype == MELGPT_BF16, MELGPT_ERR_UNSUPPORTED);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MELGPT_F32)
+    hipLaunchKernelGGL(embed_decode_kernel<float>, dim3(B), dim3(256), 0, s, idx, tok_emb, pos_emb, pos_dev, C, V, (float*)out);
+  else
+    hipLaunchKernelGGL(embed_decode_kernel<bf16_t>, dim3(B), dim3(256), 0, s, idx, tok_emb, pos_emb, pos_dev, C, V,
+                       (bf16_t*)out);
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_incr_i32(int* counter, void* stream) {
+  MELGPT_CHECK(counter, MELGPT_ERR_BAD_ARG);
+  hipLaunchKernelGGL(incr_i32_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter);
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_attn_decode(const void* qkv, long long ld, void* kcache, void* vcache, int B, int H, int head_size,
+                                  int Tmax, int pos, const int* pos_dev, void* out, float* att_row, int dtype,
+                                  void* stream) {
+  MELGPT_CHECK(qkv && kcache && vcache && out && B > 0 && H > 0, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(dtype == MELGPT_F32 || dtype == MELGPT_BF16, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK(head_size == 64 && Tmax > 0 && Tmax <= 320 && pos >= 0 && pos < Tmax, MELGPT_ERR_UNSUPPORTED);
+  const int C = H * head_size;
+  MELGPT_CHECK(ld >= 3LL * C && ld % 8 == 0 && ((((uintptr_t)qkv | (uintptr_t)kcache | (uintptr_t)vcache) & 15) == 0),
+               MELGPT_ERR_ALIGN);
+  const float scale = 1.0f / sqrtf((float)head_size);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MELGPT_F32)
+    hipLaunchKernelGGL(attn_decode_kernel<float>, dim3(H, B), dim3(64), 0, s, (const float*)qkv, ld, (float*)kcache,
+                       (float*)vcache, Tmax, C, pos, pos_dev, (float*)out, att_row, scale);
+  else
+    hipLaunchKernelGGL(attn_decode_kernel<bf16_t>, dim3(H, B), dim3(64), 0, s, (const bf16_t*)qkv, ld, (bf16_t*)kcache,
+                       (bf16_t*)vcache, Tmax, C, pos, pos_dev, (bf16_t*)out, att_row, scale);
+  return melgpt_launch_status();
+}
+
+// ====================================================================================== skinny-M linear layer
+// y[m, n] = epi( sum_k x[m, k] W[n, k] + bias[n] ) (+ residual[m, n]),  m < M (a handful of rows: the decode batch),
+// W (N, K) row-major = nn.Linear.weight.  A decode step streams every weight once and does almost no arithmetic, so
+// the tiled MFMA GEMM (one 128-row tile => N/128 workgroups, each reading its weight slice alone) leaves most of the
+// chip idle; here ONE WAVE owns 4 output columns: lanes split K in 16-byte chunks (coalesced 1 KiB per row per
+// trip, all trips of a row in flight together), accumulate 4 x 16 dot products in registers
+// (bf16 pairs unpacked to f32 by shift / mask), and a wave reduction finishes.  x rows are re-read from L1/L2.
+// grid = (N / 4, ceil(M / 16)), 1-4 waves per workgroup by K: N = 1024 already gives one workgroup per CU.
+namespace {
+
+template <typename T, int MB>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x, long long ldx, const T* __restrict__ W,
+                                                        long long ldw, const float* __restrict__ bias,
+                                                        const T* __restrict__ res, long long ldr, void* __restrict__ y,
+                                                        long long ldy, int M, int N, int K, int act, int out_f32) {
+  constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte chunk
+  // blockDim.x / 64 waves share the 4 columns and split K between them (the launcher aims at ~2 chunks per lane,
+  // so that every load of a row is in flight at once whatever K is)
+  const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int n0 = blockIdx.x * 4, m0 = blockIdx.y * MB;
+  const int mrows = min(MB, M - m0);
+  float acc[4][MB];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
+  const int nchunk = K / VEC;
+#pragma unroll 2
+  for (int c = wv_id * 64 + lane; c < nchunk; c += 64 * nwave) {
+    u32x4 wv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wv[r] = *(const u32x4*)(W + (long long)(n0 + r) * ldw + (long long)c * VEC);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      if (m < mrows) {
+        const u32x4 xv = *(const u32x4*)(x + (long long)(m0 + m) * ldx + (long long)c * VEC);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              acc[r][m] = fmaf(__uint_as_float(wv[r][e] << 16), __uint_as_float(xv[e] << 16), acc[r][m]);
+              acc[r][m] = fmaf(__uint_as_float(wv[r][e] & 0xFFFF0000u), __uint_as_float(xv[e] & 0xFFFF0000u), acc[r][m]);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[r][m] = fmaf(__uint_as_float(wv[r][e]), __uint_as_float(xv[e]), acc[r][m]);
+          }
+        }
+      }
+    }
+  }
+  // wave reduction of the 4 x MB partial sums (lane r * MB + m keeps output (m, n0 + r)), then across the waves
+  float mine = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const float s = wave_sum(acc[r][m]);
+      if (lane == r * MB + m) mine = s;
+    }
+  __shared__ float part[4][64];
+  if (nwave > 1) {
+    part[wv_id][lane] = mine;
+    __syncthreads();
+    if (wv_id == 0) {
+      mine = part[0][lane];
+      for (int q = 1; q < nwave; ++q) mine += part[q][lane];
+    }
+  }
+  if (wv_id == 0 && lane < 4 * MB) {
+    const int r = lane / MB, m = lane % MB;
+    if (m < mrows) {
+      const int n = n0 + r;
+      float v = mine + (bias ? bias[n] : 0.f);
+      if (act == MELGPT_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+      if (res) v += ldf(res + (long long)(m0 + m) * ldr + n);
+      if (out_f32) ((float*)y)[(long long)(m0 + m) * ldy + n] = v;
+      else stf((T*)y + (long long)(m0 + m) * ldy + n, v);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int melgpt_gemv_rows(const void* x, long long ldx, const void* W, long long ldw, const float* bias,
+                                const void* residual, long long ldr, void* y, long long ldy, int M, int N, int K, int act,
+                                int dtype, int out_f32, void* stream) {
+  MELGPT_CHECK(x && W && y && M > 0 && N > 0 && K > 0, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(dtype == MELGPT_F32 || dtype == MELGPT_BF16, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK(act == MELGPT_ACT_NONE || act == MELGPT_ACT_GELU, MELGPT_ERR_UNSUPPORTED);
+  const int vec = dtype == MELGPT_F32 ? 4 : 8;
+  MELGPT_CHECK(N % 4 == 0 && K % vec == 0 && ldx % vec == 0 && ldw % vec == 0 &&
+                   ((((uintptr_t)x | (uintptr_t)W) & 15) == 0),
+               MELGPT_ERR_ALIGN);
+  hipStream_t s = (hipStream_t)stream;
+  int nwave = (K / vec + 127) / 128;  // ~2 chunks of 16 bytes per lane
+  nwave = nwave < 1 ? 1 : nwave > 4 ? 4 : nwave;
+  // 16 rows of x per wave; fewer accumulators are instantiated for the common single-digit decode batches
+#define MELGPT_GEMV_LAUNCH(T, MB)                                                                                     \
+  hipLaunchKernelGGL((gemv_rows_kernel<T, MB>), dim3(N / 4, (M + MB - 1) / MB), dim3(64 * nwave), 0, s, (const T*)x, ldx, \
+                     (const T*)W, ldw, bias, (const T*)residual, ldr, y, ldy, M, N, K, act,                            \
+                     (dtype == MELGPT_F32) ? 1 : out_f32)
+  if (dtype == MELGPT_F32) {
+    if (M <= 4) MELGPT_GEMV_LAUNCH(float, 4);
+    else MELGPT_GEMV_LAUNCH(float, 16);
+  } else {
+    if (M <= 4) MELGPT_GEMV_LAUNCH(bf16_t, 4);
+    else MELGPT_GEMV_LAUNCH(bf16_t, 16);
+  }
+#undef MELGPT_GEMV_LAUNCH
+  return melgpt_launch_status();
+}

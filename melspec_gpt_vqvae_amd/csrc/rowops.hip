@@ -695,7 +695,12 @@ __global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void sample_logits_kernel(const float* __restrict__ logits, long long ld, int V,
                                                             float temperature, int top_k, int do_sample,
                                                             unsigned long long seed, unsigned step,
-                                                            long long* __restrict__ out, float* __restrict__ probs_out) {
+                                                            long long* __restrict__ out, float* __restrict__ probs_out,
+                                                            const int* __restrict__ pos_dev, int step_offset,
+                                                            long long* __restrict__ seq, long long seq_ld) {
+  // pos_dev (graph-replayed decoding): the step number and the slot of `seq` to fill are read on the device, so the
+  // same captured launch serves every position
+  if (pos_dev) step = (unsigned)(*pos_dev + step_offset);
   __shared__ float v[1024], srt[1024], red[256];
   __shared__ int redi[256];
   const int t = threadIdx.x, row = blockIdx.x;
@@ -768,6 +773,7 @@ __global__ __launch_bounds__(256) void sample_logits_kernel(const float* __restr
       }
     }
     out[row] = pick;
+    if (seq && pos_dev) seq[(long long)row * seq_ld + *pos_dev] = pick;
   }
 }
 
@@ -1090,7 +1096,17 @@ extern "C" int melgpt_sample_logits(const float* logits, long long ld, int rows,
   MELGPT_CHECK(logits && out && rows > 0 && V > 0 && ld >= V && temperature > 0.f, MELGPT_ERR_BAD_ARG);
   MELGPT_CHECK(V <= 1024, MELGPT_ERR_UNSUPPORTED);
   hipLaunchKernelGGL(sample_logits_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ld, V, temperature,
-                     top_k, do_sample, seed, step, out, probs_out);
+                     top_k, do_sample, seed, step, out, probs_out, (const int*)nullptr, 0, (long long*)nullptr, 0LL);
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_sample_logits_dev(const float* logits, long long ld, int rows, int V, float temperature, int top_k,
+                                        int do_sample, unsigned long long seed, const int* pos_dev, int step_offset,
+                                        long long* out, long long* seq, long long seq_ld, void* stream) {
+  MELGPT_CHECK(logits && out && pos_dev && rows > 0 && V > 0 && ld >= V && temperature > 0.f, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(V <= 1024, MELGPT_ERR_UNSUPPORTED);
+  hipLaunchKernelGGL(sample_logits_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ld, V, temperature,
+                     top_k, do_sample, seed, 0u, out, (float*)nullptr, pos_dev, step_offset, seq, seq_ld);
   return melgpt_launch_status();
 }
 

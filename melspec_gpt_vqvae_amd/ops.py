@@ -371,6 +371,71 @@ def attn_fwd(q, k, v, n_head, *, B, T, n_unmasked=0, drop_p=0.0, seed=0, stream_
     return out, lse, att
 
 
+def attn_decode(qkv, kcache, vcache, n_head, pos, att_row=None, pos_dev=None, out=None):
+    """one KV-cached attention step: qkv (B, 3C) [key|query|value] of the new token; caches (B, Tmax, C), appended at
+    `pos` (or at *pos_dev, a device int32, when given); -> (B, C)."""
+    B, C3 = qkv.shape
+    C = C3 // 3
+    assert qkv.stride(1) == 1 and kcache.shape == vcache.shape and kcache.shape[0] == B and kcache.shape[2] == C
+    assert kcache.is_contiguous() and vcache.is_contiguous() and kcache.dtype == qkv.dtype
+    if out is None:
+        out = torch.empty(B, C, dtype=qkv.dtype, device=qkv.device)
+    call("melgpt_attn_decode", ptr(qkv), qkv.stride(0), ptr(kcache), ptr(vcache), B, n_head, 64, kcache.shape[1], int(pos),
+         ptr(pos_dev), ptr(out), ptr(att_row), dtype_code(qkv.dtype), stream())
+    return out
+
+
+def linear_rows(x, w, *, bias=None, act=ACT_NONE, residual=None, out_dtype=None):
+    """y (M,N) = epi(x (M,K) @ w (N,K)^T + bias) (+ residual) for a handful of rows (decode steps): the weight-streaming
+    kernel melgpt_gemv_rows instead of the tiled MFMA GEMM."""
+    M, K = x.shape
+    N, K2 = w.shape
+    assert K == K2 and x.dtype == w.dtype and x.stride(1) == 1 and w.stride(1) == 1
+    odt = out_dtype or x.dtype
+    assert odt in (x.dtype, torch.float32)
+    if M > 32:  # enough rows for the MFMA tiles to pay (measured: 128 rows 5.0 vs 5.8 ms per 24-layer step)
+        return gemm(x, w, bias=bias, act=act, residual=residual, out_dtype=odt)
+    y = torch.empty(M, N, dtype=odt, device=x.device)
+    if residual is not None:
+        assert residual.shape == (M, N) and residual.dtype == x.dtype and residual.stride(1) == 1
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+    call("melgpt_gemv_rows", ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(residual),
+         residual.stride(0) if residual is not None else 0, ptr(y), N, M, N, K, int(act), dtype_code(x.dtype),
+         int(odt == torch.float32), stream())
+    return y
+
+
+def embed_decode(idx, tok_emb, pos_emb, pos_dev, dtype):
+    """x (B, C) = tok_emb[idx[:, 0]] + pos_emb[*pos_dev]; pos_emb (block_size, C) f32, pos_dev device int32."""
+    B = idx.shape[0]
+    V, C = tok_emb.shape
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and pos_emb.is_contiguous() and pos_dev.dtype == torch.int32
+    out = torch.empty(B, C, dtype=dtype, device=tok_emb.device)
+    call("melgpt_embed_decode", ptr(idx), ptr(tok_emb), ptr(pos_emb), ptr(pos_dev), B, C, V, ptr(out), dtype_code(dtype),
+         stream())
+    return out
+
+
+def incr_i32(counter):
+    assert counter.dtype == torch.int32 and counter.numel() == 1
+    call("melgpt_incr_i32", ptr(counter), stream())
+
+
+def sample_logits_dev(logits, out, pos_dev, step_offset, temperature=1.0, top_k=None, sample=False, seed=0, seq=None):
+    """sample_logits with the step number (*pos_dev + step_offset) read on the device; writes `out` (rows,1) int64 in
+    place and, when given, seq[:, *pos_dev]."""
+    assert logits.dim() == 2 and logits.dtype == torch.float32 and logits.stride(1) == 1
+    rows, V = logits.shape
+    assert out.dtype == torch.int64 and out.numel() == rows and out.is_contiguous()
+    if seq is not None:
+        assert seq.dtype == torch.int64 and seq.stride(1) == 1 and seq.shape[0] == rows
+    call("melgpt_sample_logits_dev", ptr(logits), logits.stride(0), rows, V, float(temperature), int(top_k or 0),
+         int(sample), int(seed), ptr(pos_dev), int(step_offset), ptr(out), ptr(seq), seq.stride(0) if seq is not None else 0,
+         stream())
+    return out
+
+
 def attn_bwd(q, k, v, out, dout, lse, n_head, *, B, T, dqkv=None, n_unmasked=0, drop_p=0.0, seed=0, stream_id=0):
     """-> (dq, dk, dv) as column blocks [q | k | v] of one (B*T, 3C) buffer unless dqkv views are given."""
     M, C = q.shape

@@ -2,6 +2,8 @@
 (GPTDecoder :10-123): a GPT whose first position is the latent z; per-token cross entropy summed per sequence."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -45,12 +47,39 @@ class GPTDecoder(nn.Module):
         return out
 
     @torch.no_grad()
-    def sample(self, x, c, steps, temperature=1.0, sample=False, top_k=None, callback=lambda k: None):
-        """reference :89-123."""
+    def sample(self, x, c, steps, temperature=1.0, sample=False, top_k=None, callback=lambda k: None, kv_cache=True):
+        """reference :89-123.  kv_cache=True (default): one position per step through GPT.decode_step (the latent
+        `c` (B,1,C) is the first position); kv_cache=False: the reference's full re-forward per step."""
         block_size = self.transformer.get_block_size()
         assert not self.transformer.training
         seed = _Seeds.next()
         att = None
+        if kv_cache and steps > 0:
+            tr = self.transformer
+            cond_size = c.size(-2)
+            assert cond_size == 1 and x.size(1) + cond_size + steps - 1 <= block_size
+            cache = tr.decode_begin(x.size(0))
+            logits = tr.decode_step(cache, embeddings=c)
+            for j in range(x.size(1)):
+                logits = tr.decode_step(cache, idx=x[:, j:j + 1])
+            n_prompt = x.size(1)
+            use_graph = steps >= 4 and os.environ.get('MELGPT_DECODE_GRAPH', '1') != '0'
+            for k in range(steps):
+                callback(k)
+                ix = ops.sample_logits(logits, temperature=temperature, top_k=top_k, sample=sample, seed=seed, step=k)
+                x = torch.cat((x, ix), dim=1)
+                if use_graph:
+                    # the remaining steps run as one captured HIP graph replayed per token (no host round trips)
+                    for kk in range(k + 1, steps):
+                        callback(kk)
+                    rest = tr.decode_sample_graph(cache, ix, steps - 1 - k, temperature=temperature, top_k=top_k,
+                                                   sample=sample, seed=seed, n_prompt=n_prompt)
+                    x = torch.cat((x, rest), dim=1)
+                    break
+                if k + 1 < steps:
+                    logits = tr.decode_step(cache, idx=ix)
+            _, _, att = self.transformer(x[:, :-1], c)
+            return x, att.detach().cpu()
         for k in range(steps):
             callback(k)
             cond_size = c.size(-2)

@@ -16,6 +16,8 @@ from __future__ import annotations
 import math
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -481,6 +483,122 @@ class GPT(nn.Module):
         logits = _HeadFn.apply(x, self, self.ln_f.weight, self.ln_f.bias, self.head.weight)
         return logits, att
 
+    # ------------------------------------------------------------------ KV-cached decoding
+    # The reference samples by re-running the whole model on the growing sequence (:293-360, decoders.py:89-123).
+    # decode_step feeds ONE position: per layer the new token's k, v are appended to a (B, block_size, C) cache and
+    # its query attends to the cached positions (csrc/decode.hip) - same logits as the last row of a full forward.
+    @torch.no_grad()
+    def decode_begin(self, batch_size):
+        """-> a fresh KV cache for `batch_size` sequences (eval mode only)."""
+        assert not self.training, "KV-cached decoding is an inference path (dropout is not applied)"
+        dt = _compute_dtype(self)
+        dev = self.pos_emb.device
+        C = self.tok_emb.weight.shape[1]
+        return {"pos": 0, "B": int(batch_size), "pos_dev": torch.zeros(1, dtype=torch.int32, device=dev),
+                "k": [torch.empty(batch_size, self.block_size, C, dtype=dt, device=dev) for _ in self.blocks],
+                "v": [torch.empty(batch_size, self.block_size, C, dtype=dt, device=dev) for _ in self.blocks]}
+
+    @torch.no_grad()
+    def decode_step(self, cache, idx=None, embeddings=None, pre_idx=None, want_att=False):
+        """feed one position - a token `idx` (B,1), a class token `pre_idx` (B,1) or an explicit embedding
+        `embeddings` (B,1,C) - and return the f32 logits (B, V) for the next one [, last block's attention row
+        (B, H, block_size), entries beyond the current position undefined]."""
+        assert not self.training
+        pos, B = cache["pos"], cache["B"]
+        assert pos < self.block_size, "Cannot forward, model block size is exhausted."
+        dt = _compute_dtype(self)
+        fp = ensure_flat(self)
+        C = self.tok_emb.weight.shape[1]
+        pe = self.pos_emb[0, pos:pos + 1]
+        if idx is not None:
+            _require_cuda(idx)
+            assert idx.shape == (B, 1)
+            x = ops.embed_fwd(idx, self.tok_emb.weight, pe, dtype=dt)
+        elif pre_idx is not None:
+            assert pre_idx.shape == (B, 1)
+            x = ops.embed_fwd(pre_idx.new_zeros(B, 0), self.tok_emb.weight, pe, dtype=dt, pre_idx=pre_idx,
+                              pre_table=self.embedder.weight, n_pre=1)
+        else:
+            assert embeddings is not None and embeddings.shape == (B, 1, C)
+            ev = embeddings
+            if ev.dtype != torch.float32 or not ev.is_contiguous():
+                ev = ops.cast(ev.contiguous(), torch.float32)
+            x = ops.embed_fwd(torch.zeros(B, 0, dtype=torch.int64, device=ev.device), self.tok_emb.weight, pe, dtype=dt,
+                              pre_vals=ev, n_pre=1)
+        logits, att_row = self._decode_trunk(x.view(B, C), cache, pos, None, want_att)
+        cache["pos"] = pos + 1
+        return (logits, att_row) if want_att else logits
+
+    def _decode_trunk(self, x, cache, pos, pos_dev, want_att):
+        """blocks + ln_f + head for one position; x (B, C) in the compute dtype."""
+        dt = _compute_dtype(self)
+        fp = ensure_flat(self)
+        B = x.shape[0]
+        att_row = None
+        last = len(self.blocks) - 1
+        for li, blk in enumerate(self.blocks):
+            W = _BlockWeights(blk, fp, dt)
+            a, m = blk.attn, blk.mlp
+            h1 = ops.layernorm_fwd(x, blk.ln1.weight, blk.ln1.bias, blk.ln1.eps, want_stats=False)[0]
+            qkv = ops.linear_rows(h1, W.w_qkv, bias=W.b_qkv)
+            if want_att and li == last:
+                att_row = torch.zeros(B, a.n_head, self.block_size, dtype=torch.float32, device=x.device)
+            y = ops.attn_decode(qkv, cache["k"][li], cache["v"][li], a.n_head, pos,
+                                att_row=att_row if li == last else None, pos_dev=pos_dev)
+            x1 = ops.linear_rows(y, W.w_proj, bias=a.proj.bias, residual=x)
+            h2 = ops.layernorm_fwd(x1, blk.ln2.weight, blk.ln2.bias, blk.ln2.eps, want_stats=False)[0]
+            act = ops.linear_rows(h2, W.w_fc1, bias=m[0].bias, act=ops.ACT_GELU)
+            x = ops.linear_rows(act, W.w_fc2, bias=m[2].bias, residual=x1)
+        buf = fp.compute_buffer(dt)
+        w = fp._slice(buf, self.head.weight).view(self.head.weight.shape)
+        h = ops.layernorm_fwd(x, self.ln_f.weight, self.ln_f.bias, self.ln_f.eps, want_stats=False)[0]
+        return ops.linear_rows(h, w, out_dtype=torch.float32), att_row
+
+    @torch.no_grad()
+    def decode_sample_graph(self, cache, first_token, steps, *, temperature=1.0, top_k=None, sample=False, seed=0,
+                            n_prompt=0):
+        """Sample `steps` more tokens after `first_token` (B,1) with ONE captured HIP graph replayed per token: the
+        position, the sampling-step number and the token fed back all live on the device (csrc/decode.hip,
+        melgpt_sample_logits_dev), so a replay needs no host round trip and ~200 kernel launches cost one graph
+        launch.  The cache must already hold positions 0 .. cache['pos']-1; first_token is x[cache['pos']-1].
+        -> (B, steps) int64."""
+        B, pos0 = cache["B"], cache["pos"]
+        assert first_token.shape == (B, 1) and pos0 + steps <= self.block_size
+        dt = _compute_dtype(self)
+        dev = first_token.device
+        idx = first_token.clone().contiguous()
+        seq = torch.zeros(B, self.block_size, dtype=torch.int64, device=dev)
+        pos_dev = cache["pos_dev"]
+        pe = self.pos_emb[0].contiguous()
+
+        def body():
+            x = ops.embed_decode(idx, self.tok_emb.weight, pe, pos_dev, dt)
+            logits, _ = self._decode_trunk(x, cache, 0, pos_dev, False)
+            ops.sample_logits_dev(logits, idx, pos_dev, -n_prompt, temperature=temperature, top_k=top_k, sample=sample,
+                                  seed=seed, seq=seq)
+            ops.incr_i32(pos_dev)
+
+        if steps <= 0:
+            return seq[:, :0]
+        # one eager step first: it performs every lazy one-time setup (LDS attributes, bf16 weight shadow, workspaces)
+        # outside the capture - and is itself the first of the `steps`
+        pos_dev.fill_(pos0)
+        body()
+        if steps > 1:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                body()                      # second step, on the side stream (warms that stream's workspace)
+            torch.cuda.current_stream().wait_stream(side)
+        if steps > 2:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body()                      # third step is executed by the capture's first replay below
+            for _ in range(steps - 2):
+                g.replay()
+        cache["pos"] = pos0 + steps
+        return seq[:, pos0:pos0 + steps].clone()
+
     def _stem_params(self):
         ps = [self.tok_emb.weight, self.pos_emb]
         if hasattr(self, "embedder"):
@@ -621,15 +739,44 @@ class Lit_minGPT(_LitBase):
         return out
 
     @torch.no_grad()
-    def sample(self, x, c, steps, temperature=1.0, sample=False, top_k=None, callback=lambda k: None):
-        """reference :293-360 (GPTClass branch): full re-forward per step; temperature / top-k / softmax /
-        multinomial-or-argmax run in one kernel (melgpt_sample_logits).  Returns (x, last attention on CPU)."""
+    def sample(self, x, c, steps, temperature=1.0, sample=False, top_k=None, callback=lambda k: None, kv_cache=True):
+        """reference :293-360 (GPTClass branch).  temperature / top-k / softmax / multinomial-or-argmax run in one
+        kernel (melgpt_sample_logits).  kv_cache=True (default) feeds one position per step through
+        GPT.decode_step; kv_cache=False is the reference's full re-forward per step.  Both return
+        (x, last attention on CPU); the cached path runs ONE full forward at the end for that attention map."""
         block_size = self.transformer.get_block_size()
         assert not self.transformer.training
         if self.pkeep <= 0.0:
             raise NotImplementedError('Implement for GPTClass')
         seed = _Seeds.next()
         att = None
+        if kv_cache and steps > 0:
+            tr = self.transformer
+            cond_size = c.size(-1)
+            assert cond_size == 1 and x.size(1) + cond_size + steps - 1 <= block_size
+            with torch.no_grad():
+                cache = tr.decode_begin(x.size(0))
+                logits = tr.decode_step(cache, pre_idx=c)
+                for j in range(x.size(1)):
+                    logits = tr.decode_step(cache, idx=x[:, j:j + 1])
+                n_prompt = x.size(1)
+                use_graph = steps >= 4 and os.environ.get('MELGPT_DECODE_GRAPH', '1') != '0'
+                for k in range(steps):
+                    callback(k)
+                    ix = ops.sample_logits(logits, temperature=temperature, top_k=top_k, sample=sample, seed=seed, step=k)
+                    x = torch.cat((x, ix), dim=1)
+                    if use_graph:
+                        # the remaining steps run as one captured HIP graph replayed per token (no host round trips)
+                        for kk in range(k + 1, steps):
+                            callback(kk)
+                        rest = tr.decode_sample_graph(cache, ix, steps - 1 - k, temperature=temperature, top_k=top_k,
+                                                       sample=sample, seed=seed, n_prompt=n_prompt)
+                        x = torch.cat((x, rest), dim=1)
+                        break
+                    if k + 1 < steps:
+                        logits = tr.decode_step(cache, idx=ix)
+                _, _, att = tr(x[:, :-1], c)
+            return x, att.detach().cpu()
         for k in range(steps):
             callback(k)
             cond_size = c.size(-1)
