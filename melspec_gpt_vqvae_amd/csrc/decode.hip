@@ -196,6 +196,16 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
+  // the epilogue's operands are requested now, so that they arrive together with the weights instead of costing a
+  // second memory round trip after the reduction (a decode step is a chain of ~170 such latency-bound kernels)
+  float e_bias = 0.f, e_res = 0.f;
+  if (wv_id == 0 && lane < 4 * MB) {
+    const int r = lane / MB, m = lane % MB;
+    if (m < mrows) {
+      if (bias) e_bias = bias[n0 + r];
+      if (res) e_res = ldf(res + (long long)(m0 + m) * ldr + n0 + r);
+    }
+  }
   const int nchunk = K / VEC;
 #pragma unroll 2
   for (int c = wv_id * 64 + lane; c < nchunk; c += 64 * nwave) {
@@ -244,9 +254,9 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
     const int r = lane / MB, m = lane % MB;
     if (m < mrows) {
       const int n = n0 + r;
-      float v = mine + (bias ? bias[n] : 0.f);
+      float v = mine + e_bias;
       if (act == MELGPT_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-      if (res) v += ldf(res + (long long)(m0 + m) * ldr + n);
+      v += e_res;
       if (out_f32) ((float*)y)[(long long)(m0 + m) * ldy + n] = v;
       else stf((T*)y + (long long)(m0 + m) * ldy + n, v);
     }

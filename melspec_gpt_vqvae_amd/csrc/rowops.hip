@@ -705,6 +705,8 @@ __global__ __launch_bounds__(256) void sample_logits_kernel(const float* __restr
   __shared__ int redi[256];
   const int t = threadIdx.x, row = blockIdx.x;
   const float NEG = -__builtin_inff();
+  int P = 64;  // sort width: the power of two that covers the vocabulary (128 for the VAS codebook, 1024 for VGGSound)
+  while (P < V) P <<= 1;
   for (int i = t; i < 1024; i += 256) {
     float x = i < V ? logits[(long long)row * ld + i] / temperature : NEG;
     v[i] = x;
@@ -712,9 +714,9 @@ __global__ __launch_bounds__(256) void sample_logits_kernel(const float* __restr
   }
   __syncthreads();
   if (top_k > 0 && top_k < V) {
-    for (int k = 2; k <= 1024; k <<= 1)          // bitonic sort, descending
+    for (int k = 2; k <= P; k <<= 1)             // bitonic sort, descending
       for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = t; i < 1024; i += 256) {
+        for (int i = t; i < P; i += 256) {
           const int ixj = i ^ j;
           if (ixj > i) {
             const bool up = (i & k) == 0;
