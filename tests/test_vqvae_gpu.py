@@ -178,3 +178,33 @@ def test_fused_groupnorm_swish_conv3x3(dt, H, W, Cin, Cout, B):
     y2 = ops.conv3x3_gn(xd, None, None, None, wp, bias.to(DEV), swish=False)
     ref2 = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, padding=1).permute(0, 2, 3, 1)
     assert rel_err(y2.float().cpu().numpy(), ref2.numpy()) < (2e-5 if dt == "f32" else 8e-3)
+
+
+def test_extract_codes_writes_reference_named_files(tmp_path):
+    """feature_extraction/extract_codes.py (:31-56): <class>/melspec_10s_22050hz/<v>_mel.npy -> <class>/codes_10s/
+    <v>_mel_code.npy, (5, 53) int64, equal to encoding the centre crop 2x-1 directly; existing files are skipped."""
+    import os
+
+    from melspec_gpt_vqvae_amd.feature_extraction.extract_codes import extract_all
+    from melspec_gpt_vqvae_amd.vqvae.big_model_attn_gan import LitVQVAE
+
+    g = golden("vqvae_full")
+    m = LitVQVAE(num_embeddings=128, embedding_dim=256)
+    _load(m, synth.vqvae_state_dict(int(g["seed"])), allow_missing_prefix="discriminator.")
+    m.to(DEV).eval()
+    root = os.path.join(str(tmp_path), "vas", "features")
+    mels = synth.mel_tiles(21, 3)                       # (3, 80, 860) in [0, 1]
+    for i, cls in enumerate(["dog", "dog", "gun"]):
+        d = os.path.join(root, cls, "melspec_10s_22050hz")
+        os.makedirs(d, exist_ok=True)
+        np.save(os.path.join(d, f"video_{i:05d}_mel.npy"), mels[i])
+    written = extract_all(root, m, DEV, 848, batch_size=2)
+    assert sorted(os.path.relpath(w, root) for w in written) == [
+        "dog/codes_10s/video_00000_mel_code.npy", "dog/codes_10s/video_00001_mel_code.npy",
+        "gun/codes_10s/video_00002_mel_code.npy"]
+    with torch.no_grad():
+        ref = m.encode_to_codes(t(2 * mels[:, :, 6:854] - 1, DEV).unsqueeze(1)).cpu().numpy()
+    for i, cls in enumerate(["dog", "dog", "gun"]):
+        c = np.load(os.path.join(root, cls, "codes_10s", f"video_{i:05d}_mel_code.npy"))
+        assert c.shape == (5, 53) and c.dtype == np.int64 and np.array_equal(c, ref[i])
+    assert extract_all(root, m, DEV, 848) == []         # nothing left to do
