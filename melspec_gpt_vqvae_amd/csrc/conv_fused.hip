@@ -167,7 +167,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(FusedConvParams q) {
     const int y = y0 + wm * 4 + mt;
     mrow[mt] = (y < q.H) ? ((long long)b * q.H + y) * q.W + x0 : -1;
   }
-  epilogue_rows<T, 4, 4>(p, acc, mrow, min(TW, q.W - x0), n0 + wn * 64, 0, lane, smem + w * 4096);
+  // bf16 lane: the compact "plain bf16" epilogue (bias, residual, bf16 rows) - the generic one carries every
+  // activation / dropout / f32 path and is several times the size of the K loop in instruction-cache terms
+  constexpr int EPI = sizeof(T) == 2 ? EPI_PLAIN16 : EPI_GENERIC;
+  epilogue_rows<T, 4, 4, EPI>(p, acc, mrow, min(TW, q.W - x0), n0 + wn * 64, 0, lane, smem + w * 4096);
 }
 
 template <typename T>
