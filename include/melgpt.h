@@ -297,6 +297,18 @@ int melgpt_conv3x3_gn_nhwc(const void* x, int B, int H, int W, int Cin, const fl
 int melgpt_permute_nchw_nhwc(const void* x, int x_dtype, void* y, int y_dtype, int B, int C, int HW,
                              int to_nhwc, void* stream);
 
+/* ===================================================================== MelGAN generator glue (vocoder/modules.py:24-79)
+ * Conv1d / ConvTranspose1d layers run as per-tap batched melgpt_gemm launches on shifted row windows of a
+ * channels-last (B, L, C) activation; these two kernels are the rest:
+ * y (B, L + 2 pad, C) = act(pad(x (B, L, C))): reflect != 0 is nn.ReflectionPad1d (pad < L), else zero rows;
+ * act = LeakyReLU(slope), slope = 1 for none.  C % (16 / sizeof(T)) == 0. */
+int melgpt_pad1d_act(const void* x, void* y, int B, int L, int C, int pad, int reflect, float slope, int dtype,
+                     void* stream);
+/* y (B, L) f32 = [tanh]( bias + sum_{t<K, c<C} xp[b, l + t, c] * w[t*C + c] ): the generator's last Conv1d(ngf, 1, 7)
+ * + nn.Tanh on an already padded xp (B, L + K - 1, C); w (K*C) f32 = weight[0].T flattened tap-major. */
+int melgpt_conv1d_out1(const void* xp, const float* w, const float* bias, float* y, int B, int L, int C, int K,
+                       int do_tanh, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -569,3 +569,23 @@ def codes_permute(codes, H, W, reverse=False):
     out = torch.empty_like(src)
     call("melgpt_codes_permute", ptr(src), ptr(out), B, H, W, int(reverse), stream())
     return out
+
+
+# --------------------------------------------------------------------------------- MelGAN generator glue
+def pad1d_act(x, pad, *, reflect=True, slope=1.0):
+    """x (B, L, C) contiguous -> (B, L + 2 pad, C): reflection (or zero) padding along L with LeakyReLU(slope) applied
+    on the way (slope = 1: none)."""
+    B, L, C = x.shape
+    assert x.is_contiguous()
+    y = torch.empty(B, L + 2 * pad, C, dtype=x.dtype, device=x.device)
+    call("melgpt_pad1d_act", ptr(x), ptr(y), B, L, C, int(pad), int(reflect), float(slope), dtype_code(x.dtype), stream())
+    return y
+
+
+def conv1d_out1(xp, w, bias, L, K, tanh=True):
+    """xp (B, L + K - 1, C) padded activation, w (K*C,) f32 -> (B, L) f32 = [tanh](conv to one channel)."""
+    B, Lp, C = xp.shape
+    assert Lp == L + K - 1 and xp.is_contiguous() and w.dtype == torch.float32 and w.numel() == K * C and w.is_contiguous()
+    y = torch.empty(B, L, dtype=torch.float32, device=xp.device)
+    call("melgpt_conv1d_out1", ptr(xp), ptr(w), ptr(bias), ptr(y), B, L, C, K, int(tanh), dtype_code(xp.dtype), stream())
+    return y

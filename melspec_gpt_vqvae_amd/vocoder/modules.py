@@ -1,0 +1,204 @@
+"""MelGAN generator on the HIP kernels: mel (B, 80, T) -> waveform (B, 1, 256 T).
+Mirror of the reference's vocoder/modules.py (:9-79): same classes, constructor arguments and - through
+torch.nn.utils.weight_norm - the same state_dict keys (`model.<i>.weight_g / weight_v / bias`,
+`model.<i>.block.<j>...`, `model.<i>.shortcut...`), so `best_netG.pt` checkpoints load by name
+(callbacks/GPT_callbacks.py:66-79).
+
+Execution (inference only): activations are channels-last (B, L, C).  A Conv1d with k taps and dilation d is k
+batched MFMA GEMMs (melgpt_gemm, accumulate) of shifted row windows of the padded activation against the tap's
+(Cout, Cin) weight slice; a ConvTranspose1d(stride r, kernel 2r) is r output phases x 2 taps of the same, written to
+every r-th output row.  The LeakyReLU(0.2) in front of each convolution is applied by the padding copy
+(melgpt_pad1d_act); the last Conv1d(ngf, 1, 7) + Tanh is melgpt_conv1d_out1.  No GPU work happens in torch."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.utils import weight_norm
+
+from .. import _ffi, ops
+
+LEAK = 0.2
+
+
+def weights_init(m):
+    classname = m.__class__.__name__
+    if classname.find("Conv") != -1:
+        m.weight.data.normal_(0.0, 0.02)
+    elif classname.find("BatchNorm2d") != -1:
+        m.weight.data.normal_(1.0, 0.02)
+        m.bias.data.fill_(0)
+
+
+def WNConv1d(*args, **kwargs):
+    return weight_norm(nn.Conv1d(*args, **kwargs))
+
+
+def WNConvTranspose1d(*args, **kwargs):
+    return weight_norm(nn.ConvTranspose1d(*args, **kwargs))
+
+
+def _effective_weight(m):
+    """g * v / ||v|| (norm over all dims but 0 - torch.nn.utils.weight_norm's default), recomputed from the parameters
+    so that it is right after load_state_dict; f32, on the parameters' device."""
+    g, v = m.weight_g.detach(), m.weight_v.detach()
+    return torch._weight_norm(v, g, 0)
+
+
+class _TapCache:
+    """per-module cache of the per-tap (Cout, Cin) weight slices in the compute dtype"""
+
+    def __init__(self):
+        self.key, self.taps = None, None
+
+    def get(self, m, dtype, transposed):
+        key = (m.weight_g._version, m.weight_v._version, m.weight_g.data_ptr(), dtype)
+        if key != self.key:
+            w = _effective_weight(m)                           # Conv1d: (Cout, Cin, k); ConvTranspose1d: (Cin, Cout, k)
+            k = w.shape[2]
+            taps = []
+            for t in range(k):
+                wt = w[:, :, t].t() if transposed else w[:, :, t]
+                taps.append(ops.cast(wt.contiguous(), dtype))
+            self.key, self.taps = key, taps
+        return self.taps
+
+
+def _cache(m):
+    c = getattr(m, "_melgpt_taps", None)
+    if c is None:
+        c = _TapCache()
+        object.__setattr__(m, "_melgpt_taps", c)
+    return c
+
+
+def _conv1d(h, m, *, pad, reflect=True, leaky=False, out=None, accumulate=False):
+    """h (B, L, Cin) channels-last -> (B, L, Cout): Conv1d `m` (stride 1) on the [LeakyReLU ->] padded input."""
+    B, L, Cin = h.shape
+    k, d = m.kernel_size[0], m.dilation[0]
+    assert m.stride[0] == 1 and pad * 2 == d * (k - 1), "'same' convolutions only"
+    if pad > 0 or leaky:
+        h = ops.pad1d_act(h, pad, reflect=reflect, slope=LEAK if leaky else 1.0)
+    taps = _cache(m).get(m, h.dtype, False)
+    Cout = taps[0].shape[0]
+    if out is None:
+        out = torch.empty(B, L, Cout, dtype=h.dtype, device=h.device)
+    for t in range(k):
+        a = h[:, t * d:t * d + L, :]
+        ops.gemm(a, taps[t], out=out, accumulate=accumulate or t > 0, bias=m.bias if t == 0 else None)
+    return out
+
+
+def _conv_transpose1d(h, m):
+    """LeakyReLU -> ConvTranspose1d(stride r, kernel 2r, padding r//2 + r%2, output_padding r%2): (B, L, Cin) -> (B, rL, Cout).
+    Output row o = q r + s takes x[q + c] W[:, :, phi] + x[q + c - 1] W[:, :, phi + r] with (c, phi) = divmod(s + p, r)."""
+    B, L, Cin = h.shape
+    r, k, p = m.stride[0], m.kernel_size[0], m.padding[0]
+    assert k == 2 * r and p == r // 2 + r % 2 and m.output_padding[0] == r % 2 and m.dilation[0] == 1
+    x0 = ops.pad1d_act(h, 1, reflect=False, slope=LEAK)       # one zero row on each side
+    taps = _cache(m).get(m, h.dtype, True)
+    Cout = taps[0].shape[0]
+    Lout = (L - 1) * r - 2 * p + k + m.output_padding[0]
+    assert Lout == r * L
+    y = torch.empty(B, Lout, Cout, dtype=h.dtype, device=h.device)
+    for s in range(r):
+        c, phi = divmod(s + p, r)
+        dst = y[:, s::r, :]
+        ops.gemm(x0[:, c + 1:c + 1 + L, :], taps[phi], out=dst, bias=m.bias)
+        ops.gemm(x0[:, c:c + L, :], taps[phi + r], out=dst, accumulate=True)
+    return y
+
+
+class ResnetBlock(nn.Module):
+    def __init__(self, dim, dilation=1):
+        super().__init__()
+        self.block = nn.Sequential(
+            nn.LeakyReLU(0.2),
+            nn.ReflectionPad1d(dilation),
+            WNConv1d(dim, dim, kernel_size=3, dilation=dilation),
+            nn.LeakyReLU(0.2),
+            WNConv1d(dim, dim, kernel_size=1),
+        )
+        self.shortcut = WNConv1d(dim, dim, kernel_size=1)
+
+    def _run(self, h):
+        d = self.block[1].padding[0]
+        t1 = _conv1d(h, self.block[2], pad=d, leaky=True)
+        y = _conv1d(h, self.shortcut, pad=0)
+        return _conv1d(t1, self.block[4], pad=0, leaky=True, out=y, accumulate=True)   # shortcut(x) + block(x)
+
+    def forward(self, x):  # (B, C, L) like the reference
+        return _from_cl(self._run(_to_cl(x, _dtype_of(self))), x.dtype)
+
+
+def _dtype_of(module):
+    return getattr(module, "compute_dtype", torch.float32)
+
+
+def _to_cl(x, dtype):
+    """(B, C, L) -> channels-last (B, L, C) in `dtype`"""
+    if not x.is_cuda:
+        raise _ffi.MelgptError("melspec_gpt_vqvae_amd runs on the GPU only (no CPU / eager fallback)")
+    B, C, L = x.shape
+    return ops.to_nhwc(x.reshape(B, C, 1, L), dtype).view(B, L, C)
+
+
+def _from_cl(h, dtype):
+    B, L, C = h.shape
+    return ops.to_nchw_contiguous(h.view(B, 1, L, C), dtype).view(B, C, L)
+
+
+class Generator(nn.Module):
+    def __init__(self, input_size, ngf, n_residual_layers):
+        super().__init__()
+        ratios = [8, 8, 2, 2]
+        self.hop_length = np.prod(ratios)
+        mult = int(2 ** len(ratios))
+        model = [
+            nn.ReflectionPad1d(3),
+            WNConv1d(input_size, mult * ngf, kernel_size=7, padding=0),
+        ]
+        for i, r in enumerate(ratios):  # upsample to raw audio scale
+            model += [
+                nn.LeakyReLU(0.2),
+                WNConvTranspose1d(mult * ngf, mult * ngf // 2, kernel_size=r * 2, stride=r, padding=r // 2 + r % 2,
+                                  output_padding=r % 2),
+            ]
+            for j in range(n_residual_layers):
+                model += [ResnetBlock(mult * ngf // 2, dilation=3 ** j)]
+            mult //= 2
+        model += [
+            nn.LeakyReLU(0.2),
+            nn.ReflectionPad1d(3),
+            WNConv1d(ngf, 1, kernel_size=7, padding=0),
+            nn.Tanh(),
+        ]
+        self.model = nn.Sequential(*model)
+        self.apply(weights_init)
+
+    @torch.no_grad()
+    def forward(self, x):
+        """x (B, input_size, T) -> (B, 1, 256 T) f32"""
+        dt = _dtype_of(self)
+        layers = list(self.model)
+        h = _to_cl(x, dt)
+        h = _conv1d(h, layers[1], pad=3)                      # ReflectionPad1d(3) + Conv1d(k=7)
+        i = 2
+        while i < len(layers):
+            m = layers[i]
+            if isinstance(m, nn.LeakyReLU) and isinstance(layers[i + 1], nn.ConvTranspose1d):
+                h = _conv_transpose1d(h, layers[i + 1])
+                i += 2
+            elif isinstance(m, ResnetBlock):
+                h = m._run(h)
+                i += 1
+            elif isinstance(m, nn.LeakyReLU) and isinstance(layers[i + 1], nn.ReflectionPad1d):
+                last = layers[i + 2]
+                assert isinstance(last, nn.Conv1d) and last.out_channels == 1 and isinstance(layers[i + 3], nn.Tanh)
+                hp = ops.pad1d_act(h, layers[i + 1].padding[0], reflect=True, slope=LEAK)
+                w = _effective_weight(last)[0].t().contiguous().reshape(-1)     # (k, Cin) tap-major, f32
+                y = ops.conv1d_out1(hp, w.float(), last.bias, h.shape[1], last.kernel_size[0], tanh=True)
+                return y.view(y.shape[0], 1, y.shape[1])
+            else:
+                raise RuntimeError(f"unexpected layer {type(m).__name__} at model[{i}]")
+        raise RuntimeError("generator has no output layer")

@@ -378,11 +378,39 @@ def gen_vqvae(ref_vq):
          sd_keys=np.array([k for k in m.state_dict().keys()]))
 
 
+def gen_melgan():
+    """MelGAN generator (vocoder/modules.py:38-79): the module imports librosa at the top only for a filter-bank
+    helper that the Generator never calls, so a stand-in satisfies the import."""
+    lib = _stub("librosa")
+    lib.filters = _stub("librosa.filters", mel=lambda *a, **k: None)
+    sys.path.insert(0, REF)
+    import vocoder.modules as ref_voc
+
+    hp = dict(input_size=80, ngf=8, n_residual_layers=3)
+    g = ref_voc.Generator(hp["input_size"], hp["ngf"], hp["n_residual_layers"]).eval()
+    sd = synth.melgan_state_dict(61, **hp)
+    assert [k for k in g.state_dict().keys()] == list(sd.keys()), "key names / order of the weight-normed generator"
+    load_sd(g, sd)
+    x = synth.normal(62, (2, 80, 12), 1.0)
+    with torch.no_grad():
+        y = g(t(x))
+        blk = g.model[4]                                   # first ResnetBlock (64 channels at ngf=8), dilation 1
+        xb = synth.normal(63, (2, hp["ngf"] * 8, 40), 1.0)
+        yb = blk(t(xb))
+    assert tuple(y.shape) == (2, 1, 12 * 256)
+    save("melgan_small", x=x, y=y.numpy(), xb=xb, yb=yb.numpy(), seed=61, ngf=hp["ngf"],
+         sd_keys=np.array(list(sd.keys())))
+
+
 def main():
     torch.manual_seed(synth.SEED)
     torch.set_num_threads(8)
     ref_gpt, ref_enc, ref_dec, ref_vq = import_reference()
-    which = set(sys.argv[1:]) or {"vq", "attn", "gpt", "lit", "vae", "vqvae"}
+    which = set(sys.argv[1:]) or {"vq", "attn", "gpt", "lit", "vae", "vqvae", "melgan"}
+    if which == {"melgan"}:
+        gen_melgan()
+        assert not any("__pycache__" in d for d, _, _ in os.walk(REF)), "bytecode leaked into reference"
+        return
     if "vq" in which:
         gen_vq(ref_vq)
     if "attn" in which:
@@ -395,6 +423,8 @@ def main():
         gen_vae(ref_gpt, ref_enc, ref_dec)
     if "vqvae" in which:
         gen_vqvae(ref_vq)
+    if "melgan" in which:
+        gen_melgan()
     assert not any("__pycache__" in d for d, _, _ in os.walk(REF)), "bytecode leaked into reference"
 
 

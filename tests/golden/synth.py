@@ -223,3 +223,47 @@ def waveform(seed, n=220500, sr=22050):
     for k, f0 in enumerate((220.0, 1000.0, 3300.0)):
         y += (0.3 / (k + 1)) * np.sin(2 * np.pi * f0 * t + 0.1 * k)
     return y
+
+
+def melgan_state_dict(seed, input_size=80, ngf=32, n_residual_layers=3):
+    """state_dict (numpy) of the reference's MelGAN Generator (vocoder/modules.py:38-79) in torch's old-style
+    weight_norm parametrisation: per conv `weight_g` (dim0,1,1), `weight_v`, `bias`.  Non-trivial g / bias so that
+    the normalisation and bias paths are exercised."""
+    sd = OrderedDict()
+    k = [seed * 1000]
+
+    def nxt():
+        k[0] += 1
+        return k[0]
+
+    def wn(name, d0, d1, ks):
+        sd[name + ".bias"] = normal(nxt(), (d1 if name.endswith("T") else d0,), 0.05)
+        sd[name + ".weight_g"] = uniform(nxt(), (d0, 1, 1), 0.5, 1.5)
+        sd[name + ".weight_v"] = normal(nxt(), (d0, d1, ks), 0.1)
+
+    def conv(name, cout, cin, ks):
+        sd[name + ".bias"] = normal(nxt(), (cout,), 0.05)
+        sd[name + ".weight_g"] = uniform(nxt(), (cout, 1, 1), 0.5, 1.5)
+        sd[name + ".weight_v"] = normal(nxt(), (cout, cin, ks), 0.1)
+
+    def convT(name, cin, cout, ks):
+        sd[name + ".bias"] = normal(nxt(), (cout,), 0.05)
+        sd[name + ".weight_g"] = uniform(nxt(), (cin, 1, 1), 0.5, 1.5)
+        sd[name + ".weight_v"] = normal(nxt(), (cin, cout, ks), 0.1)
+
+    ratios = [8, 8, 2, 2]
+    mult = 2 ** len(ratios)
+    conv("model.1", mult * ngf, input_size, 7)
+    i = 2
+    for r in ratios:
+        convT(f"model.{i + 1}", mult * ngf, mult * ngf // 2, 2 * r)
+        i += 2
+        for j in range(n_residual_layers):
+            dim = mult * ngf // 2
+            conv(f"model.{i}.block.2", dim, dim, 3)
+            conv(f"model.{i}.block.4", dim, dim, 1)
+            conv(f"model.{i}.shortcut", dim, dim, 1)
+            i += 1
+        mult //= 2
+    conv(f"model.{i + 2}", 1, ngf, 7)
+    return sd
