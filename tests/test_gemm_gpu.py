@@ -166,3 +166,65 @@ def test_conv_implicit_gemm(dt, case):
     ref = _conv_ref(xc, wc, bias.cpu(), stride, k // 2, ups, resc)
     assert y.shape == ref.shape
     assert rel_err(y.float().cpu().numpy(), ref.numpy()) < (1e-5 if dt == "f32" else 6e-3)
+
+
+# ------------------------------------------------------------------ persistent wide-tile kernel at multi-round sizes
+# (csrc/gemm256.hip is picked automatically for bf16 problems with >= 192 tiles of 256x256: every workgroup then
+# walks several tiles, so the ring that keeps prefetching across tile boundaries, the epilogue staged through a ring
+# slot and both tile heights are exercised; reference = fp32 matmul of the bf16-rounded operands on CPU)
+@pytest.mark.parametrize("form,M,N,K", [("nt", 20000, 1280, 384), ("nt", 33920, 1024, 264), ("nn", 24576, 1024, 320),
+                                        ("nt", 9000, 4096, 328)])
+def test_wide_kernel_many_tiles_per_workgroup(form, M, N, K):
+    from melspec_gpt_vqvae_amd import ops
+
+    torch.manual_seed(M + N + K)
+    a = (torch.randn(M, K) * 0.5).to(torch.bfloat16)
+    if form == "nt":
+        b = (torch.randn(N, K) * 0.5).to(torch.bfloat16)
+        ref = a.float() @ b.float().t()
+        out = ops.gemm(a.to(DEV), b.to(DEV), out_dtype=torch.float32)
+    else:
+        b = (torch.randn(K, N) * 0.5).to(torch.bfloat16)
+        ref = a.float() @ b.float()
+        out = ops.gemm(a.to(DEV), b.to(DEV), b_kmajor=True, out_dtype=torch.float32)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+def test_wide_kernel_fused_epilogues_and_split_k_at_size():
+    from melspec_gpt_vqvae_amd import ops
+
+    M, N, K = 16640, 1536, 256          # 65 x 6 = 390 tiles of 256 rows (512 of 192): two rounds
+    torch.manual_seed(3)
+    a = (torch.randn(M, K) * 0.5).to(torch.bfloat16)
+    b = (torch.randn(N, K) * 0.2).to(torch.bfloat16)
+    bias = torch.randn(N) * 0.1
+    res = torch.randn(M, N).to(torch.bfloat16)
+    pre_ref = a.float() @ b.float().t() + bias
+    ad, bd = a.to(DEV), b.to(DEV)
+    # bias + exact GELU + second output (fc1 of the MLP)
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    act = ops.gemm(ad, bd, bias=bias.to(DEV), act=ops.ACT_GELU, pre_out=pre)
+    assert rel_err(pre.float().cpu().numpy(), pre_ref.numpy()) < 2 ** -8
+    assert rel_err(act.float().cpu().numpy(), F.gelu(pre_ref).numpy()) < 2 ** -8
+    # bias + residual (plain mode) and bias + dropout + residual (full mode; mask replayed by dropout_apply)
+    y = ops.gemm(ad, bd, bias=bias.to(DEV), residual=res.to(DEV))
+    assert rel_err(y.float().cpu().numpy(), (pre_ref + res.float()).numpy()) < 2 ** -8
+    yd = ops.gemm(ad, bd, bias=bias.to(DEV), residual=res.to(DEV), drop_p=0.25, seed=77, stream_id=5)
+    ones = torch.ones(M, N, dtype=torch.bfloat16, device=DEV)
+    mask = ops.dropout_apply(ones, 0.25, 77, 5).float().cpu()            # 0 or 1/(1-p)
+    assert abs(float((mask > 0).float().mean()) - 0.75) < 5e-3
+    assert rel_err(yd.float().cpu().numpy(), (pre_ref * mask + res.float()).numpy()) < 2 ** -7
+    # GELU' epilogue of the backward (R = pre-activation)
+    g = ops.gemm(ad, bd, act=ops.ACT_GELU_GRAD, residual=pre)
+    x = pre.float().cpu()
+    gprime = 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+    assert rel_err(g.float().cpu().numpy(), ((a.float() @ b.float().t()) * gprime).numpy()) < 2 ** -7
+    # split-K weight gradient (K-major operands, f32 partials summed in fixed order), bit-reproducible
+    dy = (torch.randn(M, 1024) * 0.1).to(torch.bfloat16).to(DEV)
+    xw = (torch.randn(M, 768) * 0.5).to(torch.bfloat16).to(DEV)
+    gw = torch.empty(1024, 768, device=DEV)
+    ops.wgrad(dy, xw, gw, False)
+    gw2 = torch.empty_like(gw)
+    ops.wgrad(dy, xw, gw2, False)
+    assert torch.equal(gw, gw2)
+    assert rel_err(gw.cpu().numpy(), (dy.float().cpu().t() @ xw.float().cpu()).numpy()) < 1e-5
