@@ -101,9 +101,20 @@ __device__ __forceinline__ Rand4x16 rand4x16(unsigned long long seed, unsigned s
   return r;
 }
 // keep-mask for 4 consecutive elements whose first linear index is 4*q: bit i set = element kept.
-// `thresh` = round(p_drop * 2^32) (kept for ABI stability); compared on its top 16 bits: p is honoured to 2^-16.
+// `thresh` = round(p_drop * 2^32) (kept for ABI stability); compared on its top 16 bits: p is honoured to 2^-16
+// (on its top 8 bits when the lower 24 are zero, i.e. when p is a multiple of 1/256 - then exactly).
 __device__ __forceinline__ unsigned dropout_keep4(unsigned long long seed, unsigned stream_id,
                                                   unsigned long long q, unsigned thresh) {
+  if ((thresh & 0x00FFFFFFu) == 0u) {
+    // p is a multiple of 1/256 (the reference configs use 0.5 and 0.0): 8-bit uniforms are exact for it, so ONE
+    // hash chain (two integer multiplies) serves the four decisions instead of two chains
+    const unsigned c0 = (unsigned)q, c1 = (unsigned)(q >> 32);
+    const unsigned k0 = ((unsigned)seed ^ (stream_id * 0x9E3779B9u)) + ((c1 << 13) | (c1 >> 19)) + (unsigned)(seed >> 32);
+    const unsigned r = hash32(c0 + k0);
+    const unsigned t8 = thresh >> 24;
+    return ((r & 0xFFu) >= t8 ? 1u : 0u) | (((r >> 8) & 0xFFu) >= t8 ? 2u : 0u) | (((r >> 16) & 0xFFu) >= t8 ? 4u : 0u) |
+           ((r >> 24) >= t8 ? 8u : 0u);
+  }
   const Rand4x16 r = rand4x16(seed, stream_id, q);
   const unsigned t16 = thresh >> 16;
   return ((r.a & 0xFFFFu) >= t16 ? 1u : 0u) | ((r.a >> 16) >= t16 ? 2u : 0u) | ((r.b & 0xFFFFu) >= t16 ? 4u : 0u) |
