@@ -21,12 +21,6 @@
 
 using namespace gemmk;
 
-#ifndef G256_PLACE
-#define G256_PLACE 0
-#endif
-#ifndef G256_PRIO
-#define G256_PRIO 1
-#endif
 #ifndef G256_LAB
 #define G256_LAB 0  // tools/lab/gemm_lab.hip builds ablated variants; the library always builds 0
 #endif
@@ -258,7 +252,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
           for (int mt = 0; mt < TM; ++mt) fa[mt] = load_frag<ALAY, BM>(sa, wm * TM + mt, ks, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (G256_PRIO) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
 #pragma unroll

@@ -507,7 +507,7 @@ class GPT(nn.Module):
         pos, B = cache["pos"], cache["B"]
         assert pos < self.block_size, "Cannot forward, model block size is exhausted."
         dt = _compute_dtype(self)
-        fp = ensure_flat(self)
+        ensure_flat(self)
         C = self.tok_emb.weight.shape[1]
         pe = self.pos_emb[0, pos:pos + 1]
         if idx is not None:
