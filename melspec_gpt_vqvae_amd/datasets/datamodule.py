@@ -5,7 +5,6 @@ Lightning's DDP gives the reference (melspec_gpt_vqvae_amd.dp.distributed_shard)
 from __future__ import annotations
 
 import numpy as np
-import torch
 from torch.utils.data import DataLoader, Subset
 
 from .vas import VASSpecs

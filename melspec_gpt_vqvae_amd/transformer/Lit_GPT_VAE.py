@@ -6,7 +6,6 @@ from __future__ import annotations
 
 import numpy as np
 import torch
-import torch.nn as nn
 
 from .. import ops
 from .decoders import GPTDecoder

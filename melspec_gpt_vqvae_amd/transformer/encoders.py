@@ -8,7 +8,6 @@ import math
 import torch
 import torch.nn as nn
 
-from .. import ops
 from .. import _ffi
 from .minGPT import GPT, _Seeds
 

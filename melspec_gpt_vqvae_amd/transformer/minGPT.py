@@ -13,7 +13,6 @@ Numerics lanes (module attribute `compute_dtype`, see set_compute_dtype):
 """
 from __future__ import annotations
 
-import math
 
 import numpy as np
 import os

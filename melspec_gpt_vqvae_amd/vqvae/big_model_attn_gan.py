@@ -13,7 +13,6 @@ the GAN discriminator exists so that real checkpoints load, it is not on the pat
 """
 from __future__ import annotations
 
-import functools
 
 import torch
 import torch.nn as nn
