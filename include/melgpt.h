@@ -170,10 +170,12 @@ int melgpt_attn_decode(const void* qkv, long long ld, void* kcache, void* vcache
 /* skinny-M linear layer of a decode step: y (M,N) = epi(x (M,K) @ W (N,K)^T + bias) (+ residual), W = nn.Linear.weight
  * layout; act in {MELGPT_ACT_NONE, MELGPT_ACT_GELU (exact erf)}; y in `dtype`, or f32 when out_f32 (always f32 for
  * dtype f32).  One wave per 4 output columns streams the weights once with every CU busy; M is walked 16 rows at a
- * time (weights re-read from L2).  N % 4 == 0, K % (16 / sizeof(T)) == 0. */
+ * time (weights re-read from L2).  N % 4 == 0, K % (16 / sizeof(T)) == 0.
+ * ln_gamma / ln_beta (K,) f32, both or neither: the rows are LayerNorm-ed (eps ln_eps, minGPT.py:97-98) on the way in,
+ * y = W LN(x) - the pre-LN of a transformer block folded into its qkv / fc1 layer. */
 int melgpt_gemv_rows(const void* x, long long ldx, const void* W, long long ldw, const float* bias,
                      const void* residual, long long ldr, void* y, long long ldy, int M, int N, int K, int act,
-                     int dtype, int out_f32, void* stream);
+                     int dtype, int out_f32, const float* ln_gamma, const float* ln_beta, float ln_eps, void* stream);
 /* graph-replayed decoding helpers: x[b,:] = tok_emb[idx[b]] + pos_emb[*pos_dev] (minGPT.py:170-180 for one position);
  * *counter += 1 */
 int melgpt_embed_decode(const long long* idx, const float* tok_emb, const float* pos_emb, const int* pos_dev, int B,

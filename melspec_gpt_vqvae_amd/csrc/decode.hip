@@ -184,7 +184,9 @@ template <typename T, int MB>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x, long long ldx, const T* __restrict__ W,
                                                         long long ldw, const float* __restrict__ bias,
                                                         const T* __restrict__ res, long long ldr, void* __restrict__ y,
-                                                        long long ldy, int M, int N, int K, int act, int out_f32) {
+                                                        long long ldy, int M, int N, int K, int act, int out_f32,
+                                                        const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                        float ln_eps) {
   constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte chunk
   // blockDim.x / 64 waves share the 4 columns and split K between them (the launcher aims at ~2 chunks per lane,
   // so that every load of a row is in flight at once whatever K is)
@@ -207,6 +209,47 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
     }
   }
   const int nchunk = K / VEC;
+  // optional fused LayerNorm of the input rows (ln_g != null): y = W LN(x).  Every wave derives the row statistics
+  // itself (two passes over the row, which sits in L1), then normalises the chunks it multiplies - in the bf16 lane
+  // the normalised value is rounded to bf16 first, exactly what the separate LayerNorm kernel would have stored.
+  float mu[MB], rs[MB];
+  if (ln_g) {
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      mu[m] = 0.f;
+      rs[m] = 1.f;
+      if (m < mrows) {
+        const T* xr = x + (long long)(m0 + m) * ldx;
+        float s1 = 0.f;
+        for (int c = lane; c < nchunk; c += 64) {
+          const u32x4 xv = *(const u32x4*)(xr + (long long)c * VEC);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (sizeof(T) == 2) s1 += __uint_as_float(xv[e] << 16) + __uint_as_float(xv[e] & 0xFFFF0000u);
+            else s1 += __uint_as_float(xv[e]);
+          }
+        }
+        const float mean = wave_sum(s1) / (float)K;
+        float s2 = 0.f;
+        for (int c = lane; c < nchunk; c += 64) {
+          const u32x4 xv = *(const u32x4*)(xr + (long long)c * VEC);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (sizeof(T) == 2) {
+              const float d0 = __uint_as_float(xv[e] << 16) - mean, d1 = __uint_as_float(xv[e] & 0xFFFF0000u) - mean;
+              s2 = fmaf(d0, d0, s2);
+              s2 = fmaf(d1, d1, s2);
+            } else {
+              const float d0 = __uint_as_float(xv[e]) - mean;
+              s2 = fmaf(d0, d0, s2);
+            }
+          }
+        }
+        mu[m] = mean;
+        rs[m] = rsqrtf(wave_sum(s2) / (float)K + ln_eps);
+      }
+    }
+  }
 #pragma unroll 2
   for (int c = wv_id * 64 + lane; c < nchunk; c += 64 * nwave) {
     u32x4 wv[4];
@@ -215,7 +258,24 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
       if (m < mrows) {
-        const u32x4 xv = *(const u32x4*)(x + (long long)(m0 + m) * ldx + (long long)c * VEC);
+        u32x4 xv = *(const u32x4*)(x + (long long)(m0 + m) * ldx + (long long)c * VEC);
+        if (ln_g) {
+          if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int k = c * VEC + 2 * e;
+              const float h0 = (__uint_as_float(xv[e] << 16) - mu[m]) * rs[m] * ln_g[k] + ln_b[k];
+              const float h1 = (__uint_as_float(xv[e] & 0xFFFF0000u) - mu[m]) * rs[m] * ln_g[k + 1] + ln_b[k + 1];
+              xv[e] = pack_bf16x2(h0, h1);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int k = c * VEC + e;
+              xv[e] = __float_as_uint((__uint_as_float(xv[e]) - mu[m]) * rs[m] * ln_g[k] + ln_b[k]);
+            }
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if constexpr (sizeof(T) == 2) {
@@ -267,10 +327,12 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
 
 extern "C" int melgpt_gemv_rows(const void* x, long long ldx, const void* W, long long ldw, const float* bias,
                                 const void* residual, long long ldr, void* y, long long ldy, int M, int N, int K, int act,
-                                int dtype, int out_f32, void* stream) {
+                                int dtype, int out_f32, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                                void* stream) {
   MELGPT_CHECK(x && W && y && M > 0 && N > 0 && K > 0, MELGPT_ERR_BAD_ARG);
   MELGPT_CHECK(dtype == MELGPT_F32 || dtype == MELGPT_BF16, MELGPT_ERR_UNSUPPORTED);
   MELGPT_CHECK(act == MELGPT_ACT_NONE || act == MELGPT_ACT_GELU, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK((ln_gamma == nullptr) == (ln_beta == nullptr), MELGPT_ERR_BAD_ARG);
   const int vec = dtype == MELGPT_F32 ? 4 : 8;
   MELGPT_CHECK(N % 4 == 0 && K % vec == 0 && ldx % vec == 0 && ldw % vec == 0 &&
                    ((((uintptr_t)x | (uintptr_t)W) & 15) == 0),
@@ -282,7 +344,7 @@ extern "C" int melgpt_gemv_rows(const void* x, long long ldx, const void* W, lon
 #define MELGPT_GEMV_LAUNCH(T, MB)                                                                                     \
   hipLaunchKernelGGL((gemv_rows_kernel<T, MB>), dim3(N / 4, (M + MB - 1) / MB), dim3(64 * nwave), 0, s, (const T*)x, ldx, \
                      (const T*)W, ldw, bias, (const T*)residual, ldr, y, ldy, M, N, K, act,                            \
-                     (dtype == MELGPT_F32) ? 1 : out_f32)
+                     (dtype == MELGPT_F32) ? 1 : out_f32, ln_gamma, ln_beta, ln_eps)
   if (dtype == MELGPT_F32) {
     if (M <= 4) MELGPT_GEMV_LAUNCH(float, 4);
     else MELGPT_GEMV_LAUNCH(float, 16);

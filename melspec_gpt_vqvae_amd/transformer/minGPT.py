@@ -538,20 +538,18 @@ class GPT(nn.Module):
         for li, blk in enumerate(self.blocks):
             W = _BlockWeights(blk, fp, dt)
             a, m = blk.attn, blk.mlp
-            h1 = ops.layernorm_fwd(x, blk.ln1.weight, blk.ln1.bias, blk.ln1.eps, want_stats=False)[0]
-            qkv = ops.linear_rows(h1, W.w_qkv, bias=W.b_qkv)
+            qkv = ops.linear_rows(x, W.w_qkv, bias=W.b_qkv, ln=(blk.ln1.weight, blk.ln1.bias, blk.ln1.eps))
             if want_att and li == last:
                 att_row = torch.zeros(B, a.n_head, self.block_size, dtype=torch.float32, device=x.device)
             y = ops.attn_decode(qkv, cache["k"][li], cache["v"][li], a.n_head, pos,
                                 att_row=att_row if li == last else None, pos_dev=pos_dev)
             x1 = ops.linear_rows(y, W.w_proj, bias=a.proj.bias, residual=x)
-            h2 = ops.layernorm_fwd(x1, blk.ln2.weight, blk.ln2.bias, blk.ln2.eps, want_stats=False)[0]
-            act = ops.linear_rows(h2, W.w_fc1, bias=m[0].bias, act=ops.ACT_GELU)
+            act = ops.linear_rows(x1, W.w_fc1, bias=m[0].bias, act=ops.ACT_GELU,
+                                  ln=(blk.ln2.weight, blk.ln2.bias, blk.ln2.eps))
             x = ops.linear_rows(act, W.w_fc2, bias=m[2].bias, residual=x1)
         buf = fp.compute_buffer(dt)
         w = fp._slice(buf, self.head.weight).view(self.head.weight.shape)
-        h = ops.layernorm_fwd(x, self.ln_f.weight, self.ln_f.bias, self.ln_f.eps, want_stats=False)[0]
-        return ops.linear_rows(h, w, out_dtype=torch.float32), att_row
+        return ops.linear_rows(x, w, out_dtype=torch.float32, ln=(self.ln_f.weight, self.ln_f.bias, self.ln_f.eps)), att_row
 
     @torch.no_grad()
     def decode_sample_graph(self, cache, first_token, steps, *, temperature=1.0, top_k=None, sample=False, seed=0,

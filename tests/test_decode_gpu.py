@@ -109,3 +109,13 @@ def test_linear_rows_weight_streaming_kernel(dt, M, N, K):
     y = ops.linear_rows(x.to(DEV), w.to(DEV), residual=r.to(DEV), out_dtype=torch.float32)
     assert y.dtype == torch.float32
     assert rel_err(y.cpu().numpy(), (x.float() @ w.float().T + r.float()).numpy()) < tol
+    # LayerNorm folded into the layer (pre-LN of a transformer block): y = LN(x) W^T + b
+    gm, bt = t(synth.normal(5, (K,), 0.1, 1.0)), t(synth.normal(6, (K,), 0.1))
+    h = F.layer_norm(x.float() * 3 + 0.5, (K,), gm, bt, 1e-5)
+    if dt == "bf16":
+        h = h.to(torch.bfloat16).float()          # the kernel rounds LN(x) to bf16 like the separate LayerNorm kernel
+    xs = (x.float() * 3 + 0.5).to(tdt)
+    if dt == "bf16":
+        h = F.layer_norm(xs.float(), (K,), gm, bt, 1e-5).to(torch.bfloat16).float()
+    y = ops.linear_rows(xs.to(DEV), w.to(DEV), bias=b.to(DEV), ln=(gm.to(DEV), bt.to(DEV), 1e-5), out_dtype=torch.float32)
+    assert rel_err(y.cpu().numpy(), (h @ w.float().T + b).numpy()) < (2e-5 if dt == "f32" else 2e-3)
