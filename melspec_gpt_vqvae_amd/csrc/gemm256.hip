@@ -138,6 +138,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
   __amdgpu_buffer_rsrc_t ra, rb;
   unsigned a_base0, b_base0;  // byte offset of this lane's chunk in piece 0 at k = 0, or OOB when its column is out
   int pm0 = 0, pn0 = 0;       // tile origin of the plan
+  int cv_y[ALAY == LAY_CONV ? 4 : 1], cv_x[ALAY == LAY_CONV ? 4 : 1];  // LAY_CONV: per piece, top-left tap position
+  unsigned cv_img[ALAY == LAY_CONV ? 4 : 1];                           // ... and byte offset of the pixel's image
   bool pok = false;
   // ROW: rows 8 w + 64 j + (lane >> 3), logical chunk = physical chunk ^ ((row >> 1) & 7)  (row_off's swizzle)
   const int r_row0 = 8 * w + (lane >> 3), r_c = (lane & 7) ^ ((4 * w + (lane >> 4)) & 7);
@@ -150,10 +152,25 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
     pok = live(r) && decode(r, bz, pm0, pn0);  // dead: every request is out of bounds (zero fills nobody reads)
     ra = make_rsrc((const char*)p.A + (long long)bz * p.sA * 2, p.a_bytes);
     rb = make_rsrc((const char*)p.B + (long long)bz * p.sB * 2, p.b_bytes);
-    if constexpr (ALAY == LAY_KMAJ)
+    if constexpr (ALAY == LAY_KMAJ) {
       a_base0 = (pok && pm0 + k_lc * 8 < p.M) ? (unsigned)(((long long)k_row0 * p.lda + pm0) * 2) + k_lc * 16 : OOB;
-    else
+    } else if constexpr (ALAY == LAY_CONV) {
+      // implicit im2col: row m of A is output pixel m; per piece keep the pixel's image offset and its top-left tap
+      // position (a far-out y marks rows past M, so that every tap of such a row is out of the image)
+      a_base0 = pok ? (unsigned)(r_c * 16) : OOB;
+      const int ohw = p.OH * p.OW;
+#pragma unroll
+      for (int j = 0; j < PER_A; ++j) {
+        const int m = pm0 + r_row0 + 64 * j;
+        const int bb = m / ohw, rem = m - bb * ohw;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        cv_y[j] = (pok && m < p.M) ? oy * p.cstride - p.pad_t : -100000;
+        cv_x[j] = ox * p.cstride - p.pad_l;
+        cv_img[j] = (unsigned)((long long)bb * p.cH * p.cW * p.cC * 2);
+      }
+    } else {
       a_base0 = pok ? (unsigned)(((long long)(pm0 + r_row0) * p.lda) * 2) + r_c * 16 : OOB;
+    }
     if constexpr (BLAY == LAY_KMAJ)
       b_base0 = (pok && pn0 + k_lc * 8 < p.N) ? (unsigned)(((long long)k_row0 * p.ldb + pn0) * 2) + k_lc * 16 : OOB;
     else
@@ -174,7 +191,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
     dma16(rs, dst + (w + NW * j) * 1024, off);
   };
   auto issue_a_piece = [&](int u, char* dst, int j) {
-    issue_piece(std::integral_constant<int, ALAY>{}, ra, a_base0, p.lda, pm0, p.M, u, dst, j);
+    if constexpr (ALAY == LAY_CONV) {
+      // one K unit = 64 channels of one filter tap (Cin % 64 == 0): the row's source is the tap-shifted input pixel;
+      // padding, the stride-2 asymmetric pad and nearest-x2 upsampling are address predicates (zero fill)
+      const int k0 = u * KU;
+      const int tap = k0 / p.cC, ci0 = k0 - tap * p.cC;
+      const int ky = tap / p.KW, kx = tap - ky * p.KW;
+      int iy = cv_y[j] + ky, ix = cv_x[j] + kx;
+      const bool ok = a_base0 != OOB && k0 < p.K && iy >= 0 && ix >= 0 && iy < (p.cH << p.ups) && ix < (p.cW << p.ups);
+      iy >>= p.ups;
+      ix >>= p.ups;
+      const unsigned off = ok ? cv_img[j] + (unsigned)(((iy * p.cW + ix) * p.cC + ci0) * 2) + a_base0 : OOB;
+      dma16(ra, dst + (w + NW * j) * 1024, off);
+    } else {
+      issue_piece(std::integral_constant<int, ALAY>{}, ra, a_base0, p.lda, pm0, p.M, u, dst, j);
+    }
   };
   auto issue_b_piece = [&](int u, char* dst, int j) {
     issue_piece(std::integral_constant<int, BLAY>{}, rb, b_base0, p.ldb, pn0, p.N, u, dst, j);
@@ -384,8 +415,12 @@ template <int ALAY, int BLAY>
 int launch_lay(const GemmParams& p, int batch, hipStream_t s) {
   if (!p.vec_io) return MELGPT_ERR_UNSUPPORTED;
   const bool plain = p.act == MELGPT_ACT_NONE && p.drop_scale == 0.f && !p.C2;
-  if (p.out_f32) return plain ? launch_mode<ALAY, BLAY, EPI_PLAIN32>(p, batch, s) : MELGPT_ERR_UNSUPPORTED;
-  return plain ? launch_mode<ALAY, BLAY, EPI_PLAIN16>(p, batch, s) : launch_mode<ALAY, BLAY, EPI_FULL16>(p, batch, s);
+  if constexpr (ALAY == LAY_CONV) {  // convolutions: bias + residual, bf16 out - the only form the VQ-VAE uses
+    return (plain && !p.out_f32) ? launch_mode<ALAY, BLAY, EPI_PLAIN16>(p, batch, s) : MELGPT_ERR_UNSUPPORTED;
+  } else {
+    if (p.out_f32) return plain ? launch_mode<ALAY, BLAY, EPI_PLAIN32>(p, batch, s) : MELGPT_ERR_UNSUPPORTED;
+    return plain ? launch_mode<ALAY, BLAY, EPI_PLAIN16>(p, batch, s) : launch_mode<ALAY, BLAY, EPI_FULL16>(p, batch, s);
+  }
 }
 
 }  // namespace
@@ -395,5 +430,6 @@ int gemmk::launch_gemm256(const GemmParams& p, int alay, int blay, int batch, in
   if (alay == LAY_ROW && blay == LAY_ROW) return launch_lay<LAY_ROW, LAY_ROW>(p, batch, s);
   if (alay == LAY_ROW && blay == LAY_KMAJ) return launch_lay<LAY_ROW, LAY_KMAJ>(p, batch, s);
   if (alay == LAY_KMAJ && blay == LAY_KMAJ) return launch_lay<LAY_KMAJ, LAY_KMAJ>(p, batch, s);
-  return MELGPT_ERR_UNSUPPORTED;  // implicit-GEMM convolutions stay on the 128 x 128 kernel
+  if (alay == LAY_CONV && blay == LAY_ROW) return launch_lay<LAY_CONV, LAY_ROW>(p, batch, s);
+  return MELGPT_ERR_UNSUPPORTED;
 }

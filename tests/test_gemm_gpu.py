@@ -228,3 +228,41 @@ def test_wide_kernel_fused_epilogues_and_split_k_at_size():
     ops.wgrad(dy, xw, gw2, False)
     assert torch.equal(gw, gw2)
     assert rel_err(gw.cpu().numpy(), (dy.float().cpu().t() @ xw.float().cpu()).numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("case", ["s1_256", "s1_512", "s2", "up", "1x1"])
+def test_conv_on_wide_kernel_at_size(case):
+    """implicit-GEMM convolutions big enough for the persistent 256-wide kernel (im2col rows fetched by LDS-DMA with
+    address predicates for the padding / stride-2 pad / nearest x2 upsampling) == F.conv2d on CPU."""
+    from melspec_gpt_vqvae_amd import ops
+
+    torch.manual_seed(11)
+    if case == "s1_256":
+        B, H, W, Cin, Cout, k, stride, up = 6, 40, 212, 256, 256, 3, 1, False
+    elif case == "s1_512":
+        B, H, W, Cin, Cout, k, stride, up = 48, 20, 53, 512, 512, 3, 1, False
+    elif case == "s2":
+        B, H, W, Cin, Cout, k, stride, up = 6, 80, 424, 256, 256, 3, 2, False
+    elif case == "up":
+        B, H, W, Cin, Cout, k, stride, up = 4, 40, 106, 256, 256, 3, 1, True
+    else:
+        B, H, W, Cin, Cout, k, stride, up = 10, 40, 212, 256, 512, 1, 1, False
+    x = (torch.randn(B, H, W, Cin) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(Cout, Cin, k, k) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(Cout) * 0.1
+    xin = x.float().permute(0, 3, 1, 2)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    if stride == 2:
+        ref = F.conv2d(F.pad(xin, (0, 1, 0, 1)), w.float(), bias, stride=2)       # Downsample: pad (0,1,0,1), no padding
+        pad = (0, 0)
+    else:
+        ref = F.conv2d(xin, w.float(), bias, padding=k // 2)
+        pad = (k // 2, k // 2)
+    ref = ref.permute(0, 2, 3, 1)
+    res = torch.randn(ref.shape).to(torch.bfloat16)
+    wp = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = ops.conv2d_nhwc(x.to(DEV), wp, bias.to(DEV), stride=stride, pad=pad, out_hw=tuple(ref.shape[1:3]), upsample=up,
+                        residual=res.to(DEV))
+    assert y.shape == ref.shape
+    assert rel_err(y.float().cpu().numpy(), (ref + res.float()).numpy()) < 2 ** -8
