@@ -64,27 +64,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(FusedConvParams q) {
       ab[2 * c + 1] = q.beta[c] - q.mean[b * 32 + c / cg] * a;
     }
   }
-  // ---- weight tile staging plan (ROW layout, K contiguous), identical to gemm.hip's B operand
+  // ---- weight tile staging: the (128 x 128 B) tile of a K step goes L2 -> LDS by LDS-DMA in sixteen 1 KiB pieces
+  // (8 rows x 128 B each, four per wave), no VGPR round trip; the XOR swizzle of row_off() is applied on the source
+  // side (the lane fetches the chunk that belongs in its linear LDS position)
   const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
   unsigned b_base[4];
-  int b_lds[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int qq = t + 256 * i, row = qq >> 3, ch = qq & 7;
-    b_base[i] = (unsigned)(((long long)(n0 + row) * p.ldb) * ES) + ch * 16;
-    b_lds[i] = row_off(row, ch);
+    const int piece = w + 4 * i, row = piece * 8 + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
+    b_base[i] = (n0 + row < p.N) ? (unsigned)(((long long)(n0 + row) * p.ldb) * ES) + ch * 16 : OOB;
   }
-  u32x4 br[4];
-  auto issue_b = [&](int kt) {
+  auto issue_b = [&](int kt, int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) br[i] = buf_load16(rb, b_base[i] + kt * KSTEP * ES);
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(wtile + buf * 16384 + (w + 4 * i) * 1024),
+                                               16, b_base[i] == OOB ? OOB : b_base[i] + kt * KSTEP * ES, 0, 0, 0);
   };
-  auto commit_b = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *(u32x4*)(wtile + buf * 16384 + b_lds[i]) = br[i];
-  };
-  issue_b(0);
-  __syncthreads();  // ab[] visible
+  issue_b(0, 0);
+  __syncthreads();  // ab[] visible (the fence also drains the DMA)
 
   // ---- stage the input patch once (normalise + swish on the fly; out-of-image pixels are zeros)
   const T* xb = (const T*)q.x + (long long)b * q.H * q.W * Cin;
@@ -125,7 +122,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(FusedConvParams q) {
     }
     *(u32x4*)(patch + patch_off<T>(pix, ch, pix_bytes)) = v;
   }
-  commit_b(0);
   __syncthreads();
 
   f32x4 acc[4][4];
@@ -138,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(FusedConvParams q) {
   const int nk = 9 * kpt;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) issue_b(kt + 1);
+    if (kt + 1 < nk) issue_b(kt + 1, cur ^ 1);  // lands under this step's MFMAs; the barrier below waits for it
     const int tap = kt / kpt, kc = kt - tap * kpt;
     const int ky = tap / 3, kx = tap - ky * 3;
     const char* sb = wtile + cur * 16384;
@@ -157,7 +153,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(FusedConvParams q) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) mma<T>(acc[mt][nt], fb[nt], fa[mt]);
     }
-    if (kt + 1 < nk) commit_b(cur ^ 1);
     __syncthreads();
   }
 
