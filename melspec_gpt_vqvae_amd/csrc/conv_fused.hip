@@ -13,6 +13,8 @@
 //      conflict-free), while the weight tile of each K step is double-buffered through LDS like in gemm.hip;
 //   3. finishes with the shared fused epilogue (bias, residual x + h of the ResnetBlock, row-contiguous stores).
 // MFMA: v_mfma_f32_16x16x32_bf16 (bf16 lane) / v_mfma_f32_16x16x4_f32 (f32 parity lane), same fragment maps as gemm.hip.
+#include <cstdlib>
+
 #include "gemm_common.h"
 
 using namespace gemmk;
@@ -29,6 +31,7 @@ struct FusedConvParams {
   const float* gamma;    // (Cin)
   const float* beta;
   int H, W, Cin, swish, tiles_x, tiles_y;
+  unsigned x_bytes;      // addressable bytes of x (persistent kernel: patch loads through a buffer resource)
 };
 
 template <typename T>
@@ -168,6 +171,220 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(FusedConvParams q) {
   epilogue_rows<T, 4, 4, EPI>(p, acc, mrow, min(TW, q.W - x0), n0 + wn * 64, 0, lane, smem + w * 4096);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// bf16, narrow layers (Cin * 2 B * 324 pixels + 64 KiB fit the LDS: Cin <= 128 - the 80x848 / 40x424 levels that hold
+// 3/4 of the encoder's FLOPs).  Same idea with the memory system in mind:
+//   * one PERSISTENT 512-thread workgroup per CU walks 16 x 16-pixel tiles: the 288 KiB weight matrix is streamed once
+//     per 256 pixels instead of once per 128, and - since every tile wants the same 18 weight K-steps in the same
+//     order - through a 4-stage LDS-DMA ring that never restarts: three K-steps are always in flight, under counted
+//     `s_waitcnt vmcnt` + one raw `s_barrier` per K-step.  (The 128-pixel kernel above has one K-step = 0.24 us of
+//     MFMA work in flight against >= 1 us of L2 latency: it runs at the latency, not at the matrix pipe.)
+//   * 8 waves as 4 (pixel rows) x 2 (output-channel halves), each 64 pixels x 64 channels like above.
+#ifndef CONVW_LAB
+#define CONVW_LAB 0  // 1: phase stamps of workgroup 7 into melgpt_convw_dbg (development builds only)
+#endif
+#if CONVW_LAB
+__device__ unsigned long long melgpt_convw_dbg[64];
+#endif
+
+constexpr int WTH = 16, WTW = 16, WPH = WTH + 2, WPW = WTW + 2, WNPIX = WPH * WPW, WNST = 4;
+
+__global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q, int total_tiles) {
+  typedef bf16_t T;
+  constexpr int ES = 2, KSTEP = 64, VEC = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const GemmParams& p = q.g;
+  const int Cin = q.Cin, pix_bytes = Cin * ES, cpp = pix_bytes / 16;
+  char* patch = smem;                                        // [324][Cin] swizzled (also the epilogue's staging)
+  char* wring = smem + (size_t)WNPIX * pix_bytes;            // [4][128 rows x 128 B]
+  float* ab = (float*)(wring + WNST * 16384);                // [Cin][2]
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w >> 1, wn = w & 1;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.y * 128;
+  const bool norm = q.mean != nullptr;
+  const int kpt = Cin / KSTEP, nk = 9 * kpt;
+
+  // weight ring: stage s <- K-step (kg % nk); 16 pieces of 1 KiB per stage, two per wave
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+  unsigned b_base[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int piece = w + 8 * i, row = piece * 8 + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
+    b_base[i] = (n0 + row < p.N) ? (unsigned)(((long long)(n0 + row) * p.ldb) * ES) + ch * 16 : OOB;
+  }
+  int kg_issue = 0;  // next K-step (global, over all tiles) to request
+  auto issue_w = [&]() {
+    const int kt = kg_issue % nk, st = kg_issue & (WNST - 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(wring + st * 16384 + (w + 8 * i) * 1024),
+                                               16, b_base[i] == OOB ? OOB : b_base[i] + kt * KSTEP * ES, 0, 0, 0);
+    ++kg_issue;
+  };
+  issue_w();
+  issue_w();
+  issue_w();
+  int kg = 0;  // K-step being multiplied
+
+  // raw input chunks of a tile: requested one tile AHEAD (during the previous tile's K loop), so the staging pass below
+  // starts from registers.  cpp (16-byte chunks per pixel) is a power of two that divides 512: a thread keeps ONE
+  // channel chunk for all its pixels, pixel / chunk come from shifts.
+  constexpr int MAXCH = (WNPIX * 16 + 511) / 512;  // chunks per thread at Cin = 128
+  const int cshift = __builtin_ctz(cpp), ch = t & (cpp - 1), ppi = 512 >> cshift;  // pixels advanced per trip
+  u32x4 raw[MAXCH];
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(q.x, q.x_bytes);
+  auto fetch_patch = [&](int tile) {
+    const int tx = tile % q.tiles_x, ty = (tile / q.tiles_x) % q.tiles_y, b = tile / (q.tiles_x * q.tiles_y);
+    const int y0 = ty * WTH, x0 = tx * WTW;
+    // exactly MAXCH buffer loads per wave, whatever the tile (out-of-image / out-of-range lanes get an out-of-bounds
+    // offset and read zeros): the K loop's counted waits below rely on that number
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+      const int pix = (t >> cshift) + ppi * i;
+      const int py = pix / WPW, px = pix - py * WPW;
+      const int iy = y0 + py - 1, ix = x0 + px - 1;
+      const bool ok = tile < total_tiles && pix < WNPIX && iy >= 0 && iy < q.H && ix >= 0 && ix < q.W;
+      const unsigned off = ok ? (unsigned)((((long long)b * q.H + iy) * q.W + ix) * Cin * ES) + ch * 16 : OOB;
+      raw[i] = buf_load16(rx, off);
+    }
+  };
+  fetch_patch(blockIdx.x);
+
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    const int tx = tile % q.tiles_x, ty = (tile / q.tiles_x) % q.tiles_y, b = tile / (q.tiles_x * q.tiles_y);
+    const int y0 = ty * WTH, x0 = tx * WTW;
+#if CONVW_LAB
+    unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st2 = 0;
+#endif
+    if (norm) {
+      const int cg = Cin / 32;
+      for (int c = t; c < Cin; c += 512) {
+        const float a = q.rstd[b * 32 + c / cg] * q.gamma[c];
+        ab[2 * c] = a;
+        ab[2 * c + 1] = q.beta[c] - q.mean[b * 32 + c / cg] * a;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ab visible; previous tile's epilogue is out of the patch
+    // ---- stage the input patch (normalise + swish on the fly; out-of-image pixels are zeros AFTER the normalisation)
+    f32x4 sc[4];  // (a, b) of channels 8 ch .. 8 ch + 7, interleaved
+    if (norm) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sc[e] = *(const f32x4*)(ab + 2 * (ch * VEC) + 4 * e);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+      const int pix = (t >> cshift) + ppi * i;
+      if (pix < WNPIX) {
+        const int py = pix / WPW, px = pix - py * WPW;
+        const int iy = y0 + py - 1, ix = x0 + px - 1;
+        u32x4 v = raw[i];
+        if (norm && iy >= 0 && iy < q.H && ix >= 0 && ix < q.W) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float o0 = fmaf(bf16lo(v[e]), sc[e][0], sc[e][1]);
+            float o1 = fmaf(bf16hi(v[e]), sc[e][2], sc[e][3]);
+            if (q.swish) {
+              o0 = o0 * __builtin_amdgcn_rcpf(1.0f + __expf(-o0));
+              o1 = o1 * __builtin_amdgcn_rcpf(1.0f + __expf(-o1));
+            }
+            v[e] = pack_bf16x2(o0, o1);
+          }
+        }
+        *(u32x4*)(patch + patch_off<T>(pix, ch, pix_bytes)) = v;
+      }
+    }
+#if CONVW_LAB
+    st1 = __builtin_amdgcn_s_memtime();
+#endif
+    fetch_patch(tile + gridDim.x);  // lands under this tile's K loop
+    // (the first K-step's barrier below publishes the patch)
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt, ++kg) {
+      // this wave's pieces of K-step kg have landed (two younger stages = 4 pieces may be in flight); after the barrier
+      // everybody's have, and everybody is past K-step kg-1, whose stage is refilled now
+      // (the next tile's MAXCH patch loads were issued just before this loop: for the first three K-steps they are
+      // younger than the weight pieces waited for and stay in flight; from the fourth on they are older)
+      if (kt < WNST - 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 + MAXCH) : "memory");
+      else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      issue_w();
+      const int tap = kt / kpt, kc = kt - tap * kpt;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const char* sb = wring + (kg & (WNST - 1)) * 16384;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 fa[4], fb[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int pix = (wm * 4 + mt + ky) * WPW + i16 + kx;  // output row (wm*4+mt), shifted by the tap
+          fa[mt] = *(const u32x4*)(patch + patch_off<T>(pix, kc * 8 + 4 * ks + g, pix_bytes));
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) fb[nt] = *(const u32x4*)(sb + row_off((wn * 4 + nt) * 16 + i16, 4 * ks + g));
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) mma<T>(acc[mt][nt], fb[nt], fa[mt]);
+      }
+    }
+#if CONVW_LAB
+    st2 = __builtin_amdgcn_s_memtime();
+#endif
+    asm volatile("s_barrier" ::: "memory");  // everybody is done reading the patch: it becomes the epilogue's staging
+    long long mrow[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int y = y0 + wm * 4 + mt;
+      mrow[mt] = (y < q.H) ? ((long long)b * q.H + y) * q.W + x0 : -1;
+    }
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));  // keep the epilogue's per-lane offsets out of the tile loop's live range
+    epilogue_rows<T, 4, 4, EPI_PLAIN16>(p, acc, mrow, min(WTW, q.W - x0), n0 + wn * 64, 0, lane_e, smem + w * 4096);
+#if CONVW_LAB
+    if (blockIdx.x == 7 && t == 0) {
+      const int k = (tile - 7) / gridDim.x;
+      if (k < 15) {
+        melgpt_convw_dbg[4 * k] = st0; melgpt_convw_dbg[4 * k + 1] = st1; melgpt_convw_dbg[4 * k + 2] = st2;
+        melgpt_convw_dbg[4 * k + 3] = __builtin_amdgcn_s_memtime();
+      }
+    }
+#endif
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+int launch_fused_wide(const FusedConvParams& q0, int B, hipStream_t s) {
+  FusedConvParams q = q0;
+  q.tiles_x = (q.W + WTW - 1) / WTW;
+  q.tiles_y = (q.H + WTH - 1) / WTH;
+  const size_t lds = (size_t)WNPIX * q.Cin * 2 + WNST * 16384 + (size_t)q.Cin * 8;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      return MELGPT_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void*)conv3x3_gn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess)
+      return MELGPT_ERR_LAUNCH;
+    ncu = n;
+  }
+  const long long total = (long long)q.tiles_x * q.tiles_y * B;
+  if (total > 0x7FFFFFFF) return MELGPT_ERR_UNSUPPORTED;
+  const int gy = (q.g.N + 127) / 128;
+  int gx = ncu / gy;
+  if (gx < 1) gx = 1;
+  if (gx > total) gx = (int)total;
+  hipLaunchKernelGGL(conv3x3_gn_wide_kernel, dim3(gx, gy), dim3(512), lds, s, q, (int)total);
+  return melgpt_launch_status();
+}
+
 template <typename T>
 int launch_fused(const FusedConvParams& q, int B, hipStream_t s) {
   const int ES = Tr<T>::ES;
@@ -211,5 +428,18 @@ extern "C" int melgpt_conv3x3_gn_nhwc(const void* x, int B, int H, int W, int Ci
   q.H = H; q.W = W; q.Cin = Cin; q.swish = swish;
   q.tiles_x = (W + TW - 1) / TW; q.tiles_y = (H + TH - 1) / TH;
   hipStream_t s = (hipStream_t)stream;
-  return dtype == MELGPT_F32 ? launch_fused<float>(q, B, s) : launch_fused<bf16_t>(q, B, s);
+  if (dtype == MELGPT_F32) return launch_fused<float>(q, B, s);
+  // narrow bf16 layers with plenty of 16 x 16 tiles: the persistent kernel with the weight ring
+  const size_t wide_lds = (size_t)WNPIX * Cin * 2 + WNST * 16384 + (size_t)Cin * 8;
+  const long long wide_tiles = (long long)((W + WTW - 1) / WTW) * ((H + WTH - 1) / WTH) * B;
+  static int wide_off = -1;
+  if (wide_off < 0) wide_off = getenv("MELGPT_CONV_WIDE") && atoi(getenv("MELGPT_CONV_WIDE")) == 0;
+  // 16-row tiles pay for the rows they pad: take them only while they compute at most 1/4 more pixels than 8-row tiles
+  const long long wide_px = wide_tiles * WTH * WTW, narrow_px = (long long)q.tiles_x * q.tiles_y * B * TH * TW;
+  if (!wide_off && wide_lds <= 160 * 1024 && wide_tiles >= 512 && wide_px * 4 <= narrow_px * 5 && q.g.vec_io &&
+      M * Cin * 2 < 0xFFFFFF00LL) {
+    q.x_bytes = (unsigned)(M * Cin * 2);
+    return launch_fused_wide(q, B, s);
+  }
+  return launch_fused<bf16_t>(q, B, s);
 }

@@ -1,0 +1,29 @@
+// Development harness: phase stamps of the persistent fused GroupNorm+swish+conv3x3 kernel (conv3x3_gn_wide_kernel).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCONVW_LAB=1 -I include -I melspec_gpt_vqvae_amd/csrc tools/lab/convw_lab.hip
+#include <cstdio>
+#include <vector>
+#include "../../melspec_gpt_vqvae_amd/csrc/conv_fused.hip"
+
+int main() {
+  const int B = 32, H = 80, W = 848, C = 128;
+  void *x, *wp, *y, *res; float *mean, *rstd, *gamma, *beta, *bias;
+  const size_t n = (size_t)B * H * W * C;
+  hipMalloc(&x, n * 2); hipMalloc(&y, n * 2); hipMalloc(&res, n * 2); hipMalloc(&wp, (size_t)C * 9 * C * 2);
+  hipMalloc(&mean, B * 32 * 4); hipMalloc(&rstd, B * 32 * 4); hipMalloc(&gamma, C * 4); hipMalloc(&beta, C * 4); hipMalloc(&bias, C * 4);
+  hipMemset(x, 0x3c, n * 2); hipMemset(res, 0, n * 2); hipMemset(wp, 0x3c, (size_t)C * 9 * C * 2);
+  hipMemset(mean, 0, B * 32 * 4); hipMemset(rstd, 0, B * 32 * 4); hipMemset(gamma, 0, C * 4); hipMemset(beta, 0, C * 4); hipMemset(bias, 0, C * 4);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(e0, 0);
+    int st = melgpt_conv3x3_gn_nhwc(x, B, H, W, C, mean, rstd, gamma, beta, 1, wp, C, bias, res, y, MELGPT_BF16, 0);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("status %d  %.3f ms  %.1f TFLOP/s\n", st, ms, 2.0 * B * H * W * C * 9.0 * C / ms / 1e9);
+  }
+  unsigned long long h[64];
+  hipMemcpyFromSymbol(h, HIP_SYMBOL(melgpt_convw_dbg), sizeof(h));
+  for (int i = 1; i < 6 && h[4 * i]; ++i)
+    printf("tile %d: ab+stage %6llu  K loop %6llu  epilogue %6llu  (gap %6lld)\n", i, h[4 * i + 1] - h[4 * i],
+           h[4 * i + 2] - h[4 * i + 1], h[4 * i + 3] - h[4 * i + 2], h[4 * i + 4] ? (long long)(h[4 * i + 4] - h[4 * i + 3]) : -1LL);
+  return 0;
+}
