@@ -4,20 +4,31 @@
 // post-softmax, pre-dropout `att` that the reference RETURNS (:90) is emitted only on request (last block).
 //
 // Shape regime: T <= 288 (block_size 265/266), head size 64.  The whole K and V (or Q and dO) of one
-// (batch, head) live in LDS, so softmax is a plain two-pass row softmax in registers - no online rescaling.
+// (batch, head) live in LDS, so softmax is a plain two-pass row softmax - no online rescaling; pass 2 RECOMPUTES the
+// logits instead of keeping a 17-tile row of them in registers (the MFMA pipe is ~10 % busy here).
 //   forward / dQ kernel : one 512-thread workgroup per (batch, head): K and V staged into LDS ONCE, the 8 waves pull
-//                         16-query-row tiles from an LDS work counter, heaviest (latest causal rows) first; keys
-//                         beyond a tile's causal frontier are skipped
+//                         16-query-row tiles from an LDS work counter, heaviest (latest causal rows) first, and fetch
+//                         the next tile's Q / dO / O rows under the current tile's math; keys beyond a tile's causal
+//                         frontier are skipped, and only the key tiles the frontier cuts test a mask
 //   dK/dV kernel        : same shape with Q and dO in LDS; waves pull 16-key tiles (key tile 0 sees every query)
 // MFMA orientation is chosen so that no probability tile ever crosses lanes or LDS:
 //   S^T = K Q^T puts the query on the lane -> row max/sum are in-register + 2 xor-shuffles, and the S^T
 //   accumulators are directly the B operand of O^T = V^T P^T (V^T via ds_read_b64_tr_b16 transposed reads);
 //   in the dK/dV kernel S = Q K^T puts the key on the lane and the accumulators feed dV^T and dK^T.
 // The causal / n_unmasked mask (minGPT.py:65-69) is computed from (row, col, n_unmasked) - the persistent
-// (1,1,bs,bs) `mask` buffer of the reference is never read.  Dropout masks are Philox4x32-10 keyed by
-// (seed, stream, (b,h,q), key/4) and are regenerated bit-identically in the backward kernels.
+// (1,1,bs,bs) `mask` buffer of the reference is never read.  Dropout masks are a counter hash (common.h) keyed by
+// (seed, stream, (b,h)) over the counter q * 128 + key / 4, regenerated bit-identically in the backward kernels.
 // T = bf16: v_mfma_f32_16x16x32_bf16;  T = f32: v_mfma_f32_16x16x4_f32 (exact f32) - same code path.
 #include "mma.h"
+
+#ifndef ATTN_LAB
+#define ATTN_LAB 0  // tools/lab/attn_lab.hip ablations: 1 staging only, 2 no staging, 3 dQ kernel only, 4 dK/dV kernel only,
+// forward only: 5 no row-maximum pass, 6 no P V MFMAs, 7 no softmax arithmetic, 8 phase stamps of one wave
+#endif
+
+#if ATTN_LAB == 8
+__device__ unsigned long long melgpt_attn_dbg[256 + 4 * 4096];  // lab build only: phase stamps of one wave of one workgroup
+#endif
 
 namespace {
 
@@ -75,17 +86,6 @@ __device__ __forceinline__ int off(int row, int c) {
   else return offK<T>(row, c);
 }
 
-template <typename T, bool VSWZ>
-__device__ __forceinline__ void load_tile(char* tile, const T* base, long long ld, int nvalid, int nfill, int t) {
-  constexpr int CP = AT<T>::CP, VEC = AT<T>::VEC;
-  for (int q = t; q < nfill * CP; q += NTHREADS) {
-    const int row = q / CP, c = q % CP;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (row < nvalid) v = *(const u32x4*)(base + (long long)row * ld + c * VEC);
-    *(u32x4*)(tile + off<T, VSWZ>(row, c)) = v;
-  }
-}
-
 // fragment whose 16 "row" indices are tile rows 16*tile16 + (lane&15); contraction over the head dim (substep ks)
 template <typename T, bool VSWZ>
 __device__ __forceinline__ u32x4 frag_row(const char* tile, int tile16, int ks, int lane) {
@@ -135,11 +135,82 @@ __device__ __forceinline__ void store4(T* p, f32x4 v) {
 __device__ __forceinline__ bool allowed(int q, int key, int T, int nu) {
   return key < T && (key <= q || (q < nu && key < nu));
 }
+// the keys query row `row` sees are exactly [0, vis_keys): its causal frontier, widened to the n_unmasked prefix block
+__device__ __forceinline__ int vis_keys(int row, int T, int nu) {
+  int v = row + 1;
+  if (row < nu) v = max(v, nu);
+  return min(v, T);
+}
 
 __device__ __forceinline__ int rup(int x, int m) { return (x + m - 1) / m * m; }
 
+constexpr float LOG2E = 1.4426950408889634f;
+
+// Both tiles of a workgroup staged with every global load in flight at once (a load -> store loop pays the memory
+// latency once per iteration: 20 of the forward's 118 us at the training shape).
+template <typename T, bool SWZ0, bool SWZ1>
+__device__ __forceinline__ void load_tiles(char* t0, const T* b0, long long ld0, char* t1, const T* b1, long long ld1,
+                                           int nvalid, int nfill, int t) {
+  constexpr int CP = AT<T>::CP, VEC = AT<T>::VEC, NIT = (MAXT * CP + NTHREADS - 1) / NTHREADS;
+  u32x4 v0[NIT], v1[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    // unconditional loads of a clamped row (a branch around a load makes the compiler drain the loads before it)
+    const int q = t + i * NTHREADS, row = min(q / CP, nvalid - 1), c = q % CP;
+    v0[i] = *(const u32x4*)(b0 + (long long)row * ld0 + c * VEC);
+    v1[i] = *(const u32x4*)(b1 + (long long)row * ld1 + c * VEC);
+  }
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int q = t + i * NTHREADS, row = q / CP, c = q % CP;
+    if (q < nfill * CP) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      *(u32x4*)(t0 + off<T, SWZ0>(row, c)) = row < nvalid ? v0[i] : z;
+      *(u32x4*)(t1 + off<T, SWZ1>(row, c)) = row < nvalid ? v1[i] : z;
+    }
+  }
+}
+
+__device__ __forceinline__ f32x4 exp2_4(f32x4 x) {
+  return f32x4{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1]), __builtin_amdgcn_exp2f(x[2]),
+               __builtin_amdgcn_exp2f(x[3])};
+}
+__device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
+// Dropout lanes of the kernels (compile-time, so the tile loops carry no mode branches):
+//   DM_NONE  no dropout;  DM_HALF  p = 1/2 exactly (the reference's attn_pdrop): keep = top bit of the element's hash
+//   byte, applied as a sign-extended 1-bit field AND - two VALU ops per probability, no VCC;  DM_ANY  any other p.
+enum { DM_NONE = 0, DM_HALF = 1, DM_ANY = 2 };
+
+// v with the dropped ones of its 4 elements zeroed; the elements are 4 consecutive keys at low counter word c0
+template <int DM>
+__device__ __forceinline__ f32x4 drop4(const DropKeys& d, unsigned c0, f32x4 v) {
+  if constexpr (DM == DM_HALF) {
+    const int hsh = (int)hash32(c0 + d.k0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      v[r] = __uint_as_float(__float_as_uint(v[r]) & (unsigned)__builtin_amdgcn_sbfe(hsh, 8 * r + 7, 1));
+  } else if constexpr (DM == DM_ANY) {
+    bool keep[4];
+    drop_keep4(d, c0, keep);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = keep[r] ? v[r] : 0.f;
+  }
+  return v;
+}
+
+// value held by lane R of this lane's quad (DPP quad_perm broadcast)
+template <int R>
+__device__ __forceinline__ int quad_lane(int v) {
+  return __builtin_amdgcn_mov_dpp(v, 0x55 * R, 0xF, 0xF, true);
+}
+
 // ================================================================================================ forward
-template <typename T, bool BWD>
+// These kernels issue ~10x more VALU than MFMA cycles (an MFMA 16x16x32 is 16 cycles, a wave64 VALU op 4), so the
+// per-probability work is pared to: max3 (pass 1); fma + exp2 + add (pass 2, packed f32 pairs); one AND with a
+// sign-extended hash bit (dropout 1/2; ONE hash per four keys), cvt_pk.  Scaling by 1/sqrt(hs), the softmax normaliser
+// and 1/(1-p) are applied to the 16 x 64 OUTPUT tile, not to the probabilities.
+// Measured at B 128, H 16, T 265, p 1/2 (tools/lab/attn_lab.hip): forward 118 -> 82 us, backward 364 -> 275 us.
+template <typename T, bool BWD, int DM, bool ATT>
 __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kernel(AttnParams p) {
   // BWD == false: forward (O, lse, optional att).   BWD == true: dQ (+ delta) from dO, recomputing P from lse.
   using A = AT<T>;
@@ -150,178 +221,255 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kerne
   char* Kt = smem;
   char* Vt = smem + (size_t)TP * A::ROWB;
   int* ctr = (int*)(smem + 2 * (size_t)TP * A::ROWB);
+#if ATTN_LAB == 8
+  const unsigned long long ts_entry = __builtin_amdgcn_s_memtime();
+#endif
   const T* Kg = (const T*)p.K + (long long)b * Tn * p.ld + h * HS;
   const T* Vg = (const T*)p.V + (long long)b * Tn * p.ld + h * HS;
-  load_tile<T, false>(Kt, Kg, p.ld, Tn, TP, t);
-  load_tile<T, !BWD>(Vt, Vg, p.ld, Tn, TP, t);  // fwd: V only via transposed reads
+  if (ATTN_LAB != 2) load_tiles<T, false, !BWD>(Kt, Kg, p.ld, Vt, Vg, p.ld, Tn, TP, t);  // fwd: V only via transposed reads
   if (t == 0) *ctr = 0;
   __syncthreads();
+  if (ATTN_LAB == 1) {
+    if (*(volatile int*)(Kt + 4 * t) == 0x12345678) p.lse[t] = 1.f;
+    return;
+  }
   const long long bh = (long long)b * p.H + h;
   const int ntiles = (Tn + 15) / 16;
+  const float c2 = p.scale * LOG2E;
+  const float dsc = DM != DM_NONE ? p.drop_scale : 1.f;
+  const DropKeys dkeys = drop_keys(p.seed, p.stream_id, (unsigned)bh, p.drop_thresh);
 
- for (;;) {  // ---- this wave's next 16-row query tile (heaviest first)
-  int job = 0;
-  if (lane == 0) job = atomicAdd(ctr, 1);
-  job = __shfl(job, 0, 64);
-  if (job >= ntiles) break;
-  const int q0 = 16 * (ntiles - 1 - job);
-  const int q = q0 + i16, qc = min(q, Tn - 1);
-  int kw = min(q0 + 16, Tn);
-  if (nu > q0) kw = max(kw, min(nu, Tn));
-  const int nkt = (kw + 15) / 16;
-
-  u32x4 qf[A::NKS];
-  {
+  auto grab = [&]() {  // next 16-row query tile of this wave (heaviest = latest causal rows first); wave-uniform
+    int j = 0;
+    if (lane == 0) j = atomicAdd(ctr, 1);
+    return __builtin_amdgcn_readfirstlane(j);
+  };
+  auto fetch = [&](int job, u32x4 (&qf)[A::NKS], u32x4 (&dof)[A::NKS], u32x4 (&ov)[A::NKS], float& lse_q) {
+    const int qc = min(16 * (ntiles - 1 - job) + i16, Tn - 1);
     const T* qp = (const T*)p.Q + ((long long)b * Tn + qc) * p.ld + h * HS;
 #pragma unroll
     for (int ks = 0; ks < A::NKS; ++ks) qf[ks] = *(const u32x4*)(qp + (4 * ks + g) * A::VEC);
-  }
-  u32x4 dof[A::NKS];
-  float delta = 0.f, lse_q = 0.f;
-  if constexpr (BWD) {
-    const T* dp = (const T*)p.dO + ((long long)b * Tn + qc) * p.ldo + h * HS;
-    const T* op = (const T*)p.O + ((long long)b * Tn + qc) * p.ldo + h * HS;
+    if constexpr (BWD) {
+      const T* dp = (const T*)p.dO + ((long long)b * Tn + qc) * p.ldo + h * HS;
+      const T* op = (const T*)p.O + ((long long)b * Tn + qc) * p.ldo + h * HS;
+#pragma unroll
+      for (int ks = 0; ks < A::NKS; ++ks) {
+        dof[ks] = *(const u32x4*)(dp + (4 * ks + g) * A::VEC);
+        ov[ks] = *(const u32x4*)(op + (4 * ks + g) * A::VEC);
+      }
+      lse_q = p.lse[bh * Tn + qc];
+    }
+  };
+
+#if ATTN_LAB == 8
+  const bool dbg_on = !BWD && b == 3 && h == 5 && (t >> 6) == 2;
+  int dbg_n = 0;
+  unsigned long long ts_k = __builtin_amdgcn_s_memtime();
+#endif
+  int job = grab();
+  u32x4 qf[A::NKS], dof[A::NKS], ov[A::NKS];
+  float lse_q = 0.f;
+  fetch(min(job, ntiles - 1), qf, dof, ov, lse_q);
+
+ while (job < ntiles) {
+  // the NEXT tile's rows are requested now and land under this tile's math
+  const int njob = grab();
+  u32x4 nqf[A::NKS], ndof[A::NKS], nov[A::NKS];
+  float nlse = 0.f;
+  fetch(min(njob, ntiles - 1), nqf, ndof, nov, nlse);
+
+#if ATTN_LAB == 8
+  unsigned long long ts0 = __builtin_amdgcn_s_memtime(), ts1 = 0, ts2 = 0;
+#endif
+  const int q0 = 16 * (ntiles - 1 - job);
+  const int q = q0 + i16, qc = min(q, Tn - 1);
+  const int lim_g = vis_keys(qc, Tn, nu) - 4 * g;                      // key 16 kt + 4 g + r visible <=> 16 kt + r < lim_g
+  const int nkt = (vis_keys(min(q0 + 15, Tn - 1), Tn, nu) + 15) / 16;  // key tiles any row of the tile sees
+  const int nfull = vis_keys(q0, Tn, nu) / 16;                         // key tiles EVERY row sees whole: no mask test
+  const int nst = (nkt + A::TPS - 1) / A::TPS, nst_full = nfull / A::TPS;
+  const unsigned cb = (unsigned)q * 128u + (unsigned)g;                // dropout counter of keys 16 kt + 4 g ..+3: cb + 4 kt
+  const f32x4 c2v = splat4(c2);
+
+  auto scores = [&](int kt, bool masked) {  // S^T tile: keys 16 kt + 4 g + r of query q, raw (unscaled) logits
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < A::NKS; ++ks) mma<T>(acc, frag_row<T, false>(Kt, kt, ks, lane), qf[ks]);
+    if (masked) {
+      const int lim = lim_g - 16 * kt;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = (r < lim) ? acc[r] : -__builtin_inff();
+    }
+    return acc;
+  };
+  auto dropped = [&](f32x4 v, int kt) { return drop4<DM>(dkeys, cb + 4u * (unsigned)kt, v); };
+
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float oscale;
+  const char* Xt = BWD ? Kt : Vt;
+
+  if constexpr (!BWD) {
+    // pass 1: the row maximum alone.  The logits are NOT kept: pass 2 recomputes them (the MFMA pipe idles under the
+    // softmax VALU work anyway), which frees the 72 registers a 17-tile row of scores would pin.
+    float m = -__builtin_inff();
+    int kt4 = ATTN_LAB == 5 ? nkt : 0;
+    for (; kt4 + 4 <= nfull; kt4 += 4) {  // four independent tiles in flight (the compiler does not unroll MFMA loops)
+      const f32x4 a0 = scores(kt4, false), a1 = scores(kt4 + 1, false), a2 = scores(kt4 + 2, false),
+                  a3 = scores(kt4 + 3, false);
+      const float m0 = fmaxf(fmaxf(a0[0], a0[1]), fmaxf(a0[2], a0[3])), m1 = fmaxf(fmaxf(a1[0], a1[1]), fmaxf(a1[2], a1[3]));
+      const float m2 = fmaxf(fmaxf(a2[0], a2[1]), fmaxf(a2[2], a2[3])), m3 = fmaxf(fmaxf(a3[0], a3[1]), fmaxf(a3[2], a3[3]));
+      m = fmaxf(m, fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)));
+    }
+    for (int kt = kt4; kt < nfull; ++kt) {
+      const f32x4 a = scores(kt, false);
+      m = fmaxf(fmaxf(m, a[0]), fmaxf(fmaxf(a[1], a[2]), a[3]));
+    }
+    for (int kt = max(kt4, nfull); kt < nkt; ++kt) {
+      const f32x4 a = scores(kt, true);
+      m = fmaxf(fmaxf(m, a[0]), fmaxf(fmaxf(a[1], a[2]), a[3]));
+    }
+    if (ATTN_LAB == 5) m = 8.f;
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+#if ATTN_LAB == 8
+    ts1 = __builtin_amdgcn_s_memtime();
+#endif
+    const f32x4 mcv = splat4(m * c2);
+    f32x4 lv = {0.f, 0.f, 0.f, 0.f};
+    float* ap = ATT ? p.att + (bh * Tn + qc) * Tn : nullptr;
+    // pass 2: e = 2^((s - m) c2), row sum, dropout, O^T += V^T e   (an absent odd partner tile masks to e = 0)
+    auto step = [&](int st, bool masked) {
+      f32x4 e[2];
+#pragma unroll
+      for (int tt = 0; tt < A::TPS; ++tt) {
+        const int kt = A::TPS * st + tt;
+        if (ATTN_LAB == 7) {
+          e[tt] = scores(kt, masked);
+          continue;
+        }
+        e[tt] = exp2_4(scores(kt, masked) * c2v - mcv);
+        lv += e[tt];
+        if constexpr (ATT) {  // unnormalised here, rescaled below once the row sum is known
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * kt + 4 * g + r < Tn) ap[16 * kt + 4 * g + r] = e[tt][r];
+        }
+        e[tt] = dropped(e[tt], kt);
+      }
+      const u32x4 bop = pack_operand<T>(e[0], e[A::TPS - 1]);
+      if (ATTN_LAB == 6) {
+        o[0] += __builtin_bit_cast(f32x4, bop);
+        return;
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) mma<T>(o[dt], frag_tr<T, true>(Xt, st, dt, lane), bop);
+    };
+    int st2 = 0;
+    for (; st2 + 2 <= nst_full; st2 += 2) {  // two independent operand steps in flight
+      step(st2, false);
+      step(st2 + 1, false);
+    }
+    if (st2 < nst_full) step(st2, false);
+    for (int st = nst_full; st < nst; ++st) step(st, true);
+#if ATTN_LAB == 8
+    asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+    ts2 = __builtin_amdgcn_s_memtime();
+#endif
+    float l = (lv[0] + lv[1]) + (lv[2] + lv[3]);
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    oscale = inv * dsc;
+    if (g == 0 && q < Tn) p.lse[bh * Tn + q] = m * p.scale + __logf(l);
+    if (ATT && q < Tn) {  // the reference's returned post-softmax, pre-dropout map (only on request)
+      const int kend = 16 * A::TPS * nst;
+      for (int key = 4 * g; key < Tn; key += 16)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (key + r < Tn) ap[key + r] = key < kend ? ap[key + r] * inv : 0.f;  // beyond this tile's frontier: 0
+    }
+  } else {
+    float delta = 0.f;
 #pragma unroll
     for (int ks = 0; ks < A::NKS; ++ks) {
-      dof[ks] = *(const u32x4*)(dp + (4 * ks + g) * A::VEC);
-      u32x4 ov = *(const u32x4*)(op + (4 * ks + g) * A::VEC);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if constexpr (A::ES == 2) {
-          delta = fmaf(bf16lo(dof[ks][e]), bf16lo(ov[e]), delta);
-          delta = fmaf(bf16hi(dof[ks][e]), bf16hi(ov[e]), delta);
+          delta = fmaf(bf16lo(dof[ks][e]), bf16lo(ov[ks][e]), delta);
+          delta = fmaf(bf16hi(dof[ks][e]), bf16hi(ov[ks][e]), delta);
         } else {
-          delta = fmaf(__uint_as_float(dof[ks][e]), __uint_as_float(ov[e]), delta);
+          delta = fmaf(__uint_as_float(dof[ks][e]), __uint_as_float(ov[ks][e]), delta);
         }
       }
     }
     delta += __shfl_xor(delta, 16, 64);
     delta += __shfl_xor(delta, 32, 64);
     if (g == 0 && q < Tn) p.delta[bh * Tn + q] = delta;
-    lse_q = p.lse[bh * Tn + qc];
-  }
-
-  f32x4 s[MAXKT];
+    // dS = P (keep dP / (1-p) - delta) scale  =  [P (keep dP - delta (1-p))] * scale / (1-p): the bracket per element,
+    // the constant on the dQ tile
+    const f32x4 l2v = splat4(lse_q * LOG2E), dlv = splat4(delta / dsc);
+    oscale = p.scale * dsc;
+    auto step = [&](int st, bool masked) {
+      f32x4 ds[2];
 #pragma unroll
-  for (int kt = 0; kt < MAXKT; ++kt) s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const unsigned long long row_ctr = (unsigned long long)(bh * Tn + qc) * 128ull;
-
-  if constexpr (!BWD) {
-    float m = -__builtin_inff();
-#pragma unroll
-    for (int kt = 0; kt < MAXKT; ++kt) {
-      if (kt < nkt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < A::NKS; ++ks) mma<T>(acc, frag_row<T, false>(Kt, kt, ks, lane), qf[ks]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = 16 * kt + 4 * g + r;
-          const float v = allowed(qc, key, Tn, nu) ? acc[r] * p.scale : -__builtin_inff();
-          acc[r] = v;
-          m = fmaxf(m, v);
-        }
-        s[kt] = acc;
-      }
-    }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float l = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < MAXKT; ++kt) {
-      if (kt < nkt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __expf(s[kt][r] - m);
-          s[kt][r] = e;
-          l += e;
-        }
-      }
-    }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
-    if (g == 0 && q < Tn) p.lse[bh * Tn + q] = m + __logf(l);
-#pragma unroll
-    for (int kt = 0; kt < MAXKT; ++kt) {
-      if (kt < nkt) {
-        f32x4 pv = s[kt] * inv;
-        if (p.att && q < Tn) {
-          float* ap = p.att + (bh * Tn + q) * Tn;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = 16 * kt + 4 * g + r;
-            if (key < Tn) ap[key] = pv[r];
-          }
-        }
-        if (p.drop_scale != 0.f) {
-          const unsigned keep = dropout_keep4(p.seed, p.stream_id, row_ctr + (4 * kt + g), p.drop_thresh);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) pv[r] = (keep >> r & 1) ? pv[r] * p.drop_scale : 0.f;
-        }
-        s[kt] = pv;
-      }
-    }
-    // keys the other waves' causal frontier reaches but this wave's does not must read as probability 0
-    if (p.att && q < Tn) {
-      float* ap = p.att + (bh * Tn + q) * Tn;
-      for (int key = 16 * nkt + 4 * g; key < Tn; key += 16)
-        for (int r = 0; r < 4; ++r)
-          if (key + r < Tn) ap[key + r] = 0.f;
-    }
-  } else {
-#pragma unroll
-    for (int kt = 0; kt < MAXKT; ++kt) {
-      if (kt < nkt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < A::NKS; ++ks) mma<T>(acc, frag_row<T, false>(Kt, kt, ks, lane), qf[ks]);
+      for (int tt = 0; tt < A::TPS; ++tt) {
+        const int kt = A::TPS * st + tt;
+        const f32x4 pr = exp2_4(scores(kt, masked) * c2v - l2v);
+        f32x4 dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < A::NKS; ++ks) mma<T>(dp, frag_row<T, false>(Vt, kt, ks, lane), dof[ks]);
-        unsigned keep = 0xF;
-        if (p.drop_scale != 0.f) keep = dropout_keep4(p.seed, p.stream_id, row_ctr + (4 * kt + g), p.drop_thresh);
-        const float dsc = p.drop_scale != 0.f ? p.drop_scale : 1.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = 16 * kt + 4 * g + r;
-          const float pr = allowed(qc, key, Tn, nu) ? __expf(acc[r] * p.scale - lse_q) : 0.f;
-          const float dpm = (keep >> r & 1) ? dp[r] * dsc : 0.f;
-          acc[r] = pr * (dpm - delta) * p.scale;
-        }
-        s[kt] = acc;
+        dp = dropped(dp, kt);
+        ds[tt] = pr * (dp - dlv);
       }
-    }
+      const u32x4 bop = pack_operand<T>(ds[0], ds[A::TPS - 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) mma<T>(o[dt], frag_tr<T, false>(Xt, st, dt, lane), bop);
+    };
+    for (int st = 0; st < nst_full; ++st) step(st, false);  // (two steps in flight spill here)
+    for (int st = nst_full; st < nst; ++st) step(st, true);
   }
 
-  // O^T (or dQ^T) [d][q] = sum_key  X^T[d][key] * S^T[key][q],  X = V (fwd) or K (bwd)
-  f32x4 o[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nst = (nkt + A::TPS - 1) / A::TPS;
-  const char* Xt = BWD ? Kt : Vt;
-#pragma unroll
-  for (int st = 0; st < A::MAXST; ++st) {
-    if (st < nst) {
-      const u32x4 bop = pack_operand<T>(s[A::TPS * st], s[A::TPS * st + (A::TPS - 1)]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) mma<T>(o[dt], frag_tr<T, !BWD>(Xt, st, dt, lane), bop);
-    }
-  }
   if (q < Tn) {
     T* op = BWD ? (T*)p.dQ + ((long long)b * Tn + q) * p.ldg + h * HS
                 : (T*)p.O + ((long long)b * Tn + q) * p.ldo + h * HS;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) store4<T>(op + 16 * dt + 4 * g, o[dt]);
+    for (int dt = 0; dt < 4; ++dt) store4<T>(op + 16 * dt + 4 * g, o[dt] * oscale);
   }
+
+#if ATTN_LAB == 8
+  if (dbg_on && dbg_n < 8) {
+    unsigned long long* d = melgpt_attn_dbg + 8 * dbg_n++;
+    if (lane == 0) {
+      d[0] = ts0 - ts_k; d[1] = ts1 - ts0; d[2] = ts2 - ts1; d[3] = __builtin_amdgcn_s_memtime() - ts2; d[4] = nkt; d[5] = job;
+    }
+  }
+#endif
+  job = njob;
+#pragma unroll
+  for (int ks = 0; ks < A::NKS; ++ks) {
+    qf[ks] = nqf[ks];
+    dof[ks] = ndof[ks];
+    ov[ks] = nov[ks];
+  }
+  lse_q = nlse;
  }  // tile loop
+#if ATTN_LAB == 8
+  if (!BWD && t == 0 && bh < 4096) {
+    unsigned long long* d = melgpt_attn_dbg + 256 + 4 * bh;
+    d[0] = ts_entry; d[1] = ts_k; d[2] = __builtin_amdgcn_s_memtime();
+    d[3] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+  }
+#endif
 }
 
 // ============================================================================================ dK / dV
 // mma<T>(acc, a, b) computes D[row of a][col of b]:  here rows = queries (Q / dO tile fragments on the A port),
 // columns = this wave's 16 keys (K / V rows held in registers on the B port), so every lane owns one key column
 // and the S / dP accumulators are directly the B operands of  dV^T = dO^T P_drop  and  dK^T = Q^T dS.
-template <typename T>
+// An accumulator register holds ONE query row here, so the four lanes of a quad (keys 4m..4m+3 of one dropout counter)
+// would each hash the same four counters: instead quad lane j hashes row 4g+j once and the quad shares them by DPP.
+template <typename T, int DM>
 __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_dkv_kernel(AttnParams p) {
   using A = AT<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -330,27 +478,35 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_dkv_ker
   const int TP = rup(Tn, 32);
   char* Qt = smem;
   char* Dt = smem + (size_t)TP * A::ROWB;
-  float* lse_s = (float*)(smem + 2 * (size_t)TP * A::ROWB);
-  float* del_s = lse_s + TP;
+  float* lse_s = (float*)(smem + 2 * (size_t)TP * A::ROWB);  // lse * log2(e)
+  float* del_s = lse_s + TP;                                  // delta * (1 - p)
   int* ctr = (int*)(del_s + TP);
   const long long bh = (long long)b * p.H + h;
-  load_tile<T, false>(Qt, (const T*)p.Q + (long long)b * Tn * p.ld + h * HS, p.ld, Tn, TP, t);
-  load_tile<T, false>(Dt, (const T*)p.dO + (long long)b * Tn * p.ldo + h * HS, p.ldo, Tn, TP, t);
+  const float dsc = DM != DM_NONE ? p.drop_scale : 1.f;
+  if (ATTN_LAB != 2)
+    load_tiles<T, false, false>(Qt, (const T*)p.Q + (long long)b * Tn * p.ld + h * HS, p.ld, Dt,
+                                (const T*)p.dO + (long long)b * Tn * p.ldo + h * HS, p.ldo, Tn, TP, t);
   for (int j = t; j < TP; j += NTHREADS) {
-    lse_s[j] = j < Tn ? p.lse[bh * Tn + j] : 0.f;
-    del_s[j] = j < Tn ? p.delta[bh * Tn + j] : 0.f;
+    lse_s[j] = j < Tn ? p.lse[bh * Tn + j] * LOG2E : 0.f;
+    del_s[j] = j < Tn ? p.delta[bh * Tn + j] / dsc : 0.f;
   }
   if (t == 0) *ctr = 0;
   __syncthreads();
+  if (ATTN_LAB == 1) {
+    if (*(volatile int*)(Qt + 4 * t) == 0x12345678) p.delta[t] = 1.f;
+    return;
+  }
   const int ntiles = (Tn + 15) / 16;
+  const f32x4 c2v = splat4(p.scale * LOG2E);
+  const DropKeys dkeys = drop_keys(p.seed, p.stream_id, (unsigned)bh, p.drop_thresh);
+  const int qsh = 8 * (lane & 3);  // this lane's key is element (key & 3) of its counter: byte qsh of the 8-bit hash
 
- for (;;) {  // ---- this wave's next 16-key tile (key tile 0 is seen by every query: heaviest first)
+ for (;;) {  // ---- this wave's next 16-key tile (key tile 0 is seen by every query: heaviest first); wave-uniform
   int job = 0;
   if (lane == 0) job = atomicAdd(ctr, 1);
-  job = __shfl(job, 0, 64);
+  job = __builtin_amdgcn_readfirstlane(job);
   if (job >= ntiles) break;
-  const int kt = job, key0 = 16 * kt;
-  const int key = key0 + i16, kc = min(key, Tn - 1);
+  const int key0 = 16 * job, key = key0 + i16, kc = min(key, Tn - 1);
   u32x4 kf[A::NKS], vf[A::NKS];
   {
     const T* kp = (const T*)p.K + ((long long)b * Tn + kc) * p.ld + h * HS;
@@ -365,54 +521,90 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_dkv_ker
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int q_start = (nu > key0) ? 0 : key0;  // first query row that can see any of these keys
-  const int st0 = (q_start / 16) / A::TPS;
-  const int st1 = ((Tn + 15) / 16 + A::TPS - 1) / A::TPS;
-  const float dsc = p.drop_scale != 0.f ? p.drop_scale : 1.f;
-  for (int st = st0; st < st1; ++st) {
+  // dropout counter of (query q, keys key&~3 ..+3) is q * 128 + key / 4; quad lane j hashes query 16 qt + 4 g + j
+  const unsigned cq = (unsigned)(4 * g + (lane & 3)) * 128u + (unsigned)(key >> 2) + dkeys.k0;
+  const unsigned ce = (unsigned)(4 * g) * 128u + (unsigned)(key >> 2);
+
+  auto step = [&](int st, bool masked) {
     f32x4 pd[2], ds[2];
-    pd[1] = ds[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int tt = 0; tt < A::TPS; ++tt) {
-      const int qt = A::TPS * st + tt;
+      const int qt = A::TPS * st + tt, qb = 16 * qt;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < A::NKS; ++ks) mma<T>(acc, frag_row<T, false>(Qt, qt, ks, lane), kf[ks]);
 #pragma unroll
       for (int ks = 0; ks < A::NKS; ++ks) mma<T>(dp, frag_row<T, false>(Dt, qt, ks, lane), vf[ks]);
+      const f32x4 l4 = *(const f32x4*)(lse_s + qb + 4 * g), d4 = *(const f32x4*)(del_s + qb + 4 * g);
+      f32x4 pr = exp2_4(acc * c2v - l4);
+      if (masked) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int q = 16 * qt + 4 * g + r;  // accumulator row
-        const bool ok = q < Tn && allowed(q, key, Tn, nu);
-        const float pr = ok ? __expf(acc[r] * p.scale - lse_s[q]) : 0.f;
-        bool keep = true;
-        if (p.drop_scale != 0.f) {
-          const unsigned long long ctr = (unsigned long long)(bh * Tn + min(q, Tn - 1)) * 128ull + (unsigned)(key >> 2);
-          keep = (dropout_keep4(p.seed, p.stream_id, ctr, p.drop_thresh) >> (key & 3)) & 1;
+        for (int r = 0; r < 4; ++r) {
+          const int q = qb + 4 * g + r;
+          pr[r] = (q < Tn && allowed(q, key, Tn, nu)) ? pr[r] : 0.f;
         }
-        const float pdr = keep ? pr * dsc : 0.f;
-        const float dpm = keep ? dp[r] * dsc : 0.f;
-        acc[r] = pdr;
-        dp[r] = pr * (dpm - del_s[q]) * p.scale;
       }
-      pd[tt] = acc;
-      ds[tt] = dp;
+      f32x4 pk = pr;
+      if constexpr (DM == DM_HALF) {
+        const int hq = (int)hash32(cq + (unsigned)qb * 128u);
+        const int hr[4] = {quad_lane<0>(hq), quad_lane<1>(hq), quad_lane<2>(hq), quad_lane<3>(hq)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned km = (unsigned)__builtin_amdgcn_sbfe(hr[r], qsh + 7, 1);  // all ones = kept
+          pk[r] = __uint_as_float(__float_as_uint(pr[r]) & km);
+          dp[r] = __uint_as_float(__float_as_uint(dp[r]) & km);
+        }
+      } else if constexpr (DM == DM_ANY) {
+        if (dkeys.b8) {
+          const int hq = (int)hash32(cq + (unsigned)qb * 128u);
+          const int hr[4] = {quad_lane<0>(hq), quad_lane<1>(hq), quad_lane<2>(hq), quad_lane<3>(hq)};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool keep = __builtin_amdgcn_ubfe((unsigned)hr[r], (unsigned)qsh, 8u) >= dkeys.t;
+            pk[r] = keep ? pr[r] : 0.f;
+            dp[r] = keep ? dp[r] : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            bool k4[4];
+            drop_keep4(dkeys, ce + (unsigned)(qb + r) * 128u, k4);
+            const bool keep = (key & 2) ? ((key & 1) ? k4[3] : k4[2]) : ((key & 1) ? k4[1] : k4[0]);
+            pk[r] = keep ? pr[r] : 0.f;
+            dp[r] = keep ? dp[r] : 0.f;
+          }
+        }
+      }
+      pd[tt] = pk;
+      ds[tt] = pr * (dp - d4);
     }
-    const u32x4 bp = pack_operand<T>(pd[0], pd[1]);
-    const u32x4 bs = pack_operand<T>(ds[0], ds[1]);
+    const u32x4 bp = pack_operand<T>(pd[0], pd[A::TPS - 1]);
+    const u32x4 bs = pack_operand<T>(ds[0], ds[A::TPS - 1]);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       mma<T>(dv[dt], frag_tr<T, false>(Dt, st, dt, lane), bp);
       mma<T>(dk[dt], frag_tr<T, false>(Qt, st, dt, lane), bs);
     }
-  }
+  };
+  // query tiles that can see these keys: from the diagonal (or from 0 inside the unmasked block).  A tile is seen
+  // whole - no mask test - when it lies below the diagonal tile and holds no padded row or key.
+  const int q_start = (nu > key0) ? 0 : key0;
+  const int st0 = (q_start / 16) / A::TPS;
+  const int st1 = (ntiles + A::TPS - 1) / A::TPS;
+  const int stf0 = key0 + 16 <= Tn ? min(st1, (job + 1 + A::TPS - 1) / A::TPS) : st1;  // first whole step ..
+  const int stf1 = max(stf0, (Tn / 16) / A::TPS);                                        // .. and one past the last
+  for (int st = st0; st < stf0; ++st) step(st, true);
+  for (int st = stf0; st < stf1; ++st) step(st, false);
+  for (int st = stf1; st < st1; ++st) step(st, true);
+
   if (key < Tn) {
     T* kp = (T*)p.dK + ((long long)b * Tn + key) * p.ldg + h * HS;
     T* vp = (T*)p.dV + ((long long)b * Tn + key) * p.ldg + h * HS;
+    const float ksc = p.scale * dsc;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      store4<T>(kp + 16 * dt + 4 * g, dk[dt]);
-      store4<T>(vp + 16 * dt + 4 * g, dv[dt]);
+      store4<T>(kp + 16 * dt + 4 * g, dk[dt] * ksc);
+      store4<T>(vp + 16 * dt + 4 * g, dv[dt] * dsc);
     }
   }
  }  // tile loop
@@ -450,6 +642,45 @@ int set_lds(K kernel, size_t bytes) {
              : MELGPT_ERR_LAUNCH;
 }
 
+int drop_mode(const AttnParams& p) {
+  return p.drop_scale == 0.f ? DM_NONE : p.drop_thresh == 0x80000000u ? DM_HALF : DM_ANY;
+}
+
+template <typename T, bool BWD, int DM, bool ATT>
+int launch_q_att(const AttnParams& p, hipStream_t s) {
+  if (set_lds(attn_q_kernel<T, BWD, DM, ATT>, lds_bytes<T>(MAXT, false)) != MELGPT_OK) return MELGPT_ERR_LAUNCH;
+  hipLaunchKernelGGL((attn_q_kernel<T, BWD, DM, ATT>), dim3(1, p.H, p.B), dim3(NTHREADS), lds_bytes<T>(p.T, false), s, p);
+  return MELGPT_OK;
+}
+template <typename T, bool BWD, int DM>
+int launch_q(const AttnParams& p, hipStream_t s) {
+  if constexpr (!BWD)
+    if (p.att) return launch_q_att<T, BWD, DM, true>(p, s);
+  return launch_q_att<T, BWD, DM, false>(p, s);
+}
+template <typename T, int DM>
+int launch_dkv(const AttnParams& p, hipStream_t s) {
+  if (set_lds(attn_dkv_kernel<T, DM>, lds_bytes<T>(MAXT, true)) != MELGPT_OK) return MELGPT_ERR_LAUNCH;
+  hipLaunchKernelGGL((attn_dkv_kernel<T, DM>), dim3(1, p.H, p.B), dim3(NTHREADS), lds_bytes<T>(p.T, true), s, p);
+  return MELGPT_OK;
+}
+template <typename T, bool BWD>
+int launch_q_mode(const AttnParams& p, hipStream_t s) {
+  switch (drop_mode(p)) {
+    case DM_NONE: return launch_q<T, BWD, DM_NONE>(p, s);
+    case DM_HALF: return launch_q<T, BWD, DM_HALF>(p, s);
+    default: return launch_q<T, BWD, DM_ANY>(p, s);
+  }
+}
+template <typename T>
+int launch_dkv_mode(const AttnParams& p, hipStream_t s) {
+  switch (drop_mode(p)) {
+    case DM_NONE: return launch_dkv<T, DM_NONE>(p, s);
+    case DM_HALF: return launch_dkv<T, DM_HALF>(p, s);
+    default: return launch_dkv<T, DM_ANY>(p, s);
+  }
+}
+
 }  // namespace
 
 extern "C" int melgpt_attn_fwd(const void* q, const void* k, const void* v, long long ld, void* out, long long ldo,
@@ -465,18 +696,9 @@ extern "C" int melgpt_attn_fwd(const void* q, const void* k, const void* v, long
   if (st != MELGPT_OK) return st;
   MELGPT_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0, MELGPT_ERR_ALIGN);
   set_dropout(p, drop_p, seed, stream_id);
-  dim3 grid(1, H, B);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == MELGPT_F32) {
-    size_t lds = lds_bytes<float>(T, false);
-    if (set_lds(attn_q_kernel<float, false>, lds_bytes<float>(MAXT, false)) != MELGPT_OK) return MELGPT_ERR_LAUNCH;
-    hipLaunchKernelGGL((attn_q_kernel<float, false>), grid, dim3(NTHREADS), lds, s, p);
-  } else {
-    size_t lds = lds_bytes<bf16_t>(T, false);
-    if (set_lds(attn_q_kernel<bf16_t, false>, lds_bytes<bf16_t>(MAXT, false)) != MELGPT_OK) return MELGPT_ERR_LAUNCH;
-    hipLaunchKernelGGL((attn_q_kernel<bf16_t, false>), grid, dim3(NTHREADS), lds, s, p);
-  }
-  return melgpt_launch_status();
+  st = dtype == MELGPT_F32 ? launch_q_mode<float, false>(p, s) : launch_q_mode<bf16_t, false>(p, s);
+  return st != MELGPT_OK ? st : melgpt_launch_status();
 }
 
 extern "C" int melgpt_attn_bwd(const void* q, const void* k, const void* v, long long ld, const void* out,
@@ -497,19 +719,13 @@ extern "C" int melgpt_attn_bwd(const void* q, const void* k, const void* v, long
                MELGPT_ERR_ALIGN);
   set_dropout(p, drop_p, seed, stream_id);
   hipStream_t s = (hipStream_t)stream;
-  dim3 gq(1, H, B), gk(1, H, B);
-  if (dtype == MELGPT_F32) {
-    if (set_lds(attn_q_kernel<float, true>, lds_bytes<float>(MAXT, false)) != MELGPT_OK ||
-        set_lds(attn_dkv_kernel<float>, lds_bytes<float>(MAXT, true)) != MELGPT_OK)
-      return MELGPT_ERR_LAUNCH;
-    hipLaunchKernelGGL((attn_q_kernel<float, true>), gq, dim3(NTHREADS), lds_bytes<float>(T, false), s, p);
-    hipLaunchKernelGGL((attn_dkv_kernel<float>), gk, dim3(NTHREADS), lds_bytes<float>(T, true), s, p);
-  } else {
-    if (set_lds(attn_q_kernel<bf16_t, true>, lds_bytes<bf16_t>(MAXT, false)) != MELGPT_OK ||
-        set_lds(attn_dkv_kernel<bf16_t>, lds_bytes<bf16_t>(MAXT, true)) != MELGPT_OK)
-      return MELGPT_ERR_LAUNCH;
-    hipLaunchKernelGGL((attn_q_kernel<bf16_t, true>), gq, dim3(NTHREADS), lds_bytes<bf16_t>(T, false), s, p);
-    hipLaunchKernelGGL((attn_dkv_kernel<bf16_t>), gk, dim3(NTHREADS), lds_bytes<bf16_t>(T, true), s, p);
+  if (ATTN_LAB != 4) {  // dQ (writes delta, which the dK/dV kernel reads)
+    st = dtype == MELGPT_F32 ? launch_q_mode<float, true>(p, s) : launch_q_mode<bf16_t, true>(p, s);
+    if (st != MELGPT_OK) return st;
+  }
+  if (ATTN_LAB != 3) {
+    st = dtype == MELGPT_F32 ? launch_dkv_mode<float>(p, s) : launch_dkv_mode<bf16_t>(p, s);
+    if (st != MELGPT_OK) return st;
   }
   return melgpt_launch_status();
 }

@@ -73,10 +73,8 @@ __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned b
 
 // ---------------------------------------------------------------- counter-based dropout masks
 // Stateless: the keep decision of an element is a pure function of (seed, stream id, counter), so the backward
-// kernels regenerate the forward's mask instead of storing it.  One call yields FOUR 16-bit uniforms (for 4
-// consecutive elements) from two rounds of a 3-multiply avalanche hash ("triple32", bias < 2^-30 per output bit)
-// over the 64-bit counter mixed with the key - ~25 integer ops per 4 decisions.  (A Philox4x32-10 call costs ~100;
-// at one call per 4 attention probabilities / GEMM outputs it was the largest VALU cost of both kernels.)
+// kernels regenerate the forward's mask instead of storing it.  (A Philox4x32-10 call costs ~100 integer ops; at one
+// call per 4 attention probabilities / GEMM outputs it was the largest VALU cost of both kernels.)
 // 32-bit integer hash with two multiplies ("lowbias32", bias 0.17): a bijection of the counter, good avalanche.
 // Integer multiplies are quarter-rate on CDNA, so the mask generator is priced in multiplies: 4 per 4 elements.
 __device__ __forceinline__ unsigned hash32(unsigned x) {
@@ -85,40 +83,42 @@ __device__ __forceinline__ unsigned hash32(unsigned x) {
   x ^= x >> 16;
   return x;
 }
-struct Rand4x16 {
-  unsigned a, b;  // four 16-bit lanes: a.lo, a.hi, b.lo, b.hi
+// The keys fold in the seed, the stream id and the HIGH counter word (almost always zero or wave-uniform), with shifts
+// and adds only; a kernel whose high word is fixed per workgroup computes them once (attention: c1 = batch*heads + head).
+struct DropKeys {
+  unsigned k0, k1;  // hash keys of the first / second chain (8-bit mode uses k0 only)
+  unsigned t;       // threshold on the uniform's width: thresh >> 24 (8-bit mode) or thresh >> 16
+  bool b8;          // p is a multiple of 1/256: ONE hash chain yields the four 8-bit uniforms
 };
-// Counter-based: a pure function of (seed, stream_id, ctr), so a backward pass regenerates the forward mask.
-// Two independent hash chains over the same counter under two keys; the keys fold in the (almost always zero,
-// wave-uniform) high counter word with shifts and adds only.
-__device__ __forceinline__ Rand4x16 rand4x16(unsigned long long seed, unsigned stream_id, unsigned long long ctr) {
-  const unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32);
-  const unsigned k0 = ((unsigned)seed ^ (stream_id * 0x9E3779B9u)) + ((c1 << 13) | (c1 >> 19));
-  const unsigned k1 = ((unsigned)(seed >> 32) + stream_id * 0x85EBCA6Bu + 0x6A09E667u) ^ c1;
-  Rand4x16 r;
-  r.a = hash32(c0 + k0);
-  r.b = hash32((c0 ^ 0x5bd1e995u) + k1);
-  return r;
+__device__ __forceinline__ DropKeys drop_keys(unsigned long long seed, unsigned stream_id, unsigned c1, unsigned thresh) {
+  DropKeys d;
+  d.b8 = (thresh & 0x00FFFFFFu) == 0u;
+  d.k0 = ((unsigned)seed ^ (stream_id * 0x9E3779B9u)) + ((c1 << 13) | (c1 >> 19));
+  if (d.b8) d.k0 += (unsigned)(seed >> 32);
+  d.k1 = ((unsigned)(seed >> 32) + stream_id * 0x85EBCA6Bu + 0x6A09E667u) ^ c1;
+  d.t = d.b8 ? thresh >> 24 : thresh >> 16;
+  return d;
+}
+// keep decisions of the 4 consecutive elements at low counter word c0 (k[i] = element i kept)
+__device__ __forceinline__ void drop_keep4(const DropKeys& d, unsigned c0, bool (&k)[4]) {
+  if (d.b8) {
+    const unsigned r = hash32(c0 + d.k0);
+    k[0] = (r & 0xFFu) >= d.t; k[1] = ((r >> 8) & 0xFFu) >= d.t; k[2] = ((r >> 16) & 0xFFu) >= d.t; k[3] = (r >> 24) >= d.t;
+  } else {
+    const unsigned a = hash32(c0 + d.k0), b = hash32((c0 ^ 0x5bd1e995u) + d.k1);
+    k[0] = (a & 0xFFFFu) >= d.t; k[1] = (a >> 16) >= d.t; k[2] = (b & 0xFFFFu) >= d.t; k[3] = (b >> 16) >= d.t;
+  }
 }
 // keep-mask for 4 consecutive elements whose first linear index is 4*q: bit i set = element kept.
 // `thresh` = round(p_drop * 2^32) (kept for ABI stability); compared on its top 16 bits: p is honoured to 2^-16
-// (on its top 8 bits when the lower 24 are zero, i.e. when p is a multiple of 1/256 - then exactly).
+// (on its top 8 bits when the lower 24 are zero, i.e. when p is a multiple of 1/256 - then exactly; the reference
+// configs use 0.5 and 0.0).
 __device__ __forceinline__ unsigned dropout_keep4(unsigned long long seed, unsigned stream_id,
                                                   unsigned long long q, unsigned thresh) {
-  if ((thresh & 0x00FFFFFFu) == 0u) {
-    // p is a multiple of 1/256 (the reference configs use 0.5 and 0.0): 8-bit uniforms are exact for it, so ONE
-    // hash chain (two integer multiplies) serves the four decisions instead of two chains
-    const unsigned c0 = (unsigned)q, c1 = (unsigned)(q >> 32);
-    const unsigned k0 = ((unsigned)seed ^ (stream_id * 0x9E3779B9u)) + ((c1 << 13) | (c1 >> 19)) + (unsigned)(seed >> 32);
-    const unsigned r = hash32(c0 + k0);
-    const unsigned t8 = thresh >> 24;
-    return ((r & 0xFFu) >= t8 ? 1u : 0u) | (((r >> 8) & 0xFFu) >= t8 ? 2u : 0u) | (((r >> 16) & 0xFFu) >= t8 ? 4u : 0u) |
-           ((r >> 24) >= t8 ? 8u : 0u);
-  }
-  const Rand4x16 r = rand4x16(seed, stream_id, q);
-  const unsigned t16 = thresh >> 16;
-  return ((r.a & 0xFFFFu) >= t16 ? 1u : 0u) | ((r.a >> 16) >= t16 ? 2u : 0u) | ((r.b & 0xFFFFu) >= t16 ? 4u : 0u) |
-         ((r.b >> 16) >= t16 ? 8u : 0u);
+  const DropKeys d = drop_keys(seed, stream_id, (unsigned)(q >> 32), thresh);
+  bool k[4];
+  drop_keep4(d, (unsigned)q, k);
+  return (k[0] ? 1u : 0u) | (k[1] ? 2u : 0u) | (k[2] ? 4u : 0u) | (k[3] ? 8u : 0u);
 }
 
 // ---------------------------------------------------------------- Philox4x32-10 (sampling / reparameterisation draws)
