@@ -43,3 +43,28 @@ def test_known_answers_silence_and_sine_and_short_clip():
     mel, _ = wav_to_mel([short])
     assert np.abs(mel[0].cpu().numpy() - om.log_mel(om.fit_length(synth.waveform(3, n=50000)))).max() < 1e-4
     assert float(mel[0, :, 400:].abs().max()) == 0.0          # the padded tail is silence -> exactly 0
+
+
+def test_many_clips_odd_length_and_wide_filter_fallback():
+    """More blocks than the device holds workgroups (the persistent loop iterates), a clip length that is odd and not
+    a multiple of the hop, and a 16-filter bank over the whole spectrum whose dense blocks do not fit the kernel's LDS
+    budget (the banded fallback)."""
+    from melspec_gpt_vqvae_amd.feature_extraction import extract_mel_spectrogram as fe
+
+    n, L = 24, 220500
+    base = [synth.waveform(40 + i).astype(np.float32) for i in range(3)]
+    wavs = [np.roll(base[i % 3], 977 * i) for i in range(n)]
+    mel, _ = fe.wav_to_mel(wavs)
+    for i in (0, 7, 23):
+        assert np.abs(mel[i].cpu().numpy() - om.log_mel(wavs[i])).max() < 1e-4
+    odd = synth.waveform(44, n=33333).astype(np.float32)                 # 131 frames; frames 129, 130 reflect at the end
+    wide = fe.FusedTransforms([fe.MelSpectrogram(sr=22050, nfft=1024, fmin=0, fmax=11025, nmels=16, hoplen=256, spec_power=1),
+                               fe.LowerThresh(1e-5), fe.Log10(), fe.Multiply(20), fe.Subtract(20), fe.Add(100),
+                               fe.Divide(100), fe.Clip(0, 1.0), fe.TrimSpec(128)])
+    for tr, basis in ((fe.TRANSFORMS, None), (wide, om.mel_filterbank(n_mels=16, fmin=0.0, fmax=11025.0))):
+        t2 = fe.FusedTransforms(list(tr.transforms[:-1]) + [fe.TrimSpec(128)])
+        got, _ = t2.run(torch.from_numpy(odd).reshape(1, -1).cuda())
+        m = np.dot(om.mel_filterbank() if basis is None else basis, om.stft_mag(odd))
+        ref = np.clip((np.log10(np.maximum(1e-5, m)) * 20 - 20 + 100) / 100, 0, 1.0)[:, :128]
+        assert got.shape[1:] == ref.shape
+        assert np.abs(got[0].cpu().numpy() - ref).max() < 1e-4

@@ -18,7 +18,8 @@ from melspec_gpt_vqvae_amd import ops
 from melspec_gpt_vqvae_amd.vqvae.quantizer import vq_lookup
 
 DEV = "cuda:0"
-HBM_PEAK, MFMA_PEAK = 8000.0, 2500.0  # GB/s, TFLOP/s (dense bf16)
+HBM_PEAK, FP32_VALU_PEAK = 157.3  # TFLOP/s, MI355X vector fp32 (MI355X_MICROARCH.md)
+MFMA_PEAK = 8000.0, 2500.0  # GB/s, TFLOP/s (dense bf16)
 
 
 def med_ms(fn, iters=20):
@@ -69,12 +70,17 @@ def main():
                             frac_mfma_full=round(2.5 * full / ms_b / 1e9 / MFMA_PEAK, 4)))
     from melspec_gpt_vqvae_amd.feature_extraction.extract_mel_spectrogram import TRANSFORMS
 
-    for n in (8, 64):
+    # the frontend's own bound is fp32 VALU: per frame 2.5 N log2 N (real 1024-point FFT) + 16 per one-sided bin
+    # (unpacking, magnitude) + 2 per window sample and per non-zero filter weight (680) ~ 37.2 kFLOP, 862 frames
+    flop_clip = 862 * (2.5 * 1024 * 10 + 16 * 513 + 2 * 1024 + 2 * 680)
+    for n in (8, 64, 512):
         wav = 0.1 * torch.randn(n, 220500, device=DEV)
         ms = med_ms(lambda: TRANSFORMS.run(wav, tile_dtype=torch.bfloat16))
         bytes_alg = n * (220500 * 4 + 80 * 860 * 4 + 80 * 848 * 2)
         out.append(dict(kernel="mel_frontend", clips=n, us=round(ms * 1e3, 1), clips_per_s=round(n / ms * 1e3, 1),
-                        GBps=round(bytes_alg / ms / 1e6, 1), frac_hbm=round(bytes_alg / ms / 1e6 / HBM_PEAK, 4)))
+                        GBps=round(bytes_alg / ms / 1e6, 1), frac_hbm=round(bytes_alg / ms / 1e6 / HBM_PEAK, 4),
+                        TFLOPs_fp32=round(n * flop_clip / ms / 1e9, 2),
+                        frac_fp32_valu=round(n * flop_clip / ms / 1e9 / FP32_VALU_PEAK, 4)))
     for r in out:
         print(json.dumps(r))
 
