@@ -196,7 +196,8 @@ def main():
             codes = vqvae.encode_to_codes(x_mel)                 # (B,5,53) int64
             seq = ops.codes_permute(codes, 5, 53)                # (B,265) time-major (get_x)
         t1 = mark()
-        logits, _, _ = gpt(seq[:, :-1], c)                       # Lit_minGPT.forward: transformer(z[:, :-1], c)
+        with gpt.discard_att():                                  # as Lit_minGPT.forward does: the (B,H,T,T) map it
+            logits, _, _ = gpt(seq[:, :-1], c)                   # ignores (`logits, _, _ = transformer(...)`) is not written
         loss = cross_entropy(logits.reshape(-1, logits.size(-1)), seq.reshape(-1))
         t2 = mark()
         opt.zero_grad()
@@ -260,7 +261,7 @@ def main():
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/step",
                 "traffic_source": traffic_src,
                 "kernel": "MFMA GEMM family (gemm256_kernel persistent 256x256 / gemm_kernel 128x128 + implicit-GEMM conv / "
-                          "conv3x3_gn_kernel), all launches of the timed region",
+                          "conv3x3_gn_wide_kernel / conv3x3_gn_kernel with fused GroupNorm+swish), all launches of the timed region",
                 "launches_per_step": ks["launches"] // max(a.steps, 1),
                 "kernel_ms_per_step": round(ks["total_ms"] / max(a.steps, 1), 3),
                 "algorithmic_tflop_per_step": round(ks["flops"] / max(a.steps, 1) / 1e12, 3),

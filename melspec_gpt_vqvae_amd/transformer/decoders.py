@@ -21,7 +21,8 @@ class GPTDecoder(nn.Module):
 
     def forward(self, x, c=None):
         """reference :23-38: logits for p(x_i | x_<i, z); c = z (B, n_cond, C)."""
-        logits, _, _ = self.transformer(x[:, :-1], c)
+        with self.transformer.discard_att():
+            logits, _, _ = self.transformer(x[:, :-1], c)
         cond_size = c.size(-2)
         return logits[:, cond_size - 1:], x
 

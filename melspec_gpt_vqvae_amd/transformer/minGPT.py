@@ -602,12 +602,31 @@ class GPT(nn.Module):
             ps.append(self.embedder.weight)
         return ps
 
+    def discard_att(self):
+        """Context for callers that ignore forward()'s third result (`logits, _, _ = self.transformer(...)`, reference
+        :415, decoders.py:24, encoders.py:33): inside it the last block does not write the (B, H, T, T) f32 attention
+        map - 575 MB per step at the VAS training shape - and forward() returns None in its place."""
+        return _DiscardAtt(self)
+
     def forward(self, idx, embeddings=None, targets=None):
-        logits, att = self._trunk(idx, embeddings=embeddings)
+        logits, att = self._trunk(idx, embeddings=embeddings, want_att=getattr(self, "_emit_att", True))
         loss = None
         if targets is not None:
             loss = cross_entropy(logits.view(-1, logits.size(-1)), targets.view(-1))
         return logits, loss, att
+
+
+class _DiscardAtt:
+    def __init__(self, gpt):
+        self.gpt = gpt
+
+    def __enter__(self):
+        self.prev = getattr(self.gpt, "_emit_att", True)
+        object.__setattr__(self.gpt, "_emit_att", False)
+
+    def __exit__(self, *exc):
+        object.__setattr__(self.gpt, "_emit_att", self.prev)
+        return False
 
 
 class GPTClass(GPT):
@@ -620,7 +639,7 @@ class GPTClass(GPT):
         self.embedder = nn.Embedding(args.class_size, args.n_embd)
 
     def forward(self, idx, token):
-        logits, att = self._trunk(idx, pre_idx=token)
+        logits, att = self._trunk(idx, pre_idx=token, want_att=getattr(self, "_emit_att", True))
         return logits, None, att
 
 
@@ -725,7 +744,8 @@ class Lit_minGPT(_LitBase):
 
     def forward(self, x, c=None):
         """reference :260-285: logits for p(z_i | z_<i, c); the target is the full sequence."""
-        logits, _, _ = self.transformer(x[:, :-1], c)
+        with self.transformer.discard_att():
+            logits, _, _ = self.transformer(x[:, :-1], c)
         cond_size = c.size(-1)
         return logits[:, cond_size - 1:], x
 

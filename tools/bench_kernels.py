@@ -18,8 +18,8 @@ from melspec_gpt_vqvae_amd import ops
 from melspec_gpt_vqvae_amd.vqvae.quantizer import vq_lookup
 
 DEV = "cuda:0"
-HBM_PEAK, FP32_VALU_PEAK = 157.3  # TFLOP/s, MI355X vector fp32 (MI355X_MICROARCH.md)
-MFMA_PEAK = 8000.0, 2500.0  # GB/s, TFLOP/s (dense bf16)
+HBM_PEAK, MFMA_PEAK = 8000.0, 2500.0  # GB/s, TFLOP/s (dense bf16)
+FP32_VALU_PEAK = 157.3  # TFLOP/s, MI355X vector fp32
 
 
 def med_ms(fn, iters=20):
