@@ -67,12 +67,19 @@ __global__ __launch_bounds__(256) void vq_f32_kernel(const float* __restrict__ z
   const int r16 = lane & 15, g = lane >> 4;
 
   // ---- codebook -> LDS (coalesced float4, skewed rows), |e|^2 as four 64-long FMA chains per code
-  for (int i = t; i < VQ_K * VQ_D / 4; i += 256) {
-    f32x4 v = *(const f32x4*)(codebook + (size_t)i * 4);
-    int code = i >> 6, c = (i & 63) * 4;
-    float* dst = cb + code * F32_ROW + c;
-    *(f32x2*)dst = f32x2{v[0], v[1]};
-    *(f32x2*)(dst + 2) = f32x2{v[2], v[3]};
+  // (eight loads in flight per trip: a load -> store loop pays one memory round trip per element, and this staging is
+  // most of the kernel's time at small batches)
+  for (int i0 = t; i0 < VQ_K * VQ_D / 4; i0 += 256 * 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(codebook + (size_t)(i0 + 256 * u) * 4);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 256 * u, code = i >> 6, c = (i & 63) * 4;
+      float* dst = cb + code * F32_ROW + c;
+      *(f32x2*)dst = f32x2{v[u][0], v[u][1]};
+      *(f32x2*)(dst + 2) = f32x2{v[u][2], v[u][3]};
+    }
   }
   if (t < VQ_K) hist_s[t] = 0;
   __syncthreads();
@@ -236,29 +243,6 @@ __global__ __launch_bounds__(64 * B16_WAVES, EXTRAS ? 2 : 4) void vq_bf16_kernel
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int r16 = lane & 15, g = lane >> 4;
 
-  for (int q = t; q < VQ_K * 32; q += 64 * B16_WAVES) {  // 16-byte chunk q = (code, chunk)
-    const int code = q >> 5, ch = q & 31;
-    const float* e = codebook + (size_t)code * VQ_D + ch * 8;
-    f32x4 lo = *(const f32x4*)e, hi = *(const f32x4*)(e + 4);
-    *(u32x4*)(cbs + cb_off(code, ch)) =
-        u32x4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
-  }
-  if (t < VQ_K) hist_s[t] = 0;
-  __syncthreads();
-  if (t < VQ_K) {  // |e|^2: one FMA chain over the 256 rounded components (any fixed order is fine in this lane)
-    float p = 0.f;
-    for (int ch = 0; ch < 32; ++ch) {
-      u32x4 v = *(const u32x4*)(cbs + cb_off(t, ch));
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        p = fmaf(bf16lo(v[e]), bf16lo(v[e]), p);
-        p = fmaf(bf16hi(v[e]), bf16hi(v[e]), p);
-      }
-    }
-    bsq[t] = p;
-  }
-  __syncthreads();
-
   const long long ntiles = (N + 15) / 16;
   const long long stride = (long long)gridDim.x * B16_WAVES;
   float err = 0.f;
@@ -282,7 +266,40 @@ __global__ __launch_bounds__(64 * B16_WAVES, EXTRAS ? 2 : 4) void vq_bf16_kernel
   };
   u32x4 xf[8], xn[8];
   long long tile = (long long)blockIdx.x * B16_WAVES + w;
-  if (tile < ntiles) load_x(tile, xf);
+  if (tile < ntiles) load_x(tile, xf);  // the first tile's vectors fly under the codebook staging
+  {  // 16-byte chunk q = (code, chunk) of the rounded codebook; all 16 loads of a thread in flight before the first store
+    static_assert(VQ_K * 32 == 8 * 64 * B16_WAVES, "eight chunks per thread");
+    f32x4 lo[8], hi[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = t + 64 * B16_WAVES * u;
+      const float* e = codebook + (size_t)(q >> 5) * VQ_D + (q & 31) * 8;
+      lo[u] = *(const f32x4*)e;
+      hi[u] = *(const f32x4*)(e + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = t + 64 * B16_WAVES * u;
+      *(u32x4*)(cbs + cb_off(q >> 5, q & 31)) = u32x4{pack_bf16x2(lo[u][0], lo[u][1]), pack_bf16x2(lo[u][2], lo[u][3]),
+                                                      pack_bf16x2(hi[u][0], hi[u][1]), pack_bf16x2(hi[u][2], hi[u][3])};
+    }
+  }
+  if (t < VQ_K) hist_s[t] = 0;
+  __syncthreads();
+  if (t < VQ_K) {  // |e|^2: one FMA chain over the 256 rounded components (any fixed order is fine in this lane)
+    float p = 0.f;
+    for (int ch = 0; ch < 32; ++ch) {
+      u32x4 v = *(const u32x4*)(cbs + cb_off(t, ch));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        p = fmaf(bf16lo(v[e]), bf16lo(v[e]), p);
+        p = fmaf(bf16hi(v[e]), bf16hi(v[e]), p);
+      }
+    }
+    bsq[t] = p;
+  }
+  __syncthreads();
+
   for (; tile < ntiles; tile += stride) {
     const long long n = tile * 16 + r16;
     const bool valid = n < N;
