@@ -7,7 +7,7 @@
 // (every earlier token is visible to the newest one whatever n_unmasked is; eval mode, so no dropout).
 // One 64-lane wave per (batch, head): lanes own key positions for the scores and head dimensions for the output;
 // HBM-bound on the cache read (2 * (pos+1) * 64 * sizeof(T) bytes per wave).
-#include "common.h"
+#include "mma.h"
 
 namespace {
 
@@ -323,7 +323,107 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
   }
 }
 
+// ---------------------------------------------------------------------------------------------- skinny MFMA linear
+// y (M, N) = epi(x (M, K) W (N, K)^T + bias) (+ residual) for 5 .. 128 rows (decode steps at batch 5 .. 128), bf16.
+// The tiled GEMMs give such a problem one row of 128-wide tiles - 8 to 32 workgroups on a 256-CU chip - and the VALU
+// weight-streaming kernel above re-reads the weights once per 16 rows.  Here a workgroup owns 16 output columns: its
+// four waves split K in 128-element chunks, each streams its part of the 16 weight rows ONCE (A operand straight from
+// memory, 16-byte fragments) against all rows of x (B operand, from L2), MFMA 16x16x32 with the output columns on the
+// accumulator rows - so a lane ends up with 4 consecutive columns of one row; partial tiles are summed across the waves
+// in LDS in wave order (deterministic) and the epilogue runs on the summing wave.  N / 16 workgroups: 64 .. 256 for the
+// VAS layer shapes whatever M is.
+template <int MT>  // 16-row tiles of x
+__global__ __launch_bounds__(256) void linear_skinny_kernel(const bf16_t* __restrict__ x, long long ldx,
+                                                            const bf16_t* __restrict__ W, long long ldw,
+                                                            const float* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                            long long ldr, void* __restrict__ y, long long ldy, int M, int N,
+                                                            int K, int act, int out_f32) {
+  constexpr int KS = MT <= 4 ? 4 : 2;  // k-steps (32 elements) whose loads are in flight together
+  __shared__ f32x4 part[3][MT][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const bf16_t* wp = W + (long long)(n0 + r16) * ldw + 8 * g;
+  const bf16_t* xp[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) xp[mt] = x + (long long)min(16 * mt + r16, M - 1) * ldx + 8 * g;
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // wave w takes the 128-element chunks w, w + 4, ...
+  for (int k0 = 128 * w; k0 < K; k0 += 512) {
+#pragma unroll
+    for (int h = 0; h < 4 / KS; ++h) {
+      u32x4 a[KS], b[KS][MT];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int k = k0 + 32 * (KS * h + s);
+        a[s] = *(const u32x4*)(wp + k);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) b[s][mt] = *(const u32x4*)(xp[mt] + k);
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, a[s]), __builtin_bit_cast(s16x8, b[s][mt]),
+                                                            acc[mt], 0, 0, 0);
+    }
+  }
+  if (w > 0) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) part[w - 1][mt][lane] = acc[mt];
+  }
+  __syncthreads();
+  if (w == 0) {
+    // acc[mt][v] = y[16 mt + r16][n0 + 4 g + v]
+    const int n = n0 + 4 * g;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *(const f32x4*)(bias + n);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = 16 * mt + r16;
+      f32x4 v = ((acc[mt] + part[0][mt][lane]) + part[1][mt][lane]) + part[2][mt][lane];
+      v += bv;
+      if (act == MELGPT_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+      }
+      if (m < M) {
+        if (res) {
+          const u32x2 rv = *(const u32x2*)(res + (long long)m * ldr + n);
+          v += f32x4{bf16lo(rv[0]), bf16hi(rv[0]), bf16lo(rv[1]), bf16hi(rv[1])};
+        }
+        if (out_f32) *(f32x4*)((float*)y + (long long)m * ldy + n) = v;
+        else *(u32x2*)((bf16_t*)y + (long long)m * ldy + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      }
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int melgpt_linear_skinny(const void* x, long long ldx, const void* W, long long ldw, const float* bias,
+                                    const void* residual, long long ldr, void* y, long long ldy, int M, int N, int K,
+                                    int act, int dtype, int out_f32, void* stream) {
+  MELGPT_CHECK(x && W && y && M > 0 && N > 0 && K > 0, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(dtype == MELGPT_BF16 && M <= 128, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK(act == MELGPT_ACT_NONE || act == MELGPT_ACT_GELU, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK(N % 16 == 0 && K % 128 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldy % 4 == 0 && (!residual || ldr % 4 == 0),
+               MELGPT_ERR_ALIGN);
+  MELGPT_CHECK((((uintptr_t)x | (uintptr_t)W | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)bias) & 15) == 0,
+               MELGPT_ERR_ALIGN);
+  hipStream_t s = (hipStream_t)stream;
+#define MELGPT_SKINNY_LAUNCH(MT)                                                                                        \
+  hipLaunchKernelGGL((linear_skinny_kernel<MT>), dim3(N / 16), dim3(256), 0, s, (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, \
+                     bias, (const bf16_t*)residual, ldr, y, ldy, M, N, K, act, out_f32)
+  const int mt = (M + 15) / 16;
+  if (mt <= 1) MELGPT_SKINNY_LAUNCH(1);
+  else if (mt <= 2) MELGPT_SKINNY_LAUNCH(2);
+  else if (mt <= 4) MELGPT_SKINNY_LAUNCH(4);
+  else MELGPT_SKINNY_LAUNCH(8);
+#undef MELGPT_SKINNY_LAUNCH
+  return melgpt_launch_status();
+}
 
 extern "C" int melgpt_gemv_rows(const void* x, long long ldx, const void* W, long long ldw, const float* bias,
                                 const void* residual, long long ldr, void* y, long long ldy, int M, int N, int K, int act,

@@ -398,13 +398,19 @@ def linear_rows(x, w, *, bias=None, act=ACT_NONE, residual=None, out_dtype=None,
         # every workgroup re-derives the row statistics: pays for 1-4 rows (one launch less: 1.37 -> 1.26 ms per
         # 24-layer step at batch 1) but not for 16 (2.7 -> 3.6 ms) - normalise once, separately
         x, ln = layernorm_fwd(x.contiguous(), ln[0], ln[1], ln[2], want_stats=False)[0], None
-    if M > 32:  # enough rows for the MFMA tiles to pay (measured: 128 rows 5.0 vs 5.8 ms per 24-layer step)
+    skinny = x.dtype == torch.bfloat16 and 4 < M <= 128 and N % 16 == 0 and K % 128 == 0
+    if M > 32 and not skinny:  # enough rows for the MFMA tiles to pay (measured: 128 rows 5.0 vs 5.8 ms per 24-layer step)
         return gemm(x, w, bias=bias, act=act, residual=residual, out_dtype=odt)
     y = torch.empty(M, N, dtype=odt, device=x.device)
     if residual is not None:
         assert residual.shape == (M, N) and residual.dtype == x.dtype and residual.stride(1) == 1
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+    if skinny:  # 5 .. 128 bf16 rows: N / 16 workgroups stream the weights once as MFMA operands
+        call("melgpt_linear_skinny", ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(residual),
+             residual.stride(0) if residual is not None else 0, ptr(y), N, M, N, K, int(act), dtype_code(x.dtype),
+             int(odt == torch.float32), stream())
+        return y
     g = b = None
     eps = 0.0
     if ln is not None:

@@ -119,3 +119,29 @@ def test_linear_rows_weight_streaming_kernel(dt, M, N, K):
         h = F.layer_norm(xs.float(), (K,), gm, bt, 1e-5).to(torch.bfloat16).float()
     y = ops.linear_rows(xs.to(DEV), w.to(DEV), bias=b.to(DEV), ln=(gm.to(DEV), bt.to(DEV), 1e-5), out_dtype=torch.float32)
     assert rel_err(y.cpu().numpy(), (h @ w.float().T + b).numpy()) < (2e-5 if dt == "f32" else 2e-3)
+
+
+@pytest.mark.parametrize("M", [5, 16, 17, 33, 64, 100, 128])
+@pytest.mark.parametrize("N,K,act,res,f32out", [(1024, 1024, 0, True, False), (4096, 1024, 1, False, False),
+                                                (1024, 4096, 0, True, False), (128, 1024, 0, False, True)])
+def test_skinny_mfma_linear_matches_torch(M, N, K, act, res, f32out):
+    """5..128 bf16 rows go through melgpt_linear_skinny (one workgroup per 16 output columns, four waves split K);
+    same rounding points as the tiled GEMM: f32 accumulation, bias + exact-erf GELU + residual in f32, one rounding."""
+    from melspec_gpt_vqvae_amd import ops
+
+    x = (synth.normal(300 + M, (M, K)) * 0.5).astype(np.float32)
+    w = (synth.normal(301, (N, K)) * 0.05).astype(np.float32)
+    b = synth.normal(302, (N,)).astype(np.float32)
+    r = synth.normal(303, (M, N)).astype(np.float32)
+    xb, wb, rb = (t(a, DEV).to(torch.bfloat16) for a in (x, w, r))
+    y = ops.linear_rows(xb, wb, bias=t(b, DEV), act=act, residual=rb if res else None,
+                        out_dtype=torch.float32 if f32out else None)
+    ref = xb.float().cpu() @ wb.float().cpu().T + t(b)
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    if res:
+        ref = ref + rb.float().cpu()
+    assert y.dtype == (torch.float32 if f32out else torch.bfloat16) and y.shape == (M, N)
+    assert rel_err(y.float().cpu().numpy(), ref.numpy()) < (2e-5 if f32out else 6e-3)
+    y2 = ops.gemm(xb, wb, bias=t(b, DEV), act=act, residual=rb if res else None, out_dtype=torch.float32 if f32out else None)
+    assert rel_err(y.float().cpu().numpy(), y2.float().cpu().numpy()) < (2e-5 if f32out else 6e-3)
