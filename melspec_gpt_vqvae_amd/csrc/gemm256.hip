@@ -59,8 +59,24 @@ __device__ __forceinline__ u32x4 load_frag(const char* tile, int st, int ks, int
   }
 }
 
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* lds_wave_base, unsigned voff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
+// One LDS-DMA piece: 64 lanes x 16 bytes from the buffer `rs` (per-lane byte offset voff, out of range -> zeros) to the
+// 1 KiB of LDS at lds_wave_base.  Written as inline asm ON PURPOSE: hipcc models the builtin as an LDS store that is
+// complete only at vmcnt(0) and put a full `s_waitcnt vmcnt(0)` into every K unit (in front of the first LDS read, and in
+// front of the first write to the registers next to the piece's address register), draining the half-unit the ring is
+// built to keep in flight.  Instructions the compiler cannot see get no such waits; ordering is ours: the counted wait +
+// barrier of wait_vm_barrier, and the drain in front of the epilogue.  (Invisible operations can only make the
+// compiler's own vmcnt waits for the epilogue's loads longer, never shorter: the counter is in order.)
+typedef u32x4 rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc4(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  return rsrc_t{(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};  // stride 0, raw buffer (as make_rsrc)
+}
+__device__ __forceinline__ void dma16(rsrc_t rs, char* lds_wave_base, unsigned voff) {
+  const unsigned m0v = (unsigned)(size_t)LDS_PTR(char, lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :
+               : "s"(m0v), "v"(voff), "s"(rs)
+               : "memory", "m0");
 }
 
 // wait until at most N of this wave's vector-memory operations are outstanding, then workgroup barrier
@@ -135,7 +151,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
   // ---- issue cursor: source plan of the tile whose half-units are being requested.  Piece j of a wave is piece
   // w + 8 j of the half-unit; its rows are 64 j rows (ROW) / 16 j k-rows (K-major) below piece 0's, and the swizzled
   // chunk a lane fetches is the same for every j, so one base offset per operand describes all four pieces.
-  __amdgpu_buffer_rsrc_t ra, rb;
+  rsrc_t ra, rb;
   unsigned a_base0, b_base0;  // byte offset of this lane's chunk in piece 0 at k = 0, or OOB when its column is out
   int pm0 = 0, pn0 = 0;       // tile origin of the plan
   int cv_y[ALAY == LAY_CONV ? 4 : 1], cv_x[ALAY == LAY_CONV ? 4 : 1];  // LAY_CONV: per piece, top-left tap position
@@ -150,8 +166,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
     int bz = 0;
     pm0 = pn0 = 0;
     pok = live(r) && decode(r, bz, pm0, pn0);  // dead: every request is out of bounds (zero fills nobody reads)
-    ra = make_rsrc((const char*)p.A + (long long)bz * p.sA * 2, p.a_bytes);
-    rb = make_rsrc((const char*)p.B + (long long)bz * p.sB * 2, p.b_bytes);
+    ra = make_rsrc4((const char*)p.A + (long long)bz * p.sA * 2, p.a_bytes);
+    rb = make_rsrc4((const char*)p.B + (long long)bz * p.sB * 2, p.b_bytes);
     if constexpr (ALAY == LAY_KMAJ) {
       a_base0 = (pok && pm0 + k_lc * 8 < p.M) ? (unsigned)(((long long)k_row0 * p.lda + pm0) * 2) + k_lc * 16 : OOB;
     } else if constexpr (ALAY == LAY_CONV) {
@@ -178,7 +194,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
   };
   // piece j (of PER) of one operand's half-unit u: `lay`-layout source with leading dimension ld, tile origin o0 of
   // extent lim
-  auto issue_piece = [&](auto lay, __amdgpu_buffer_rsrc_t rs, unsigned base0, long long ld, int o0, int lim, int u,
+  auto issue_piece = [&](auto lay, rsrc_t rs, unsigned base0, long long ld, int o0, int lim, int u,
                          char* dst, int j) {
     const int k0 = u * KU;
     unsigned off;
@@ -247,7 +263,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
 #pragma unroll
       for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int u = 0; u < nu; ++u) {
+    auto unit = [&](int u) {
       // H(2u), H(2u+1) must have landed for every wave and every wave must be past its reads of unit u-1, whose two
       // slots are refilled now.  One younger half-unit (an A half: PER_A operations) may still be in flight.  The half-units
       // requested before the previous tile's epilogue were drained there (vmcnt(0)): barrier only.
@@ -310,7 +326,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
         for (int j = 0; j < PER_A; ++j) issue_a_piece(iu, dst_a, j);
       }
       slot = slot + 2 >= NSLOT ? slot + 2 - NSLOT : slot + 2;
-    }
+    };
+    // The first unit of a tile is peeled off the loop: the registers that held the previous tile's epilogue loads are
+    // re-used by the loop body, the compiler guards their first re-use with a vector-memory wait, and inside the loop
+    // that wait would run - and drain the ring - on every unit.
+    unit(0);
+    for (int u = 1; u < nu; ++u) unit(u);
     first = false;
     if ((G256_LAB & 8)) ts1 = __builtin_amdgcn_s_memtime();
     // this wave's pieces of the next three half-units have landed; every wave is past its reads of the last unit,
@@ -406,7 +427,11 @@ int launch_mode(const GemmParams& p, int batch, hipStream_t s) {
       const char* e = getenv("MELGPT_GEMM_TM");
       forced = e ? atoi(e) : 0;
     }
-    if (forced == 6 || (forced != 8 && cost(192, 6) < cost(256, 8))) return launch_tm<ALAY, BLAY, MODE, 6>(p, batch, ncu, s);
+    // the full-epilogue kernel with a K-major B operand spills 8 VGPRs at 256 rows, and its reloads sit in the K loop
+    // where their vmcnt(0) drains the ring on every unit (GELU' dgrad: 11.1 -> 15.3 ms per step): ties go to 192 rows
+    const bool tie6 = MODE == EPI_FULL16 && BLAY == LAY_KMAJ;
+    const long long c6 = cost(192, 6), c8 = cost(256, 8);
+    if (forced == 6 || (forced != 8 && (c6 < c8 || (tie6 && c6 == c8)))) return launch_tm<ALAY, BLAY, MODE, 6>(p, batch, ncu, s);
   }
   return launch_tm<ALAY, BLAY, MODE, 8>(p, batch, ncu, s);
 }
