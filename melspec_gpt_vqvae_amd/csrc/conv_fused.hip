@@ -206,7 +206,11 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
   const int kpt = Cin / KSTEP, nk = 9 * kpt;
 
   // weight ring: stage s <- K-step (kg % nk); 16 pieces of 1 KiB per stage, two per wave
-  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+  // (the pieces are issued by an asm block, not the builtin: hipcc completes the builtin's LDS write only at vmcnt(0) and
+  // put that wait in front of every K-step's fragment reads, draining the ring and the next tile's patch loads - see
+  // dma16 in gemm256.hip)
+  const unsigned long long wb_addr = (unsigned long long)p.B;
+  const u32x4 rb = {(unsigned)wb_addr, (unsigned)(wb_addr >> 32) & 0xFFFFu, p.b_bytes, 0x00020000u};
   unsigned b_base[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -217,9 +221,14 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
   auto issue_w = [&]() {
     const int kt = kg_issue % nk, st = kg_issue & (WNST - 1);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(wring + st * 16384 + (w + 8 * i) * 1024),
-                                               16, b_base[i] == OOB ? OOB : b_base[i] + kt * KSTEP * ES, 0, 0, 0);
+    for (int i = 0; i < 2; ++i) {
+      const unsigned m0v = (unsigned)(size_t)LDS_PTR(char, wring + st * 16384 + (w + 8 * i) * 1024);
+      const unsigned voff = b_base[i] == OOB ? OOB : b_base[i] + kt * KSTEP * ES;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                   :
+                   : "s"(m0v), "v"(voff), "s"(rb)
+                   : "memory", "m0");
+    }
     ++kg_issue;
   };
   issue_w();
