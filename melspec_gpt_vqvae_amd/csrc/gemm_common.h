@@ -319,16 +319,43 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
       // one copy of the batch body: a uniform switch copies the batch's accumulators and row origins out of the
       // register arrays
       static_assert(!ROLLED || (NB == 2 && TM % 2 == 0 && TM <= 8), "rolled epilogue: up to four batches of two slabs");
-#pragma clang loop unroll(disable)
-      for (int b = 0; b < NBATCH; ++b) {
-        long long mr[NB];
+      // R is fetched ONE BATCH AHEAD into a second register set (the persistent kernel's LDS-DMA is invisible to the
+      // compiler now, so a fetch issued between two uses keeps flying - before, hipcc drained vmcnt(0) at every use)
+      auto rows_of = [&](int b, long long (&mr)[NB]) {
 #pragma clang loop unroll(full)
         for (int k = 0; k < NB; ++k) {
           mr[k] = mrow[k];
 #pragma clang loop unroll(full)
           for (int q = 1; q < NBATCH; ++q) mr[k] = b == q ? mrow[q * NB + k] : mr[k];
         }
-        if (Rb) {
+      };
+      // (only for the 192-row tile: at 256 rows the second set does not fit the register file - 30 spilled VGPRs)
+      constexpr bool AHEAD = TM <= 6;
+      u32x4 rnx[AHEAD ? NB : 1][NR];
+      if (AHEAD && Rb) {
+        long long mr0[NB];
+        rows_of(0, mr0);
+#pragma clang loop unroll(full)
+        for (int k = 0; k < NB; ++k) fetch_r(mr0[k], rnx[AHEAD ? k : 0]);
+      }
+#pragma clang loop unroll(disable)
+      for (int b = 0; b < NBATCH; ++b) {
+        long long mr[NB];
+        rows_of(b, mr);
+        if constexpr (AHEAD) {
+          if (Rb) {
+#pragma clang loop unroll(full)
+            for (int k = 0; k < NB; ++k)
+#pragma clang loop unroll(full)
+              for (int j = 0; j < NR; ++j) rin[k][j] = rnx[AHEAD ? k : 0][j];
+            if (b + 1 < NBATCH) {
+              long long mn[NB];
+              rows_of(b + 1, mn);
+#pragma clang loop unroll(full)
+              for (int k = 0; k < NB; ++k) fetch_r(mn[k], rnx[AHEAD ? k : 0]);
+            }
+          }
+        } else if (Rb) {
 #pragma clang loop unroll(full)
           for (int k = 0; k < NB; ++k) fetch_r(mr[k], rin[k]);
         }

@@ -7,14 +7,17 @@
 #include "../../melspec_gpt_vqvae_amd/csrc/gemm256.hip"
 
 
+static int g_pad = 0;  // extra elements in the leading dimension of row-major operands (address-stride experiments)
 static float run(int alay, int blay, int M, int N, int K, int cfg, int iters, int full = 0) {
   void *A, *B, *C;
-  hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&B, (size_t)N * K * 2); hipMalloc(&C, (size_t)M * N * 2);
-  hipMemset(A, 0x3c, (size_t)M * K * 2); hipMemset(B, 0x3c, (size_t)N * K * 2);
+  const size_t lda = alay == LAY_KMAJ ? M : K + g_pad, ldb = blay == LAY_KMAJ ? N : K + g_pad;
+  const size_t an = (alay == LAY_KMAJ ? (size_t)K : (size_t)M) * lda, bn = (blay == LAY_KMAJ ? (size_t)K : (size_t)N) * ldb;
+  hipMalloc(&A, an * 2); hipMalloc(&B, bn * 2); hipMalloc(&C, (size_t)M * N * 2);
+  hipMemset(A, 0x3c, an * 2); hipMemset(B, 0x3c, bn * 2);
   GemmParams p{};
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
-  p.lda = alay == LAY_KMAJ ? M : K; p.ldb = blay == LAY_KMAJ ? N : K; p.ldc = N; p.ldr = N;
-  p.a_bytes = (unsigned)((size_t)M * K * 2); p.b_bytes = (unsigned)((size_t)N * K * 2);
+  p.lda = lda; p.ldb = ldb; p.ldc = N; p.ldr = N;
+  p.a_bytes = (unsigned)(an * 2); p.b_bytes = (unsigned)(bn * 2);
   p.alpha = 1.f; p.vec_io = 1;
   void *C2 = nullptr, *R = nullptr; float* bias = nullptr;
   if (full) {
@@ -92,11 +95,13 @@ int main(int argc, char** argv) {
       {"nn fc2d", LAY_ROW, LAY_KMAJ, 33920, 4096, 1024}, {"nn fc1d", LAY_ROW, LAY_KMAJ, 33920, 1024, 4096},
       {"tn wfc1", LAY_KMAJ, LAY_KMAJ, 4096, 4096, 8192},
       {"nt sq8k", LAY_ROW, LAY_ROW, 8192, 8192, 8192}};
-  for (auto& s : shapes)
-    for (int cfg = 3; cfg <= 3; ++cfg) {
-      float ms = run(s.al, s.bl, s.M, s.N, s.K, cfg, 10);
-      printf("lab=%d %s cfg=%d  %8.3f ms  %7.1f TFLOP/s\n", G256_LAB, s.name, cfg, ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
+  for (int pad : {0, 64, 8})
+    for (auto& s : shapes) {
+      g_pad = pad;
+      float ms = run(s.al, s.bl, s.M, s.N, s.K, 3, 10);
+      printf("lab=%d pad=%2d %s  %8.3f ms  %7.1f TFLOP/s\n", G256_LAB, pad, s.name, ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
     }
+  g_pad = 0;
   if (G256_LAB == 0) {
     printf("fc1 +bias+gelu+C2     %8.3f ms\n", run(LAY_ROW, LAY_ROW, 33920, 4096, 1024, 3, 10, 1));
     printf("proj +bias+drop+R     %8.3f ms\n", run(LAY_ROW, LAY_ROW, 33920, 1024, 1024, 3, 10, 2));
