@@ -60,7 +60,12 @@ def main():
     gem = [v for k, v in table if "gemm" in k or "conv3x3_gn" in k]
     js = dict(tag=tag, gemm_family_ms=sum(v["ns"] for v in gem) / 1e6,
               gemm_family_hbm_read_MB=sum(2 * v["fetch_kib"] for v in gem) / 1024,
-              gemm_family_hbm_write_MB=sum(v["write_kib"] for v in gem) / 1024, all_kernels_ms=tot_ns / 1e6)
+              gemm_family_hbm_write_MB=sum(v["write_kib"] for v in gem) / 1024, all_kernels_ms=tot_ns / 1e6,
+              steps_profiled=int(os.environ.get("PROFILE_STEPS", "5")),  # tools/profile_round.sh: --steps 3 --warmup 2
+              command="rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE (three separate runs) -- "
+                      "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline",
+              note="hbm_read = 2 x FETCH_SIZE (gfx950 counts wide coalesced reads at half their bytes), hbm_write = "
+                   "WRITE_SIZE; KiB -> MB; GEMM family = gemm256_kernel + gemm_kernel + conv3x3_gn*_kernel")
     json.dump(js, open(os.path.join(root, f"summary_{tag}.json"), "w"), indent=1)
     print(open(out_csv).read()[:4000])
     print(json.dumps(js))
