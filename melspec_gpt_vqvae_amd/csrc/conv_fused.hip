@@ -232,8 +232,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
     ++kg_issue;
   };
   issue_w();
-  issue_w();
-  issue_w();
+  issue_w();  // the first PAIR of K-steps (the K loop below works in pairs: one barrier per two steps)
   int kg = 0;  // K-step being multiplied
 
   // raw input chunks of a tile: requested one tile AHEAD (during the previous tile's K loop), so the staging pass below
@@ -315,31 +314,38 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int kt = 0; kt < nk; ++kt, ++kg) {
-      // this wave's pieces of K-step kg have landed (two younger stages = 4 pieces may be in flight); after the barrier
-      // everybody's have, and everybody is past K-step kg-1, whose stage is refilled now
-      // (the next tile's MAXCH patch loads were issued just before this loop: for the first three K-steps they are
-      // younger than the weight pieces waited for and stay in flight; from the fourth on they are older)
-      if (kt < WNST - 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 + MAXCH) : "memory");
-      else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // Two K-steps per barrier (nk is even: the launcher checks): the ring's four stages are two pairs - while pair p is
+    // multiplied pair p + 1 lands in the stages pair p - 1 was read from.  At one barrier per 64-wide step the SIMD's two
+    // waves spent as long waiting (barrier skew + the fragment reads right behind it) as multiplying.
+    for (int pr = 0; pr < nk / 2; ++pr) {
+      // this wave's pieces of the pair have landed; after the barrier everybody's have, and everybody is past the
+      // previous pair, whose two stages are refilled now.  (The next tile's MAXCH patch loads were issued just before
+      // this loop: younger than the first pair's pieces - they stay in flight - and older than all later ones.)
+      if (pr == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(MAXCH) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       issue_w();
-      const int tap = kt / kpt, kc = kt - tap * kpt;
-      const int ky = tap / 3, kx = tap - ky * 3;
-      const char* sb = wring + (kg & (WNST - 1)) * 16384;
+      issue_w();
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        u32x4 fa[4], fb[4];
+      for (int hh = 0; hh < 2; ++hh, ++kg) {
+        const int kt = 2 * pr + hh;
+        const int tap = kt / kpt, kc = kt - tap * kpt;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const char* sb = wring + (kg & (WNST - 1)) * 16384;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const int pix = (wm * 4 + mt + ky) * WPW + i16 + kx;  // output row (wm*4+mt), shifted by the tap
-          fa[mt] = *(const u32x4*)(patch + patch_off<T>(pix, kc * 8 + 4 * ks + g, pix_bytes));
+        for (int ks = 0; ks < 2; ++ks) {
+          u32x4 fa[4], fb[4];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const int pix = (wm * 4 + mt + ky) * WPW + i16 + kx;  // output row (wm*4+mt), shifted by the tap
+            fa[mt] = *(const u32x4*)(patch + patch_off<T>(pix, kc * 8 + 4 * ks + g, pix_bytes));
+          }
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) fb[nt] = *(const u32x4*)(sb + row_off((wn * 4 + nt) * 16 + i16, 4 * ks + g));
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) mma<T>(acc[mt][nt], fb[nt], fa[mt]);
         }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) fb[nt] = *(const u32x4*)(sb + row_off((wn * 4 + nt) * 16 + i16, 4 * ks + g));
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) mma<T>(acc[mt][nt], fb[nt], fa[mt]);
       }
     }
 #if CONVW_LAB
@@ -446,6 +452,7 @@ extern "C" int melgpt_conv3x3_gn_nhwc(const void* x, int B, int H, int W, int Ci
   // 16-row tiles pay for the rows they pad: take them only while they compute at most 1/4 more pixels than 8-row tiles
   const long long wide_px = wide_tiles * WTH * WTW, narrow_px = (long long)q.tiles_x * q.tiles_y * B * TH * TW;
   if (!wide_off && wide_lds <= 160 * 1024 && wide_tiles >= 512 && wide_px * 4 <= narrow_px * 5 && q.g.vec_io &&
+      (9 * (Cin / 64)) % 2 == 0 &&
       M * Cin * 2 < 0xFFFFFF00LL) {
     q.x_bytes = (unsigned)(M * Cin * 2);
     return launch_fused_wide(q, B, s);
