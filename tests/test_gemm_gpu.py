@@ -266,3 +266,21 @@ def test_conv_on_wide_kernel_at_size(case):
                         residual=res.to(DEV))
     assert y.shape == ref.shape
     assert rel_err(y.float().cpu().numpy(), (ref + res.float()).numpy()) < 2 ** -8
+
+
+@pytest.mark.parametrize("ak,bk,M,N,K", [(False, False, 33920, 1024, 1024), (False, True, 8192, 1024, 4096),
+                                         (True, True, 4096, 1024, 8480)])
+def test_wide_kernel_is_bit_reproducible(ak, bk, M, N, K):
+    """The persistent kernel's LDS-DMA ring is ordered by hand (inline-asm pieces, counted waits, one barrier per K
+    unit): a missing wait would read a half-landed tile - noise from run to run.  Twenty repeats must be bit-identical
+    and agree with an f32 product of the same bf16 operands."""
+    from melspec_gpt_vqvae_amd import ops
+
+    torch.manual_seed(5)
+    a = torch.randn((K, M) if ak else (M, K), device=DEV).bfloat16()
+    b = torch.randn((K, N) if bk else (N, K), device=DEV).bfloat16()
+    ref = ops.gemm(a, b, a_kmajor=ak, b_kmajor=bk)
+    for _ in range(20):
+        assert torch.equal(ops.gemm(a, b, a_kmajor=ak, b_kmajor=bk), ref)
+    r32 = (a.float().T if ak else a.float()) @ (b.float() if bk else b.float().T)
+    assert float((ref.float() - r32).abs().max() / r32.abs().max()) < 6e-3
