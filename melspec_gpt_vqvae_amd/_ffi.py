@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libmelgpt_hip.so")
 
 F32, BF16 = 0, 1
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+ERR_UNSUPPORTED = -2  # MELGPT_ERR_UNSUPPORTED (include/melgpt.h)
 _u64 = C.c_uint64
 
 
@@ -78,6 +79,9 @@ _PROTOS = {
     "melgpt_mel_frontend_fwd": [_p, _i, _l, _i, _i, _p, _p, _p, _i, _f, _f, _f, _f, _f, _f, _f, _p, _i, _p, _i, _i, _i,
                                 _p],
     "melgpt_conv3x3_gn_nhwc": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _p],
+    "melgpt_conv3x3_gn_stats_workspace": [_i, _i, _i],
+    "melgpt_conv3x3_gn_nhwc_stats": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i, _f, _p, _p, _p, _p],
+    "melgpt_groupnorm_finalize": [_p, _i, _i, C.c_double, _f, _p, _p, _p],
 }
 _RESTYPE = {"melgpt_strerror": C.c_char_p}
 

@@ -32,6 +32,7 @@ struct FusedConvParams {
   const float* beta;
   int H, W, Cin, swish, tiles_x, tiles_y;
   unsigned x_bytes;      // addressable bytes of x (persistent kernel: patch loads through a buffer resource)
+  float* stat_part;      // persistent kernel, optional: (B, tiles_y*tiles_x, 32, 2) sum / sum of squares of the OUTPUT
 };
 
 template <typename T>
@@ -189,6 +190,9 @@ __device__ unsigned long long melgpt_convw_dbg[64];
 
 constexpr int WTH = 16, WTW = 16, WPH = WTH + 2, WPW = WTW + 2, WNPIX = WPH * WPW, WNST = 4;
 
+// STATS: also emit the GroupNorm partial sums of the output tile (a separate instance: its extra live values would cost
+// the plain one 8 spilled VGPRs)
+template <bool STATS>
 __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q, int total_tiles) {
   typedef bf16_t T;
   constexpr int ES = 2, KSTEP = 64, VEC = 8;
@@ -198,6 +202,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
   char* patch = smem;                                        // [324][Cin] swizzled (also the epilogue's staging)
   char* wring = smem + (size_t)WNPIX * pix_bytes;            // [4][128 rows x 128 B]
   float* ab = (float*)(wring + WNST * 16384);                // [Cin][2]
+  float* stp = ab + 2 * Cin;                                 // [4 wm][32 groups][2]: output statistics of a tile
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w >> 1, wn = w & 1;
   const int i16 = lane & 15, g = lane >> 4;
@@ -352,6 +357,51 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
     st2 = __builtin_amdgcn_s_memtime();
 #endif
     asm volatile("s_barrier" ::: "memory");  // everybody is done reading the patch: it becomes the epilogue's staging
+    if constexpr (STATS) {
+      // GroupNorm(32) statistics of THIS conv's output (Cout = 128: a lane's four consecutive channels are one group),
+      // taken on the values as they are stored (bias added, rounded to bf16): the next ResnetBlock norm then needs no
+      // pass over the 2.2 GB tensor.  Per tile a (32, 2) partial, summed across the four pixel-row waves in wave
+      // order; melgpt_groupnorm_finalize adds the tiles of an image in tile order.
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+      const bool xin = x0 + i16 < q.W;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wn * 64 + nt * 16 + g * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          if (xin && y0 + wm * 4 + mt < q.H) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float v = bf16_to_f32(f32_to_bf16(acc[mt][nt][e] + bv[e]));
+              s1[nt] += v;
+              s2[nt] = fmaf(v, v, s2[nt]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          s1[nt] += __shfl_xor(s1[nt], o, 64);
+          s2[nt] += __shfl_xor(s2[nt], o, 64);
+        }
+      if (i16 == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int grp = wn * 16 + nt * 4 + g;
+          stp[(wm * 32 + grp) * 2] = s1[nt];
+          stp[(wm * 32 + grp) * 2 + 1] = s2[nt];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (w == 0) {
+        const float v = ((stp[lane] + stp[64 + lane]) + stp[128 + lane]) + stp[192 + lane];
+        q.stat_part[(long long)tile * 64 + lane] = v;  // tile = (b * tiles_y + ty) * tiles_x + tx
+      }
+    }
     long long mrow[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -378,15 +428,17 @@ int launch_fused_wide(const FusedConvParams& q0, int B, hipStream_t s) {
   FusedConvParams q = q0;
   q.tiles_x = (q.W + WTW - 1) / WTW;
   q.tiles_y = (q.H + WTH - 1) / WTH;
-  const size_t lds = (size_t)WNPIX * q.Cin * 2 + WNST * 16384 + (size_t)q.Cin * 8;
+  const size_t lds = (size_t)WNPIX * q.Cin * 2 + WNST * 16384 + (size_t)q.Cin * 8 + 1024;
   static int ncu = 0;
   if (!ncu) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
       return MELGPT_ERR_LAUNCH;
-    if (hipFuncSetAttribute((const void*)conv3x3_gn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-        hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3x3_gn_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv3x3_gn_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
       return MELGPT_ERR_LAUNCH;
     ncu = n;
   }
@@ -396,7 +448,12 @@ int launch_fused_wide(const FusedConvParams& q0, int B, hipStream_t s) {
   int gx = ncu / gy;
   if (gx < 1) gx = 1;
   if (gx > total) gx = (int)total;
-  hipLaunchKernelGGL(conv3x3_gn_wide_kernel, dim3(gx, gy), dim3(512), lds, s, q, (int)total);
+  if (q.stat_part) {
+    if (gy != 1) return MELGPT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(conv3x3_gn_wide_kernel<true>, dim3(gx, gy), dim3(512), lds, s, q, (int)total);
+  } else {
+    hipLaunchKernelGGL(conv3x3_gn_wide_kernel<false>, dim3(gx, gy), dim3(512), lds, s, q, (int)total);
+  }
   return melgpt_launch_status();
 }
 
@@ -419,9 +476,14 @@ int launch_fused(const FusedConvParams& q, int B, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int melgpt_conv3x3_gn_nhwc(const void* x, int B, int H, int W, int Cin, const float* mean, const float* rstd,
-                                      const float* gamma, const float* beta, int swish, const void* wpack, int Cout,
-                                      const float* bias, const void* residual, void* y, int dtype, void* stream) {
+extern "C" int melgpt_groupnorm_finalize(const float* partial, int nchunks, int B, double count, float eps, float* mean,
+                                         float* rstd, void* stream);
+
+// stat_part != null: the output's GroupNorm partials are wanted; MELGPT_ERR_UNSUPPORTED (nothing launched) when this
+// configuration does not run on the persistent kernel or the lane-to-group mapping does not hold
+static int conv3x3_gn_impl(const void* x, int B, int H, int W, int Cin, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, int swish, const void* wpack, int Cout,
+                           const float* bias, const void* residual, void* y, int dtype, float* stat_part, void* stream) {
   MELGPT_CHECK(x && wpack && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, MELGPT_ERR_BAD_ARG);
   MELGPT_CHECK(dtype == MELGPT_F32 || dtype == MELGPT_BF16, MELGPT_ERR_UNSUPPORTED);
   MELGPT_CHECK((mean == nullptr) == (rstd == nullptr), MELGPT_ERR_BAD_ARG);
@@ -443,9 +505,11 @@ extern "C" int melgpt_conv3x3_gn_nhwc(const void* x, int B, int H, int W, int Ci
   q.H = H; q.W = W; q.Cin = Cin; q.swish = swish;
   q.tiles_x = (W + TW - 1) / TW; q.tiles_y = (H + TH - 1) / TH;
   hipStream_t s = (hipStream_t)stream;
+  q.stat_part = stat_part;
+  if (stat_part && (dtype != MELGPT_BF16 || Cout != 128 || residual)) return MELGPT_ERR_UNSUPPORTED;
   if (dtype == MELGPT_F32) return launch_fused<float>(q, B, s);
   // narrow bf16 layers with plenty of 16 x 16 tiles: the persistent kernel with the weight ring
-  const size_t wide_lds = (size_t)WNPIX * Cin * 2 + WNST * 16384 + (size_t)Cin * 8;
+  const size_t wide_lds = (size_t)WNPIX * Cin * 2 + WNST * 16384 + (size_t)Cin * 8 + 1024;
   const long long wide_tiles = (long long)((W + WTW - 1) / WTW) * ((H + WTH - 1) / WTH) * B;
   static int wide_off = -1;
   if (wide_off < 0) wide_off = getenv("MELGPT_CONV_WIDE") && atoi(getenv("MELGPT_CONV_WIDE")) == 0;
@@ -457,5 +521,30 @@ extern "C" int melgpt_conv3x3_gn_nhwc(const void* x, int B, int H, int W, int Ci
     q.x_bytes = (unsigned)(M * Cin * 2);
     return launch_fused_wide(q, B, s);
   }
+  if (stat_part) return MELGPT_ERR_UNSUPPORTED;
   return launch_fused<bf16_t>(q, B, s);
+}
+
+extern "C" int melgpt_conv3x3_gn_nhwc(const void* x, int B, int H, int W, int Cin, const float* mean, const float* rstd,
+                                      const float* gamma, const float* beta, int swish, const void* wpack, int Cout,
+                                      const float* bias, const void* residual, void* y, int dtype, void* stream) {
+  return conv3x3_gn_impl(x, B, H, W, Cin, mean, rstd, gamma, beta, swish, wpack, Cout, bias, residual, y, dtype, nullptr,
+                         stream);
+}
+
+extern "C" int melgpt_conv3x3_gn_stats_workspace(int B, int H, int W) {
+  return B * ((W + WTW - 1) / WTW) * ((H + WTH - 1) / WTH) * 64;
+}
+
+extern "C" int melgpt_conv3x3_gn_nhwc_stats(const void* x, int B, int H, int W, int Cin, const float* mean,
+                                            const float* rstd, const float* gamma, const float* beta, int swish,
+                                            const void* wpack, int Cout, const float* bias, void* y, int dtype,
+                                            float out_eps, float* out_mean, float* out_rstd, float* workspace,
+                                            void* stream) {
+  MELGPT_CHECK(out_mean && out_rstd && workspace, MELGPT_ERR_BAD_ARG);
+  int st = conv3x3_gn_impl(x, B, H, W, Cin, mean, rstd, gamma, beta, swish, wpack, Cout, bias, nullptr, y, dtype, workspace,
+                           stream);
+  if (st != MELGPT_OK) return st;
+  const int nchunks = ((W + WTW - 1) / WTW) * ((H + WTH - 1) / WTH);
+  return melgpt_groupnorm_finalize(workspace, nchunks, B, (double)H * W * (Cout / 32), out_eps, out_mean, out_rstd, stream);
 }

@@ -316,6 +316,14 @@ extern "C" int melgpt_groupnorm_stats(const void* x, int B, int HW, int C, float
   return melgpt_launch_status();
 }
 
+extern "C" int melgpt_groupnorm_finalize(const float* partial, int nchunks, int B, double count, float eps, float* mean,
+                                         float* rstd, void* stream) {
+  MELGPT_CHECK(partial && mean && rstd && nchunks > 0 && B > 0 && count > 0, MELGPT_ERR_BAD_ARG);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * GN_GROUPS + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial,
+                     nchunks, B, count, eps, mean, rstd);
+  return melgpt_launch_status();
+}
+
 extern "C" int melgpt_groupnorm_apply(const void* x, const float* mean, const float* rstd, const float* gamma,
                                       const float* beta, void* y, int B, int HW, int C, int swish, int dtype,
                                       void* stream) {

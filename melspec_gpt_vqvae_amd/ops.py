@@ -504,6 +504,31 @@ def conv3x3_gn(x, stats, gamma, beta, wpack, bias, *, swish=True, residual=None)
     return out
 
 
+def conv3x3_gn_with_out_stats(x, stats, gamma, beta, wpack, bias, out_eps, *, swish=True):
+    """conv3x3_gn that also returns the GroupNorm(32) statistics (mean, rstd) of its OUTPUT, accumulated in the conv's
+    epilogue (the next norm of a ResnetBlock then needs no pass over the tensor).  Returns None when this shape does
+    not run on the persistent fused kernel (bf16, Cout 128, no residual) - nothing has been launched then."""
+    B, H, W, Cin = x.shape
+    Cout = wpack.shape[0]
+    if x.dtype != torch.bfloat16 or Cout != 128:
+        return None
+    assert x.is_contiguous() and wpack.is_contiguous() and wpack.shape[1:] == (3, 3, Cin) and wpack.dtype == x.dtype
+    L = _ffi.lib()
+    ws = workspace(L.melgpt_conv3x3_gn_stats_workspace(B, H, W), x.device)
+    out = torch.empty(B, H, W, Cout, dtype=x.dtype, device=x.device)
+    omean = torch.empty(B * 32, dtype=torch.float32, device=x.device)
+    orstd = torch.empty(B * 32, dtype=torch.float32, device=x.device)
+    mean, rstd = stats if stats is not None else (None, None)
+    with _timed(2.0 * B * H * W * Cout * 9 * Cin, f"conv3x3+gn {H}x{W} {Cin}->{Cout}"):
+        code = L.melgpt_conv3x3_gn_nhwc_stats(ptr(x), B, H, W, Cin, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), int(swish),
+                                              ptr(wpack), Cout, ptr(bias), ptr(out), dtype_code(x.dtype), float(out_eps),
+                                              ptr(omean), ptr(orstd), ptr(ws), stream())
+    if code == _ffi.ERR_UNSUPPORTED:
+        return None
+    _ffi.check(code, "melgpt_conv3x3_gn_nhwc_stats")
+    return out, (omean, orstd)
+
+
 def groupnorm(x, gamma, beta, eps=1e-6, swish=True):
     """x (B,H,W,C) contiguous -> GroupNorm(32) [+ swish]."""
     B, H, W, C = x.shape

@@ -94,14 +94,26 @@ def _gn(norm, h, swish):
     return ops.groupnorm(h, _f32(norm.weight), _f32(norm.bias), norm.eps, swish=swish)
 
 
-def _gn_swish_conv3x3(norm, conv, h, residual=None):
+def _gn_swish_conv3x3(norm, conv, h, residual=None, stats=None, next_norm=None):
     """norm -> swish -> 3x3 conv (reference :117-119 / :124-127).  One fused halo-tiled launch when the input patch
-    fits LDS (the normalised tensor then never exists in HBM), else GroupNorm-apply followed by the implicit-GEMM conv."""
+    fits LDS (the normalised tensor then never exists in HBM), else GroupNorm-apply followed by the implicit-GEMM conv.
+    stats: (mean, rstd) of h for `norm` if a previous launch already produced them.  next_norm: the GroupNorm that will
+    be applied to THIS conv's output - returns (y, its statistics or None) instead of y."""
+    out_stats = None
     if conv.kernel_size[0] == 3 and conv.stride[0] == 1 and ops.fused_conv_supported(h.shape[-1], h.dtype, occupancy=2):
-        stats = ops.groupnorm_stats(h, norm.eps)
-        return ops.conv3x3_gn(h, stats, _f32(norm.weight), _f32(norm.bias), _packed_weight(conv, h.dtype), _f32(conv.bias),
-                              swish=True, residual=residual)
-    return _conv(conv, _gn(norm, h, True), residual=residual)
+        if stats is None:
+            stats = ops.groupnorm_stats(h, norm.eps)
+        args = (h, stats, _f32(norm.weight), _f32(norm.bias), _packed_weight(conv, h.dtype), _f32(conv.bias))
+        y = None
+        if next_norm is not None and residual is None:
+            r = ops.conv3x3_gn_with_out_stats(*args, next_norm.eps, swish=True)
+            if r is not None:
+                y, out_stats = r
+        if y is None:
+            y = ops.conv3x3_gn(*args, swish=True, residual=residual)
+    else:
+        y = _conv(conv, _gn(norm, h, True), residual=residual)
+    return (y, out_stats) if next_norm is not None else y
 
 
 class ResnetBlock(nn.Module):
@@ -126,12 +138,12 @@ class ResnetBlock(nn.Module):
 
     def _nhwc(self, h):
         """reference :114-135 on an NHWC tensor (temb is None on this path, dropout p = 0)."""
-        t = _gn_swish_conv3x3(self.norm1, self.conv1, h)
+        t, t_stats = _gn_swish_conv3x3(self.norm1, self.conv1, h, next_norm=self.norm2)
         if self.in_channels != self.out_channels:
             sc = _conv(self.conv_shortcut if self.use_conv_shortcut else self.nin_shortcut, h)
         else:
             sc = h
-        return _gn_swish_conv3x3(self.norm2, self.conv2, t, residual=sc)
+        return _gn_swish_conv3x3(self.norm2, self.conv2, t, residual=sc, stats=t_stats)
 
     def forward(self, x, temb):
         assert temb is None, "the mel VQ-VAE has no timestep embedding (temb_ch = 0, reference :196)"

@@ -180,6 +180,32 @@ def test_fused_groupnorm_swish_conv3x3(dt, H, W, Cin, Cout, B):
     assert rel_err(y2.float().cpu().numpy(), ref2.numpy()) < (2e-5 if dt == "f32" else 8e-3)
 
 
+@pytest.mark.parametrize("H,W,B", [(80, 848, 8), (40, 424, 9), (37, 250, 16)])
+def test_fused_conv_also_yields_groupnorm_stats_of_its_output(H, W, B):
+    """bf16, 128 -> 128, no residual: the persistent fused conv accumulates the GroupNorm(32) statistics of its own
+    output in its epilogue (melgpt_conv3x3_gn_nhwc_stats).  Same tensor as the plain call, statistics equal to a
+    separate melgpt_groupnorm_stats pass over it (edge tiles and padded rows included)."""
+    from melspec_gpt_vqvae_amd import ops
+
+    C = 128
+    x = t(synth.normal(11, (B, H, W, C), 1.1, 0.3)).to(torch.bfloat16).to(DEV)
+    w = t(synth.normal(12, (C, C, 3, 3), 0.03)).to(torch.bfloat16)
+    bias = t(synth.normal(13, (C,), 0.2)).to(DEV)
+    gm, bt = t(synth.normal(14, (C,), 0.1, 1.0)).to(DEV), t(synth.normal(15, (C,), 0.1)).to(DEV)
+    wp = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    stats = ops.groupnorm_stats(x, 1e-6)
+    r = ops.conv3x3_gn_with_out_stats(x, stats, gm, bt, wp, bias, 1e-6, swish=True)
+    y0 = ops.conv3x3_gn(x, stats, gm, bt, wp, bias, swish=True)
+    if r is None:
+        pytest.skip("this shape does not run on the persistent fused kernel")
+    y, (mean, rstd) = r
+    assert torch.equal(y, y0)
+    m2, r2 = ops.groupnorm_stats(y, 1e-6)
+    assert float((mean - m2).abs().max()) < 2e-5 * max(1.0, float(m2.abs().max()))
+    assert float(((rstd - r2) / r2).abs().max()) < 1e-4
+    assert ops.conv3x3_gn_with_out_stats(x.float(), None, None, None, wp.float(), bias, 1e-6, swish=False) is None
+
+
 def test_extract_codes_writes_reference_named_files(tmp_path):
     """feature_extraction/extract_codes.py (:31-56): <class>/melspec_10s_22050hz/<v>_mel.npy -> <class>/codes_10s/
     <v>_mel_code.npy, (5, 53) int64, equal to encoding the centre crop 2x-1 directly; existing files are skipped."""
