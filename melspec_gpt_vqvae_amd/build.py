@@ -16,7 +16,8 @@ OBJ = os.path.join(PKG, "build")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmelgpt_hip.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+# -Wno-inline-asm: the LDS-DMA asm blocks list m0 as clobbered (they set it); clang warns that m0 is "reserved"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
          "-ffp-contract=fast", "-fno-gpu-rdc"]
 
 
