@@ -229,7 +229,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
     for (int i = 0; i < 2; ++i) {
       const unsigned m0v = (unsigned)(size_t)LDS_PTR(char, wring + st * 16384 + (w + 8 * i) * 1024);
       const unsigned voff = b_base[i] == OOB ? OOB : b_base[i] + kt * KSTEP * ES;
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+      asm volatile("s_nop 2\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                    :
                    : "s"(m0v), "v"(voff), "s"(rb)
                    : "memory", "m0");

@@ -66,6 +66,9 @@ __device__ __forceinline__ u32x4 load_frag(const char* tile, int st, int ks, int
 // built to keep in flight.  Instructions the compiler cannot see get no such waits; ordering is ours: the counted wait +
 // barrier of wait_vm_barrier, and the drain in front of the epilogue.  (Invisible operations can only make the
 // compiler's own vmcnt waits for the epilogue's loads longer, never shorter: the counter is in order.)
+// Hazards are ours as well: the block opens with `s_nop 2` because the resource SGPRs may just have been restored from a
+// spill lane by v_readlane (VALU write of an SGPR -> VMEM read: 5 wait states, which the hazard recogniser only inserts
+// for instructions it can see), and keeps one wait state between the m0 write and the load.
 typedef u32x4 rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc4(const void* base, unsigned bytes) {
   const unsigned long long a = (unsigned long long)base;
@@ -73,7 +76,7 @@ __device__ __forceinline__ rsrc_t make_rsrc4(const void* base, unsigned bytes) {
 }
 __device__ __forceinline__ void dma16(rsrc_t rs, char* lds_wave_base, unsigned voff) {
   const unsigned m0v = (unsigned)(size_t)LDS_PTR(char, lds_wave_base);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+  asm volatile("s_nop 2\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                :
                : "s"(m0v), "v"(voff), "s"(rs)
                : "memory", "m0");
@@ -443,8 +446,13 @@ int launch_lay(const GemmParams& p, int batch, hipStream_t s) {
   if constexpr (ALAY == LAY_CONV) {  // convolutions: bias + residual, bf16 out - the only form the VQ-VAE uses
     return (plain && !p.out_f32) ? launch_mode<ALAY, BLAY, EPI_PLAIN16>(p, batch, s) : MELGPT_ERR_UNSUPPORTED;
   } else {
-    if (p.out_f32) return plain ? launch_mode<ALAY, BLAY, EPI_PLAIN32>(p, batch, s) : MELGPT_ERR_UNSUPPORTED;
-    return plain ? launch_mode<ALAY, BLAY, EPI_PLAIN16>(p, batch, s) : launch_mode<ALAY, BLAY, EPI_FULL16>(p, batch, s);
+    const bool loads = p.R || p.accumulate;
+    if (p.out_f32) {
+      if (!plain) return MELGPT_ERR_UNSUPPORTED;
+      return loads ? launch_mode<ALAY, BLAY, EPI_PLAIN32>(p, batch, s) : launch_mode<ALAY, BLAY, EPI_PLAIN32N>(p, batch, s);
+    }
+    if (!plain) return launch_mode<ALAY, BLAY, EPI_FULL16>(p, batch, s);
+    return loads ? launch_mode<ALAY, BLAY, EPI_PLAIN16>(p, batch, s) : launch_mode<ALAY, BLAY, EPI_PLAIN16N>(p, batch, s);
   }
 }
 

@@ -125,7 +125,12 @@ __device__ __forceinline__ int stage_off(int row, int chunk) { return row * ROWB
 
 // MODE picks what is compiled in (the persistent 256-wide kernel instantiates one kernel per mode so that its
 // epilogue stays small enough for the instruction cache; the generic mode serves gemm.hip and conv_fused.hip):
-enum { EPI_GENERIC = 0, EPI_PLAIN16 = 1, EPI_PLAIN32 = 2, EPI_FULL16 = 3 };
+enum { EPI_GENERIC = 0, EPI_PLAIN16 = 1, EPI_PLAIN32 = 2, EPI_FULL16 = 3,
+       // the two plain modes without a residual operand and without accumulation: NO load besides the bias slabs is
+       // compiled in (a conditional load the row predicates can skip leaves its registers "pending" in the compiler's
+       // wait-count bookkeeping, and the persistent GEMM's next tile then opens with a vmcnt(0) that waits for this
+       // tile's output rows to be acknowledged)
+       EPI_PLAIN16N = 4, EPI_PLAIN32N = 5 };
 //   EPI_GENERIC  everything, decided at run time; slabs unrolled
 //   EPI_PLAIN16  alpha, bias, +R, accumulate; bf16 output; slabs unrolled (a few hundred instructions in all)
 //   EPI_PLAIN32  the same with f32 output (split-K weight gradients)
@@ -152,8 +157,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
                                               int row_limit, int n_base, int bz, int lane, char* stage) {
   constexpr int ES = Tr<T>::ES;
   constexpr bool ACT = MODE == EPI_GENERIC || MODE == EPI_FULL16;           // activation / dropout / C2 compiled in
-  constexpr bool CAN32 = MODE == EPI_GENERIC || MODE == EPI_PLAIN32;
-  constexpr bool CAN16 = MODE != EPI_PLAIN32 && ES == 2;
+  constexpr bool CAN32 = MODE == EPI_GENERIC || MODE == EPI_PLAIN32 || MODE == EPI_PLAIN32N;
+  constexpr bool CAN16 = MODE != EPI_PLAIN32 && MODE != EPI_PLAIN32N && ES == 2;
+  constexpr bool LOADS = MODE != EPI_PLAIN16N && MODE != EPI_PLAIN32N;  // R and accumulate compiled in
   constexpr bool ROLLED = MODE == EPI_FULL16;
   static_assert(CAN32 || CAN16, "no output type left");
   using RV = typename std::conditional<ES == 4, f32x4, u32x2>::type;  // one 4-element group of R / C in dtype T
@@ -161,7 +167,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
   const bool f32out = CAN32 && (!CAN16 || p.out_f32);
   char* Cb = (char*)p.C + (long long)bz * p.sC * (f32out ? 4 : ES);
   char* C2b = (ACT && p.C2) ? (char*)p.C2 + (long long)bz * p.sC * (f32out ? 4 : ES) : nullptr;
-  const char* Rb = p.R ? (const char*)p.R + (long long)bz * p.sR * ES : nullptr;
+  const char* Rb = (LOADS && p.R) ? (const char*)p.R + (long long)bz * p.sR * ES : nullptr;
 
   f32x4 bv[TN];
 #pragma clang loop unroll(full)
@@ -170,6 +176,11 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
     bv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.bias && n < p.N) bv[nt] = *(const f32x4*)(p.bias + n);
   }
+  // an (empty) use right here: the compiler waits for the four loads now, on every path.  Left to the first arithmetic
+  // use - which row predicates can skip - their registers stayed "pending" past the epilogue, and the persistent GEMM's
+  // next tile opened with a vmcnt(0) guarding their re-use.
+#pragma clang loop unroll(full)
+  for (int nt = 0; nt < TN; ++nt) asm volatile("" : "+v"(bv[nt]));
   auto unpack = [](RV r) -> f32x4 {
     if constexpr (ES == 4) return r;
     else return f32x4{bf16lo(r[0]), bf16hi(r[0]), bf16lo(r[1]), bf16hi(r[1])};
@@ -255,7 +266,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
               if (mr >= 0 && row < row_limit && mm < p.M && nn < p.N) {
                 f32x4 o = *(const f32x4*)(stage + stage_off<ROWB>(row, ch));
                 float* dst = (float*)(Ob + (mm * p.ldc + nn) * 4);
-                if (pass == 1 && p.accumulate) o += *(const f32x4*)dst;
+                if (LOADS && pass == 1 && p.accumulate) o += *(const f32x4*)dst;
                 *(f32x4*)dst = o;
               }
             }
@@ -278,7 +289,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
               if (mr >= 0 && row < row_limit && mm < p.M && nn < p.N) {
                 u32x4 o = *(const u32x4*)(stage + stage_off<ROWB>(row, ch));
                 u32x4* dst = (u32x4*)(Ob + (mm * p.ldc + nn) * 2);
-                if (pass == 1 && p.accumulate) {
+                if (LOADS && pass == 1 && p.accumulate) {
                   const u32x4 c = *dst;
 #pragma unroll
                   for (int e = 0; e < 4; ++e)
