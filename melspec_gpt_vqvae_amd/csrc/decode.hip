@@ -5,8 +5,7 @@
 // the tokens before it, so a step is: append this token's k, v to a per-layer cache, then
 //   y[b, h, :] = softmax_t( q[b, h, :] . K[b, t, h, :] / sqrt(hs) ) @ V[b, t, h, :],   t = 0 .. pos
 // (every earlier token is visible to the newest one whatever n_unmasked is; eval mode, so no dropout).
-// One 64-lane wave per (batch, head): lanes own key positions for the scores and head dimensions for the output;
-// HBM-bound on the cache read (2 * (pos+1) * 64 * sizeof(T) bytes per wave).
+// One workgroup per (batch, head); latency-bound on the cache read (2 * (pos+1) * 64 * sizeof(T) bytes).
 #include "mma.h"
 
 namespace {
@@ -23,96 +22,154 @@ __device__ __forceinline__ void stf(T* p, float v) {
 }
 
 // qkv: (B, 3C) rows [key | query | value] of the new token (row stride ld); caches: (B, Tmax, C)
+// One 256-thread workgroup per (batch, head).  A step is latency-bound (<= 2 x 320 cache rows of 128 / 256 bytes), so
+// every load of a phase is independent and in flight at once:
+//   scores: thread t owns key position t (and t + 256): its whole K row = ROWCH 16-byte loads, dotted with q from LDS;
+//   output: thread = (position group g, 16-byte chunk c of the head dimension): V[g + G i][chunk c] for all i, weighted
+//           by the probabilities in LDS, then summed over the groups (DPP inside a wave, LDS across the four waves).
 template <typename T>
-__global__ __launch_bounds__(64) void attn_decode_kernel(const T* __restrict__ qkv, long long ld, T* __restrict__ kc,
-                                                         T* __restrict__ vc, int Tmax, int C, int pos,
-                                                         const int* __restrict__ pos_dev, T* __restrict__ out,
-                                                         float* __restrict__ att_row, float scale) {
-  constexpr int HS = 64, MAXT = 320;  // <= 5 key positions per lane
+__global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ qkv, long long ld, T* __restrict__ kc,
+                                                          T* __restrict__ vc, int Tmax, int C, int pos,
+                                                          const int* __restrict__ pos_dev, T* __restrict__ out,
+                                                          float* __restrict__ att_row, float scale) {
+  constexpr int HS = 64, MAXT = 320, NT = 256;
+  constexpr int VEC = 16 / sizeof(T);      // elements per 16-byte chunk
+  constexpr int ROWCH = HS / VEC;          // chunks per cache row: 8 (bf16) / 16 (f32)
+  constexpr int G = NT / ROWCH;            // position groups of the output phase: 32 / 16
+  constexpr int NIT = (MAXT + G - 1) / G;  // 10 / 20
   if (pos_dev) pos = *pos_dev;  // graph-replayed decoding: the position lives on the device
   if (pos >= Tmax) return;
-  const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __shared__ float prob[MAXT];
   __shared__ float qs[HS];
+  __shared__ float vnew[HS];
+  __shared__ float red[2][4];
+  __shared__ float s_new_sh;
+  __shared__ float osum[4][HS];
   const T* row = qkv + (long long)b * ld;
   T* kb = kc + ((long long)b * Tmax) * C + h * HS;
   T* vb = vc + ((long long)b * Tmax) * C + h * HS;
-  // append this token's key / value (lane = head dimension), keep q in LDS
-  const float kn = ldf(row + h * HS + lane), qn = ldf(row + C + h * HS + lane), vn = ldf(row + 2 * C + h * HS + lane);
-  stf(kb + (long long)pos * C + lane, kn);
-  stf(vb + (long long)pos * C + lane, vn);
-  qs[lane] = qn;
-  __syncthreads();
   const int len = pos + 1;
-  // scores: lane owns positions lane, lane + 64, ...  The newest key's score comes from registers (a wave reduction
-  // of k_new * q): its cache row was stored by all 64 lanes a moment ago and no other lane should have to read it
-  // back (the value row IS read back below, but each lane only re-reads the element it stored itself).
-  const float s_new = wave_sum(kn * qn);
-  float s[MAXT / 64];
+  // the cache rows this thread will need do not depend on the new token: request them first
+  u32x4 kr[2][ROWCH];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int t = min(tid + NT * i, pos);  // clamped: always a valid row (row `pos` may hold anything: not used)
+    if (i == 0 || pos >= NT) {             // uniform
+#pragma unroll
+      for (int c = 0; c < ROWCH; ++c) kr[i][c] = *(const u32x4*)(kb + (long long)t * C + c * VEC);
+    }
+  }
+  const int g = tid / ROWCH, cch = tid % ROWCH;
+  u32x4 vr[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int t = min(g + G * i, max(pos - 1, 0));  // clamped to rows that exist; weight 0 beyond the end
+    vr[i] = *(const u32x4*)(vb + (long long)t * C + cch * VEC);
+  }
+  // append this token's key / value (wave 0: lane = head dimension); q and v stay in LDS, the newest key's score comes
+  // from registers - nobody reads the freshly stored rows back
+  if (wave == 0) {
+    const float kn = ldf(row + h * HS + lane), qn = ldf(row + C + h * HS + lane), vn = ldf(row + 2 * C + h * HS + lane);
+    stf(kb + (long long)pos * C + lane, kn);
+    stf(vb + (long long)pos * C + lane, vn);
+    qs[lane] = qn;
+    // what the cache row holds is the ROUNDED value (bf16 lane): use the same for this step
+    if constexpr (sizeof(T) == 2) {
+      vnew[lane] = bf16_to_f32(f32_to_bf16(vn));
+    } else {
+      vnew[lane] = vn;
+    }
+    const float sn = wave_sum(kn * qn);
+    if (lane == 0) s_new_sh = sn;
+  }
+  __syncthreads();
+  float s[2];
   float mx = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < MAXT / 64; ++i) {
-    const int t = lane + 64 * i;
+  for (int i = 0; i < 2; ++i) {
+    const int t = tid + NT * i;
     s[i] = -INFINITY;
     if (t < len) {
-      const T* kr = kb + (long long)t * C;
       float acc = 0.f;
       if (t == pos) {
-        acc = s_new;
+        acc = s_new_sh;
       } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
-        for (int c = 0; c < HS / 8; ++c) {
-          const u32x4 v = *(const u32x4*)(kr + 8 * c);
+        for (int c = 0; c < ROWCH; ++c)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            acc = fmaf(__uint_as_float(v[e] << 16), qs[8 * c + 2 * e], acc);
-            acc = fmaf(__uint_as_float(v[e] & 0xFFFF0000u), qs[8 * c + 2 * e + 1], acc);
+            acc = fmaf(__uint_as_float(kr[i][c][e] << 16), qs[8 * c + 2 * e], acc);
+            acc = fmaf(__uint_as_float(kr[i][c][e] & 0xFFFF0000u), qs[8 * c + 2 * e + 1], acc);
           }
-        }
       } else {
 #pragma unroll
-        for (int c = 0; c < HS / 4; ++c) {
-          const f32x4 v = *(const f32x4*)(kr + 4 * c);
+        for (int c = 0; c < ROWCH; ++c)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc = fmaf(v[e], qs[4 * c + e], acc);
-        }
+          for (int e = 0; e < 4; ++e) acc = fmaf(__uint_as_float(kr[i][c][e]), qs[4 * c + e], acc);
       }
       s[i] = acc * scale;
       mx = fmaxf(mx, s[i]);
     }
   }
   mx = wave_max(mx);
+  if (lane == 0) red[0][wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXT / 64; ++i) {
-    const int t = lane + 64 * i;
-    if (t < len) {
+  for (int i = 0; i < 2; ++i)
+    if (tid + NT * i < len) {
       s[i] = __expf(s[i] - mx);
       sum += s[i];
     }
-  }
   sum = wave_sum(sum);
-  const float inv = 1.0f / sum;
+  if (lane == 0) red[1][wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
 #pragma unroll
-  for (int i = 0; i < MAXT / 64; ++i) {
-    const int t = lane + 64 * i;
+  for (int i = 0; i < 2; ++i) {
+    const int t = tid + NT * i;
     if (t < len) {
       prob[t] = s[i] * inv;
       if (att_row) att_row[((long long)b * gridDim.x + h) * Tmax + t] = s[i] * inv;
     }
   }
   __syncthreads();
-  // output: lane = head dimension, four independent chains over the positions
-  float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-  int t = 0;
-  for (; t + 3 < len; t += 4) {
-    o0 = fmaf(prob[t], ldf(vb + (long long)t * C + lane), o0);
-    o1 = fmaf(prob[t + 1], ldf(vb + (long long)(t + 1) * C + lane), o1);
-    o2 = fmaf(prob[t + 2], ldf(vb + (long long)(t + 2) * C + lane), o2);
-    o3 = fmaf(prob[t + 3], ldf(vb + (long long)(t + 3) * C + lane), o3);
+  float o[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) o[e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int t = g + G * i;
+    if (t >= pos) continue;  // the newest position is added from LDS below; a clamped load may hold anything (NaN)
+    const float p = prob[t];
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[2 * e] = fmaf(p, __uint_as_float(vr[i][e] << 16), o[2 * e]);
+        o[2 * e + 1] = fmaf(p, __uint_as_float(vr[i][e] & 0xFFFF0000u), o[2 * e + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaf(p, __uint_as_float(vr[i][e]), o[e]);
+    }
   }
-  for (; t < len; ++t) o0 = fmaf(prob[t], ldf(vb + (long long)t * C + lane), o0);
-  stf(out + (long long)b * C + h * HS + lane, (o0 + o1) + (o2 + o3));
+  // sum over the position groups: lanes with equal chunk index differ in lane bits >= log2(ROWCH)
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+#pragma unroll
+    for (int m = ROWCH; m < 64; m <<= 1) o[e] += __shfl_xor(o[e], m, 64);
+  }
+  if (lane < ROWCH) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) osum[wave][lane * VEC + e] = o[e];
+  }
+  __syncthreads();
+  if (tid < HS) {
+    const float v = (osum[0][tid] + osum[1][tid]) + (osum[2][tid] + osum[3][tid]) + prob[pos] * vnew[tid];
+    stf(out + (long long)b * C + h * HS + tid, v);
+  }
 }
 
 // x[b, :] = tok_emb[idx[b]] + pos_emb[*pos_dev]   (the stem of GPT.forward for one position, minGPT.py:170-180)
@@ -162,10 +219,10 @@ extern "C" int melgpt_attn_decode(const void* qkv, long long ld, void* kcache, v
   const float scale = 1.0f / sqrtf((float)head_size);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MELGPT_F32)
-    hipLaunchKernelGGL(attn_decode_kernel<float>, dim3(H, B), dim3(64), 0, s, (const float*)qkv, ld, (float*)kcache,
+    hipLaunchKernelGGL(attn_decode_kernel<float>, dim3(H, B), dim3(256), 0, s, (const float*)qkv, ld, (float*)kcache,
                        (float*)vcache, Tmax, C, pos, pos_dev, (float*)out, att_row, scale);
   else
-    hipLaunchKernelGGL(attn_decode_kernel<bf16_t>, dim3(H, B), dim3(64), 0, s, (const bf16_t*)qkv, ld, (bf16_t*)kcache,
+    hipLaunchKernelGGL(attn_decode_kernel<bf16_t>, dim3(H, B), dim3(256), 0, s, (const bf16_t*)qkv, ld, (bf16_t*)kcache,
                        (bf16_t*)vcache, Tmax, C, pos, pos_dev, (bf16_t*)out, att_row, scale);
   return melgpt_launch_status();
 }
@@ -180,12 +237,12 @@ extern "C" int melgpt_attn_decode(const void* qkv, long long ld, void* kcache, v
 // grid = (N / 4, ceil(M / 16)), 1-4 waves per workgroup by K: N = 1024 already gives one workgroup per CU.
 namespace {
 
-template <typename T, int MB>
+template <typename T, int MB, bool LN>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x, long long ldx, const T* __restrict__ W,
                                                         long long ldw, const float* __restrict__ bias,
                                                         const T* __restrict__ res, long long ldr, void* __restrict__ y,
                                                         long long ldy, int M, int N, int K, int act, int out_f32,
-                                                        const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                        const float* ln_g, const float* ln_b,
                                                         float ln_eps) {
   constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte chunk
   // blockDim.x / 64 waves share the 4 columns and split K between them (the launcher aims at ~2 chunks per lane,
@@ -200,20 +257,127 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
     for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
   // the epilogue's operands are requested now, so that they arrive together with the weights instead of costing a
   // second memory round trip after the reduction (a decode step is a chain of ~170 such latency-bound kernels)
-  float e_bias = 0.f, e_res = 0.f;
-  if (wv_id == 0 && lane < 4 * MB) {
-    const int r = lane / MB, m = lane % MB;
-    if (m < mrows) {
-      if (bias) e_bias = bias[n0 + r];
-      if (res) e_res = ldf(res + (long long)(m0 + m) * ldr + n0 + r);
-    }
+  // (branch-free: a load inside a branch is waited for where the branch ends; absent operands read a valid dummy)
+  T e_res_raw;
+  float e_bias;
+  {
+    const int r = (lane / MB) & 3, m = min(lane % MB, mrows - 1);
+    e_bias = *(bias ? bias + n0 + r : (const float*)W);
+    e_res_raw = *(res ? res + (long long)(m0 + m) * ldr + n0 + r : W);
   }
   const int nchunk = K / VEC;
+  bool done = false;
+  if constexpr (MB <= 4) {
+    // The common decode shapes give a lane at most two chunks of K (the launcher sizes nwave for that): then EVERY
+    // operand - the weight rows, the x rows, the LayerNorm affine - is requested up front and the kernel costs one
+    // memory round trip instead of three (statistics pass, second pass, weights).  With one wave per workgroup the
+    // lane's chunks of x are the whole row's share, so the LayerNorm statistics come from the same registers.
+    if (nchunk <= 128 * nwave && (!LN || nwave == 1)) {
+      done = true;
+      u32x4 wv[2][4], xv[2][MB];
+      f32x4 gv[2][2], bv[2][2];  // LayerNorm gamma / beta of the lane's chunks (VEC / 4 quads each)
+      bool ok[2];
+      long long off[2];
+      // x and the LayerNorm affine first (L2-resident), the weight rows (HBM) last: loads return in issue order, so the
+      // statistics below run while the weights are still on their way
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = wv_id * 64 + lane + 64 * nwave * j;
+        ok[j] = c < nchunk;
+        off[j] = (long long)(ok[j] ? c : 0) * VEC;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) xv[j][m] = *(const u32x4*)(x + (long long)(m0 + (m < mrows ? m : 0)) * ldx + off[j]);
+        if constexpr (LN) {
+#pragma unroll
+          for (int q = 0; q < VEC / 4; ++q) {
+            gv[j][q] = *(const f32x4*)(ln_g + off[j] + 4 * q);
+            bv[j][q] = *(const f32x4*)(ln_b + off[j] + 4 * q);
+          }
+        }
+      }
+      // keep the issue order (the scheduler would put the weight loads first)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wv[j][r] = *(const u32x4*)(W + (long long)(n0 + r) * ldw + off[j]);
+      if constexpr (LN) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          if (m >= mrows) break;  // uniform; the rows beyond M are copies of row 0 and never stored
+          float s1 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (ok[j]) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                if constexpr (sizeof(T) == 2) s1 += __uint_as_float(xv[j][m][e] << 16) + __uint_as_float(xv[j][m][e] & 0xFFFF0000u);
+                else s1 += __uint_as_float(xv[j][m][e]);
+              }
+            }
+          const float mean = wave_sum(s1) / (float)K;
+          float s2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (ok[j]) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                if constexpr (sizeof(T) == 2) {
+                  const float d0 = __uint_as_float(xv[j][m][e] << 16) - mean, d1 = __uint_as_float(xv[j][m][e] & 0xFFFF0000u) - mean;
+                  s2 = fmaf(d0, d0, s2);
+                  s2 = fmaf(d1, d1, s2);
+                } else {
+                  const float d0 = __uint_as_float(xv[j][m][e]) - mean;
+                  s2 = fmaf(d0, d0, s2);
+                }
+              }
+            }
+          const float rstd = rsqrtf(wave_sum(s2) / (float)K + ln_eps);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float h0 = (__uint_as_float(xv[j][m][e] << 16) - mean) * rstd * gv[j][e >> 1][(2 * e) & 3] + bv[j][e >> 1][(2 * e) & 3];
+                const float h1 = (__uint_as_float(xv[j][m][e] & 0xFFFF0000u) - mean) * rstd * gv[j][e >> 1][(2 * e + 1) & 3] +
+                                 bv[j][e >> 1][(2 * e + 1) & 3];
+                xv[j][m][e] = pack_bf16x2(h0, h1);
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                xv[j][m][e] = __float_as_uint((__uint_as_float(xv[j][m][e]) - mean) * rstd * gv[j][0][e] + bv[j][0][e]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (ok[j]) {
+#pragma unroll
+          for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  acc[r][m] = fmaf(__uint_as_float(wv[j][r][e] << 16), __uint_as_float(xv[j][m][e] << 16), acc[r][m]);
+                  acc[r][m] = fmaf(__uint_as_float(wv[j][r][e] & 0xFFFF0000u), __uint_as_float(xv[j][m][e] & 0xFFFF0000u), acc[r][m]);
+                }
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[r][m] = fmaf(__uint_as_float(wv[j][r][e]), __uint_as_float(xv[j][m][e]), acc[r][m]);
+              }
+            }
+        }
+    }
+  }
   // optional fused LayerNorm of the input rows (ln_g != null): y = W LN(x).  Every wave derives the row statistics
   // itself (two passes over the row, which sits in L1), then normalises the chunks it multiplies - in the bf16 lane
   // the normalised value is rounded to bf16 first, exactly what the separate LayerNorm kernel would have stored.
   float mu[MB], rs[MB];
-  if (ln_g) {
+  if (LN && !done) {
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
       mu[m] = 0.f;
@@ -251,7 +415,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
     }
   }
 #pragma unroll 2
-  for (int c = wv_id * 64 + lane; c < nchunk; c += 64 * nwave) {
+  for (int c = done ? nchunk : wv_id * 64 + lane; c < nchunk; c += 64 * nwave) {
     u32x4 wv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) wv[r] = *(const u32x4*)(W + (long long)(n0 + r) * ldw + (long long)c * VEC);
@@ -259,7 +423,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
     for (int m = 0; m < MB; ++m) {
       if (m < mrows) {
         u32x4 xv = *(const u32x4*)(x + (long long)(m0 + m) * ldx + (long long)c * VEC);
-        if (ln_g) {
+        if constexpr (LN) {
           if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -314,9 +478,9 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
     const int r = lane / MB, m = lane % MB;
     if (m < mrows) {
       const int n = n0 + r;
-      float v = mine + e_bias;
+      float v = mine + (bias ? e_bias : 0.f);
       if (act == MELGPT_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-      v += e_res;
+      if (res) v += ldf(&e_res_raw);
       if (out_f32) ((float*)y)[(long long)(m0 + m) * ldy + n] = v;
       else stf((T*)y + (long long)(m0 + m) * ldy + n, v);
     }
@@ -441,10 +605,15 @@ extern "C" int melgpt_gemv_rows(const void* x, long long ldx, const void* W, lon
   int nwave = (K / vec + 127) / 128;  // ~2 chunks of 16 bytes per lane
   nwave = nwave < 1 ? 1 : nwave > 4 ? 4 : nwave;
   // 16 rows of x per wave; fewer accumulators are instantiated for the common single-digit decode batches
-#define MELGPT_GEMV_LAUNCH(T, MB)                                                                                     \
-  hipLaunchKernelGGL((gemv_rows_kernel<T, MB>), dim3(N / 4, (M + MB - 1) / MB), dim3(64 * nwave), 0, s, (const T*)x, ldx, \
-                     (const T*)W, ldw, bias, (const T*)residual, ldr, y, ldy, M, N, K, act,                            \
+#define MELGPT_GEMV_LAUNCH_LN(T, MB, LN)                                                                              \
+  hipLaunchKernelGGL((gemv_rows_kernel<T, MB, LN>), dim3(N / 4, (M + MB - 1) / MB), dim3(64 * nwave), 0, s, (const T*)x, \
+                     ldx, (const T*)W, ldw, bias, (const T*)residual, ldr, y, ldy, M, N, K, act,                        \
                      (dtype == MELGPT_F32) ? 1 : out_f32, ln_gamma, ln_beta, ln_eps)
+#define MELGPT_GEMV_LAUNCH(T, MB)                    \
+  do {                                               \
+    if (ln_gamma) MELGPT_GEMV_LAUNCH_LN(T, MB, true); \
+    else MELGPT_GEMV_LAUNCH_LN(T, MB, false);         \
+  } while (0)
   if (dtype == MELGPT_F32) {
     if (M <= 4) MELGPT_GEMV_LAUNCH(float, 4);
     else MELGPT_GEMV_LAUNCH(float, 16);
@@ -453,5 +622,6 @@ extern "C" int melgpt_gemv_rows(const void* x, long long ldx, const void* W, lon
     else MELGPT_GEMV_LAUNCH(bf16_t, 16);
   }
 #undef MELGPT_GEMV_LAUNCH
+#undef MELGPT_GEMV_LAUNCH_LN
   return melgpt_launch_status();
 }
