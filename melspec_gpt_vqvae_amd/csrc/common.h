@@ -51,16 +51,29 @@ struct Elem<bf16_t> {
   static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
-// ---------------------------------------------------------------- wave64 reductions (DPP/shuffle based)
+// ---------------------------------------------------------------- wave64 reductions
+// DPP inside each row of 16 lanes (xor 1, xor 2, half mirror, mirror: ~4 VALU issue slots each, against ~100 cycles
+// for a ds_bpermute shuffle), then the four row results through v_readlane.  Every lane gets the same value.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v, float absent = 0.f) {  // absent: what a disabled source lane yields
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(absent), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_value(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);  // row_half_mirror
+  v += dpp_move<0x140>(v);  // row_mirror
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_move<0xB1>(v, v));
+  v = fmaxf(v, dpp_move<0x4E>(v, v));
+  v = fmaxf(v, dpp_move<0x141>(v, v));
+  v = fmaxf(v, dpp_move<0x140>(v, v));
+  return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
 // ---------------------------------------------------------------- buffer resources (OOB loads return 0)

@@ -462,6 +462,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
+      if (m >= mrows) continue;  // uniform
       const float s = wave_sum(acc[r][m]);
       if (lane == r * MB + m) mine = s;
     }
@@ -604,7 +605,7 @@ extern "C" int melgpt_gemv_rows(const void* x, long long ldx, const void* W, lon
   hipStream_t s = (hipStream_t)stream;
   int nwave = (K / vec + 127) / 128;  // ~2 chunks of 16 bytes per lane
   nwave = nwave < 1 ? 1 : nwave > 4 ? 4 : nwave;
-  // 16 rows of x per wave; fewer accumulators are instantiated for the common single-digit decode batches
+  // 16 rows of x per wave; fewer accumulators are instantiated for the common single-digit decode batches (1, 2-4)
 #define MELGPT_GEMV_LAUNCH_LN(T, MB, LN)                                                                              \
   hipLaunchKernelGGL((gemv_rows_kernel<T, MB, LN>), dim3(N / 4, (M + MB - 1) / MB), dim3(64 * nwave), 0, s, (const T*)x, \
                      ldx, (const T*)W, ldw, bias, (const T*)residual, ldr, y, ldy, M, N, K, act,                        \
@@ -615,10 +616,12 @@ extern "C" int melgpt_gemv_rows(const void* x, long long ldx, const void* W, lon
     else MELGPT_GEMV_LAUNCH_LN(T, MB, false);         \
   } while (0)
   if (dtype == MELGPT_F32) {
-    if (M <= 4) MELGPT_GEMV_LAUNCH(float, 4);
+    if (M == 1) MELGPT_GEMV_LAUNCH(float, 1);
+    else if (M <= 4) MELGPT_GEMV_LAUNCH(float, 4);
     else MELGPT_GEMV_LAUNCH(float, 16);
   } else {
-    if (M <= 4) MELGPT_GEMV_LAUNCH(bf16_t, 4);
+    if (M == 1) MELGPT_GEMV_LAUNCH(bf16_t, 1);
+    else if (M <= 4) MELGPT_GEMV_LAUNCH(bf16_t, 4);
     else MELGPT_GEMV_LAUNCH(bf16_t, 16);
   }
 #undef MELGPT_GEMV_LAUNCH
