@@ -504,35 +504,54 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const bf16_t* __rest
                                                             long long ldr, void* __restrict__ y, long long ldy, int M, int N,
                                                             int K, int act, int out_f32) {
   constexpr int KS = MT <= 4 ? 4 : 2;  // k-steps (32 elements) whose loads are in flight together
-  __shared__ f32x4 part[3][MT][64];
+  constexpr int NW = 4;
+  __shared__ f32x4 part[NW - 1][MT][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 16;
+  const int n0 = blockIdx.x * 16, m_base = blockIdx.y * 16 * MT;  // blockIdx.y: row blocks (same weights, same XCD)
   const bf16_t* wp = W + (long long)(n0 + r16) * ldw + 8 * g;
   const bf16_t* xp[MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) xp[mt] = x + (long long)min(16 * mt + r16, M - 1) * ldx + 8 * g;
+  for (int mt = 0; mt < MT; ++mt) xp[mt] = x + (long long)min(m_base + 16 * mt + r16, M - 1) * ldx + 8 * g;
   f32x4 acc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // wave w takes the 128-element chunks w, w + 4, ...
-  for (int k0 = 128 * w; k0 < K; k0 += 512) {
+  // wave w takes the 128-element chunks w, w + 4, ... in steps of KS k-steps; the loads of the next step are issued
+  // before the MFMAs of the current one (two register sets, A / B), so a wave pays one memory round trip, not one per step
+  constexpr int H = 4 / KS;
+  constexpr int KW = 128 * NW;  // K covered by one round of the workgroup
+  const int nst = 128 * w < K ? ((K - 128 * w + KW - 1) / KW) * H : 0;
+  auto load = [&](int i, u32x4(&a)[KS], u32x4(&b)[KS][MT]) {
+    i = min(i, nst - 1);  // past the end: a redundant reload instead of a branch around loads
+    const int kb = 128 * w + KW * (i / H) + 32 * KS * (i % H);
 #pragma unroll
-    for (int h = 0; h < 4 / KS; ++h) {
-      u32x4 a[KS], b[KS][MT];
+    for (int s = 0; s < KS; ++s) {
+      a[s] = *(const u32x4*)(wp + kb + 32 * s);
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int k = k0 + 32 * (KS * h + s);
-        a[s] = *(const u32x4*)(wp + k);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) b[s][mt] = *(const u32x4*)(xp[mt] + k);
-      }
-#pragma unroll
-      for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, a[s]), __builtin_bit_cast(s16x8, b[s][mt]),
-                                                            acc[mt], 0, 0, 0);
+      for (int mt = 0; mt < MT; ++mt) b[s][mt] = *(const u32x4*)(xp[mt] + kb + 32 * s);
     }
+  };
+  auto mma = [&](const u32x4(&a)[KS], const u32x4(&b)[KS][MT]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, a[s]), __builtin_bit_cast(s16x8, b[s][mt]),
+                                                          acc[mt], 0, 0, 0);
+  };
+  if (nst > 0) {
+    u32x4 aA[KS], bA[KS][MT], aB[KS], bB[KS][MT];
+    load(0, aA, bA);
+    int i = 0;
+    for (; i + 1 < nst; i += 2) {  // both halves unconditional: a load used only under a branch is sunk into it
+      load(i + 1, aB, bB);
+      __builtin_amdgcn_sched_barrier(0);  // the scheduler would move the loads below the MFMAs (register pressure)
+      mma(aA, bA);
+      __builtin_amdgcn_sched_barrier(0);
+      load(i + 2, aA, bA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(aB, bB);
+    }
+    if (i < nst) mma(aA, bA);  // odd tail
   }
   if (w > 0) {
 #pragma unroll
@@ -546,8 +565,10 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const bf16_t* __rest
     if (bias) bv = *(const f32x4*)(bias + n);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int m = 16 * mt + r16;
-      f32x4 v = ((acc[mt] + part[0][mt][lane]) + part[1][mt][lane]) + part[2][mt][lane];
+      const int m = m_base + 16 * mt + r16;
+      f32x4 v = acc[mt];
+#pragma unroll
+      for (int q = 0; q < NW - 1; ++q) v += part[q][mt][lane];  // wave order: deterministic
       v += bv;
       if (act == MELGPT_ACT_GELU) {
 #pragma unroll
@@ -579,9 +600,16 @@ extern "C" int melgpt_linear_skinny(const void* x, long long ldx, const void* W,
                MELGPT_ERR_ALIGN);
   hipStream_t s = (hipStream_t)stream;
 #define MELGPT_SKINNY_LAUNCH(MT)                                                                                        \
-  hipLaunchKernelGGL((linear_skinny_kernel<MT>), dim3(N / 16), dim3(256), 0, s, (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, \
-                     bias, (const bf16_t*)residual, ldr, y, ldy, M, N, K, act, out_f32)
-  const int mt = (M + 15) / 16;
+  hipLaunchKernelGGL((linear_skinny_kernel<MT>), dim3(N / 16, (mt_all + MT - 1) / MT), dim3(256), 0, s, (const bf16_t*)x, ldx, \
+                     (const bf16_t*)W, ldw, bias, (const bf16_t*)residual, ldr, y, ldy, M, N, K, act, out_f32)
+  // N / 16 workgroups stream the weights; when that leaves CUs idle (N = 1024: 64) the rows are split over up to
+  // 256 / (N / 16) workgroups per column block, which read the same weight slab (from L2 after the first).
+  // What bounds these launches is the bytes ONE CU takes in (~16-25 GB/s per CU, L2 hits included: its share of W plus
+  // all the x rows it multiplies): fc2 (N 1024, K 4096) costs ~12 us at any batch because every workgroup reads 128 KB
+  // of weights plus its rows of x over K = 4096; 4-column workgroups (x read 4 x as often) and 16 waves per workgroup
+  // measured the same or worse - only a split of K over workgroups (a cross-workgroup reduction) would cut it.
+  const int mt_all = (M + 15) / 16, split = 256 / (N / 16) > 1 ? 256 / (N / 16) : 1;
+  const int mt = (mt_all + split - 1) / split;
   if (mt <= 1) MELGPT_SKINNY_LAUNCH(1);
   else if (mt <= 2) MELGPT_SKINNY_LAUNCH(2);
   else if (mt <= 4) MELGPT_SKINNY_LAUNCH(4);
