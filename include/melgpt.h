@@ -178,10 +178,13 @@ int melgpt_gemv_rows(const void* x, long long ldx, const void* W, long long ldw,
                      int dtype, int out_f32, const float* ln_gamma, const float* ln_beta, float ln_eps, void* stream);
 /* the same layer for 5 .. 128 rows, bf16: one workgroup per 16 output columns, its four waves split K and stream their part
  * of the weights once against all rows as MFMA 16x16x32 (decode steps at batch 5 .. 128; the tiled GEMM would run such a
- * problem on N / 128 workgroups).  M <= 128, N % 16 == 0, K % 128 == 0; residual / y rows 8-byte aligned. */
+ * problem on N / 128 workgroups).  M <= 128, N % 16 == 0, K % 128 == 0; residual / y rows 8-byte aligned.
+ * ln_gamma / ln_beta (both or neither, as in melgpt_gemv_rows): y = W LN(x), statistics derived inside the kernel;
+ * only for K in {512, 1024} and M <= 64, otherwise MELGPT_ERR_UNSUPPORTED (normalise first). */
 int melgpt_linear_skinny(const void* x, long long ldx, const void* W, long long ldw, const float* bias,
                          const void* residual, long long ldr, void* y, long long ldy, int M, int N, int K, int act,
-                         int dtype, int out_f32, void* stream);
+                         int dtype, int out_f32, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                         void* stream);
 /* graph-replayed decoding helpers: x[b,:] = tok_emb[idx[b]] + pos_emb[*pos_dev] (minGPT.py:170-180 for one position);
  * *counter += 1 */
 int melgpt_embed_decode(const long long* idx, const float* tok_emb, const float* pos_emb, const int* pos_dev, int B,

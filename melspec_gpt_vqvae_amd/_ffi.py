@@ -44,7 +44,7 @@ _PROTOS = {
     "melgpt_pad1d_act": [_p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "melgpt_conv1d_out1": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "melgpt_gemv_rows": [_p, _l, _p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p],
-    "melgpt_linear_skinny": [_p, _l, _p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _p],
+    "melgpt_linear_skinny": [_p, _l, _p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p],
     "melgpt_attn_bwd": [_p, _p, _p, _l, _p, _p, _l, _p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _f, _u64, C.c_uint,
                         _i, _p],
     "melgpt_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _l, _i, _f, _i, _p],

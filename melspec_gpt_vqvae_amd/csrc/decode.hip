@@ -497,12 +497,18 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
 // accumulator rows - so a lane ends up with 4 consecutive columns of one row; partial tiles are summed across the waves
 // in LDS in wave order (deterministic) and the epilogue runs on the summing wave.  N / 16 workgroups: 64 .. 256 for the
 // VAS layer shapes whatever M is.
-template <int MT>  // 16-row tiles of x
+// LN: the rows of x are LayerNorm-ed on the way in (y = W LN(x), the block's pre-LN folded into qkv / fc1 as in
+// gemv_rows_kernel).  K is 512 or 1024 then, so a wave's two steps hold ALL of its share of x in registers: the row
+// statistics (two passes, like the LayerNorm kernel) come from those registers - partial sums over the lane's
+// fragments, over the four k-groups of the wave by shuffle, over the four waves through LDS - and the fragments are
+// normalised and rounded to bf16 in place before the MFMAs.  Costs two workgroup barriers instead of a launch.
+template <int MT, bool LN>  // 16-row tiles of x
 __global__ __launch_bounds__(256) void linear_skinny_kernel(const bf16_t* __restrict__ x, long long ldx,
                                                             const bf16_t* __restrict__ W, long long ldw,
                                                             const float* __restrict__ bias, const bf16_t* __restrict__ res,
                                                             long long ldr, void* __restrict__ y, long long ldy, int M, int N,
-                                                            int K, int act, int out_f32) {
+                                                            int K, int act, int out_f32, const float* ln_g,
+                                                            const float* ln_b, float ln_eps) {
   constexpr int KS = MT <= 4 ? 4 : 2;  // k-steps (32 elements) whose loads are in flight together
   constexpr int NW = 4;
   __shared__ f32x4 part[NW - 1][MT][64];
@@ -538,7 +544,76 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const bf16_t* __rest
         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, a[s]), __builtin_bit_cast(s16x8, b[s][mt]),
                                                           acc[mt], 0, 0, 0);
   };
-  if (nst > 0) {
+  if constexpr (LN) {
+    // host: K % 512 == 0 and K <= 1024, so 1 <= nst <= 2 for every wave (KS = 4: MT <= 4)
+    __shared__ float lnred[2][NW][MT][16];
+    __shared__ f32x4 lng[256], lnb[256];  // gamma / beta of the whole row, staged once per workgroup
+    u32x4 aA[KS], bA[KS][MT], aB[KS], bB[KS][MT];
+    const bool two = nst > 1;
+    const int t4 = min((int)threadIdx.x, K / 4 - 1);  // K = 512: the upper half rewrites the last quad
+    const f32x4 g4 = *(const f32x4*)(ln_g + 4 * t4), b4 = *(const f32x4*)(ln_b + 4 * t4);
+    load(0, aA, bA);
+    load(1, aB, bB);  // nst == 1: a copy of step 0, left out below
+    lng[t4] = g4;     // (issued first, so they are the first to arrive; visible after the barrier of pass 0)
+    lnb[t4] = b4;
+    float mean[MT], rstd[MT];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        float p = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a0 = bf16lo(bA[s][mt][e]), a1 = bf16hi(bA[s][mt][e]);
+            const float b0 = two ? bf16lo(bB[s][mt][e]) : 0.f, b1 = two ? bf16hi(bB[s][mt][e]) : 0.f;
+            if (pass == 0) {
+              p += (a0 + a1) + (b0 + b1);
+            } else {
+              const float mu = mean[mt];
+              p = fmaf(a0 - mu, a0 - mu, p);
+              p = fmaf(a1 - mu, a1 - mu, p);
+              if (two) {
+                p = fmaf(b0 - mu, b0 - mu, p);
+                p = fmaf(b1 - mu, b1 - mu, p);
+              }
+            }
+          }
+        p += __shfl_xor(p, 16, 64);
+        p += __shfl_xor(p, 32, 64);
+        if (g == 0) lnred[pass][w][mt][r16] = p;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float t = (lnred[pass][0][mt][r16] + lnred[pass][1][mt][r16]) + (lnred[pass][2][mt][r16] + lnred[pass][3][mt][r16]);
+        if (pass == 0) mean[mt] = t / (float)K;
+        else rstd[mt] = rsqrtf(t / (float)K + ln_eps);
+      }
+    }
+    auto norm = [&](u32x4(&b)[KS][MT], int st) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int q0 = (128 * w + KW * st + 32 * s + 8 * g) / 4;
+        const f32x4 gm[2] = {lng[q0], lng[q0 + 1]}, bt[2] = {lnb[q0], lnb[q0 + 1]};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float h0 = (bf16lo(b[s][mt][e]) - mean[mt]) * rstd[mt] * gm[e >> 1][(2 * e) & 3] + bt[e >> 1][(2 * e) & 3];
+            const float h1 = (bf16hi(b[s][mt][e]) - mean[mt]) * rstd[mt] * gm[e >> 1][(2 * e + 1) & 3] + bt[e >> 1][(2 * e + 1) & 3];
+            b[s][mt][e] = pack_bf16x2(h0, h1);
+          }
+      }
+    };
+    norm(bA, 0);
+    mma(aA, bA);
+    if (two) {
+      norm(bB, 1);
+      mma(aB, bB);
+    }
+  } else if (nst > 0) {
     u32x4 aA[KS], bA[KS][MT], aB[KS], bB[KS][MT];
     load(0, aA, bA);
     int i = 0;
@@ -590,7 +665,8 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const bf16_t* __rest
 
 extern "C" int melgpt_linear_skinny(const void* x, long long ldx, const void* W, long long ldw, const float* bias,
                                     const void* residual, long long ldr, void* y, long long ldy, int M, int N, int K,
-                                    int act, int dtype, int out_f32, void* stream) {
+                                    int act, int dtype, int out_f32, const float* ln_gamma, const float* ln_beta,
+                                    float ln_eps, void* stream) {
   MELGPT_CHECK(x && W && y && M > 0 && N > 0 && K > 0, MELGPT_ERR_BAD_ARG);
   MELGPT_CHECK(dtype == MELGPT_BF16 && M <= 128, MELGPT_ERR_UNSUPPORTED);
   MELGPT_CHECK(act == MELGPT_ACT_NONE || act == MELGPT_ACT_GELU, MELGPT_ERR_UNSUPPORTED);
@@ -598,10 +674,20 @@ extern "C" int melgpt_linear_skinny(const void* x, long long ldx, const void* W,
                MELGPT_ERR_ALIGN);
   MELGPT_CHECK((((uintptr_t)x | (uintptr_t)W | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)bias) & 15) == 0,
                MELGPT_ERR_ALIGN);
+  MELGPT_CHECK((ln_gamma == nullptr) == (ln_beta == nullptr), MELGPT_ERR_BAD_ARG);
+  // fused LayerNorm: a wave must hold its whole share of the rows in two register sets
+  MELGPT_CHECK(!ln_gamma || ((K == 512 || K == 1024) && M <= 64 && ((((uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15) == 0)),
+               MELGPT_ERR_UNSUPPORTED);
   hipStream_t s = (hipStream_t)stream;
-#define MELGPT_SKINNY_LAUNCH(MT)                                                                                        \
-  hipLaunchKernelGGL((linear_skinny_kernel<MT>), dim3(N / 16, (mt_all + MT - 1) / MT), dim3(256), 0, s, (const bf16_t*)x, ldx, \
-                     (const bf16_t*)W, ldw, bias, (const bf16_t*)residual, ldr, y, ldy, M, N, K, act, out_f32)
+#define MELGPT_SKINNY_LAUNCH_LN(MT, LN)                                                                                \
+  hipLaunchKernelGGL((linear_skinny_kernel<MT, LN>), dim3(N / 16, (mt_all + MT - 1) / MT), dim3(256), 0, s,             \
+                     (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, bias, (const bf16_t*)residual, ldr, y, ldy, M, N, K, \
+                     act, out_f32, ln_gamma, ln_beta, ln_eps)
+#define MELGPT_SKINNY_LAUNCH(MT)                          \
+  do {                                                    \
+    if (MT <= 4 && ln_gamma) MELGPT_SKINNY_LAUNCH_LN((MT <= 4 ? MT : 4), true); \
+    else MELGPT_SKINNY_LAUNCH_LN(MT, false);              \
+  } while (0)
   // N / 16 workgroups stream the weights; when that leaves CUs idle (N = 1024: 64) the rows are split over up to
   // 256 / (N / 16) workgroups per column block, which read the same weight slab (from L2 after the first).
   // What bounds these launches is the bytes ONE CU takes in (~16-25 GB/s per CU, L2 hits included: its share of W plus
@@ -615,6 +701,7 @@ extern "C" int melgpt_linear_skinny(const void* x, long long ldx, const void* W,
   else if (mt <= 4) MELGPT_SKINNY_LAUNCH(4);
   else MELGPT_SKINNY_LAUNCH(8);
 #undef MELGPT_SKINNY_LAUNCH
+#undef MELGPT_SKINNY_LAUNCH_LN
   return melgpt_launch_status();
 }
 

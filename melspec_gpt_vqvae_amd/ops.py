@@ -3,6 +3,8 @@ host, allocates outputs with torch (plumbing), and launches on torch's current H
 here has a non-HIP fallback."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _ffi
@@ -385,6 +387,9 @@ def attn_decode(qkv, kcache, vcache, n_head, pos, att_row=None, pos_dev=None, ou
     return out
 
 
+SKINNY_LN_MAX_ROWS = int(os.environ.get("MELGPT_SKINNY_LN_MAX_ROWS", "64"))  # lab switch (0: never fuse)
+
+
 def linear_rows(x, w, *, bias=None, act=ACT_NONE, residual=None, out_dtype=None, ln=None):
     """y (M,N) = epi(x (M,K) @ w (N,K)^T + bias) (+ residual) for a handful of rows (decode steps): the weight-streaming
     kernel melgpt_gemv_rows instead of the tiled MFMA GEMM.  ln = (gamma, beta, eps): the rows are LayerNorm-ed on the
@@ -394,11 +399,12 @@ def linear_rows(x, w, *, bias=None, act=ACT_NONE, residual=None, out_dtype=None,
     assert K == K2 and x.dtype == w.dtype and x.stride(1) == 1 and w.stride(1) == 1
     odt = out_dtype or x.dtype
     assert odt in (x.dtype, torch.float32)
-    if ln is not None and M > 4:
-        # every workgroup re-derives the row statistics: pays for 1-4 rows (one launch less: 1.37 -> 1.26 ms per
-        # 24-layer step at batch 1) but not for 16 (2.7 -> 3.6 ms) - normalise once, separately
-        x, ln = layernorm_fwd(x.contiguous(), ln[0], ln[1], ln[2], want_stats=False)[0], None
     skinny = x.dtype == torch.bfloat16 and 4 < M <= 128 and N % 16 == 0 and K % 128 == 0
+    skinny_ln = skinny and ln is not None and M <= SKINNY_LN_MAX_ROWS and K in (512, 1024)
+    if ln is not None and M > 4 and not skinny_ln:
+        # the weight-streaming kernels re-derive the row statistics in every workgroup: that pays for a few rows (one
+        # launch less per LayerNorm) but not for many - normalise once, separately
+        x, ln = layernorm_fwd(x.contiguous(), ln[0], ln[1], ln[2], want_stats=False)[0], None
     if M > 32 and not skinny:  # enough rows for the MFMA tiles to pay (measured: 128 rows 5.0 vs 5.8 ms per 24-layer step)
         return gemm(x, w, bias=bias, act=act, residual=residual, out_dtype=odt)
     y = torch.empty(M, N, dtype=odt, device=x.device)
@@ -406,16 +412,16 @@ def linear_rows(x, w, *, bias=None, act=ACT_NONE, residual=None, out_dtype=None,
         assert residual.shape == (M, N) and residual.dtype == x.dtype and residual.stride(1) == 1
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
-    if skinny:  # 5 .. 128 bf16 rows: N / 16 workgroups stream the weights once as MFMA operands
-        call("melgpt_linear_skinny", ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(residual),
-             residual.stride(0) if residual is not None else 0, ptr(y), N, M, N, K, int(act), dtype_code(x.dtype),
-             int(odt == torch.float32), stream())
-        return y
     g = b = None
     eps = 0.0
     if ln is not None:
         g, b, eps = ln
         assert g.dtype == torch.float32 and b.dtype == torch.float32 and g.numel() == K and b.numel() == K
+    if skinny:  # 5 .. 128 bf16 rows: N / 16 workgroups stream the weights once as MFMA operands
+        call("melgpt_linear_skinny", ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(residual),
+             residual.stride(0) if residual is not None else 0, ptr(y), N, M, N, K, int(act), dtype_code(x.dtype),
+             int(odt == torch.float32), ptr(g), ptr(b), float(eps), stream())
+        return y
     call("melgpt_gemv_rows", ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(residual),
          residual.stride(0) if residual is not None else 0, ptr(y), N, M, N, K, int(act), dtype_code(x.dtype),
          int(odt == torch.float32), ptr(g), ptr(b), float(eps), stream())

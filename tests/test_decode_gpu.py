@@ -145,3 +145,30 @@ def test_skinny_mfma_linear_matches_torch(M, N, K, act, res, f32out):
     assert rel_err(y.float().cpu().numpy(), ref.numpy()) < (2e-5 if f32out else 6e-3)
     y2 = ops.gemm(xb, wb, bias=t(b, DEV), act=act, residual=rb if res else None, out_dtype=torch.float32 if f32out else None)
     assert rel_err(y.float().cpu().numpy(), y2.float().cpu().numpy()) < (2e-5 if f32out else 6e-3)
+
+
+@pytest.mark.parametrize("M", [5, 16, 31, 64])
+@pytest.mark.parametrize("N,K,act", [(3072, 1024, 0), (4096, 1024, 1), (256, 512, 0)])
+def test_skinny_linear_with_layernorm_folded_in(M, N, K, act):
+    """y = W LN(x) in one launch (the pre-LN of a Block folded into its qkv / fc1 layer at batch 5 .. 64): row statistics
+    from the MFMA operand registers; same rounding points as LayerNorm kernel -> linear (normalised rows rounded to
+    bf16), so the two agree to bf16 rounding of a few borderline elements."""
+    from melspec_gpt_vqvae_amd import ops
+
+    x = (synth.normal(400 + M, (M, K)) * 1.5 + 0.3).astype(np.float32)
+    w = (synth.normal(401, (N, K)) * 0.05).astype(np.float32)
+    b = synth.normal(402, (N,)).astype(np.float32)
+    gam = (1.0 + 0.2 * synth.normal(403, (K,))).astype(np.float32)
+    bet = (0.1 * synth.normal(404, (K,))).astype(np.float32)
+    xb, wb = t(x, DEV).to(torch.bfloat16), t(w, DEV).to(torch.bfloat16)
+    y = ops.linear_rows(xb, wb, bias=t(b, DEV), act=act, ln=(t(gam, DEV), t(bet, DEV), 1e-5))
+    xn = torch.nn.functional.layer_norm(xb.float().cpu(), (K,), t(gam), t(bet), 1e-5).to(torch.bfloat16).float()
+    ref = xn @ wb.float().cpu().T + t(b)
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    assert y.dtype == torch.bfloat16 and y.shape == (M, N)
+    assert rel_err(y.float().cpu().numpy(), ref.numpy()) < 8e-3
+    # and against the two-launch path (LayerNorm kernel, then the same linear)
+    xs = ops.layernorm_fwd(xb, t(gam, DEV), t(bet, DEV), 1e-5, want_stats=False)[0]
+    y2 = ops.linear_rows(xs, wb, bias=t(b, DEV), act=act)
+    assert rel_err(y.float().cpu().numpy(), y2.float().cpu().numpy()) < 8e-3
