@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma   [+ add_in]   [then optional dropout replay
 // into a second output `dx_drop` = keep(dx)*scale, which is the gradient of the dropout-ed branch input]
-template <typename T, int NCH>
+template <typename T, int NCH, bool ADD>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean,
@@ -128,13 +128,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   for (int i = 0; i < NCH; ++i)
 #pragma unroll
     for (int e = 0; e < N; ++e) dg[i][e] = db[i][e] = 0.f;
+  // EVERY load of this kernel is unconditional, with its index clamped into range: a value loaded inside a branch is
+  // waited for where the branch ends (`s_waitcnt vmcnt(0)`), which drained the row requested ahead along with it and
+  // made each row cost a full memory latency.  Lanes / rows beyond the end compute on copies and store nothing.
+  int chc[NCH];   // this lane's chunks, clamped
+  bool live[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    live[i] = lane + 64 * i < nch;
+    chc[i] = min(lane + 64 * i, nch - 1);
+  }
   // gamma chunks of this lane (row-invariant)
   float gm[NCH][N];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int ch = lane + 64 * i;
 #pragma unroll
-    for (int e = 0; e < N; ++e) gm[i][e] = ch < nch ? gamma[ch * N + e] : 0.f;
+    for (int e4 = 0; e4 < N; e4 += 4) {
+      const f32x4 gv = *(const f32x4*)(gamma + chc[i] * N + e4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gm[i][e4 + e] = gv[e];
+    }
   }
 
   // A row's three inputs (dy, x, add_in) are requested TOGETHER and one row ahead of their use: a wave handles its
@@ -144,16 +157,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     float mu, rs;
   };
   auto load_row = [&](long long row, RowIn& r) {
+    row = row < M ? row : M - 1;
     r.mu = mean[row];
     r.rs = rstd[row];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int ch = lane + 64 * i;
-      if (ch < nch) {
-        r.d[i] = *(const Raw*)(dy + row * C + ch * N);
-        r.xv[i] = *(const Raw*)(x + row * C + ch * N);
-        if (add_in) r.a[i] = *(const Raw*)(add_in + row * C + ch * N);
-      }
+      r.d[i] = *(const Raw*)(dy + row * C + chc[i] * N);
+      r.xv[i] = *(const Raw*)(x + row * C + chc[i] * N);
+      if constexpr (ADD) r.a[i] = *(const Raw*)(add_in + row * C + chc[i] * N);
     }
   };
   auto unpack = [](const Raw& v, float* o) {
@@ -173,51 +184,45 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      if (lane + 64 * i < nch) {
-        float d[N], xv[N];
-        unpack(r.d[i], d);
-        unpack(r.xv[i], xv);
+      float d[N], xv[N];
+      unpack(r.d[i], d);
+      unpack(r.xv[i], xv);
+      const float on = live[i] ? 1.f : 0.f;  // a lane past the end of the row adds nothing to the row sums
 #pragma unroll
-        for (int e = 0; e < N; ++e) {
-          const float xhat = (xv[e] - r.mu) * r.rs;
-          const float gg = d[e] * gm[i][e];
-          xh[i][e] = xhat;
-          g[i][e] = gg;
-          s1 += gg;
-          s2 = fmaf(gg, xhat, s2);
-          dg[i][e] = fmaf(d[e], xhat, dg[i][e]);
-          db[i][e] += d[e];
-        }
+      for (int e = 0; e < N; ++e) {
+        const float xhat = (xv[e] - r.mu) * r.rs;
+        const float gg = d[e] * gm[i][e];
+        xh[i][e] = xhat;
+        g[i][e] = gg;
+        s1 = fmaf(on, gg, s1);
+        s2 = fmaf(on * gg, xhat, s2);
+        dg[i][e] = fmaf(d[e], xhat, dg[i][e]);
+        db[i][e] += d[e];
       }
     }
     const float c1 = wave_sum(s1) / (float)C, c2 = wave_sum(s2) / (float)C;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int ch = lane + 64 * i;
-      if (ch < nch) {
-        float o[N];
-        if (add_in) unpack(r.a[i], o);
-        else {
+      float o[N];
+      if constexpr (ADD) unpack(r.a[i], o);
+      else {
 #pragma unroll
-          for (int e = 0; e < N; ++e) o[e] = 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < N; ++e) o[e] += r.rs * (g[i][e] - c1 - xh[i][e] * c2);
-        V16<T>::st(dx + row * C + ch * N, o);
+        for (int e = 0; e < N; ++e) o[e] = 0.f;
       }
+#pragma unroll
+      for (int e = 0; e < N; ++e) o[e] += r.rs * (g[i][e] - c1 - xh[i][e] * c2);
+      if (live[i]) V16<T>::st(dx + row * C + chc[i] * N, o);
     }
   };
   RowIn ra, rb;
   long long row = wave;
-  if (row < M) load_row(row, ra);
+  load_row(row, ra);
   for (; row < M; row += 2LL * nwaves) {  // two rows per trip: the register sets swap roles without copies
     const long long r1 = row + nwaves, r2 = r1 + nwaves;
-    if (r1 < M) load_row(r1, rb);
+    load_row(r1, rb);
     do_row(row, ra);
-    if (r1 < M) {
-      if (r2 < M) load_row(r2, ra);
-      do_row(r1, rb);
-    }
+    load_row(r2, ra);
+    if (r1 < M) do_row(r1, rb);
   }
   if (partials) {
     // the block's 4 waves combine their column sums through LDS (fixed order) -> ONE partial row per block
@@ -915,9 +920,15 @@ extern "C" int melgpt_layernorm_bwd(const void* dy, const void* x, const float* 
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = dgamma ? (size_t)4 * 2 * C * sizeof(float) : 0;
   MELGPT_CHECK(lds <= 64 * 1024, MELGPT_ERR_UNSUPPORTED);
-  DISPATCH_LN(dtype, C, hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH>), dim3(nwaves / 4), dim3(256), lds, s, (const T*)dy,
-                                       (const T*)x, gamma, mean, rstd, (const T*)add_in, (T*)dx,
-                                       dgamma ? workspace : nullptr, M, C));
+  if (add_in) {
+    DISPATCH_LN(dtype, C, hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH, true>), dim3(nwaves / 4), dim3(256), lds, s,
+                                         (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)add_in, (T*)dx,
+                                         dgamma ? workspace : nullptr, M, C));
+  } else {
+    DISPATCH_LN(dtype, C, hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH, false>), dim3(nwaves / 4), dim3(256), lds, s,
+                                         (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)add_in, (T*)dx,
+                                         dgamma ? workspace : nullptr, M, C));
+  }
   if (dgamma) {
     const int nblocks = nwaves / 4;
     launch_reduce_rows(workspace, nblocks, 2LL * C, 2LL * C, dgamma, dbeta, (long long)C, accumulate, 1.0f, s);
