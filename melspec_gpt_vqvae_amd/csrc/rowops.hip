@@ -309,11 +309,49 @@ __global__ __launch_bounds__(256) void reduce_rows4_kernel(const float* __restri
   }
 }
 
+// The same sum for a FEW partial rows (R <= RB <= 8: split-K slabs of a weight gradient, N K columns each): one thread
+// per 16-byte column chunk requests all its rows at once (unconditional loads, row index clamped - a branch around a load
+// would be waited for at its end) and adds them in the order reduce_rows4_kernel does (phase sums, then the pair tree),
+// so both kernels give the same bits.  reduce_rows4_kernel spends a 256-thread workgroup on 64 columns and keeps
+// R of its 16 row phases busy: 3 TB/s on 4 x 16 MB slabs.
+template <int RB>  // row phases in use: 2, 4 or 8 (R <= RB)
+__global__ __launch_bounds__(256) void reduce_few_rows_kernel(const float* __restrict__ part, int R, long long ld,
+                                                              long long ncols, float* __restrict__ out,
+                                                              float* __restrict__ out2, long long split, int accumulate,
+                                                              float scale) {
+  const long long c = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= ncols) return;
+  float* dst = (out2 && c >= split) ? out2 + (c - split) : out + c;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 prev = *(const f32x4*)dst;  // (only used when accumulating; dst is always readable)
+  f32x4 v[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) v[r] = *(const f32x4*)(part + (long long)min(r, R - 1) * ld + c);
+#pragma unroll
+  for (int r = 0; r < RB; ++r) v[r] = r < R ? v[r] : zero;
+  f32x4 t[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = (2 * i + 1 < RB) ? v[(2 * i) % RB] + v[(2 * i + 1) % RB] : ((2 * i < RB) ? v[(2 * i) % RB] + zero : zero + zero);
+  f32x4 sum = (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) * scale;
+  if (accumulate) sum += prev;
+  *(f32x4*)dst = sum;
+}
+
 // picks the vectorised form when columns, leading dimension, split and pointers allow 16-byte accesses
 static void launch_reduce_rows(const float* part, int R, long long ld, long long ncols, float* out, float* out2,
                                long long split, int accumulate, float scale, hipStream_t s) {
   const bool vec = ncols % 4 == 0 && ld % 4 == 0 && split % 4 == 0 &&
                    ((((uintptr_t)part | (uintptr_t)out | (uintptr_t)out2) & 15) == 0);
+  if (vec && R <= 8 && ncols >= (1 << 16)) {  // (16 rows keep every phase of reduce_rows4_kernel busy: 11 vs 14.5 us at 1 M columns)
+    const dim3 grid((unsigned)((ncols / 4 + 255) / 256));
+#define MELGPT_FEW(RB) \
+  hipLaunchKernelGGL(reduce_few_rows_kernel<RB>, grid, dim3(256), 0, s, part, R, ld, ncols, out, out2, split, accumulate, scale)
+    if (R <= 2) MELGPT_FEW(2);
+    else if (R <= 4) MELGPT_FEW(4);
+    else MELGPT_FEW(8);
+#undef MELGPT_FEW
+    return;
+  }
   if (vec) {
     hipLaunchKernelGGL(reduce_rows4_kernel, dim3((unsigned)((ncols / 4 + 15) / 16)), dim3(256), 0, s, part, R, ld, ncols,
                        out, out2, split, accumulate, scale);
@@ -349,6 +387,22 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     float a1[NV], a2[NV], a3[NV];
 #pragma unroll
     for (int e = 0; e < NV; ++e) a1[e] = a2[e] = a3[e] = 0.f;
+    // eight rows per trip while they last (same accumulator order as two trips of four: the sums are unchanged, but
+    // eight loads are in flight per lane - at N = 1024 only 512 workgroups cover the matrix)
+    for (; r + 7 * step < M; r += 8 * step) {
+      float v[8][NV];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) V16<T>::ld(a + (r + j * step) * lda + ch * NV, v[j]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+          acc[e] += v[4 * h][e];
+          a1[e] += v[4 * h + 1][e];
+          a2[e] += v[4 * h + 2][e];
+          a3[e] += v[4 * h + 3][e];
+        }
+    }
     for (; r + 3 * step < M; r += 4 * step) {
       float v0[NV], v1[NV], v2[NV], v3[NV];
       V16<T>::ld(a + r * lda + ch * NV, v0);
