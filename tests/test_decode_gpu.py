@@ -172,3 +172,28 @@ def test_skinny_linear_with_layernorm_folded_in(M, N, K, act):
     xs = ops.layernorm_fwd(xb, t(gam, DEV), t(bet, DEV), 1e-5, want_stats=False)[0]
     y2 = ops.linear_rows(xs, wb, bias=t(b, DEV), act=act)
     assert rel_err(y.float().cpu().numpy(), y2.float().cpu().numpy()) < 8e-3
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_decode_never_reads_cache_rows_it_has_not_written(dt):
+    """the KV cache comes from torch.empty: rows at and beyond the current position hold anything.  The attention step
+    requests clamped rows unconditionally (loads in flight together), so their VALUES must never reach the result -
+    a cache pre-filled with NaN has to give the same logits as a zeroed one."""
+    from melspec_gpt_vqvae_amd.transformer.minGPT import set_compute_dtype
+
+    lit, g, x, c = _lit()
+    tr = lit.transformer
+    if dt == "bf16":
+        set_compute_dtype(tr, torch.bfloat16)
+    outs = []
+    with torch.no_grad():
+        for fill in (0.0, float("nan")):
+            cache = tr.decode_begin(x.size(0))
+            for buf in cache["k"] + cache["v"]:
+                buf.fill_(fill)
+            rows = [tr.decode_step(cache, pre_idx=c)]
+            for j in range(6):
+                rows.append(tr.decode_step(cache, idx=x[:, j:j + 1]))
+            outs.append(torch.stack(rows).cpu().numpy())
+    assert np.isfinite(outs[1]).all()
+    assert np.array_equal(outs[0], outs[1])
