@@ -262,6 +262,13 @@ int melgpt_sum_f32(const float* in, long long n, float scale, float* out, int ac
 /* y = keep(x)/(1-p) with the same Philox mask an epilogue used for element i of a contiguous tensor */
 int melgpt_dropout_apply(const void* x, void* y, long long n, float drop_p, unsigned long long seed,
                          unsigned stream_id, int dtype, void* stream);
+/* the same replay AND out[n] (+)= sum_m y[m, n] in one pass over an (M, N) row-major tensor: the backward of
+ * drop(linear(.)) (minGPT.py:88-89,101-105) needs the masked gradient and, for the bias, its column sums; the sums are
+ * taken on y as stored and in melgpt_colsum's order (same bits as melgpt_dropout_apply followed by melgpt_colsum).
+ * workspace: melgpt_colsum_rows() * N floats. */
+int melgpt_dropout_apply_colsum(const void* x, void* y, long long M, int N, float drop_p, unsigned long long seed,
+                                unsigned stream_id, float* out, int accumulate, float* workspace, int dtype,
+                                void* stream);
 int melgpt_cast(const void* x, int src_dtype, void* y, int dst_dtype, long long n, void* stream);
 /* torch.optim.AdamW step (minGPT.py:660-664) fused over a flat f32 buffer; optional bf16 shadow copy. */
 int melgpt_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16,

@@ -438,6 +438,62 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   }
 }
 
+// y = keep(x) * scale (the dropout mask of a forward site replayed on its upstream gradient) AND the column sums of y in
+// one pass: the backward of `drop(linear(...))` needs both d = drop'(dy) and the bias gradient sum_m d[m, :], and the
+// separate column-sum pass re-read the tensor this kernel has just written.  Same grid, row order and accumulators as
+// colsum_partial_kernel on the ROUNDED values, so the partials - and the bias gradients - are the same bits.
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_colsum_kernel(const T* __restrict__ x, T* __restrict__ y, long long M, int N,
+                                                             float scale, unsigned thresh, unsigned long long seed,
+                                                             unsigned sid, float* __restrict__ partials) {
+  constexpr int NV = V16<T>::N;
+  const int ch = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rsub = threadIdx.x >> 6;
+  const int nch = N / NV;
+  float acc[4][NV];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < NV; ++e) acc[j][e] = 0.f;
+  if (ch < nch) {
+    const long long step = (long long)gridDim.y * 4;
+    long long r = (long long)blockIdx.y * 4 + rsub;
+    auto finish = [&](long long row, float* v, float* a) {
+      keep_mask(seed, sid, (unsigned long long)row * N + ch * NV, NV, thresh, scale, v);
+      V16<T>::st(y + row * N + ch * NV, v);
+#pragma unroll
+      for (int e = 0; e < NV; ++e) {
+        if constexpr (sizeof(T) == 2) a[e] += bf16_to_f32(f32_to_bf16(v[e]));
+        else a[e] += v[e];
+      }
+    };
+    for (; r + 3 * step < M; r += 4 * step) {
+      float v[4][NV];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) V16<T>::ld(x + (r + j * step) * N + ch * NV, v[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) finish(r + j * step, v[j], acc[j]);
+    }
+    for (; r < M; r += step) {
+      float v[NV];
+      V16<T>::ld(x + r * N + ch * NV, v);
+      finish(r, v, acc[0]);
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e) acc[0][e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
+  }
+  __shared__ float sh[4][64][NV + 1];
+#pragma unroll
+  for (int e = 0; e < NV; ++e) sh[rsub][threadIdx.x & 63][e] = acc[0][e];
+  __syncthreads();
+  if (rsub == 0 && ch < nch) {
+    const int l = threadIdx.x & 63;
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+      partials[(long long)blockIdx.y * N + ch * NV + e] = (sh[0][l][e] + sh[1][l][e]) + (sh[2][l][e] + sh[3][l][e]);
+  }
+}
+
 // ================================================================================== embedding stem
 // out[b,t,:] = drop( (t < n_pre ? PRE(b,t) : tok_emb[idx[b,t-n_pre]]) + pos_emb[t] )
 //   PRE = pre_table[pre_idx[b*n_pre+t]]  (GPTClass.embedder, minGPT.py:207-212)  or  pre_vals[b,t,:] (f32)
@@ -1088,6 +1144,25 @@ extern "C" int melgpt_dropout_apply(const void* x, void* y, long long n, float d
   DISPATCH_T(dtype, hipLaunchKernelGGL(dropout_apply_kernel<T>, dim3(grid_for(n / vec, 256)), dim3(256), 0,
                                        (hipStream_t)stream, (const T*)x, (T*)y, n, 1.f / (1.f - drop_p),
                                        thresh_of(drop_p), seed, stream_id));
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_dropout_apply_colsum(const void* x, void* y, long long M, int N, float drop_p,
+                                           unsigned long long seed, unsigned stream_id, float* out, int accumulate,
+                                           float* workspace, int dtype, void* stream) {
+  MELGPT_CHECK(x && y && out && workspace && M > 0 && N > 0 && drop_p > 0.f && drop_p < 1.f, MELGPT_ERR_BAD_ARG);
+  const int vec = dtype == MELGPT_F32 ? 4 : 8;
+  MELGPT_CHECK(N % vec == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, MELGPT_ERR_ALIGN);
+  // the geometry of melgpt_colsum
+  long long rows = (M + 3) / 4;
+  const int nch = N / vec;
+  int gy = 2048 / ((nch + 63) / 64);
+  gy = gy < 16 ? 16 : gy > 256 ? 256 : gy;
+  if (rows < gy) gy = (int)rows;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(dropout_colsum_kernel<T>, dim3((nch + 63) / 64, gy), dim3(256), 0, s, (const T*)x,
+                                       (T*)y, M, N, 1.f / (1.f - drop_p), thresh_of(drop_p), seed, stream_id, workspace));
+  launch_reduce_rows(workspace, gy, (long long)N, (long long)N, out, nullptr, 0, accumulate, 1.0f, s);
   return melgpt_launch_status();
 }
 

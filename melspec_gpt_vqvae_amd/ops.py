@@ -342,6 +342,17 @@ def dropout_apply(x, drop_p, seed, stream_id):
     return y
 
 
+def dropout_apply_colsum(x, drop_p, seed, stream_id, out, accumulate=False):
+    """-> y = dropout_apply(x, ...), and out[n] (+)= sum_m y[m, n] from the same pass (x (M,N) contiguous)."""
+    M, N = x.shape
+    assert x.is_contiguous() and out.dtype == torch.float32 and out.numel() == N
+    y = torch.empty_like(x)
+    ws = workspace(_ffi.lib().melgpt_colsum_rows() * N, x.device)
+    call("melgpt_dropout_apply_colsum", ptr(x), ptr(y), M, N, float(drop_p), int(seed), int(stream_id), ptr(out),
+         int(accumulate), ptr(ws), dtype_code(x.dtype), stream())
+    return y
+
+
 def cast(x, dtype, out=None):
     assert x.is_contiguous()
     if out is None:

@@ -113,11 +113,14 @@ def _attention_core_bwd(dy, x2d, saved, w_qkv, w_proj, fp, blkw_params, *, B, T,
     qkv, a, lse = saved
     C = x2d.shape[1]
     (qkv_p, qkvb_p, proj_w, proj_b) = blkw_params
-    d = ops.dropout_apply(dy, resid_p, seed, site + 1) if resid_p > 0 else dy
+    gb, acc = fp.grad_target(proj_b)
+    if resid_p > 0:   # mask replay and the bias gradient (column sums of the masked gradient) in one pass
+        d = ops.dropout_apply_colsum(dy, resid_p, seed, site + 1, gb, accumulate=acc)
+    else:
+        d = dy
+        ops.colsum(d, gb, accumulate=acc)
     gw, acc = fp.grad_target(proj_w)
     ops.wgrad(d, a, gw, acc)         # dW_proj = d^T a
-    gb, acc = fp.grad_target(proj_b)
-    ops.colsum(d, gb, accumulate=acc)
     da = ops.gemm(d, w_proj, b_kmajor=True)
     dqkv = torch.empty_like(qkv)
     k, q, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
@@ -177,11 +180,14 @@ class _BlockFn(torch.autograd.Function):
         if dy2.dtype != dt or not dy2.is_contiguous():
             dy2 = ops.cast(dy2.contiguous(), dt)
         # ---- MLP branch: y = x1 + drop(fc2(gelu(fc1(ln2(x1)))))
-        d = ops.dropout_apply(dy2, mlp_p, seed, site + 2) if mlp_p > 0 else dy2
+        gb, acc = fp.grad_target(m[2].bias)
+        if mlp_p > 0:
+            d = ops.dropout_apply_colsum(dy2, mlp_p, seed, site + 2, gb, accumulate=acc)
+        else:
+            d = dy2
+            ops.colsum(d, gb, accumulate=acc)
         gw, acc = fp.grad_target(m[2].weight)
         ops.wgrad(d, act, gw, acc)
-        gb, acc = fp.grad_target(m[2].bias)
-        ops.colsum(d, gb, accumulate=acc)
         dpre = ops.gemm(d, W.w_fc2, b_kmajor=True, act=ops.ACT_GELU_GRAD, residual=pre)
         gw, acc = fp.grad_target(m[0].weight)
         ops.wgrad(dpre, h2, gw, acc)
