@@ -55,7 +55,22 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
   for (int e = 0; e < N; ++e) s[e] = ss[e] = 0.f;
   if (prow < nrows) {
     const T* xb = x + ((long long)b * HW) * C + col * N;
-    for (int p = p0 + prow; p < p1; p += nrows) {
+    // eight pixels requested per trip, added in the same order as one at a time (same bits): a thread otherwise has a
+    // single 16-byte load in flight and pays a memory latency per pixel
+    int p = p0 + prow;
+    for (; p + 7 * nrows < p1; p += 8 * nrows) {
+      float v[8][N];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) V16<T>::ld(xb + (long long)(p + j * nrows) * C, v[j]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          s[e] += v[j][e];
+          ss[e] = fmaf(v[j][e], v[j][e], ss[e]);
+        }
+    }
+    for (; p < p1; p += nrows) {
       float v[N];
       V16<T>::ld(xb + (long long)p * C, v);
 #pragma unroll
@@ -92,10 +107,23 @@ __global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunk
   if (i >= B * GN_GROUPS) return;
   const int b = i / GN_GROUPS, g = i % GN_GROUPS;
   double a = 0.0, q = 0.0;
-  for (int c = 0; c < nchunks; ++c) {
-    const float* o = partial + (((long long)b * nchunks + c) * GN_GROUPS + g) * 2;
-    a += (double)o[0];
-    q += (double)o[1];
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t* o = (const f32x2_t*)partial + ((long long)b * nchunks) * GN_GROUPS + g;
+  int c = 0;
+  for (; c + 7 < nchunks; c += 8) {  // eight chunks requested together, added in chunk order (same bits as one by one)
+    f32x2_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = o[(long long)(c + j) * GN_GROUPS];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a += (double)v[j][0];
+      q += (double)v[j][1];
+    }
+  }
+  for (; c < nchunks; ++c) {
+    const f32x2_t v = o[(long long)c * GN_GROUPS];
+    a += (double)v[0];
+    q += (double)v[1];
   }
   const double m = a / count;
   double var = q / count - m * m;
