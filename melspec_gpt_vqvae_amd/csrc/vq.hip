@@ -20,19 +20,34 @@ constexpr int VQ_MAX_GRID = 2048;
 struct VqAddr {
   long long inner, s_outer, s_inner, s_c;
 };
+// inner == 0 marks rows at ONE pitch (s_outer == inner * s_inner, folded on the host by vq_fold): no 64-bit
+// division per row - it was ~130 instructions with branches in front of every tile's loads.
 __device__ __forceinline__ long long vq_off(const VqAddr& a, long long n, int c) {
+  if (a.inner == 0) return n * a.s_inner + (long long)c * a.s_c;
   return (n / a.inner) * a.s_outer + (n % a.inner) * a.s_inner + (long long)c * a.s_c;
+}
+inline VqAddr vq_fold(VqAddr a) {
+  if (a.s_outer == a.inner * a.s_inner) a.inner = 0;
+  return a;
 }
 
 __device__ __forceinline__ float bf16lo(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf16hi(unsigned v) { return __uint_as_float(v & 0xFFFF0000u); }
 
 // lexicographic (distance, code) minimum == torch.argmin's first-minimal-index rule
+// Branch-free on purpose: written with `if`, each call became an exec-mask region (s_and_saveexec ... s_or exec) and
+// the 32 regions per tile fenced the scheduler: no LDS read or MFMA of the next code tile could move above them.
 __device__ __forceinline__ void lexmin(float& d, int& k, float d2, int k2) {
-  if (d2 < d || (d2 == d && k2 < k)) {
-    d = d2;
-    k = k2;
-  }
+  const bool c = (d2 < d) | ((d2 == d) & (k2 < k));
+  d = c ? d2 : d;
+  k = c ? k2 : k;
+}
+// Same rule when k2 is known to exceed every index taken so far (codes visited in ascending order in a lane):
+// the tie clause can never fire, a strict compare is the whole test.
+__device__ __forceinline__ void lexmin_asc(float& d, int& k, float d2, int k2) {
+  const bool c = d2 < d;
+  d = c ? d2 : d;
+  k = c ? k2 : k;
 }
 __device__ __forceinline__ void lexmin_xor(float& d, int& k, int mask) {
   float d2 = __shfl_xor(d, mask, 64);
@@ -223,14 +238,32 @@ __global__ __launch_bounds__(256) void vq_f32_kernel(const float* __restrict__ z
 // No staging buffer, no barrier inside the tile loop: waves run independently and 16 of them (2 workgroups of 8)
 // share a CU, so HBM latency is hidden by occupancy.  Strided (NCHW) latents take a scalar gather path.
 constexpr int B16_WAVES = 8;
+#ifndef VQ_CT_UNROLL
+#define VQ_CT_UNROLL 8
+#endif
 constexpr size_t B16_LDS_BYTES = (size_t)VQ_K * 512 + VQ_K * 4 + VQ_K * 4;
 
 __device__ __forceinline__ int cb_off(int code, int chunk) { return code * 512 + ((chunk ^ (code & 15)) << 4); }
 
+// |x|^2 of a lane's vector on the matrix pipe: G = X.X^T over the fragments the distance MFMAs use anyway (8 MFMAs;
+// as 128 shift / and / fma instructions it was 40 % of the tile's vector issue, and the kernel is issue-bound).
+// Lane (v, g) ends with G[4g .. 4g+3][v]; the diagonal G[v][v] sits in lane (v, v >> 2), slot v & 3, and all four
+// lanes of a vector fetch it from there, so they agree on A bit for bit.
+__device__ __forceinline__ float xsq_mfma(const u32x4 (&xf)[8], int r16) {
+  f32x4 gg = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+    gg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, xf[ks]), __builtin_bit_cast(s16x8, xf[ks]), gg,
+                                                 0, 0, 0);
+  const int slot = r16 & 3;
+  const float lo = (slot & 1) ? gg[1] : gg[0], hi = (slot & 1) ? gg[3] : gg[2];
+  return __shfl((slot & 2) ? hi : lo, r16 + 16 * (r16 >> 2), 64);
+}
+
 // FLAT: channel-contiguous latents (16-byte fragment loads).  EXTRAS: gather / squared error / distances wanted.
 // The lean <true,false> instantiation is the hot path of extract_codes (indices only).
-template <bool FLAT, bool EXTRAS>
-__global__ __launch_bounds__(64 * B16_WAVES, EXTRAS ? 2 : 4) void vq_bf16_kernel(const bf16_t* __restrict__ z, VqAddr za, long long N,
+template <bool FLAT, bool EXTRAS, int VAR = 0>
+__global__ __launch_bounds__(64 * B16_WAVES, (EXTRAS || VAR == 2) ? 2 : 4) void vq_bf16_kernel(const bf16_t* __restrict__ z, VqAddr za, long long N,
                                                                    const float* __restrict__ codebook,
                                                                    long long* __restrict__ indices,
                                                                    bf16_t* __restrict__ qout, float* __restrict__ sq_err,
@@ -243,12 +276,12 @@ __global__ __launch_bounds__(64 * B16_WAVES, EXTRAS ? 2 : 4) void vq_bf16_kernel
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int r16 = lane & 15, g = lane >> 4;
 
-  const long long ntiles = (N + 15) / 16;
-  const long long stride = (long long)gridDim.x * B16_WAVES;
+  const int ntiles = (int)((N + 15) / 16);  // the launcher refuses N beyond 2^31 tiles
+  const int stride = (int)gridDim.x * B16_WAVES;
   float err = 0.f;
   // this lane's fragments of the 16 vectors of `tile` (clamped row for the ragged tail)
-  auto load_x = [&](long long tile, u32x4 (&dst)[8]) {
-    long long nn = tile * 16 + r16;
+  auto load_x = [&](int tile, u32x4 (&dst)[8]) {
+    long long nn = (long long)tile * 16 + r16;
     if (nn >= N) nn = N - 1;
     if constexpr (FLAT) {
       const bf16_t* xp = z + vq_off(za, nn, 8 * g);
@@ -265,7 +298,7 @@ __global__ __launch_bounds__(64 * B16_WAVES, EXTRAS ? 2 : 4) void vq_bf16_kernel
     }
   };
   u32x4 xf[8], xn[8];
-  long long tile = (long long)blockIdx.x * B16_WAVES + w;
+  int tile = (int)blockIdx.x * B16_WAVES + w;
   if (tile < ntiles) load_x(tile, xf);  // the first tile's vectors fly under the codebook staging
   {  // 16-byte chunk q = (code, chunk) of the rounded codebook; all 16 loads of a thread in flight before the first store
     static_assert(VQ_K * 32 == 8 * 64 * B16_WAVES, "eight chunks per thread");
@@ -301,26 +334,22 @@ __global__ __launch_bounds__(64 * B16_WAVES, EXTRAS ? 2 : 4) void vq_bf16_kernel
   __syncthreads();
 
   for (; tile < ntiles; tile += stride) {
-    const long long n = tile * 16 + r16;
+    const long long n = (long long)tile * 16 + r16;
     const bool valid = n < N;
     const bool more = tile + stride < ntiles;
-    if (FLAT && more) load_x(tile + stride, xn);  // next tile's loads fly under this tile's MFMAs
-    float A = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        A = fmaf(bf16lo(xf[ks][e]), bf16lo(xf[ks][e]), A);
-        A = fmaf(bf16hi(xf[ks][e]), bf16hi(xf[ks][e]), A);
-      }
-    A += __shfl_xor(A, 16, 64);
-    A += __shfl_xor(A, 32, 64);
+    if (FLAT && VAR != 1 && more) load_x(tile + stride, xn);  // next tile's loads fly under this tile's MFMAs
+    const float A = xsq_mfma(xf, r16);
 
+    // starts at the lane's first code, not at a sentinel: a row whose distances are all +inf then resolves to code 0
+    // through the cross-lane rule below, as torch.argmin does
     float best = __builtin_inff();
-    int bk = 0x7fffffff;
-#pragma unroll 2
+    int bk = 4 * g;
+    // one basic block per VQ_CT_UNROLL code tiles: the code fragments and the |e|^2 quad of the next code tile are
+    // requested while the current tile's distances are compared
+#pragma unroll VQ_CT_UNROLL
     for (int ct = 0; ct < 8; ++ct) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 b4 = *(const f32x4*)(bsq + 16 * ct + 4 * g);  // this lane's four codes of the tile: one ds_read_b128
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const u32x4 cf = *(const u32x4*)(cbs + cb_off(16 * ct + r16, 4 * ks + g));
@@ -330,11 +359,20 @@ __global__ __launch_bounds__(64 * B16_WAVES, EXTRAS ? 2 : 4) void vq_bf16_kernel
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int code = 16 * ct + 4 * g + rg;
-        const float d = (A + bsq[code]) - 2.0f * acc[rg];
+        const float d = (A + b4[rg]) - 2.0f * acc[rg];
         if constexpr (EXTRAS) {
           if (dist_out && valid) dist_out[n * VQ_K + code] = d;
         }
-        lexmin(best, bk, d, code);
+        lexmin_asc(best, bk, d, code);  // a lane meets its codes in ascending order
+      }
+      if constexpr (VAR == 2) {  // LDS reads two ahead of the MFMA that consumes them, across code tiles
+        if (ct == 0) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
     }
     lexmin_xor(best, bk, 16);
@@ -371,7 +409,7 @@ __global__ __launch_bounds__(64 * B16_WAVES, EXTRAS ? 2 : 4) void vq_bf16_kernel
       }
     }
     if (more) {
-      if constexpr (FLAT) {
+      if constexpr (FLAT && VAR != 1) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) xf[ks] = xn[ks];
       } else {
@@ -392,6 +430,135 @@ __global__ __launch_bounds__(64 * B16_WAVES, EXTRAS ? 2 : 4) void vq_bf16_kernel
   } else {
     __syncthreads();
   }
+  if (hist && t < VQ_K && hist_s[t]) atomicAdd(&hist[t], hist_s[t]);
+}
+
+// ------------------------------------------------------------------------------ BF16, indices only (extract_codes)
+// Same arithmetic as vq_bf16_kernel<true, false> (same fragments, same MFMA order, same bits); what differs is how the
+// latent vectors reach the registers.  A B-operand lane owns ONE vector, so fragment loads straight from global
+// memory touch 16 rows per 16-lane pass, 16 bytes each: 512 line look-ups per 8 KB tile, and the vector L1's
+// address path, not HBM, set the pace (4.0 of 8 TB/s at 1 M vectors).  Here every wave instruction reads four
+// 256-byte row segments (16 lanes x 16 B contiguous), the raw registers go through a wave-private 4 KiB LDS block
+// (two half-tiles, chunks XOR-swizzled by the row like the codebook: conflict-free both ways, no barrier - a wave's
+// LDS operations complete in order) and come back in fragment layout; the next tile's raw loads are issued right
+// after the LDS writes have read the registers.  One workgroup per CU (WAVES = 16 shares one codebook image, 8 for
+// small N so that more CUs take part).
+template <int WAVES, int MODE = 0>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES / 4, WAVES / 4))) void vq_bf16_staged_kernel(const bf16_t* __restrict__ z, VqAddr za, long long N,
+                                                                    const float* __restrict__ codebook,
+                                                                    long long* __restrict__ indices,
+                                                                    int* __restrict__ hist) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* cbs = smem;                          // [128][512 B] bf16, swizzled
+  float* bsq = (float*)(smem + VQ_K * 512);  // [128] |e|^2 of the ROUNDED codes
+  int* hist_s = (int*)(bsq + VQ_K);          // [128]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  char* xs = smem + VQ_K * 512 + VQ_K * 8 + w * 4096;  // this wave's half-tile: [16 rows][256 B]
+
+  const int ntiles = (int)((N + 15) / 16);
+  const int stride = (int)gridDim.x * WAVES;
+  // raw[4h + jr] = 16 bytes at (row 4jr + lane/16, chunk 16h + lane%16) of the tile
+  auto load_raw = [&](int tile, u32x4 (&dst)[8]) {
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr) {
+      long long nn = (long long)tile * 16 + 4 * jr + g;
+      if (nn >= N) nn = N - 1;
+      const bf16_t* xp = z + vq_off(za, nn, 8 * r16);
+      dst[jr] = *(const u32x4*)xp;
+      dst[4 + jr] = *(const u32x4*)(xp + 128);
+    }
+  };
+  u32x4 raw[8], xf[8];
+  int tile = (int)blockIdx.x * WAVES + w;
+  if (tile < ntiles) load_raw(tile, raw);  // the first tile flies under the codebook staging
+  {
+    // 16-byte chunks of the rounded codebook per thread; a thread count that does not divide 4096 re-does a few
+    // chunks of the last code (clamped index, same bytes stored twice) instead of branching around loads
+    constexpr int CHUNKS = (VQ_K * 32 + 64 * WAVES - 1) / (64 * WAVES);
+    f32x4 lo[CHUNKS], hi[CHUNKS];
+#pragma unroll
+    for (int u = 0; u < CHUNKS; ++u) {
+      int q = t + 64 * WAVES * u;
+      q = q < VQ_K * 32 ? q : VQ_K * 32 - 1;
+      const float* e = codebook + (size_t)(q >> 5) * VQ_D + (q & 31) * 8;
+      lo[u] = *(const f32x4*)e;
+      hi[u] = *(const f32x4*)(e + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < CHUNKS; ++u) {
+      int q = t + 64 * WAVES * u;
+      q = q < VQ_K * 32 ? q : VQ_K * 32 - 1;
+      *(u32x4*)(cbs + cb_off(q >> 5, q & 31)) = u32x4{pack_bf16x2(lo[u][0], lo[u][1]), pack_bf16x2(lo[u][2], lo[u][3]),
+                                                      pack_bf16x2(hi[u][0], hi[u][1]), pack_bf16x2(hi[u][2], hi[u][3])};
+    }
+  }
+  if (t < VQ_K) hist_s[t] = 0;
+  __syncthreads();
+  if (t < VQ_K) {  // same chain as vq_bf16_kernel
+    float p = 0.f;
+    for (int ch = 0; ch < 32; ++ch) {
+      u32x4 v = *(const u32x4*)(cbs + cb_off(t, ch));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        p = fmaf(bf16lo(v[e]), bf16lo(v[e]), p);
+        p = fmaf(bf16hi(v[e]), bf16hi(v[e]), p);
+      }
+    }
+    bsq[t] = p;
+  }
+  __syncthreads();
+
+  for (; tile < ntiles; tile += stride) {
+    const long long n = (long long)tile * 16 + r16;
+    const bool valid = n < N;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int jr = 0; jr < 4; ++jr) {
+        const int r = 4 * jr + g;
+        *(u32x4*)(xs + r * 256 + ((r16 ^ r) << 4)) = raw[4 * h + jr];
+      }
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) xf[4 * h + k4] = *(const u32x4*)(xs + r16 * 256 + (((4 * k4 + g) ^ r16) << 4));
+    }
+    {  // next tile (clamped: the last round re-reads its own tile rather than branching around the loads)
+      const int nt = tile + stride < ntiles ? tile + stride : tile;
+      if constexpr (MODE != 2) load_raw(nt, raw);
+    }
+    if constexpr (MODE == 1) {  // lab: loads + transposition only
+      unsigned x = 0;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) x ^= xf[ks][0] ^ xf[ks][1] ^ xf[ks][2] ^ xf[ks][3];
+      if (g == 0 && valid) indices[n] = (long long)(x & 127);
+      continue;
+    }
+    const float A = xsq_mfma(xf, r16);
+
+    float best = __builtin_inff();
+    int bk = 4 * g;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 b4 = *(const f32x4*)(bsq + 16 * ct + 4 * g);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const u32x4 cf = *(const u32x4*)(cbs + cb_off(16 * ct + r16, 4 * ks + g));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, cf), __builtin_bit_cast(s16x8, xf[ks]),
+                                                      acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) lexmin_asc(best, bk, (A + b4[rg]) - 2.0f * acc[rg], 16 * ct + 4 * g + rg);
+    }
+    lexmin_xor(best, bk, 16);
+    lexmin_xor(best, bk, 32);
+    bk &= (VQ_K - 1);
+    if (g == 0 && valid) {
+      indices[n] = (long long)bk;
+      if (hist) atomicAdd(&hist_s[bk], 1);
+    }
+  }
+  __syncthreads();
   if (hist && t < VQ_K && hist_s[t]) atomicAdd(&hist[t], hist_s[t]);
 }
 
@@ -491,7 +658,7 @@ extern "C" int melgpt_vq_argmin_fwd_ex(const void* z, int z_dtype, int64_t n_vec
   int st = validate_addr(n_vectors, dim, inner, num_codes);
   if (st != MELGPT_OK) return st;
   MELGPT_CHECK(((uintptr_t)codebook & 15) == 0, MELGPT_ERR_ALIGN);
-  VqAddr za{inner, stride_outer, stride_inner, stride_c};
+  VqAddr za = vq_fold(VqAddr{inner, stride_outer, stride_inner, stride_c});
   hipStream_t s = (hipStream_t)stream;
   if (z_dtype == MELGPT_F32) {
     int flat = (stride_c == 1 && (stride_inner % 4) == 0 && (stride_outer % 4) == 0 &&
@@ -512,11 +679,14 @@ extern "C" int melgpt_vq_argmin_fwd_ex(const void* z, int z_dtype, int64_t n_vec
   } else if (z_dtype == MELGPT_BF16) {
     int flat = (stride_c == 1 && (stride_inner % 8) == 0 && (stride_outer % 8) == 0 &&
                 ((uintptr_t)z & 15) == 0 && (!quantized || ((uintptr_t)quantized & 15) == 0));
+    MELGPT_CHECK(n_vectors <= (int64_t)16 * 0x7ffffff0, MELGPT_ERR_UNSUPPORTED);  // tile numbers are 32-bit in the kernel
     long long wg_tiles = ((n_vectors + 15) / 16 + B16_WAVES - 1) / B16_WAVES;  // 16 vectors per wave, 8 waves
     int grid = (int)(wg_tiles < 512 ? wg_tiles : 512);                         // 2 persistent workgroups per CU
     static bool attr16 = false;
     if (!attr16) {
       bool ok = hipFuncSetAttribute((const void*)vq_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B16_LDS_BYTES) == hipSuccess;
+      ok = ok && hipFuncSetAttribute((const void*)vq_bf16_kernel<true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B16_LDS_BYTES) == hipSuccess;
+      ok = ok && hipFuncSetAttribute((const void*)vq_bf16_kernel<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B16_LDS_BYTES) == hipSuccess;
       ok = ok && hipFuncSetAttribute((const void*)vq_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B16_LDS_BYTES) == hipSuccess;
       ok = ok && hipFuncSetAttribute((const void*)vq_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B16_LDS_BYTES) == hipSuccess;
       if (!ok) return MELGPT_ERR_LAUNCH;
@@ -527,6 +697,50 @@ extern "C" int melgpt_vq_argmin_fwd_ex(const void* z, int z_dtype, int64_t n_vec
   hipLaunchKernelGGL((vq_bf16_kernel<F, E>), dim3(grid), dim3(64 * B16_WAVES), B16_LDS_BYTES, s, (const bf16_t*)z, za, \
                      (long long)n_vectors, codebook, (long long*)indices, (bf16_t*)quantized, sq_err, (int*)histogram, \
                      distances)
+    static const int lab_var = getenv("MELGPT_VQ_VAR") ? atoi(getenv("MELGPT_VQ_VAR")) : 0;
+    if (flat && !extras && lab_var >= 3) {
+      const long long ntl = (n_vectors + 15) / 16;
+      static bool attr_st = false;
+      if (!attr_st) {
+        bool ok = hipFuncSetAttribute((const void*)vq_bf16_staged_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B16_LDS_BYTES + 16 * 4096)) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)vq_bf16_staged_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B16_LDS_BYTES + 12 * 4096)) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)vq_bf16_staged_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B16_LDS_BYTES + 8 * 4096)) == hipSuccess;
+        if (!ok) return MELGPT_ERR_LAUNCH;
+        attr_st = true;
+      }
+      const int wv = lab_var == 3 ? (ntl >= 256 * 16 ? 16 : 8) : lab_var == 4 ? (ntl >= 256 * 12 ? 12 : 8) : 8;
+      const long long wgs = (ntl + wv - 1) / wv;
+      grid = (int)(wgs < 256 ? wgs : 256);
+#define VQST_LAUNCH(W)                                                                                                 \
+  hipLaunchKernelGGL(vq_bf16_staged_kernel<W>, dim3(grid), dim3(64 * W), B16_LDS_BYTES + W * 4096, s, (const bf16_t*)z, \
+                     za, (long long)n_vectors, codebook, (long long*)indices, (int*)histogram)
+      if (lab_var == 6 || lab_var == 7) {
+        static bool a2 = false;
+        if (!a2) {
+          (void)hipFuncSetAttribute((const void*)vq_bf16_staged_kernel<12, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B16_LDS_BYTES + 12 * 4096));
+          (void)hipFuncSetAttribute((const void*)vq_bf16_staged_kernel<12, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B16_LDS_BYTES + 12 * 4096));
+          a2 = true;
+        }
+        const long long w12 = (ntl + 11) / 12;
+        grid = (int)(w12 < 256 ? w12 : 256);
+        if (lab_var == 6)
+          hipLaunchKernelGGL((vq_bf16_staged_kernel<12, 1>), dim3(grid), dim3(768), B16_LDS_BYTES + 12 * 4096, s, (const bf16_t*)z, za, (long long)n_vectors, codebook, (long long*)indices, (int*)histogram);
+        else
+          hipLaunchKernelGGL((vq_bf16_staged_kernel<12, 2>), dim3(grid), dim3(768), B16_LDS_BYTES + 12 * 4096, s, (const bf16_t*)z, za, (long long)n_vectors, codebook, (long long*)indices, (int*)histogram);
+      } else
+      if (wv == 16) VQST_LAUNCH(16);
+      else if (wv == 12) VQST_LAUNCH(12);
+      else VQST_LAUNCH(8);
+#undef VQST_LAUNCH
+    } else
+    if (flat && !extras && lab_var == 1) {
+      hipLaunchKernelGGL((vq_bf16_kernel<true, false, 1>), dim3(grid), dim3(64 * B16_WAVES), B16_LDS_BYTES, s, (const bf16_t*)z, za,
+                     (long long)n_vectors, codebook, (long long*)indices, (bf16_t*)quantized, sq_err, (int*)histogram, distances);
+    } else if (flat && !extras && lab_var == 2) {
+      if (grid > 256) grid = 256;
+      hipLaunchKernelGGL((vq_bf16_kernel<true, false, 2>), dim3(grid), dim3(64 * B16_WAVES), B16_LDS_BYTES, s, (const bf16_t*)z, za,
+                     (long long)n_vectors, codebook, (long long*)indices, (bf16_t*)quantized, sq_err, (int*)histogram, distances);
+    } else
     if (flat && !extras) VQ16_LAUNCH(true, false);
     else if (flat) VQ16_LAUNCH(true, true);
     else VQ16_LAUNCH(false, true);
@@ -562,7 +776,7 @@ extern "C" int melgpt_vq_gather(const int64_t* indices, int64_t n_vectors, const
                                 int64_t stride_outer, int64_t stride_inner, int64_t stride_c, void* stream) {
   MELGPT_CHECK(indices && codebook && out && n_vectors > 0 && dim > 0 && num_codes > 0 && inner > 0,
                MELGPT_ERR_BAD_ARG);
-  VqAddr oa{inner, stride_outer, stride_inner, stride_c};
+  VqAddr oa = vq_fold(VqAddr{inner, stride_outer, stride_inner, stride_c});
   long long total = (long long)n_vectors * dim;
   int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipStream_t s = (hipStream_t)stream;
@@ -593,7 +807,7 @@ extern "C" int melgpt_vq_bwd(const void* z, const void* g_quantized, int dtype, 
                              const float* g_loss, float commitment_cost, void* dz, float* dcodebook,
                              void* stream) {
   MELGPT_CHECK(z && codebook && indices && n_vectors > 0 && dim > 0 && inner > 0, MELGPT_ERR_BAD_ARG);
-  VqAddr za{inner, stride_outer, stride_inner, stride_c};
+  VqAddr za = vq_fold(VqAddr{inner, stride_outer, stride_inner, stride_c});
   long long total = (long long)n_vectors * dim;
   int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipStream_t s = (hipStream_t)stream;

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""VQ lookup lab: in-stream time per launch of melgpt_vq_argmin_fwd_ex (indices only), `reps` launches back to back
+between two HIP events so that host launch overhead is not what is measured; batch sweep, both lanes.
+MELGPT_VQ_VAR selects a lab variant of the lean bf16 kernel where one is compiled in.  Prints one JSON line per case
+plus a checksum of the indices so that variants can be compared bit for bit."""
+import ctypes
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+
+from melspec_gpt_vqvae_amd import _ffi
+
+DEV = "cuda:0"
+
+
+def run(z, cb, idx, reps):
+    N, D = z.shape
+    grid = ctypes.c_int(0)
+
+    def launch():
+        _ffi.call("melgpt_vq_argmin_fwd_ex", _ffi.ptr(z), _ffi.dtype_code(z.dtype), N, D, N, N * D, D, 1, _ffi.ptr(cb), 128,
+                  _ffi.ptr(idx), None, None, None, None, ctypes.addressof(grid), _ffi.stream())
+
+    for _ in range(5):
+        launch()
+    torch.cuda.synchronize()
+    best = []
+    for _ in range(7):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            launch()
+        e.record()
+        torch.cuda.synchronize()
+        best.append(s.elapsed_time(e) / reps)
+    best.sort()
+    return best[len(best) // 2], grid.value
+
+
+def main():
+    var = os.environ.get("MELGPT_VQ_VAR", "0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    cb = torch.randn(128, 256, generator=g).to(DEV)
+    for dt, es in ((torch.bfloat16, 2), (torch.float32, 4)):
+        for B in (64, 256, 1024, 4096):
+            n = B * 265
+            z = torch.randn(n, 256, generator=g).to(DEV).to(dt)
+            idx = torch.empty(n, dtype=torch.int64, device=DEV)
+            ms, grid = run(z, cb, idx, 50 if B <= 1024 else 20)
+            by = n * (256 * es + 8) + 128 * 256 * 4
+            h = hashlib.sha1(idx.cpu().numpy().tobytes()).hexdigest()[:12]
+            print(json.dumps(dict(kernel=f"vq_argmin_{'bf16' if es == 2 else 'f32'}", var=var, batch=B, vectors=n, grid=grid,
+                                  us=round(ms * 1e3, 2), algorithmic_MB=round(by / 1e6, 2), GBps=round(by / ms / 1e6, 1),
+                                  frac_hbm=round(by / ms / 1e6 / 8000.0, 4), idx_sha=h)), flush=True)
+        if os.environ.get("VQ_LAB_BF16_ONLY"):
+            break
+
+
+if __name__ == "__main__":
+    main()
