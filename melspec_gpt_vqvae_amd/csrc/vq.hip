@@ -237,10 +237,11 @@ __global__ __launch_bounds__(256) void vq_f32_kernel(const float* __restrict__ z
 //   |x|^2 from the same registers, argmin in-lane + 2 xor-shuffles, optional gather / error / histogram.
 // No staging buffer, no barrier inside the tile loop: waves run independently and 16 of them (2 workgroups of 8)
 // share a CU, so HBM latency is hidden by occupancy.  Strided (NCHW) latents take a scalar gather path.
+// What bounds it (tools/lab/vq_lab.py, profiles/r01_m_vq_lab.jsonl; 1.09 M vectors = 565 MB): the loads alone
+// take 107 us (5.3 TB/s), the MFMA + compare work alone 93 us - 72 MFMAs per tile at the clock the chip holds under
+// matrix load - and the two overlap only in part: 128 us.  A variant with coalesced loads transposed through a
+// wave-private LDS block measured the same (131-139 us), so the fragment loads are not what limits it.
 constexpr int B16_WAVES = 8;
-#ifndef VQ_CT_UNROLL
-#define VQ_CT_UNROLL 8
-#endif
 constexpr size_t B16_LDS_BYTES = (size_t)VQ_K * 512 + VQ_K * 4 + VQ_K * 4;
 
 __device__ __forceinline__ int cb_off(int code, int chunk) { return code * 512 + ((chunk ^ (code & 15)) << 4); }
@@ -262,13 +263,18 @@ __device__ __forceinline__ float xsq_mfma(const u32x4 (&xf)[8], int r16) {
 
 // FLAT: channel-contiguous latents (16-byte fragment loads).  EXTRAS: gather / squared error / distances wanted.
 // The lean <true,false> instantiation is the hot path of extract_codes (indices only).
-template <bool FLAT, bool EXTRAS, int VAR = 0>
-__global__ __launch_bounds__(64 * B16_WAVES, (EXTRAS || VAR == 2) ? 2 : 4) void vq_bf16_kernel(const bf16_t* __restrict__ z, VqAddr za, long long N,
+template <bool FLAT, bool EXTRAS>
+__global__ __launch_bounds__(64 * B16_WAVES, EXTRAS ? 2 : 4) void vq_bf16_kernel(const bf16_t* __restrict__ z, VqAddr za, long long N,
                                                                    const float* __restrict__ codebook,
                                                                    long long* __restrict__ indices,
                                                                    bf16_t* __restrict__ qout, float* __restrict__ sq_err,
                                                                    int* __restrict__ hist, float* __restrict__ dist_out) {
   constexpr bool flat = FLAT;
+  // The kernels with extra outputs still need xf after the MFMAs (gather, error), so their next tile is fetched into a
+  // second register set under the MFMAs.  The lean kernel reloads xf in place once the last MFMA has read it and
+  // leaves the latency to the other three waves of its SIMD: measured faster at every size (r01_m_vq_lab.jsonl),
+  // the 32 registers let the compiler run the LDS fragment reads ahead of the MFMAs instead of one at a time.
+  constexpr bool PF = FLAT && EXTRAS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* cbs = smem;                                   // [128][512 B] bf16, swizzled
   float* bsq = (float*)(smem + VQ_K * 512);           // [128] |e|^2 of the ROUNDED codes
@@ -337,16 +343,16 @@ __global__ __launch_bounds__(64 * B16_WAVES, (EXTRAS || VAR == 2) ? 2 : 4) void 
     const long long n = (long long)tile * 16 + r16;
     const bool valid = n < N;
     const bool more = tile + stride < ntiles;
-    if (FLAT && VAR != 1 && more) load_x(tile + stride, xn);  // next tile's loads fly under this tile's MFMAs
+    if (PF && more) load_x(tile + stride, xn);  // next tile's loads fly under this tile's MFMAs
     const float A = xsq_mfma(xf, r16);
 
     // starts at the lane's first code, not at a sentinel: a row whose distances are all +inf then resolves to code 0
     // through the cross-lane rule below, as torch.argmin does
     float best = __builtin_inff();
     int bk = 4 * g;
-    // one basic block per VQ_CT_UNROLL code tiles: the code fragments and the |e|^2 quad of the next code tile are
+    // one basic block for the eight code tiles: the code fragments and the |e|^2 quad of the next code tile are
     // requested while the current tile's distances are compared
-#pragma unroll VQ_CT_UNROLL
+#pragma unroll
     for (int ct = 0; ct < 8; ++ct) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const f32x4 b4 = *(const f32x4*)(bsq + 16 * ct + 4 * g);  // this lane's four codes of the tile: one ds_read_b128
@@ -364,15 +370,6 @@ __global__ __launch_bounds__(64 * B16_WAVES, (EXTRAS || VAR == 2) ? 2 : 4) void 
           if (dist_out && valid) dist_out[n * VQ_K + code] = d;
         }
         lexmin_asc(best, bk, d, code);  // a lane meets its codes in ascending order
-      }
-      if constexpr (VAR == 2) {  // LDS reads two ahead of the MFMA that consumes them, across code tiles
-        if (ct == 0) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
     }
     lexmin_xor(best, bk, 16);
@@ -409,7 +406,7 @@ __global__ __launch_bounds__(64 * B16_WAVES, (EXTRAS || VAR == 2) ? 2 : 4) void 
       }
     }
     if (more) {
-      if constexpr (FLAT && VAR != 1) {
+      if constexpr (PF) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) xf[ks] = xn[ks];
       } else {
@@ -430,135 +427,6 @@ __global__ __launch_bounds__(64 * B16_WAVES, (EXTRAS || VAR == 2) ? 2 : 4) void 
   } else {
     __syncthreads();
   }
-  if (hist && t < VQ_K && hist_s[t]) atomicAdd(&hist[t], hist_s[t]);
-}
-
-// ------------------------------------------------------------------------------ BF16, indices only (extract_codes)
-// Same arithmetic as vq_bf16_kernel<true, false> (same fragments, same MFMA order, same bits); what differs is how the
-// latent vectors reach the registers.  A B-operand lane owns ONE vector, so fragment loads straight from global
-// memory touch 16 rows per 16-lane pass, 16 bytes each: 512 line look-ups per 8 KB tile, and the vector L1's
-// address path, not HBM, set the pace (4.0 of 8 TB/s at 1 M vectors).  Here every wave instruction reads four
-// 256-byte row segments (16 lanes x 16 B contiguous), the raw registers go through a wave-private 4 KiB LDS block
-// (two half-tiles, chunks XOR-swizzled by the row like the codebook: conflict-free both ways, no barrier - a wave's
-// LDS operations complete in order) and come back in fragment layout; the next tile's raw loads are issued right
-// after the LDS writes have read the registers.  One workgroup per CU (WAVES = 16 shares one codebook image, 8 for
-// small N so that more CUs take part).
-template <int WAVES, int MODE = 0>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES / 4, WAVES / 4))) void vq_bf16_staged_kernel(const bf16_t* __restrict__ z, VqAddr za, long long N,
-                                                                    const float* __restrict__ codebook,
-                                                                    long long* __restrict__ indices,
-                                                                    int* __restrict__ hist) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* cbs = smem;                          // [128][512 B] bf16, swizzled
-  float* bsq = (float*)(smem + VQ_K * 512);  // [128] |e|^2 of the ROUNDED codes
-  int* hist_s = (int*)(bsq + VQ_K);          // [128]
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int r16 = lane & 15, g = lane >> 4;
-  char* xs = smem + VQ_K * 512 + VQ_K * 8 + w * 4096;  // this wave's half-tile: [16 rows][256 B]
-
-  const int ntiles = (int)((N + 15) / 16);
-  const int stride = (int)gridDim.x * WAVES;
-  // raw[4h + jr] = 16 bytes at (row 4jr + lane/16, chunk 16h + lane%16) of the tile
-  auto load_raw = [&](int tile, u32x4 (&dst)[8]) {
-#pragma unroll
-    for (int jr = 0; jr < 4; ++jr) {
-      long long nn = (long long)tile * 16 + 4 * jr + g;
-      if (nn >= N) nn = N - 1;
-      const bf16_t* xp = z + vq_off(za, nn, 8 * r16);
-      dst[jr] = *(const u32x4*)xp;
-      dst[4 + jr] = *(const u32x4*)(xp + 128);
-    }
-  };
-  u32x4 raw[8], xf[8];
-  int tile = (int)blockIdx.x * WAVES + w;
-  if (tile < ntiles) load_raw(tile, raw);  // the first tile flies under the codebook staging
-  {
-    // 16-byte chunks of the rounded codebook per thread; a thread count that does not divide 4096 re-does a few
-    // chunks of the last code (clamped index, same bytes stored twice) instead of branching around loads
-    constexpr int CHUNKS = (VQ_K * 32 + 64 * WAVES - 1) / (64 * WAVES);
-    f32x4 lo[CHUNKS], hi[CHUNKS];
-#pragma unroll
-    for (int u = 0; u < CHUNKS; ++u) {
-      int q = t + 64 * WAVES * u;
-      q = q < VQ_K * 32 ? q : VQ_K * 32 - 1;
-      const float* e = codebook + (size_t)(q >> 5) * VQ_D + (q & 31) * 8;
-      lo[u] = *(const f32x4*)e;
-      hi[u] = *(const f32x4*)(e + 4);
-    }
-#pragma unroll
-    for (int u = 0; u < CHUNKS; ++u) {
-      int q = t + 64 * WAVES * u;
-      q = q < VQ_K * 32 ? q : VQ_K * 32 - 1;
-      *(u32x4*)(cbs + cb_off(q >> 5, q & 31)) = u32x4{pack_bf16x2(lo[u][0], lo[u][1]), pack_bf16x2(lo[u][2], lo[u][3]),
-                                                      pack_bf16x2(hi[u][0], hi[u][1]), pack_bf16x2(hi[u][2], hi[u][3])};
-    }
-  }
-  if (t < VQ_K) hist_s[t] = 0;
-  __syncthreads();
-  if (t < VQ_K) {  // same chain as vq_bf16_kernel
-    float p = 0.f;
-    for (int ch = 0; ch < 32; ++ch) {
-      u32x4 v = *(const u32x4*)(cbs + cb_off(t, ch));
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        p = fmaf(bf16lo(v[e]), bf16lo(v[e]), p);
-        p = fmaf(bf16hi(v[e]), bf16hi(v[e]), p);
-      }
-    }
-    bsq[t] = p;
-  }
-  __syncthreads();
-
-  for (; tile < ntiles; tile += stride) {
-    const long long n = (long long)tile * 16 + r16;
-    const bool valid = n < N;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int jr = 0; jr < 4; ++jr) {
-        const int r = 4 * jr + g;
-        *(u32x4*)(xs + r * 256 + ((r16 ^ r) << 4)) = raw[4 * h + jr];
-      }
-#pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) xf[4 * h + k4] = *(const u32x4*)(xs + r16 * 256 + (((4 * k4 + g) ^ r16) << 4));
-    }
-    {  // next tile (clamped: the last round re-reads its own tile rather than branching around the loads)
-      const int nt = tile + stride < ntiles ? tile + stride : tile;
-      if constexpr (MODE != 2) load_raw(nt, raw);
-    }
-    if constexpr (MODE == 1) {  // lab: loads + transposition only
-      unsigned x = 0;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) x ^= xf[ks][0] ^ xf[ks][1] ^ xf[ks][2] ^ xf[ks][3];
-      if (g == 0 && valid) indices[n] = (long long)(x & 127);
-      continue;
-    }
-    const float A = xsq_mfma(xf, r16);
-
-    float best = __builtin_inff();
-    int bk = 4 * g;
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const f32x4 b4 = *(const f32x4*)(bsq + 16 * ct + 4 * g);
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const u32x4 cf = *(const u32x4*)(cbs + cb_off(16 * ct + r16, 4 * ks + g));
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, cf), __builtin_bit_cast(s16x8, xf[ks]),
-                                                      acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) lexmin_asc(best, bk, (A + b4[rg]) - 2.0f * acc[rg], 16 * ct + 4 * g + rg);
-    }
-    lexmin_xor(best, bk, 16);
-    lexmin_xor(best, bk, 32);
-    bk &= (VQ_K - 1);
-    if (g == 0 && valid) {
-      indices[n] = (long long)bk;
-      if (hist) atomicAdd(&hist_s[bk], 1);
-    }
-  }
-  __syncthreads();
   if (hist && t < VQ_K && hist_s[t]) atomicAdd(&hist[t], hist_s[t]);
 }
 
@@ -685,8 +553,6 @@ extern "C" int melgpt_vq_argmin_fwd_ex(const void* z, int z_dtype, int64_t n_vec
     static bool attr16 = false;
     if (!attr16) {
       bool ok = hipFuncSetAttribute((const void*)vq_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B16_LDS_BYTES) == hipSuccess;
-      ok = ok && hipFuncSetAttribute((const void*)vq_bf16_kernel<true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B16_LDS_BYTES) == hipSuccess;
-      ok = ok && hipFuncSetAttribute((const void*)vq_bf16_kernel<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B16_LDS_BYTES) == hipSuccess;
       ok = ok && hipFuncSetAttribute((const void*)vq_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B16_LDS_BYTES) == hipSuccess;
       ok = ok && hipFuncSetAttribute((const void*)vq_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B16_LDS_BYTES) == hipSuccess;
       if (!ok) return MELGPT_ERR_LAUNCH;
@@ -697,50 +563,6 @@ extern "C" int melgpt_vq_argmin_fwd_ex(const void* z, int z_dtype, int64_t n_vec
   hipLaunchKernelGGL((vq_bf16_kernel<F, E>), dim3(grid), dim3(64 * B16_WAVES), B16_LDS_BYTES, s, (const bf16_t*)z, za, \
                      (long long)n_vectors, codebook, (long long*)indices, (bf16_t*)quantized, sq_err, (int*)histogram, \
                      distances)
-    static const int lab_var = getenv("MELGPT_VQ_VAR") ? atoi(getenv("MELGPT_VQ_VAR")) : 0;
-    if (flat && !extras && lab_var >= 3) {
-      const long long ntl = (n_vectors + 15) / 16;
-      static bool attr_st = false;
-      if (!attr_st) {
-        bool ok = hipFuncSetAttribute((const void*)vq_bf16_staged_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B16_LDS_BYTES + 16 * 4096)) == hipSuccess;
-        ok = ok && hipFuncSetAttribute((const void*)vq_bf16_staged_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B16_LDS_BYTES + 12 * 4096)) == hipSuccess;
-        ok = ok && hipFuncSetAttribute((const void*)vq_bf16_staged_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B16_LDS_BYTES + 8 * 4096)) == hipSuccess;
-        if (!ok) return MELGPT_ERR_LAUNCH;
-        attr_st = true;
-      }
-      const int wv = lab_var == 3 ? (ntl >= 256 * 16 ? 16 : 8) : lab_var == 4 ? (ntl >= 256 * 12 ? 12 : 8) : 8;
-      const long long wgs = (ntl + wv - 1) / wv;
-      grid = (int)(wgs < 256 ? wgs : 256);
-#define VQST_LAUNCH(W)                                                                                                 \
-  hipLaunchKernelGGL(vq_bf16_staged_kernel<W>, dim3(grid), dim3(64 * W), B16_LDS_BYTES + W * 4096, s, (const bf16_t*)z, \
-                     za, (long long)n_vectors, codebook, (long long*)indices, (int*)histogram)
-      if (lab_var == 6 || lab_var == 7) {
-        static bool a2 = false;
-        if (!a2) {
-          (void)hipFuncSetAttribute((const void*)vq_bf16_staged_kernel<12, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B16_LDS_BYTES + 12 * 4096));
-          (void)hipFuncSetAttribute((const void*)vq_bf16_staged_kernel<12, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B16_LDS_BYTES + 12 * 4096));
-          a2 = true;
-        }
-        const long long w12 = (ntl + 11) / 12;
-        grid = (int)(w12 < 256 ? w12 : 256);
-        if (lab_var == 6)
-          hipLaunchKernelGGL((vq_bf16_staged_kernel<12, 1>), dim3(grid), dim3(768), B16_LDS_BYTES + 12 * 4096, s, (const bf16_t*)z, za, (long long)n_vectors, codebook, (long long*)indices, (int*)histogram);
-        else
-          hipLaunchKernelGGL((vq_bf16_staged_kernel<12, 2>), dim3(grid), dim3(768), B16_LDS_BYTES + 12 * 4096, s, (const bf16_t*)z, za, (long long)n_vectors, codebook, (long long*)indices, (int*)histogram);
-      } else
-      if (wv == 16) VQST_LAUNCH(16);
-      else if (wv == 12) VQST_LAUNCH(12);
-      else VQST_LAUNCH(8);
-#undef VQST_LAUNCH
-    } else
-    if (flat && !extras && lab_var == 1) {
-      hipLaunchKernelGGL((vq_bf16_kernel<true, false, 1>), dim3(grid), dim3(64 * B16_WAVES), B16_LDS_BYTES, s, (const bf16_t*)z, za,
-                     (long long)n_vectors, codebook, (long long*)indices, (bf16_t*)quantized, sq_err, (int*)histogram, distances);
-    } else if (flat && !extras && lab_var == 2) {
-      if (grid > 256) grid = 256;
-      hipLaunchKernelGGL((vq_bf16_kernel<true, false, 2>), dim3(grid), dim3(64 * B16_WAVES), B16_LDS_BYTES, s, (const bf16_t*)z, za,
-                     (long long)n_vectors, codebook, (long long*)indices, (bf16_t*)quantized, sq_err, (int*)histogram, distances);
-    } else
     if (flat && !extras) VQ16_LAUNCH(true, false);
     else if (flat) VQ16_LAUNCH(true, true);
     else VQ16_LAUNCH(false, true);

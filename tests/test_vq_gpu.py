@@ -134,3 +134,25 @@ def test_product_fails_loudly_without_gpu_tensor():
 
     with pytest.raises(_ffi.MelgptError):
         vq_lookup(torch.zeros(1, 256, 5, 53), torch.zeros(128, 256))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_batch_strided_latents_match_packed(dt):
+    """Channels-last latents whose batch stride is not H*W*C (every second clip of a larger buffer) go through the
+    (n // HW, n % HW) addressing; packed ones are folded to one pitch on the host (vq_fold).  Same vectors, same
+    codes, and the quantized output lands at the strided positions only."""
+    from melspec_gpt_vqvae_amd.vqvae.quantizer import vq_lookup
+
+    big = t(synth.normal(31, (6, 256, 5, 53)), DEV).to(dt).contiguous(memory_format=torch.channels_last)
+    E = t(synth.normal(32, (128, 256)), DEV)
+    view = big[::2]
+    assert view.stride(0) == 2 * 5 * 53 * 256 and view.stride(1) == 1
+    packed = view.clone(memory_format=torch.channels_last)
+    assert packed.stride(0) == 5 * 53 * 256
+    for kw in (dict(want_quantized=False, want_stats=False), dict()):
+        a = vq_lookup(view, E, **kw)
+        b = vq_lookup(packed, E, **kw)
+        assert a["z"].data_ptr() == view.data_ptr()  # no hidden copy: the strided path itself ran
+        assert torch.equal(a["indices"], b["indices"])
+        if a["quantized"] is not None:
+            assert torch.equal(a["quantized"], b["quantized"])

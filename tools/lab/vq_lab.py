@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """VQ lookup lab: in-stream time per launch of melgpt_vq_argmin_fwd_ex (indices only), `reps` launches back to back
 between two HIP events so that host launch overhead is not what is measured; batch sweep, both lanes.
-MELGPT_VQ_VAR selects a lab variant of the lean bf16 kernel where one is compiled in.  Prints one JSON line per case
-plus a checksum of the indices so that variants can be compared bit for bit."""
+Prints one JSON line per case plus a checksum of the indices so that kernel versions can be compared bit for bit.
+(The variants compared in profiles/r01_m_vq_lab.jsonl - selected then by MELGPT_VQ_VAR: 0 register prefetch, 1 reload in
+place [kept], 2 scheduling barriers, 3/4/5 coalesced loads through wave-private LDS with 16/12/8 waves, 6 loads only,
+7 compute only - are in the tree of commit 740ff5a.)"""
 import ctypes
 import hashlib
 import json
