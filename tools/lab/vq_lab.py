@@ -46,10 +46,12 @@ def run(z, cb, idx, reps):
 
 def main():
     var = os.environ.get("MELGPT_VQ_VAR", "0")
+    # optional: batch sizes as arguments (one size per profiler run keeps the per-kernel stats unmixed)
+    batches = tuple(int(a) for a in sys.argv[1:]) or (64, 256, 1024, 4096)
     g = torch.Generator(device="cpu").manual_seed(5)
     cb = torch.randn(128, 256, generator=g).to(DEV)
     for dt, es in ((torch.bfloat16, 2), (torch.float32, 4)):
-        for B in (64, 256, 1024, 4096):
+        for B in batches:
             n = B * 265
             z = torch.randn(n, 256, generator=g).to(DEV).to(dt)
             idx = torch.empty(n, dtype=torch.int64, device=DEV)
