@@ -58,6 +58,21 @@ def main():
                             algorithmic_MB=round(bytes_alg / 1e6, 2), GBps=round(bytes_alg / ms / 1e6, 1),
                             frac_hbm=round(bytes_alg / ms / 1e6 / HBM_PEAK, 4),
                             TFLOPs=round(2.0 * n * 128 * 256 / ms / 1e9, 1)))
+    # the quantiser's forward as the module calls it (bf16): indices + quantized tensor + squared-error partials +
+    # histogram in the same pass; bytes = read z, write q, write idx
+    for B in (64, 1024, 4096):
+        z = torch.randn(B, 5, 53, 256, device=DEV).to(torch.bfloat16).permute(0, 3, 1, 2)
+        reps = 50 if B <= 1024 else 20
+
+        def many_fwd():
+            for _ in range(reps):
+                vq_lookup(z, cb)
+        ms = med_ms(many_fwd, iters=7) / reps
+        n = B * 265
+        bytes_alg = n * (256 * 2 * 2 + 8) + 128 * 256 * 4
+        out.append(dict(kernel="vq_forward_bf16(idx+quantized+stats)", batch=B, vectors=n, us=round(ms * 1e3, 2),
+                        algorithmic_MB=round(bytes_alg / 1e6, 2), GBps=round(bytes_alg / ms / 1e6, 1),
+                        frac_hbm=round(bytes_alg / ms / 1e6 / HBM_PEAK, 4)))
     B, H, T = 128, 16, 265
     C = 64 * H
     for dt in (torch.bfloat16,):
