@@ -305,7 +305,6 @@ __global__ __launch_bounds__(64 * B16_WAVES, EXTRAS ? 2 : 4) void vq_bf16_kernel
   };
   u32x4 xf[8], xn[8];
   int tile = (int)blockIdx.x * B16_WAVES + w;
-  if (tile < ntiles) load_x(tile, xf);  // the first tile's vectors fly under the codebook staging
   {  // 16-byte chunk q = (code, chunk) of the rounded codebook; all 16 loads of a thread in flight before the first store
     static_assert(VQ_K * 32 == 8 * 64 * B16_WAVES, "eight chunks per thread");
     f32x4 lo[8], hi[8];
@@ -316,6 +315,9 @@ __global__ __launch_bounds__(64 * B16_WAVES, EXTRAS ? 2 : 4) void vq_bf16_kernel
       lo[u] = *(const f32x4*)e;
       hi[u] = *(const f32x4*)(e + 4);
     }
+    // The first tile's vectors are requested AFTER the codebook: loads return in issue order, so the codebook (L2
+    // hits) is rounded and stored while the vectors are still on their way from HBM, instead of queueing behind them.
+    if (tile < ntiles) load_x(tile, xf);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int q = t + 64 * B16_WAVES * u;
