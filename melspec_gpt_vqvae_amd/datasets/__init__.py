@@ -2,8 +2,9 @@
 [0, 1], `<clip>_mel_code.npy` (5, 53) int64 VQ codes, the `data/vas_*.txt` / `data/vggsound_*.txt` split lists, and the
 Lightning checkpoint key conventions.  Host-side plumbing only: numpy + torch DataLoader, no GPU work here."""
 from .datamodule import DataModule
-from .transforms import Crop, StandardNormalizeAudio, ToTensor
+from .specs import ClipRecord, SpecCodeDataset
+from .transforms import Crop
 from .vas import VASSpecs
-from .vggsound import VGGSound, VGGSoundSpecs
+from .vggsound import VGGSoundSpecs
 
-__all__ = ["DataModule", "Crop", "StandardNormalizeAudio", "ToTensor", "VASSpecs", "VGGSound", "VGGSoundSpecs"]
+__all__ = ["DataModule", "Crop", "ClipRecord", "SpecCodeDataset", "VASSpecs", "VGGSoundSpecs"]

@@ -41,8 +41,10 @@ class DataModule:
         if self.world > 1:
             from ..dp import distributed_shard
 
+            # Lightning injects DistributedSampler(drop_last=False): the permutation is PADDED to a multiple of world;
+            # the DataLoader's own drop_last=True (reference datamodule.py:70-72) then drops the ragged last batch
             idx = distributed_shard(len(ds), self.rank, self.world, seed=self.seed, epoch=self.epoch, shuffle=shuffle,
-                                    drop_last=True)
+                                    drop_last=False)
             ds, shuffle = Subset(ds, idx), False
         return DataLoader(ds, batch_size=self.batch_size, num_workers=self.num_workers,
                           worker_init_fn=self.worker_init_fn, drop_last=True, shuffle=shuffle)

@@ -1,115 +1,89 @@
-"""VGGSound spectrogram / code dataset (reference datasets/vggsound.py:18-174).  Layout on disk:
-    <root>/melspec_10s_22050hz/<youtube id>_<start ms>_<end ms>_mel.npy     (80, 860) float in [0, 1]
-    <root>/codes_10s/<same stem>_mel_code.npy                               (5, 53) int64
-    <splits_path>/vggsound_{train,valid,test}.txt                           one clip stem per line
-    <meta_path> vggsound.csv                                                rows: id, start, label, train|test
-The first 11 characters of a clip stem are the YouTube id that keys the label table."""
+"""VGGSound manifest builder: same constructor as the reference's VGGSoundSpecs (datasets/vggsound.py:151-174), items
+come from specs.SpecCodeDataset.  Layout on disk:
+    <root>/melspec_10s_22050hz/<youtube id>_<start ms>_<end ms>_mel.npy
+    <root>/codes_10s/<same stem>_mel_code.npy
+    <splits_path>/vggsound_{train,valid,test}.txt     one clip stem per line
+    <meta_path>  vggsound.csv                         rows: youtube id, start second, label, train|test
+A clip's label is looked up by the first 11 characters of its stem (the YouTube id)."""
 from __future__ import annotations
 
-import collections
 import csv
 import os
 import random
-from glob import glob
-from pathlib import Path
+from collections import Counter, defaultdict
 
-import numpy as np
 import torch
 
-from .transforms import Crop
+from .specs import CODE_SUFFIX, MEL_SUFFIX, ClipRecord, SpecCodeDataset, class_index, sibling_codes_dir
+
+YT_ID_LEN = 11
 
 
-class VGGSound(torch.utils.data.Dataset):
-    def __init__(self, split, specs_dir, transforms=None, splits_path='./data', meta_path='./data/vggsound.csv'):
-        super().__init__()
-        self.split, self.specs_dir, self.transforms = split, specs_dir, transforms
-        self.splits_path, self.meta_path = splits_path, meta_path
-        meta = list(csv.reader(open(meta_path), quotechar='"'))
-        unique_classes = sorted(set(row[2] for row in meta))
-        self.label2target = {label: target for target, label in enumerate(unique_classes)}
-        self.target2label = {target: label for label, target in self.label2target.items()}
-        self.video2target = {row[0]: self.label2target[row[2]] for row in meta}
-        parts = specs_dir.split("/")[:-1]
-        parts[-1] = "codes_10s"
-        self.codes_dir_path = '/'.join(parts)
-        self.feat_codes_suffix = '_mel_code.npy'
-        split_file = os.path.join(splits_path, f'vggsound_{split}.txt')
-        if not os.path.exists(split_file):
-            self.make_split_files()
-        ids = open(split_file).read().splitlines()
-        self.dataset = [os.path.join(specs_dir, v + '_mel.npy') for v in ids]
-        counts = collections.Counter(self.video2target[Path(p).stem[:11]] for p in self.dataset)
-        self.class_counts = torch.tensor([counts[c] for c in range(len(counts))])
+class LabelTable:
+    """vggsound.csv: which label (and official train/test part) a YouTube id has."""
 
-    def __getitem__(self, idx):
-        spec_path = self.dataset[idx]
-        video_name = Path(spec_path).stem[:11]
-        codes_path = os.path.join(self.codes_dir_path,
-                                  spec_path.split('/')[-1].replace('_mel.npy', self.feat_codes_suffix))
-        item = {'input': np.load(spec_path), 'input_path': spec_path, 'target': self.video2target[video_name]}
-        item['label'] = self.target2label[item['target']]
-        if self.transforms is not None:
-            item = self.transforms(item)
-        if os.path.isfile(codes_path):
-            item["codes"] = np.load(codes_path)
-        return item
-
-    def __len__(self):
-        return len(self.dataset)
-
-    def make_split_files(self):
-        """reference :95-148: seed 1337; videos the csv marks `test` stay test; per class, as many `train` videos as
-        that class has test videos are drawn (shuffle) into valid, the rest stay train; only clips present on disk are
-        listed.  (The reference shuffles in set-iteration order, which depends on the interpreter's string hashing;
-        here each class's videos are sorted first, so the split is reproducible.)"""
-        random.seed(1337)
-        available = sorted(glob(os.path.join(self.specs_dir, '*_mel.npy')))
-        meta = list(csv.reader(open(self.meta_path), quotechar='"'))
-        train_vids = {row[0] for row in meta if row[3] == 'train'}
-        test_vids = {row[0] for row in meta if row[3] == 'test'}
-        unique_classes = sorted(set(row[2] for row in meta))
-        label2target = {label: target for target, label in enumerate(unique_classes)}
-        video2target = {row[0]: label2target[row[2]] for row in meta}
-        test_count = collections.Counter(video2target[v] for v in test_vids)
-        train_wo_valid, valid_vids = set(), set()
-        for target in range(len(unique_classes)):
-            vids = sorted(v for v in train_vids if video2target[v] == target)
-            random.shuffle(vids)
-            valid_vids.update(vids[:test_count[target]])
-            train_wo_valid.update(vids[test_count[target]:])
-        os.makedirs(self.splits_path, exist_ok=True)
-        files = {n: open(os.path.join(self.splits_path, f'vggsound_{n}.txt'), 'w') for n in ('train', 'valid', 'test')}
-        try:
-            for path in available:
-                name = Path(path.replace('_mel.npy', '')).name
-                vid = name[:11]
-                if vid in train_wo_valid:
-                    files['train'].write(name + '\n')
-                elif vid in valid_vids:
-                    files['valid'].write(name + '\n')
-                elif vid in test_vids:
-                    files['test'].write(name + '\n')
-                else:
-                    raise Exception(f'Clip {name} is neither in train, valid nor test. Strange.')
-        finally:
-            for f in files.values():
-                f.close()
+    def __init__(self, meta_path):
+        with open(meta_path, newline="") as f:
+            rows = [r for r in csv.reader(f, quotechar='"') if r]
+        self.label2target = class_index(r[2] for r in rows)
+        self.target2label = {t: name for name, t in self.label2target.items()}
+        self.video2target = {r[0]: self.label2target[r[2]] for r in rows}
+        self.part = {r[0]: r[3] for r in rows}
 
 
-class VGGSoundSpecs(VGGSound):
-    """VGGSound items in the VQ-VAE's convention: `image` in [-1, 1], `file_path_` (reference :151-174)."""
+def write_vggsound_splits(specs_dir, table: LabelTable, splits_path, seed=1337):
+    """Derive vggsound_{train,valid,test}.txt when they are absent (the reference does this on first use,
+    datasets/vggsound.py:95-148): `test` ids stay test; from every class's `train` ids as many as that class has test
+    ids go to valid (seeded shuffle of the SORTED id list - reproducible, unlike the reference's set-order shuffle);
+    only clips present on disk are listed; a clip whose id the table does not know is an error."""
+    by_class = defaultdict(lambda: {"train": [], "test": []})
+    for vid, part in table.part.items():
+        by_class[table.video2target[vid]][part].append(vid)
+    rng = random.Random(seed)
+    bucket = {}
+    for target in sorted(by_class):
+        pool = sorted(by_class[target]["train"])
+        rng.shuffle(pool)
+        n_valid = len(by_class[target]["test"])
+        bucket.update({v: "valid" for v in pool[:n_valid]})
+        bucket.update({v: "train" for v in pool[n_valid:]})
+        bucket.update({v: "test" for v in by_class[target]["test"]})
+    listing = {"train": [], "valid": [], "test": []}
+    for fn in sorted(os.listdir(specs_dir)):
+        if not fn.endswith(MEL_SUFFIX):
+            continue
+        stem = fn[:-len(MEL_SUFFIX)]
+        where = bucket.get(stem[:YT_ID_LEN])
+        if where is None:
+            raise KeyError(f"clip {stem}: its id is not in the label table, cannot assign it to a split")
+        listing[where].append(stem)
+    os.makedirs(splits_path, exist_ok=True)
+    for name, stems in listing.items():
+        with open(os.path.join(splits_path, f"vggsound_{name}.txt"), "w") as f:
+            f.writelines(s + "\n" for s in stems)
 
+
+class VGGSoundSpecs(SpecCodeDataset):
     def __init__(self, split, spec_dir_path, mel_num=None, spec_len=None, spec_crop_len=None, random_crop=None,
                  crop_coord=None, for_which_class=None, splits_path='./data', meta_path='./data/vggsound.csv'):
-        super().__init__(split, spec_dir_path, splits_path=splits_path, meta_path=meta_path)
         if for_which_class:
-            raise NotImplementedError
-        self.transforms = Crop([mel_num, spec_crop_len], random_crop)
-
-    def __getitem__(self, idx):
-        item = super().__getitem__(idx)
-        item['image'] = 2 * item['input'] - 1
-        item['file_path_'] = item['input_path']
-        item.pop('input')
-        item.pop('input_path')
-        return item
+            raise NotImplementedError("per-class VGGSound subsets do not exist in the reference either (:160-161)")
+        self.split, self.specs_dir = split, spec_dir_path
+        table = LabelTable(meta_path)
+        self.label2target, self.target2label, self.video2target = table.label2target, table.target2label, table.video2target
+        split_file = os.path.join(splits_path, f"vggsound_{split}.txt")
+        if not os.path.exists(split_file):
+            write_vggsound_splits(spec_dir_path, table, splits_path)
+        with open(split_file) as f:
+            stems = [ln for ln in f.read().splitlines() if ln]
+        self.codes_dir_path = sibling_codes_dir(spec_dir_path)
+        records = []
+        for stem in stems:
+            target = table.video2target[stem[:YT_ID_LEN]]
+            records.append(ClipRecord(os.path.join(spec_dir_path, stem + MEL_SUFFIX),
+                                      os.path.join(self.codes_dir_path, stem + CODE_SUFFIX),
+                                      table.target2label[target], target))
+        self.dataset = [r.spec_path for r in records]
+        seen = Counter(r.target for r in records)
+        self.class_counts = torch.tensor([seen[t] for t in sorted(seen)])
+        super().__init__(records, (mel_num, spec_crop_len), random_crop)

@@ -10,7 +10,8 @@ while the earlier blocks are still in their backward GEMMs - sized for 7 x ~153 
 than for NVSwitch-style many-small-bucket traffic; no parameter broadcast per step (the `mask` buffers the
 reference re-broadcasts every forward do not exist here) and averaging is folded into the optimizer's
 grad_scale.  The engine only needs a flat gradient tensor and (lo, hi) segments, so it is exercised on CPU with
-the gloo backend in tests/test_dp_cpu.py.
+the gloo backend in tests/test_host_cpu.py; the DataParallel wrapper itself (hooks + segments) runs with two ranks
+sharing one GPU in tests/test_dp_gpu.py.
 """
 from __future__ import annotations
 
@@ -34,6 +35,12 @@ class GradientExchange:
         """start reducing grad[lo:hi] (asynchronously on GPU backends); safe to call from a backward hook."""
         if self.world == 1 or hi <= lo:
             return
+        if (lo, hi) in self._done:
+            # a block's backward ran twice before finish() (gradient accumulation / two backward passes): the first
+            # all-reduce already summed a PARTIAL gradient across ranks - refuse instead of producing wrong sums
+            raise RuntimeError(f"gradient segment [{lo}, {hi}) was launched twice in one step: call finish() once per "
+                               "backward pass, or disable early launches (DataParallel(..., overlap=False)) when "
+                               "accumulating gradients")
         self._done.append((lo, hi))
         pos = lo
         while pos < hi:
@@ -89,37 +96,64 @@ def block_segments(fp, block):
 
 
 class DataParallel:
-    """Wraps a GPT-like module: hooks every Block's end-of-backward to start its gradient all-reduce, and
-    exposes finish() to be called once per step before the optimizer (grad_scale = 1/world there)."""
+    """Wraps a module tree holding minGPT Blocks - a GPT / GPTClass, a Lit_minGPT, or a GPT_VAE with its TWO
+    transformers (encoder.transformer + decoder.transformer, Lit_GPT_VAE.py:42-43; the only model the reference
+    trains under DDP, GPT_VAE_train.py:172-174).  All parameters of the tree live in one flat buffer; every Block,
+    wherever it sits in the tree, announces the end of its backward and its two gradient slices are all-reduced
+    at once while earlier blocks are still in their GEMMs.  finish() is called once per step before the optimizer
+    (whose grad_scale = 1/world folds the averaging in)."""
 
-    def __init__(self, module, group=None):
+    def __init__(self, module, group=None, overlap=True, max_bucket_elems: int = 64 << 20):
         from .flat import ensure_flat
 
         self.module = module
         self.fp = ensure_flat(module)
-        self.ex = GradientExchange(self.fp.grad, group)
+        self.ex = GradientExchange(self.fp.grad, group, max_bucket_elems=max_bucket_elems)
         self.world = self.ex.world
-        blocks = getattr(module, "blocks", None)
-        if blocks is None and hasattr(module, "transformer"):
-            blocks = getattr(module.transformer, "blocks", None)
+        self.overlap = bool(overlap)
+        self.hook_calls = 0           # Block hooks fired since construction (tests count them)
         self._segs = {}
-        if blocks is not None and self.world > 1:
-            for blk in blocks:
+        self.blocks = [m for m in module.modules() if hasattr(m, "_layer_index") and hasattr(m, "attn")]
+        if self.world > 1 and self.overlap:
+            for blk in self.blocks:
                 self._segs[id(blk)] = block_segments(self.fp, blk)
                 object.__setattr__(blk, "_grad_ready_hook", self._on_block_done)
 
     def _on_block_done(self, blk):
+        self.hook_calls += 1
         for lo, hi in self._segs[id(blk)]:
             self.ex.launch(lo, hi)
 
     def finish(self):
+        """all-reduce whatever the Block hooks have not launched (stem, head, ln_f, parameters without a gradient this
+        step - zeroed first so that no stale slice is summed), then wait for every launched piece."""
+        if self.world > 1:
+            self.fp.zero_missing_grads()
         self.ex.finish()
+
+    def detach(self):
+        for blk in self.blocks:
+            if getattr(blk, "_grad_ready_hook", None) is not None:
+                object.__setattr__(blk, "_grad_ready_hook", None)
 
     def broadcast_parameters(self, src=0):
         """C1 of SURVEY §2b: one broadcast of the flat parameter buffer at start-up (skipped when every rank
         seeds identically)."""
         if self.world > 1:
             dist.broadcast(self.fp.data, src=src, group=self.ex.group)
+            self.fp._shadow_key = None      # the bf16 shadow is refreshed from the received master copy
+
+    def reduce_metrics(self, *values):
+        """C4 of SURVEY §2b: the logged scalars of a step (Lit_GPT_VAE.py:310-313 logs loss / kl_weight / rec / KL with
+        sync_dist=True = four separate all-reduces) as ONE all-reduce of a small f32 vector -> tuple of rank means
+        (0-dim tensors on the values' device).  Accepts tensors or Python numbers."""
+        dev = next((v.device for v in values if isinstance(v, torch.Tensor)), self.fp.device)
+        vec = torch.stack([v.detach().float().reshape(()) if isinstance(v, torch.Tensor)
+                           else torch.tensor(float(v), device=dev) for v in values]).to(dev)
+        if self.world > 1:
+            dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.ex.group)
+            vec = vec / self.world
+        return tuple(vec.unbind(0))
 
 
 def distributed_shard(n: int, rank: int, world: int, seed: int = 0, epoch: int = 0, shuffle: bool = True,

@@ -146,6 +146,17 @@ class FlatParams:
     def zero_grad(self):
         self.grad.zero_()
 
+    def zero_missing_grads(self):
+        """Zero the flat-gradient slices of parameters that received NO gradient since zero_grad (p.grad is None:
+        unused branch, frozen sub-module, class embedder when no class token is fed).  The fused optimizer and the
+        data-parallel exchange run over the whole buffer, so a stale slice would otherwise be applied / summed;
+        torch.optim.AdamW in the reference skips such parameters - a zero gradient with zero moments is the same
+        no-op for them apart from weight decay, which the caller masks by `missing` if it needs to."""
+        missing = [p for p in self.params if p.grad is None]
+        for p in missing:
+            self._slice(self.grad, p).zero_()
+        return missing
+
 
 def ensure_flat(module: nn.Module) -> FlatParams:
     """The FlatParams owning `module`'s parameters: an intact one made for it or for an ancestor, else a new one."""

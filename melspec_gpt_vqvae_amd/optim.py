@@ -43,6 +43,7 @@ class FusedAdamW:
     @torch.no_grad()
     def step(self):
         fp = self._state()
+        fp.zero_missing_grads()   # never apply a previous step's gradient to a parameter this step did not touch
         self.step_count += 1
         nd = fp.n_decay
         shadow = fp.shadow
@@ -65,3 +66,6 @@ class FusedAdamW:
         self.step_count = int(sd["step"])
         self._m.copy_(sd["exp_avg"])
         self._v.copy_(sd["exp_avg_sq"])
+        for k in ("lr", "betas", "eps", "weight_decay"):
+            if k in sd:
+                setattr(self, k, tuple(sd[k]) if k == "betas" else sd[k])

@@ -55,7 +55,7 @@ class GPTDecoder(nn.Module):
         assert not self.transformer.training
         seed = _Seeds.next()
         att = None
-        if kv_cache and steps > 0:
+        if kv_cache and steps > 0 and self.transformer.kv_cacheable():
             tr = self.transformer
             cond_size = c.size(-2)
             assert cond_size == 1 and x.size(1) + cond_size + steps - 1 <= block_size

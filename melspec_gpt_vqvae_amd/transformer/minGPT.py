@@ -492,10 +492,17 @@ class GPT(nn.Module):
     # The reference samples by re-running the whole model on the growing sequence (:293-360, decoders.py:89-123).
     # decode_step feeds ONE position: per layer the new token's k, v are appended to a (B, block_size, C) cache and
     # its query attends to the cached positions (csrc/decode.hip) - same logits as the last row of a full forward.
+    def kv_cacheable(self):
+        """True when a position's K/V never change once computed, i.e. every block is strictly causal."""
+        return all(blk.attn.n_unmasked == 0 for blk in self.blocks)
+
     @torch.no_grad()
     def decode_begin(self, batch_size):
         """-> a fresh KV cache for `batch_size` sequences (eval mode only)."""
         assert not self.training, "KV-cached decoding is an inference path (dropout is not applied)"
+        # positions below n_unmasked attend bidirectionally in the reference (:65-69), so their K/V change as the
+        # sequence grows - a cache of them would be stale
+        assert self.kv_cacheable(), "KV-cached decoding needs n_unmasked == 0 (use kv_cache=False)"
         dt = _compute_dtype(self)
         dev = self.pos_emb.device
         C = self.tok_emb.weight.shape[1]
@@ -773,7 +780,7 @@ class Lit_minGPT(_LitBase):
             raise NotImplementedError('Implement for GPTClass')
         seed = _Seeds.next()
         att = None
-        if kv_cache and steps > 0:
+        if kv_cache and steps > 0 and self.transformer.kv_cacheable():
             tr = self.transformer
             cond_size = c.size(-1)
             assert cond_size == 1 and x.size(1) + cond_size + steps - 1 <= block_size
@@ -863,7 +870,8 @@ class Lit_minGPT(_LitBase):
         return self.first_stage_model.decode(quant_z)
 
     def configure_optimizers(self):
-        return make_adamw(self, self.args.learning_rate)
+        # the reference walks self.transformer only (:632,652): a loaded first_stage_model (VQ-VAE) stays frozen
+        return make_adamw(self.transformer, self.args.learning_rate)
 
     def configure_fused_optimizer(self):
         """MI355X-native alternative: one fused AdamW launch per weight-decay group over the flat store."""

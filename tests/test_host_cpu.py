@@ -68,6 +68,29 @@ def test_gpt_vae_structure():
     assert len(opt.param_groups) == 2
 
 
+def test_lit_optimizer_leaves_the_first_stage_model_frozen_and_kv_cache_guard():
+    """reference minGPT.py:632,652: configure_optimizers walks self.transformer ONLY - with a VQ-VAE attached (the
+    documented training command sets reconstruct_spec) its Conv2d / GroupNorm weights must neither trip the
+    'not separated' assertion nor be trained."""
+    from melspec_gpt_vqvae_amd.transformer.minGPT import GPT, Lit_minGPT
+    from melspec_gpt_vqvae_amd.vqvae.big_model_attn_gan import LitVQVAE
+
+    a = synth.gpt_args(n_layer=2, n_head=4, n_embd=64, reconstruct_spec="", device="cpu", learning_rate=1e-6)
+    lit = Lit_minGPT(a)
+    lit.first_stage_model = LitVQVAE(num_embeddings=128, embedding_dim=256)
+    opt = lit.configure_optimizers()
+    trained = {id(p) for g in opt.param_groups for p in g["params"]}
+    assert trained == {id(p) for p in lit.transformer.parameters()}
+    assert not trained & {id(p) for p in lit.first_stage_model.parameters()}
+    assert [g["weight_decay"] for g in opt.param_groups] == [0.01, 0.0] and opt.param_groups[0]["betas"] == (0.9, 0.95)
+    # KV-cached decoding is only equivalent to the reference's re-forward loop for strictly causal blocks
+    assert lit.transformer.kv_cacheable()
+    enc = GPT(synth.gpt_args(n_layer=1, n_head=4, n_embd=64), n_unmasked=5).eval()
+    assert not enc.kv_cacheable()
+    with pytest.raises(AssertionError, match="n_unmasked"):
+        enc.decode_begin(1)
+
+
 def test_distributed_shard_is_the_distributed_sampler_rule():
     from torch.utils.data.distributed import DistributedSampler
 
@@ -107,6 +130,14 @@ def _dp_worker(rank, world, port, q):
     g.copy_(torch.ones(n) * (rank + 1))
     ex.finish()
     ok = ok and torch.equal(g, torch.ones(n) * sum(r + 1 for r in range(world)))
+    # a segment announced twice in one step (two backward passes through one block) is refused, not double-summed
+    ex.launch(10, 20)
+    try:
+        ex.launch(10, 20)
+        ok = False
+    except RuntimeError:
+        pass
+    ex.finish()
     q.put((rank, ok))
     dist.destroy_process_group()
 
