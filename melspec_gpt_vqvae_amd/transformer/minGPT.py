@@ -745,7 +745,25 @@ class Lit_minGPT(_LitBase):
             self.first_stage_model.eval().to(self.args.device)
 
     def datamodule_loader(self):
+        """reference :461-477: DataModule over args.spec_dir_path (80 x 860 spectrograms, centre crop 848, the code
+        files beside them).  Modules built without a data path (tests, benches, sampling-only use) get data = None."""
         self.data = None
+        if getattr(self.args, "spec_dir_path", None) and getattr(self.args, "load_data", True):
+            from ..datasets import DataModule
+
+            kw = {"splits_dir": self.args.splits_dir} if hasattr(self.args, "splits_dir") else {}
+            self.data = DataModule(batch_size=self.args.batch_size, spec_dir_path=self.args.spec_dir_path, mel_num=80,
+                                   spec_len=860, spec_crop_len=848, random_crop=False,
+                                   num_workers=getattr(self.args, "workers", 0), **kw)
+            self.data.setup()
+
+    def train_dataloader(self):
+        self.len_train_data = len(self.data.train_dataset)
+        return self.data.train_dataloader()
+
+    def val_dataloader(self):
+        self.len_val_data = len(self.data.val_dataset)
+        return self.data.val_dataloader()
 
     def init_from_ckpt(self, path, ignore_keys=list()):
         sd = torch.load(path, map_location="cpu")["state_dict"]

@@ -163,6 +163,46 @@ def vae_loss(enc_sd, dec_sd, x, eps, kl_weight, n_layer, n_head, block_size):
     return loss, rec, KL, mu, logvar
 
 
+def vae_anneal(kl_weight, kl_start, warm_up, len_train_data, batch_size, beta=1.0):
+    """KL-weight schedule of GPT_VAE (Lit_GPT_VAE.py:70-73, 253-256): one increment per training step."""
+    if beta == 0:
+        return beta
+    rate = (1.0 - kl_start) / (warm_up * (len_train_data / batch_size)) if warm_up > 0 else 0
+    return min(1.0, kl_weight + rate)
+
+
+def vae_training_step(enc_sd, dec_sd, x, eps, kl_weight, n_layer, n_head, block_size, fb=0, target_kl=0.0, beta=1.0):
+    """GPT_VAE.training_step after the anneal update (Lit_GPT_VAE.py:265-293): the free-bits variants.
+    fb 0: rec + w*KL;  fb 1: KL counted per sequence where KL > target_kl;  fb 2: per latent dimension where the
+    dimension's KL > target_kl / nz;  fb 3: all-or-nothing on the batch-mean KL.  Returns the batch-mean loss."""
+    mu, logvar, _ = vae_encode_stats(enc_sd, x, n_layer, n_head, block_size)
+    z = mu.unsqueeze(1) + eps * (0.5 * logvar).exp().unsqueeze(1)
+    kl_dim = 0.5 * (mu.pow(2) + logvar.exp() - logvar - 1)
+    KL = kl_dim.sum(dim=1)
+    logits, _, _ = gpt_forward(dec_sd, x[:, :-1], n_layer, n_head, embeddings=z)
+    logits = logits[:, z.size(-2) - 1:]
+    ce = F.cross_entropy(logits.reshape(-1, logits.size(-1)), x.reshape(-1), reduction="none")
+    rec = ce.view(x.size(0), z.size(1), -1).sum(-1).mean(dim=1)
+    if beta == 0 or fb == 0:
+        loss = rec + kl_weight * KL
+    elif fb == 1:
+        loss = rec + (KL > target_kl).float() * kl_weight * KL
+    elif fb == 2:
+        nz = mu.size(1)
+        loss = rec + kl_weight * ((kl_dim > target_kl / float(nz)).float() * kl_dim).sum(dim=1)
+    else:
+        loss = rec + (KL.mean() > target_kl).float() * kl_weight * KL
+    return loss.mean(dim=-1), rec, KL
+
+
+def vae_validation_step(enc_sd, dec_sd, x, eps, n_layer, n_head, block_size):
+    """GPT_VAE.validation_step for beta != 0 (Lit_GPT_VAE.py:321-361): ELBO at KL weight 1.0, summed over the batch."""
+    _, rec, KL, _, _ = vae_loss(enc_sd, dec_sd, x, eps, 1.0, n_layer, n_head, block_size)
+    rec = rec.mean(dim=1)
+    return {"val_loss": (rec + KL).sum(), "val_loss_rc": rec.sum(), "val_loss_kl": KL.sum(),
+            "report_num_words": (x.size(1) - 1) * x.size(0), "report_num_sents": x.size(0)}
+
+
 def optimizer_groups(param_names):
     """configure_optimizers' partition (minGPT.py:618-665) expressed on parameter NAMES:
     decay = weights of Linear layers; no_decay = biases, LayerNorm/Embedding weights, pos_emb."""

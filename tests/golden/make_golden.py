@@ -334,6 +334,161 @@ def gen_vae(ref_gpt, ref_enc, ref_dec):
     save("gpt_vae_small", **out)
 
 
+# ------------------------------------------------------------------ GPT_VAE.training_step / validation_step
+def _import_ref_gpt_vae():
+    """the reference's real LightningModule (transformer/Lit_GPT_VAE.py:23-89); its data loading
+    (datamodule_loader / *_dataloader, :945-957) is overridden as SURVEY 8c describes - nothing on the recorded
+    arithmetic path is touched."""
+    sys.path.insert(0, REF)
+    import transformer.Lit_GPT_VAE as ref_lit
+
+    class RefVAE(ref_lit.GPT_VAE):
+        def datamodule_loader(self):
+            self.len_train_data = self.args.len_train_data
+
+        def train_dataloader(self):
+            return None
+
+        def val_dataloader(self):
+            return None
+
+        def test_dataloader(self):
+            return None
+
+    return RefVAE
+
+
+def _vae_args(**kw):
+    d = dict(n_layer=2, n_head=4, n_embd=256, block_size=265, fix_var=0, kl_start=0.1, warm_up=2, batch_size=2,
+             target_kl=8.0, beta=1.0, nsamples=1, fb=0, device="cpu", learning_rate=1e-6, len_train_data=12,
+             iw_train_nsamples=-1)
+    d.update(kw)
+    return synth.gpt_args(**d)
+
+
+def gen_vae_steps():
+    """One training_step per free-bits branch fb in {0,1,2,3} (Lit_GPT_VAE.py:246-315) with the reparameterisation
+    noise captured (the only random draw at dropout 0: `zeros_like(std).normal_()` right after manual_seed), the
+    KL-weight anneal over 3 consecutive steps (:70-73,253-256), the beta = 0 branch, and validation_step (:321-361)."""
+    print("GPT_VAE.training_step / validation_step")
+    RefVAE = _import_ref_gpt_vae()
+    codes = synth.randint(500, 0, 128, (2, 5, 53))
+    batch = {"codes": t(codes)}
+    out = dict(codes=codes, enc_seed=5, dec_seed=6, len_train_data=12, warm_up=2, kl_start=0.1, batch_size=2)
+    # thresholds chosen from a probe run so that every mask has both outcomes somewhere (see the probe values stored)
+    probe = None
+    for fb in (0, 1, 2, 3):
+        for variant in ("a", "b"):
+            if fb == 0 and variant == "b":
+                continue
+            args = _vae_args(fb=fb)
+            m = RefVAE(args)
+            load_sd(m.encoder.transformer, synth.gpt_state_dict(args, 5, block_size=265, with_embedder=False,
+                                                                out_features=512))
+            load_sd(m.decoder.transformer, synth.gpt_state_dict(args, 6, block_size=266, with_embedder=False))
+            m.train()
+            if probe is None:
+                with torch.no_grad():
+                    mu, logvar, _ = m.encoder(m.get_input(batch))
+                    kl = 0.5 * (mu.pow(2) + logvar.exp() - logvar - 1)
+                probe = dict(kl_per_seq=kl.sum(1).numpy(), kl_dim_median=float(kl.median()))
+                out["probe_kl_per_seq"] = probe["kl_per_seq"]
+            kls = probe["kl_per_seq"]
+            if fb == 1:      # per-sequence mask: (a) one of two sequences above the threshold, (b) none
+                args.target_kl = float(kls.mean()) if variant == "a" else float(kls.max() * 2)
+            elif fb == 2:    # per-dimension mask: threshold at the median dimension (a) / tiny (b: all kept)
+                args.target_kl = probe["kl_dim_median"] * 256 if variant == "a" else 1e-9
+                m.dim_target_kl = args.target_kl / float(args.n_embd)
+            elif fb == 3:    # batch-mean mask: (a) below the mean -> on, (b) above -> off
+                args.target_kl = float(kls.mean()) * (0.5 if variant == "a" else 2.0)
+            tag = f"fb{fb}{variant}"
+            seed = 600 + 10 * fb + (variant == "b")
+            torch.manual_seed(seed)
+            eps = torch.zeros(2, 1, 256).normal_()
+            torch.manual_seed(seed)
+            m.zero_grad()
+            loss = m.training_step(batch, 0)
+            loss.backward()
+            out[tag + ".eps"] = eps.numpy()
+            out[tag + ".target_kl"] = args.target_kl
+            out[tag + ".loss"] = loss.item()
+            out[tag + ".kl_weight"] = m.kl_weight
+            for nm in ("encoder.transformer.head.weight", "encoder.transformer.blocks.0.attn.query.weight",
+                       "decoder.transformer.tok_emb.weight", "decoder.transformer.blocks.1.mlp.2.weight"):
+                out[tag + ".gnorm." + nm] = float(dict(m.named_parameters())[nm].grad.double().norm())
+    # anneal: three consecutive steps of one module, fb = 0
+    args = _vae_args(fb=0)
+    m = RefVAE(args)
+    load_sd(m.encoder.transformer, synth.gpt_state_dict(args, 5, block_size=265, with_embedder=False, out_features=512))
+    load_sd(m.decoder.transformer, synth.gpt_state_dict(args, 6, block_size=266, with_embedder=False))
+    m.train()
+    out["anneal_rate"] = m.anneal_rate
+    ws, ls, es = [], [], []
+    for k in range(3):
+        torch.manual_seed(700 + k)
+        es.append(torch.zeros(2, 1, 256).normal_().numpy())
+        torch.manual_seed(700 + k)
+        ls.append(m.training_step(batch, k).item())
+        ws.append(m.kl_weight)
+    out.update(anneal_kl_weights=np.array(ws), anneal_losses=np.array(ls), anneal_eps=np.stack(es))
+    # beta == 0: kl_weight pinned to 0 (plain autoencoder objective)
+    args = _vae_args(beta=0.0)
+    m = RefVAE(args)
+    load_sd(m.encoder.transformer, synth.gpt_state_dict(args, 5, block_size=265, with_embedder=False, out_features=512))
+    load_sd(m.decoder.transformer, synth.gpt_state_dict(args, 6, block_size=266, with_embedder=False))
+    m.train()
+    torch.manual_seed(800)
+    out["beta0.eps"] = torch.zeros(2, 1, 256).normal_().numpy()
+    torch.manual_seed(800)
+    out["beta0.loss"] = m.training_step(batch, 0).item()
+    out["beta0.kl_weight"] = float(m.kl_weight)
+    # validation_step: kl weight 1.0 whatever the anneal state; sums, not means
+    args = _vae_args()
+    m = RefVAE(args)
+    load_sd(m.encoder.transformer, synth.gpt_state_dict(args, 5, block_size=265, with_embedder=False, out_features=512))
+    load_sd(m.decoder.transformer, synth.gpt_state_dict(args, 6, block_size=266, with_embedder=False))
+    m.eval()
+    torch.manual_seed(900)
+    out["val.eps"] = torch.zeros(2, 1, 256).normal_().numpy()
+    torch.manual_seed(900)
+    with torch.no_grad():
+        r = m.validation_step(batch, 0)
+    out.update({"val.val_loss": float(r["val_loss"]), "val.val_loss_rc": float(r["val_loss_rc"]),
+                "val.val_loss_kl": float(r["val_loss_kl"]), "val.report_num_words": r["report_num_words"],
+                "val.report_num_sents": r["report_num_sents"]})
+    save("gpt_vae_steps", **out)
+
+
+def gen_vae_xl(ref_enc, ref_dec):
+    """2-layer GPT-VAE at the XL WIDTH of BASELINE configs[3] (config/config_GPT_VAE_vggsound.py:43-58: C = 1472,
+    23 heads, vocab 1024, block 265): mu / logvar / rec / KL / loss / per-parameter gradient norms."""
+    print("GPT-VAE, XL width")
+    args = synth.gpt_args(vocab_size=1024, n_layer=2, n_head=23, n_embd=1472, block_size=265, fix_var=0)
+    enc = ref_enc.GPTEncoder(args, n_unmasked=265, last_linear=2944)
+    dec = ref_dec.GPTDecoder(args, block_size=266)
+    load_sd(enc.transformer, synth.gpt_state_dict(args, 8, block_size=265, with_embedder=False, out_features=2944))
+    load_sd(dec.transformer, synth.gpt_state_dict(args, 9, block_size=266, with_embedder=False))
+    x = synth.randint(410, 0, 1024, (2, 265))
+    mu, logvar, att = enc(t(x))
+    eps = synth.normal(411, (2, 1, 1472))
+    z = mu.unsqueeze(1) + t(eps) * (0.5 * logvar).exp().unsqueeze(1)
+    KL = 0.5 * (mu.pow(2) + logvar.exp() - logvar - 1).sum(dim=1)
+    logits, _ = dec(t(x), z)
+    rec = dec.reconstruct_error(t(x), z)
+    kl_w = 0.5
+    loss = (rec.mean(dim=1) + kl_w * KL).mean()
+    loss.backward()
+    out = dict(x=x, eps=eps, mu=mu.detach().numpy(), logvar=logvar.detach().numpy(), KL=KL.detach().numpy(),
+               rec=rec.detach().numpy(), loss=loss.item(), kl_weight=kl_w, enc_seed=8, dec_seed=9,
+               dec_logits_b0_t100=logits[0, 100].detach().numpy(), dec_logits_b1_last=logits[1, -1].detach().numpy(),
+               enc_att_h22_row264=att[:, 22, 264].detach().numpy())
+    for nm, p in enc.transformer.named_parameters():
+        out["enc.gnorm." + nm] = float(p.grad.double().norm())
+    for nm, p in dec.transformer.named_parameters():
+        out["dec.gnorm." + nm] = float(p.grad.double().norm())
+    save("gpt_vae_xl2", **out)
+
+
 # ---------------------------------------------------------------------------- VQVAE
 def gen_vqvae(ref_vq):
     print("VQVAE encoder / decoder")
@@ -406,7 +561,7 @@ def main():
     torch.manual_seed(synth.SEED)
     torch.set_num_threads(8)
     ref_gpt, ref_enc, ref_dec, ref_vq = import_reference()
-    which = set(sys.argv[1:]) or {"vq", "attn", "gpt", "lit", "vae", "vqvae", "melgan"}
+    which = set(sys.argv[1:]) or {"vq", "attn", "gpt", "lit", "vae", "vae_steps", "vae_xl", "vqvae", "melgan"}
     if which == {"melgan"}:
         gen_melgan()
         assert not any("__pycache__" in d for d, _, _ in os.walk(REF)), "bytecode leaked into reference"
@@ -421,6 +576,10 @@ def main():
         gen_lit(ref_gpt)
     if "vae" in which:
         gen_vae(ref_gpt, ref_enc, ref_dec)
+    if "vae_steps" in which:
+        gen_vae_steps()
+    if "vae_xl" in which:
+        gen_vae_xl(ref_enc, ref_dec)
     if "vqvae" in which:
         gen_vqvae(ref_vq)
     if "melgan" in which:

@@ -32,6 +32,54 @@ def test_nt_plain(dt, M, N, K):
     assert rel_err(out.cpu().numpy(), (ac @ bc.t()).numpy()) < 1e-5
 
 
+# GPT-VAE XL widths (config_GPT_VAE_vggsound.py:43-58: C = 1472 = 23 * 64, not a multiple of 128 / 256):
+# qkv N = 4416, fc1 N = 5888, fc2 K = 5888, the encoder's head N = 2944, V = 1024
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("form,M,N,K", [("nt", 530, 1472, 1472), ("nt", 530, 4416, 1472), ("nt", 530, 5888, 1472),
+                                        ("nt", 530, 1472, 5888), ("nt", 265, 2944, 1472), ("nt", 530, 1024, 1472),
+                                        ("nn", 530, 1472, 5888), ("nn", 530, 5888, 1472), ("nn", 530, 1472, 2944),
+                                        ("tn", 1472, 5888, 530), ("tn", 2944, 1472, 530), ("tn", 5888, 1472, 530)])
+def test_xl_width_shapes(dt, form, M, N, K):
+    from melspec_gpt_vqvae_amd import ops
+
+    if form == "nt":
+        a, ac = _rand(40, (M, K), DT[dt], 0.5)
+        b, bc = _rand(41, (N, K), DT[dt], 0.5)
+        out, ref = ops.gemm(a, b, out_dtype=torch.float32), ac @ bc.t()
+    elif form == "nn":
+        a, ac = _rand(42, (M, K), DT[dt], 0.5)
+        b, bc = _rand(43, (K, N), DT[dt], 0.5)
+        out, ref = ops.gemm(a, b, b_kmajor=True, out_dtype=torch.float32), ac @ bc
+    else:   # weight gradient dW (M x N) = dY^T X over K = tokens, through the split-K path the step uses
+        a, ac = _rand(44, (K, M), DT[dt], 0.5)
+        b, bc = _rand(45, (K, N), DT[dt], 0.5)
+        out = torch.empty(M, N, device=DEV)
+        ops.wgrad(a, b, out, False)
+        ref = ac.t() @ bc
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+def test_xl_width_persistent_kernel_at_step_size():
+    """the XL shapes at the token count of one rank's step slice (M = 64 * 265), bf16, on the persistent kernel"""
+    from melspec_gpt_vqvae_amd import ops
+
+    M = 64 * 265
+    torch.manual_seed(9)
+    a = (torch.randn(M, 1472) * 0.5).to(torch.bfloat16)
+    for N in (4416, 5888, 1472):
+        b = (torch.randn(N, 1472) * 0.2).to(torch.bfloat16)
+        out = ops.gemm(a.to(DEV), b.to(DEV), out_dtype=torch.float32)
+        assert rel_err(out.cpu().numpy(), (a.float() @ b.float().t()).numpy()) < 1e-5
+    a2 = (torch.randn(M, 5888) * 0.5).to(torch.bfloat16)
+    b2 = (torch.randn(1472, 5888) * 0.2).to(torch.bfloat16)
+    out = ops.gemm(a2.to(DEV), b2.to(DEV), out_dtype=torch.float32)
+    assert rel_err(out.cpu().numpy(), (a2.float() @ b2.float().t()).numpy()) < 1e-5
+    dy = (torch.randn(M, 5888) * 0.1).to(torch.bfloat16).to(DEV)
+    gw = torch.empty(5888, 1472, device=DEV)
+    ops.wgrad(dy, a.to(DEV), gw, False)
+    assert rel_err(gw.cpu().numpy(), (dy.float().cpu().t() @ a.float()).numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("form", ["nn", "tn", "tt"])
 def test_transposed_operands(dt, form):

@@ -122,3 +122,118 @@ def test_gpt_vae_loss_and_grads_vs_reference_golden():
     zg = mu.unsqueeze(1) + t(g["eps"], DEV) * (0.5 * logvar).exp().unsqueeze(1)
     xs, _ = vae.decoder.sample(x[:, :3], zg.detach(), steps=8, sample=False)
     assert np.array_equal(xs.cpu().numpy(), g["dec_greedy8"])
+
+
+# ------------------------------------------------------------------ GPT_VAE.training_step / validation_step (V3)
+def _vae_from_steps_golden(g, **kw):
+    from melspec_gpt_vqvae_amd.transformer.Lit_GPT_VAE import GPT_VAE
+
+    d = dict(n_layer=2, n_head=4, n_embd=256, block_size=265, fix_var=0, kl_start=float(g["kl_start"]),
+             warm_up=int(g["warm_up"]), batch_size=int(g["batch_size"]), target_kl=8.0, beta=1.0, nsamples=1, fb=0,
+             device=DEV, learning_rate=1e-6, len_train_data=int(g["len_train_data"]), iw_train_nsamples=-1)
+    d.update(kw)
+    args = synth.gpt_args(**d)
+    vae = GPT_VAE(args)
+    _load(vae.encoder.transformer, synth.gpt_state_dict(args, int(g["enc_seed"]), block_size=265, with_embedder=False,
+                                                         out_features=512))
+    _load(vae.decoder.transformer, synth.gpt_state_dict(args, int(g["dec_seed"]), block_size=266, with_embedder=False))
+    return vae.to(DEV)
+
+
+@pytest.mark.parametrize("tag", ["fb0a", "fb1a", "fb1b", "fb2a", "fb2b", "fb3a", "fb3b"])
+def test_gpt_vae_training_step_free_bits_branches_vs_reference(tag):
+    """one real-reference training_step per free-bits branch (both outcomes of each mask), replayed with the
+    reference's reparameterisation noise: loss 1e-4, sampled gradient norms 2e-4 (reference Lit_GPT_VAE.py:246-315)"""
+    g = golden("gpt_vae_steps")
+    vae = _vae_from_steps_golden(g, fb=int(tag[2]), target_kl=float(g[tag + ".target_kl"])).train()
+    batch = {"codes": t(g["codes"], DEV)}
+    loss = vae.training_step(batch, 0, eps=t(g[tag + ".eps"], DEV))
+    assert abs(vae.kl_weight - float(g[tag + ".kl_weight"])) < 1e-12
+    assert abs(loss.item() - float(g[tag + ".loss"])) <= 1e-4 * abs(float(g[tag + ".loss"]))
+    loss.backward()
+    params = dict(vae.named_parameters())
+    for k in g.files:
+        if k.startswith(tag + ".gnorm."):
+            nm = k[len(tag) + 7:]
+            gnorm_check(nm, float(params[nm].grad.double().norm()), float(g[k]), 2e-4)
+    m = vae.last_metrics
+    assert set(m) == {"train/loss", "train/loss_rc", "train/loss_kl", "train/kl_weight"}
+    assert abs(float(m["train/loss"]) - float(m["train/loss_rc"]) - float(m["train/loss_kl"])) < 1e-2
+
+
+def test_gpt_vae_anneal_beta0_and_validation_step_vs_reference():
+    g = golden("gpt_vae_steps")
+    batch = {"codes": t(g["codes"], DEV)}
+    vae = _vae_from_steps_golden(g).train()
+    assert abs(vae.anneal_rate - float(g["anneal_rate"])) < 1e-12
+    for k in range(3):
+        loss = vae.training_step(batch, k, eps=t(g["anneal_eps"][k], DEV))
+        assert abs(vae.kl_weight - float(g["anneal_kl_weights"][k])) < 1e-12
+        assert abs(loss.item() - float(g["anneal_losses"][k])) <= 1e-4 * float(g["anneal_losses"][k])
+    for _ in range(20):       # saturates at 1.0
+        vae.kl_weight = min(1.0, vae.kl_weight + vae.anneal_rate)
+    assert vae.kl_weight == 1.0
+    v0 = _vae_from_steps_golden(g, beta=0.0).train()
+    loss = v0.training_step(batch, 0, eps=t(g["beta0.eps"], DEV))
+    assert v0.kl_weight == 0.0 and abs(loss.item() - float(g["beta0.loss"])) <= 1e-4 * float(g["beta0.loss"])
+    ve = _vae_from_steps_golden(g).eval()
+    r = ve.validation_step(batch, 0, eps=t(g["val.eps"], DEV))
+    for k in ("val_loss", "val_loss_rc", "val_loss_kl"):
+        assert abs(float(r[k]) - float(g["val." + k])) <= 1e-4 * float(g["val." + k]), k
+    assert r["report_num_words"] == int(g["val.report_num_words"]) and r["report_num_sents"] == 2
+    ve.validation_epoch_end([r, r])
+    assert abs(float(ve.test_loss) - float(g["val.val_loss"]) / 2) <= 1e-4 * float(g["val.val_loss"])
+    assert abs(float(ve.nll) - (float(g["val.val_loss_rc"]) + float(g["val.val_loss_kl"])) / 2) < 0.2
+    assert abs(float(ve.ppl) - np.exp(float(ve.nll) * 4 / 1056)) < 1e-2 * float(ve.ppl)
+
+
+# ---------------------------------------------------------------------------- XL width (BASELINE configs[3])
+@pytest.mark.parametrize("lane", ["f32", "bf16"])
+def test_gpt_vae_xl_width_vs_reference(lane):
+    """2-layer GPT-VAE at C = 1472, 23 heads, V = 1024 (config_GPT_VAE_vggsound.py:43-58) against the real reference:
+    f32 lane at 1e-4 (mu, logvar, KL, rec, loss, logits, attention row, every gradient norm at 2e-4); bf16 lane
+    reported against the same numbers at its own tolerance."""
+    from melspec_gpt_vqvae_amd.transformer.Lit_GPT_VAE import GPT_VAE
+    from melspec_gpt_vqvae_amd.transformer.minGPT import set_compute_dtype
+
+    g = golden("gpt_vae_xl2")
+    args = synth.gpt_args(vocab_size=1024, n_layer=2, n_head=23, n_embd=1472, block_size=265, fix_var=0, kl_start=0.5,
+                          warm_up=0, batch_size=2, target_kl=0.0, beta=1.0, nsamples=1, fb=0, device=DEV,
+                          learning_rate=1e-6)
+    vae = GPT_VAE(args)
+    _load(vae.encoder.transformer, synth.gpt_state_dict(args, int(g["enc_seed"]), block_size=265, with_embedder=False,
+                                                         out_features=2944))
+    _load(vae.decoder.transformer, synth.gpt_state_dict(args, int(g["dec_seed"]), block_size=266, with_embedder=False))
+    vae.to(DEV)
+    tol, gtol = (1e-4, 2e-4) if lane == "f32" else (3e-2, 5e-2)
+    if lane == "bf16":
+        set_compute_dtype(vae, torch.bfloat16)
+    x = t(g["x"], DEV)
+    mu, logvar, att = vae.encoder(x)
+    assert rel_err(mu.detach().cpu().numpy(), g["mu"]) < tol and rel_err(logvar.detach().cpu().numpy(), g["logvar"]) < tol
+    assert att.shape == (2, 23, 265, 265)
+    assert rel_err(att[:, 22, 264].detach().cpu().numpy(), g["enc_att_h22_row264"]) < tol
+    eps = t(g["eps"], DEV)
+    z = vae.encoder.reparameterize(mu, logvar, 1, eps=eps)
+    logits, _ = vae.decoder(x, z)
+    assert rel_err(logits[0, 100].detach().cpu().numpy(), g["dec_logits_b0_t100"]) < tol
+    assert rel_err(logits[1, -1].detach().cpu().numpy(), g["dec_logits_b1_last"]) < tol
+    total, rec, KL = vae.loss(x, float(g["kl_weight"]), nsamples=1, eps=eps)
+    assert rel_err(KL.detach().cpu().numpy(), g["KL"]) < tol
+    assert rel_err(rec.detach().cpu().numpy(), g["rec"].reshape(-1)) < (1e-4 if lane == "f32" else 2e-3)
+    loss = total.mean()
+    assert abs(loss.item() - float(g["loss"])) <= (1e-4 if lane == "f32" else 2e-3) * abs(float(g["loss"]))
+    loss.backward()
+    enc = dict(vae.encoder.transformer.named_parameters())
+    dec = dict(vae.decoder.transformer.named_parameters())
+    worst = 0.0
+    for k in g.files:
+        for pre, params in (("enc.gnorm.", enc), ("dec.gnorm.", dec)):
+            if k.startswith(pre):
+                nm = k[len(pre):]
+                got = float(params[nm].grad.double().norm())
+                # key.bias gradients are mathematically zero: rounding noise only, larger on the bf16 lane
+                gnorm_check(nm, got, float(g[k]), gtol, zero_floor=1e-3 if lane == "f32" else 0.1)
+                if not nm.endswith("key.bias"):
+                    worst = max(worst, abs(got - float(g[k])) / float(g[k]))
+    print(f"XL width, {lane} lane: worst gradient-norm deviation {worst:.2e}")

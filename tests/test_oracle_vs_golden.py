@@ -190,6 +190,82 @@ def test_gpt_vae_loss():
             assert abs(float(dec[k[10:]].grad.double().norm()) - float(g[k])) <= 5e-5 * float(g[k]) + 1e-9, k
 
 
+def _vae_small_sds(g, requires_grad=False):
+    args = synth.gpt_args(n_layer=2, n_head=4, n_embd=256, block_size=265)
+    enc = ogpt.as_torch_sd(synth.gpt_state_dict(args, int(g["enc_seed"]), block_size=265, with_embedder=False,
+                                                out_features=512), requires_grad=requires_grad)
+    dec = ogpt.as_torch_sd(synth.gpt_state_dict(args, int(g["dec_seed"]), block_size=266, with_embedder=False),
+                           requires_grad=requires_grad)
+    return enc, dec
+
+
+VAE_STEP_TAGS = ["fb0a", "fb1a", "fb1b", "fb2a", "fb2b", "fb3a", "fb3b"]
+
+
+@pytest.mark.parametrize("tag", VAE_STEP_TAGS)
+def test_gpt_vae_training_step_free_bits_branches(tag):
+    """the REAL GPT_VAE.training_step of the reference (Lit_GPT_VAE.py:246-315), one step per fb branch with both
+    outcomes of each mask, vs the oracle's restatement: loss and gradient norms."""
+    g = golden("gpt_vae_steps")
+    enc, dec = _vae_small_sds(g, requires_grad=True)
+    x = ogpt.codes_to_sequence(t(g["codes"]))
+    w = ogpt.vae_anneal(float(g["kl_start"]), float(g["kl_start"]), int(g["warm_up"]), int(g["len_train_data"]),
+                        int(g["batch_size"]))
+    assert abs(w - float(g[tag + ".kl_weight"])) < 1e-12
+    loss, _, _ = ogpt.vae_training_step(enc, dec, x, t(g[tag + ".eps"]), w, 2, 4, 265, fb=int(tag[2]),
+                                        target_kl=float(g[tag + ".target_kl"]))
+    assert abs(loss.item() - float(g[tag + ".loss"])) <= 2e-6 * abs(float(g[tag + ".loss"]))
+    loss.backward()
+    for k in g.files:
+        if k.startswith(tag + ".gnorm."):
+            nm = k[len(tag) + 7:]
+            sd, key = (enc, nm[len("encoder.transformer."):]) if nm.startswith("encoder.") else \
+                (dec, nm[len("decoder.transformer."):])
+            assert abs(float(sd[key].grad.double().norm()) - float(g[k])) <= 5e-5 * float(g[k]), k
+
+
+def test_gpt_vae_anneal_beta0_and_validation_step():
+    g = golden("gpt_vae_steps")
+    enc, dec = _vae_small_sds(g)
+    x = ogpt.codes_to_sequence(t(g["codes"]))
+    assert abs(float(g["anneal_rate"]) - 0.9 / (2 * 6)) < 1e-12
+    w = float(g["kl_start"])
+    with torch.no_grad():
+        for k in range(3):
+            w = ogpt.vae_anneal(w, float(g["kl_start"]), 2, 12, 2)
+            assert abs(w - float(g["anneal_kl_weights"][k])) < 1e-12
+            loss, _, _ = ogpt.vae_training_step(enc, dec, x, t(g["anneal_eps"][k]), w, 2, 4, 265)
+            assert abs(loss.item() - float(g["anneal_losses"][k])) <= 2e-6 * float(g["anneal_losses"][k])
+        w0 = ogpt.vae_anneal(0.1, 0.1, 2, 12, 2, beta=0.0)
+        assert w0 == 0.0 == float(g["beta0.kl_weight"])
+        loss, _, _ = ogpt.vae_training_step(enc, dec, x, t(g["beta0.eps"]), w0, 2, 4, 265, beta=0.0)
+        assert abs(loss.item() - float(g["beta0.loss"])) <= 2e-6 * float(g["beta0.loss"])
+        r = ogpt.vae_validation_step(enc, dec, x, t(g["val.eps"]), 2, 4, 265)
+    for k in ("val_loss", "val_loss_rc", "val_loss_kl"):
+        assert abs(float(r[k]) - float(g["val." + k])) <= 2e-6 * float(g["val." + k]), k
+    assert r["report_num_words"] == int(g["val.report_num_words"]) == 528 and r["report_num_sents"] == 2
+
+
+def test_gpt_vae_xl_width():
+    """BASELINE configs[3] width (C 1472, 23 heads, V 1024): 2-layer GPT-VAE from the real reference."""
+    g = golden("gpt_vae_xl2")
+    args = synth.gpt_args(vocab_size=1024, n_layer=2, n_head=23, n_embd=1472, block_size=265)
+    enc = ogpt.as_torch_sd(synth.gpt_state_dict(args, int(g["enc_seed"]), block_size=265, with_embedder=False,
+                                                out_features=2944), requires_grad=True)
+    dec = ogpt.as_torch_sd(synth.gpt_state_dict(args, int(g["dec_seed"]), block_size=266, with_embedder=False),
+                           requires_grad=True)
+    loss, rec, KL, mu, logvar = ogpt.vae_loss(enc, dec, t(g["x"]), t(g["eps"]), float(g["kl_weight"]), 2, 23, 265)
+    assert rel_err(mu.detach().numpy(), g["mu"]) < 5e-6 and rel_err(logvar.detach().numpy(), g["logvar"]) < 5e-6
+    assert rel_err(KL.detach().numpy(), g["KL"]) < 1e-5 and rel_err(rec.detach().numpy(), g["rec"]) < 1e-5
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    for k in g.files:
+        if k.startswith("enc.gnorm."):
+            assert abs(float(enc[k[10:]].grad.double().norm()) - float(g[k])) <= 5e-5 * float(g[k]) + 1e-9, k
+        if k.startswith("dec.gnorm."):
+            assert abs(float(dec[k[10:]].grad.double().norm()) - float(g[k])) <= 5e-5 * float(g[k]) + 1e-9, k
+
+
 # ---------------------------------------------------------------------------------- VQVAE
 def test_vqvae_narrow_encoder_decoder():
     g = golden("vqvae_narrow")
