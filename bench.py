@@ -68,31 +68,55 @@ def synthetic_batch(batch, rank, device):
     return x, c
 
 
-def pmc_traffic():
-    """HBM bytes per step of the GEMM-family kernels, from the committed rocprofv3 PMC passes of this same command
-    (profiles/*_summary.json, written by tools/profile_round.sh; bench.py itself cannot collect PMC counters).
-    None when no summary is committed."""
+def pmc_summary(workload="class_gpt"):
+    """The newest committed rocprofv3 PMC summary OF THIS WORKLOAD's training step (profiles/*_summary.json written by
+    tools/profile_round.sh; bench.py itself cannot collect PMC counters): HBM bytes per step of the GEMM-family kernels
+    (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections of the guide applied there) and, when the MFMA pass
+    was collected, the matrix-pipe busy fraction of that family.  Files without the GEMM-family keys (e.g. the VQ
+    lookup's own summary) are skipped, and said so on stderr."""
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
-    files = sorted(glob.glob(os.path.join(here, "profiles", "*_summary.json")))
-    if not files:
-        return None, None
+    best = None
+    for f in sorted(glob.glob(os.path.join(here, "profiles", "*_summary.json"))):
+        try:
+            j = json.load(open(f))
+        except (OSError, ValueError) as e:
+            print(f"bench.py: {os.path.basename(f)} unreadable ({e})", file=sys.stderr)
+            continue
+        if "gemm_family_hbm_read_MB" not in j or j.get("workload", "class_gpt") != workload:
+            print(f"bench.py: {os.path.basename(f)} is not a {workload} training-step summary - skipped", file=sys.stderr)
+            continue
+        best = (f, j)            # sorted(): the last matching file is the newest round / letter
+    if best is None:
+        return {}
+    f, j = best
+    steps = max(int(j.get("steps_profiled", 1)), 1)
+    out = {"traffic": round((j["gemm_family_hbm_read_MB"] + j["gemm_family_hbm_write_MB"]) * 1e6 / steps),
+           "traffic_source": "profiles/" + os.path.basename(f)}
+    if j.get("gemm_family_mfma_busy") is not None:
+        out["mfma_busy"] = j["gemm_family_mfma_busy"]
+        out["mfma_busy_by_kernel"] = j.get("mfma_busy_by_kernel")
+    return out
+
+
+def cpu_model():
     try:
-        j = json.load(open(files[-1]))
-        per_step = (j["gemm_family_hbm_read_MB"] + j["gemm_family_hbm_write_MB"]) * 1e6 / j["steps_profiled"]
-        return round(per_step), "profiles/" + os.path.basename(files[-1])
-    except Exception:
-        return None, None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
-def cpu_baseline(batch=4, reps=2):
+def cpu_baseline(batch=8, reps=3):
     """The CPU oracle (kind "port": torch-CPU fp32 restatement pinned to the reference by tests/golden) running the
     same step - VQ-encode + class-GPT fwd/bwd + AdamW - on a bounded sample."""
     import synth
     from oracle import gpt as ogpt
     from oracle import vqvae as ovq
 
-    threads = min(os.cpu_count() or 1, 64)
+    threads = os.cpu_count() or 1
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(1)
     a = vas_args()
@@ -128,13 +152,115 @@ def cpu_baseline(batch=4, reps=2):
         opt.step()
 
     step()
-    t0 = time.perf_counter()
+    times = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         step()
-    dt = (time.perf_counter() - t0) / reps
-    return {"value": round(batch / dt, 4), "unit": "seq/s", "cores": threads, "kind": "port",
-            "sample": f"batch {batch}, {reps} steps after 1 warm-up: oracle VQ-encode + class-GPT VAS fwd/bwd + AdamW, "
-                      f"fp32, {dt:.2f} s/step"}
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
+    return {"value": round(batch / dt, 4), "unit": "seq/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
+            "sample": f"batch {batch}, median of {reps} steps after 1 warm-up: oracle VQ-encode + class-GPT VAS fwd/bwd + "
+                      f"AdamW, fp32, torch threads = os.cpu_count() = {threads}, {dt:.2f} s/step"}
+
+
+def xl_args(**kw):
+    from types import SimpleNamespace
+
+    d = dict(vocab_size=1024, block_size=265, n_layer=40, n_head=23, n_embd=1472, embd_pdrop=0.0, resid_pdrop=0.0,
+             attn_pdrop=0.0, n_unmasked=0, last_linear=None, learning_rate=1e-6, fix_var=0, kl_start=0.3, warm_up=0,
+             batch_size=128, target_kl=0.0, beta=1.0, nsamples=1, fb=0, iw_train_nsamples=-1)
+    d.update(kw)
+    return SimpleNamespace(**d)  # config/config_GPT_VAE_vggsound.py:43-58 + GPT_VAE_train.py flag defaults
+
+
+class ClassGPTStep:
+    """BASELINE configs[2] (+ the VQ-encode of configs[1]): the default workload, the one `metric` is quoted on."""
+    name = "class_gpt"
+    seq_len = 265
+
+    def __init__(self, a, device, dtype, rank, world):
+        from melspec_gpt_vqvae_amd.dp import DataParallel
+        from melspec_gpt_vqvae_amd.optim import FusedAdamW
+
+        self.a = a
+        gargs = vas_args(n_layer=a.layers)
+        self.gpt, self.vqvae = build_models(device, dtype, gargs)
+        self.x_mel, self.c = synthetic_batch(a.batch, rank, device)
+        self.opt = FusedAdamW(self.gpt, lr=gargs.learning_rate, betas=(0.9, 0.95), weight_decay=0.01)
+        self.opt.grad_scale = 1.0 / world
+        self.dp = DataParallel(self.gpt) if world > 1 else None
+        self.full = a.layers == 24
+        self.workload = ("VQ-encode (LitVQVAE encoder + 128-code L2 argmin on 80x848 mel tiles) + class-GPT VAS "
+                         f"({a.layers} L, 1024, 16 H, T=265, V=128, dropout 0.5) fwd/bwd + AdamW")
+        self.metric = "mel-token seqs/sec training step (VQ-encode + GPT fwd/bwd)"
+
+    def step(self, mark):
+        from melspec_gpt_vqvae_amd import ops
+        from melspec_gpt_vqvae_amd.transformer.minGPT import cross_entropy
+
+        t0 = mark()
+        with torch.no_grad():
+            codes = self.vqvae.encode_to_codes(self.x_mel)       # (B,5,53) int64
+            seq = ops.codes_permute(codes, 5, 53)                # (B,265) time-major (get_x)
+        t1 = mark()
+        with self.gpt.discard_att():                             # as Lit_minGPT.forward does: the (B,H,T,T) map it
+            logits, _, _ = self.gpt(seq[:, :-1], self.c)         # ignores (`logits, _, _ = transformer(...)`) is not written
+        loss = cross_entropy(logits.reshape(-1, logits.size(-1)), seq.reshape(-1))
+        t2 = mark()
+        self.opt.zero_grad()
+        loss.backward()
+        if self.dp is not None:
+            self.dp.finish()
+        t3 = mark()
+        self.opt.step()
+        t4 = mark()
+        return loss, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)
+
+
+class GPTVAEXLStep:
+    """BASELINE configs[3]: GPT-VAE XL (config_GPT_VAE_vggsound.py:43-58; the model GPT_VAE_train.py:166-190 trains
+    under DDP) - encoder GPT (bidirectional, last_linear 2C) + decoder GPT, 2.09 B parameters, batch 128 per GPU,
+    loss = rec + kl_weight * KL, ONE flat gradient buffer over both transformers exchanged by dp.DataParallel."""
+    name = "gpt_vae_xl"
+    seq_len = 265
+
+    def __init__(self, a, device, dtype, rank, world):
+        from melspec_gpt_vqvae_amd.dp import DataParallel
+        from melspec_gpt_vqvae_amd.optim import FusedAdamW
+        from melspec_gpt_vqvae_amd.transformer.Lit_GPT_VAE import GPT_VAE
+        from melspec_gpt_vqvae_amd.transformer.minGPT import set_compute_dtype
+
+        self.a = a
+        layers = a.layers if a.layers != 24 else 40
+        args = xl_args(n_layer=layers, batch_size=a.batch, device=str(device))
+        torch.manual_seed(SEED)
+        self.vae = GPT_VAE(args).to(device).train()
+        set_compute_dtype(self.vae, dtype)
+        g = torch.Generator().manual_seed(SEED + 17 * rank)
+        self.x = torch.randint(0, 1024, (a.batch, 265), generator=g).to(device)
+        self.opt = FusedAdamW(self.vae, lr=args.learning_rate, betas=(0.9, 0.95), weight_decay=0.01)
+        self.opt.grad_scale = 1.0 / world
+        self.dp = DataParallel(self.vae) if world > 1 else None
+        self.full = layers == 40
+        self.n_params = sum(p.numel() for p in self.vae.parameters())
+        self.workload = (f"GPT-VAE XL (encoder + decoder GPT, {layers}+{layers} L, 1472, 23 H, T=265, V=1024, "
+                         f"{self.n_params / 1e9:.2f} B parameters) training step: ELBO fwd/bwd + AdamW, per-GPU batch "
+                         f"{a.batch}, f32 gradient exchange {4 * self.n_params / 1e9:.2f} GB per step")
+        self.metric = "mel-token seqs/sec training step (GPT-VAE XL fwd/bwd, BASELINE configs[3])"
+
+    def step(self, mark):
+        t0 = mark()
+        total, rec, kl = self.vae.loss(self.x, 0.5, nsamples=1)
+        loss = total.mean()
+        t2 = mark()
+        self.opt.zero_grad()
+        loss.backward()
+        if self.dp is not None:
+            self.dp.finish()
+        t3 = mark()
+        self.opt.step()
+        t4 = mark()
+        return loss, (0.0, t2 - t0, t3 - t2, t4 - t3)
 
 
 def main():
@@ -142,9 +268,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=128, help="sequences per GPU per step (BASELINE config 3: 128)")
+    ap.add_argument("--workload", default="class_gpt", choices=["class_gpt", "gpt_vae_xl"],
+                    help="class_gpt = BASELINE configs[1]+[2] (the metric's configuration); gpt_vae_xl = configs[3]")
+    ap.add_argument("--batch", type=int, default=128, help="sequences per GPU per step (BASELINE configs 3 and 4: 128)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--layers", type=int, default=24, help="debug only; anything but 24 is flagged in config")
+    ap.add_argument("--layers", type=int, default=24, help="debug only; anything but the configuration's depth is flagged")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print per-phase timings to stderr")
     a = ap.parse_args()
@@ -171,17 +299,9 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from melspec_gpt_vqvae_amd import ops
-    from melspec_gpt_vqvae_amd.dp import DataParallel
-    from melspec_gpt_vqvae_amd.optim import FusedAdamW
-    from melspec_gpt_vqvae_amd.transformer.minGPT import cross_entropy
 
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    gargs = vas_args(n_layer=a.layers)
-    gpt, vqvae = build_models(device, dtype, gargs)
-    x_mel, c = synthetic_batch(a.batch, rank, device)
-    opt = FusedAdamW(gpt, lr=gargs.learning_rate, betas=(0.9, 0.95), weight_decay=0.01)
-    opt.grad_scale = 1.0 / world
-    dp = DataParallel(gpt) if world > 1 else None
+    job = (ClassGPTStep if a.workload == "class_gpt" else GPTVAEXLStep)(a, device, dtype, rank, world)
 
     phases = {"encode": 0.0, "fwd": 0.0, "bwd": 0.0, "opt": 0.0}
 
@@ -191,24 +311,9 @@ def main():
         return time.perf_counter()
 
     def step():
-        t0 = mark()
-        with torch.no_grad():
-            codes = vqvae.encode_to_codes(x_mel)                 # (B,5,53) int64
-            seq = ops.codes_permute(codes, 5, 53)                # (B,265) time-major (get_x)
-        t1 = mark()
-        with gpt.discard_att():                                  # as Lit_minGPT.forward does: the (B,H,T,T) map it
-            logits, _, _ = gpt(seq[:, :-1], c)                   # ignores (`logits, _, _ = transformer(...)`) is not written
-        loss = cross_entropy(logits.reshape(-1, logits.size(-1)), seq.reshape(-1))
-        t2 = mark()
-        opt.zero_grad()
-        loss.backward()
-        if dp is not None:
-            dp.finish()
-        t3 = mark()
-        opt.step()
-        t4 = mark()
+        loss, dts = job.step(mark)
         if a.breakdown:
-            for k, v in zip(phases, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+            for k, v in zip(phases, dts):
                 phases[k] += v
         return loss
 
@@ -242,41 +347,49 @@ def main():
 
     ks = timer.summary()
     achieved = ks["flops"] / (ks["total_ms"] * 1e-3) / 1e12 if ks["total_ms"] > 0 else 0.0
-    traffic, traffic_src = pmc_traffic()
     if rank == 0:
+        pmc = pmc_summary(job.name)
+        # per-instantiation table: one row per (layout, shape, epilogue) of the GEMM family, slowest rate first among
+        # the rows that matter (>= 0.5 % of the family's time) - names the shape the family's `frac` is held down by
+        rows = [{"shape": tag, "calls_per_step": round(n / a.steps, 2), "ms_per_step": round(ms / a.steps, 3),
+                 "tflop_per_step": round(fl / a.steps / 1e12, 3), "tflops": round(fl / ms / 1e9, 1) if ms > 0 else 0.0}
+                for tag, n, ms, fl in timer.by_tag()]
+        major = [r for r in rows if r["ms_per_step"] * a.steps >= 0.005 * ks["total_ms"]]
+        worst = min(major, key=lambda r: r["tflops"]) if major else None
         out = {
-            "metric": "mel-token seqs/sec training step (VQ-encode + GPT fwd/bwd)",
+            "metric": job.metric,
             "value": round(value, 3), "unit": "seq/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
             "config": {
-                "workload": "VQ-encode (LitVQVAE encoder + 128-code L2 argmin on 80x848 mel tiles) + class-GPT VAS "
-                            f"({a.layers} L, 1024, 16 H, T=265, V=128, dropout 0.5) fwd/bwd + AdamW",
-                "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": 265,
+                "workload": job.workload,
+                "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": job.seq_len,
                 "parallelism": f"dp{world}" if world > 1 else "single",
                 "final_loss": round(loss_val, 4),
             },
             "roofline": {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/step",
-                "traffic_source": traffic_src,
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc.get("traffic"),
+                "traffic_unit": "bytes/step", "traffic_source": pmc.get("traffic_source"),
+                "mfma_busy": pmc.get("mfma_busy"), "mfma_busy_by_kernel": pmc.get("mfma_busy_by_kernel"),
                 "kernel": "MFMA GEMM family (gemm256_kernel persistent 256x256 / gemm_kernel 128x128 + implicit-GEMM conv / "
                           "conv3x3_gn_wide_kernel / conv3x3_gn_kernel with fused GroupNorm+swish), all launches of the timed region",
                 "launches_per_step": ks["launches"] // max(a.steps, 1),
                 "kernel_ms_per_step": round(ks["total_ms"] / max(a.steps, 1), 3),
                 "algorithmic_tflop_per_step": round(ks["flops"] / max(a.steps, 1) / 1e12, 3),
+                "worst_shape": worst, "per_shape": major,
             },
         }
-        if a.layers != 24:
+        if not job.full:
             out["config"]["INVALID_debug_layers"] = a.layers
         if share:
             out["config"]["INVALID_debug_shared_gpu"] = True
         if a.breakdown:
             print({k: round(1e3 * v / a.steps, 2) for k, v in phases.items()}, file=sys.stderr)
-            for tag, n, ms, fl in timer.by_tag()[:40]:
-                print(f"  {tag:44s} n/step={n / a.steps:6.1f} ms/step={ms / a.steps:8.3f} "
-                      f"TFLOP/s={fl / ms / 1e9 if ms > 0 else 0:7.1f}", file=sys.stderr)
-        if world == 1 and not a.no_cpu_baseline:
+            for r in rows[:40]:
+                print(f"  {r['shape']:44s} n/step={r['calls_per_step']:6.1f} ms/step={r['ms_per_step']:8.3f} "
+                      f"TFLOP/s={r['tflops']:7.1f}", file=sys.stderr)
+        if world == 1 and not a.no_cpu_baseline and job.name == "class_gpt":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -1,0 +1,59 @@
+"""dp.DataParallel with world = 2 on ONE GPU: two fresh child processes (started before they touch the GPU) share
+cuda:0 and rendezvous over gloo - the same wrapper, Block hooks, segments and finish() that run over RCCL on an
+8-GPU node; only the transport differs.  Checked: the reduced flat gradient x 1/world == the single-process gradient
+of the concatenated batch (1e-6), the Block hooks fired (early launches happened), the fused metric all-reduce, and
+the double-backward guard.  Covers a GPTClass and a GPT_VAE (two transformers in one flat buffer - the model the
+reference trains under DDP, GPT_VAE_train.py:166-190)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import dp_models
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("which", ["gptclass", "vae"])
+def test_two_ranks_share_one_gpu_gradients_equal_single_process(which, tmp_path):
+    from melspec_gpt_vqvae_amd.flat import ensure_flat
+
+    world, port = 2, _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), which, str(tmp_path)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    # the single-process answer, computed here while the children run
+    model, batch, loss_fn = dp_models.build(which, "cuda:0")
+    loss = loss_fn(model, batch)
+    loss.backward()
+    fp = ensure_flat(model)
+    want = fp.grad.cpu()
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    res = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(world)]
+    n_blocks = 2 if which == "gptclass" else 4
+    for r in res:
+        assert r["names"] == fp.names and r["offsets"] == fp.offsets
+        assert r["hook_calls"] == n_blocks and r["launched_early"] == 2 * n_blocks     # two slices per Block, before finish()
+        got = r["grad"] / world                                                        # the optimizer's grad_scale
+        err = float((got - want).abs().max() / want.abs().max())
+        assert err < 1e-6, err
+        assert abs(r["metrics"][0] - sum(x["loss"] for x in res) / world) < 1e-5
+        assert r["metrics"][1] == 0.5 and r["metrics"][2] == 3.0                      # mean of the ranks' values
+    assert torch.equal(res[0]["grad"], res[1]["grad"])                                 # both ranks hold the same sum
+    assert abs(sum(x["loss"] for x in res) / world - float(loss)) < 1e-5
+    for rnk in range(world):
+        assert torch.load(os.path.join(str(tmp_path), f"rank{rnk}_guard.pt"))["refused"]

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import synth
-from util import gnorm_check, golden, grad_check, rel_err, t
+from util import report, gnorm_check, golden, grad_check, rel_err, t
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -130,7 +130,7 @@ def test_gptclass_vas_width_and_bf16_lane():
     set_compute_dtype(m, torch.bfloat16)
     logits_b, _, _ = m(x[:, :-1], c)
     err = rel_err(logits_b.detach().cpu().numpy(), g["logits"])
-    print("bf16 lane logits rel-to-max err:", err)
+    report("gptclass_vas2_bf16_lane_vs_f32_reference", logits_rel_to_max_err=err)
     assert err < 3e-2
     loss_b = cross_entropy(logits_b.reshape(-1, 128), x.reshape(-1))
     assert abs(loss_b.item() - float(g["loss"])) < 2e-2
@@ -141,7 +141,7 @@ def test_gptclass_vas_width_and_bf16_lane():
             continue  # mathematically zero gradient: pure rounding noise on both lanes
         a, b = p.grad.double().flatten(), f32_grads[k].double().flatten()
         cos.append(float((a @ b) / (a.norm() * b.norm() + 1e-30)))
-    print("bf16 lane min grad cosine:", min(cos))
+    report("gptclass_vas2_bf16_lane_vs_f32_lane", min_grad_cosine=min(cos))
     assert min(cos) > 0.98
 
 

@@ -6,7 +6,7 @@ import torch
 import torch.nn.functional as F
 
 import synth
-from util import gnorm_check, golden, rel_err, t
+from util import report, gnorm_check, golden, rel_err, t
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -236,4 +236,5 @@ def test_gpt_vae_xl_width_vs_reference(lane):
                 gnorm_check(nm, got, float(g[k]), gtol, zero_floor=1e-3 if lane == "f32" else 0.1)
                 if not nm.endswith("key.bias"):
                     worst = max(worst, abs(got - float(g[k])) / float(g[k]))
-    print(f"XL width, {lane} lane: worst gradient-norm deviation {worst:.2e}")
+    report("gpt_vae_xl2_vs_reference", lane=lane, worst_grad_norm_rel_dev=worst,
+           loss_rel_err=abs(loss.item() - float(g["loss"])) / abs(float(g["loss"])))

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import synth
-from util import golden, rel_err, t
+from util import report, golden, rel_err, t
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -33,7 +33,7 @@ def test_generator_matches_reference_golden(dt):
     y = m(t(g["x"], DEV))
     assert y.shape == (2, 1, 12 * 256) and y.dtype == torch.float32 and int(m.hop_length) == 256
     err = rel_err(y.cpu().numpy(), g["y"])
-    print(f"melgan {dt}: rel-to-max err {err:.3e}")
+    report("melgan_vs_reference", lane=dt, rel_to_max_err=err)
     assert err < (1e-4 if dt == "f32" else 6e-2)
     assert float(y.abs().max()) <= 1.0                       # tanh range
 

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import synth
-from util import check_indices_with_tie_policy, golden, rel_err, t
+from util import report, check_indices_with_tie_policy, golden, rel_err, t
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -34,8 +34,11 @@ def test_f32_lane_bit_exact_vs_c_oracle_and_reference_b64(layout):
     assert np.array_equal(idx, ref["indices"]), "HIP F32 lane must equal the C oracle bit for bit"
     assert np.array_equal(r["distances"].cpu().numpy().view(np.uint32), ref["distances"].view(np.uint32)), \
         "distances are an exact k-ordered FMA chain on both sides"
-    n_near = check_indices_with_tie_policy(idx, g["indices"], g["gap_ulps"], g["top2"])
-    print("near-tie vectors:", n_near)
+    n_near, n_flip = check_indices_with_tie_policy(idx, g["indices"], g["gap_ulps"], g["top2"], counts=True)
+    listed = int((g["gap_ulps"] < 8.0).sum())        # the fixture's own near-tie list (2 of 16 960)
+    report("vq_b64_f32_vs_reference", layout=layout, vectors=idx.size, near_ties_lt_8ulp=n_near,
+           resolved_to_other_code=n_flip, fixture_listed=listed)
+    assert n_near == listed <= 2 and n_flip <= n_near
     q = r["quantized"].permute(0, 2, 3, 1).reshape(-1, 256).cpu().numpy()
     assert np.array_equal(q, ref["quantized"])
     sq = float(r["sq_err"][: r["grid"]].double().sum())
@@ -117,8 +120,12 @@ def test_bf16_lane_b64(layout):
     d = np.sort(ref["distances"], axis=1)
     gap = (d[:, 1] - d[:, 0]) / np.spacing(np.abs(d[:, 0]))
     top2 = np.argsort(ref["distances"], axis=1, kind="stable")[:, :2]
-    n_near = check_indices_with_tie_policy(r["indices"].cpu().numpy(), ref["indices"], gap, top2, ulp_thresh=64.0)
-    print("bf16 lane near-ties (<64 ulp):", n_near)
+    n_near, n_flip = check_indices_with_tie_policy(r["indices"].cpu().numpy(), ref["indices"], gap, top2,
+                                                   ulp_thresh=64.0, counts=True)
+    report("vq_b64_bf16_vs_c_oracle_on_rounded_inputs", layout=layout, vectors=int(gap.size), near_ties_lt_64ulp=n_near,
+           resolved_to_other_code=n_flip)
+    # gaps are ~uniform at this scale: 4 of 16 960 vectors sit within 64 ulp for the f32 fixture; same order here
+    assert n_near <= 16 and n_flip <= n_near
     assert rel_err(r["distances"].cpu().numpy(), ref["distances"]) < 1e-5
     q = r["quantized"].float().permute(0, 2, 3, 1).reshape(-1, 256).cpu().numpy()
     qref = t(ref["quantized"]).to(torch.bfloat16).float().numpy()

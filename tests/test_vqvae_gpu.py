@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 import synth
-from util import check_indices_with_tie_policy, golden, rel_err, t
+from util import report, check_indices_with_tie_policy, golden, rel_err, t
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -121,9 +121,12 @@ def test_full_vqvae_tile_to_codes_vs_reference_golden():
         assert codes.shape == (2, 5, 53) and codes.dtype == torch.int64
         # the encoder's own 1e-6-level differences can move a distance by a few hundred ulp: ties within 2048 ulp
         # may resolve to either of the two nearest codes, everything else must be bit-identical
-        n_near = check_indices_with_tie_policy(codes.cpu().numpy(), g["indices"], g["gap_ulps"], g["top2"],
-                                               ulp_thresh=2048.0)
-        print("near-tie vectors (<2048 ulp):", n_near)
+        n_near, n_flip = check_indices_with_tie_policy(codes.cpu().numpy(), g["indices"], g["gap_ulps"], g["top2"],
+                                                       ulp_thresh=2048.0, counts=True)
+        listed = int((g["gap_ulps"] < 2048.0).sum())     # 4 of 530 in the fixture; none below 64 ulp
+        report("vqvae_full_f32_codes_vs_reference", vectors=530, near_ties_lt_2048ulp=n_near,
+               resolved_to_other_code=n_flip, fixture_listed=listed, fixture_lt_8ulp=int((g["gap_ulps"] < 8.0).sum()))
+        assert n_near == listed <= 4 and n_flip <= n_near
         loss, q, (perp, enc1h, idx) = m._vq_vae(z)
         assert abs(loss.item() - float(g["vq_loss"])) <= 1e-4 * abs(float(g["vq_loss"]))
         assert abs(perp.item() - float(g["perplexity"])) <= 1e-3 * float(g["perplexity"])
@@ -146,7 +149,7 @@ def test_full_vqvae_bf16_lane_reports_code_agreement():
         codes = m.encode_to_codes(t(g["x"], DEV))
     err = rel_err(z.float().cpu().numpy(), g["z"])
     agree = float((codes.cpu().numpy().ravel() == g["indices"].astype(np.int64)).mean())
-    print(f"bf16 encoder: latent rel-to-max err {err:.3e}, code agreement {agree:.3f}")
+    report("vqvae_full_bf16_lane_vs_f32_reference", latent_rel_to_max_err=err, code_agreement=agree, vectors=530)
     assert err < 5e-2 and agree > 0.9
 
 

@@ -26,10 +26,11 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-def check_indices_with_tie_policy(got, want, gap_ulps, top2, ulp_thresh=8.0):
+def check_indices_with_tie_policy(got, want, gap_ulps, top2, ulp_thresh=8.0, counts=False):
     """SURVEY §8a tie policy: indices must be bit-identical wherever the reference's two smallest
     distances are >= `ulp_thresh` ulp apart; on the listed near-ties either of the two nearest codes
-    is accepted.  Returns the number of near-tie vectors (reported by the caller)."""
+    is accepted.  Returns the number of near-tie vectors; with counts=True -> (near-tie vectors, how many of them
+    actually resolved to the OTHER code).  Callers assert both against a bound and report() them."""
     got = np.asarray(got).astype(np.int64).ravel()
     want = np.asarray(want).astype(np.int64).ravel()
     near = np.asarray(gap_ulps).ravel() < ulp_thresh
@@ -38,7 +39,26 @@ def check_indices_with_tie_policy(got, want, gap_ulps, top2, ulp_thresh=8.0):
     nt = np.nonzero(near)[0]
     for n in nt:
         assert got[n] in (int(top2[n][0]), int(top2[n][1])), (n, got[n], top2[n])
+    if counts:
+        return int(near.sum()), int((got != want)[near].sum())
     return int(near.sum())
+
+
+def report(test, **values):
+    """Append one JSON record of measured parity figures (near-tie counts, bf16-lane errors) to
+    $MELGPT_REPORT_DIR/parity_report.jsonl (default <repo>/gpurun_out): `pytest -q` swallows prints, the judge reads
+    the copy committed under profiles/."""
+    import json
+
+    d = os.environ.get("MELGPT_REPORT_DIR", os.path.join(os.path.dirname(GOLDEN.rstrip("/")), "..", "gpurun_out"))
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_report.jsonl"), "a") as f:
+            f.write(json.dumps({"test": test, **{k: (float(v) if isinstance(v, (np.floating, float)) else
+                                                      int(v) if isinstance(v, (np.integer, int)) else v)
+                                                 for k, v in values.items()}}) + "\n")
+    except OSError:
+        pass
 
 
 def grad_check(name, got, ref, tol, zero_floor=2e-5):
