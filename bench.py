@@ -99,6 +99,19 @@ def pmc_summary(workload="class_gpt"):
     return out
 
 
+def usable_cores():
+    """CPU cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a
+    one-GPU job a share of the host - os.cpu_count() there is the whole machine and oversubscribing it is slow)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -116,7 +129,7 @@ def cpu_baseline(batch=8, reps=3):
     from oracle import gpt as ogpt
     from oracle import vqvae as ovq
 
-    threads = os.cpu_count() or 1
+    threads = usable_cores()
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(1)
     a = vas_args()
@@ -151,16 +164,22 @@ def cpu_baseline(batch=8, reps=3):
         loss.backward()
         opt.step()
 
+    t0 = time.perf_counter()
     step()
+    warm = time.perf_counter() - t0
+    print(f"bench.py: cpu_baseline warm-up step {warm:.1f} s on {threads} threads", file=sys.stderr, flush=True)
+    if warm > 40.0:        # keep the sample bounded (~2 min of CPU work at most): a slow host gets one timed step
+        reps = 1
     times = []
     for _ in range(reps):
         t0 = time.perf_counter()
         step()
         times.append(time.perf_counter() - t0)
+        print(f"bench.py: cpu_baseline step {times[-1]:.1f} s", file=sys.stderr, flush=True)
     dt = sorted(times)[len(times) // 2]
     return {"value": round(batch / dt, 4), "unit": "seq/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
             "sample": f"batch {batch}, median of {reps} steps after 1 warm-up: oracle VQ-encode + class-GPT VAS fwd/bwd + "
-                      f"AdamW, fp32, torch threads = os.cpu_count() = {threads}, {dt:.2f} s/step"}
+                      f"AdamW, fp32, torch threads = usable cores (affinity / cgroup quota) = {threads} of os.cpu_count() = {os.cpu_count()}, {dt:.2f} s/step"}
 
 
 def xl_args(**kw):
