@@ -90,6 +90,25 @@ int melgpt_vq_argmin_fwd_ex(const void* z, int z_dtype, int64_t n_vectors, int d
 /* max workgroups melgpt_vq_argmin_fwd will ever use (size sq_err with it). */
 int melgpt_vq_max_grid(void);
 
+/* Prepared codebook image for the bf16 lookup (indices only - the hot path of feature_extraction/extract_codes.py:
+ * 48-50 and of the training step's VQ-encode).  Everything a launch of melgpt_vq_argmin_fwd derives from the codebook
+ * (bf16 rounding, swizzled MFMA fragment layout, the |e|^2 chains) is computed ONCE per codebook version:
+ *   conv_weight == NULL : plain image; melgpt_vq_lookup_image(fused = 0) returns the same bits as the bf16 lane of
+ *                         melgpt_vq_argmin_fwd.
+ *   conv_weight != NULL : the 1x1 `quant_conv` (big_model_attn_gan.py:578,607; weight (D,D) out x in, bias (D) or
+ *                         NULL) is folded in:  argmin_k |W x + b - e_k|^2 = argmin_k (|e_k|^2 - 2 b.e_k) - 2 x.(W^T e_k),
+ *                         so the lookup (fused = 1) runs on the ENCODER's output x and z = quant_conv(x) is never formed.
+ *                         with_lo = 1 keeps W^T e_k as two bf16 planes (hi + lo, 2^-17 relative); 0 = one plane.
+ * `image` is a device buffer of melgpt_vq_image_bytes(with_lo) bytes, 16-byte aligned; D = 256, K = 128.
+ * melgpt_vq_lookup_image: z bf16, channel-contiguous (stride_c = 1) latents in the addressing of z above;
+ * histogram optional (K,) int32 in/out. */
+int64_t melgpt_vq_image_bytes(int with_lo);
+int melgpt_vq_prepare_image(const float* codebook, int num_codes, int dim, const float* conv_weight,
+                            const float* conv_bias, int with_lo, void* image, void* stream);
+int melgpt_vq_lookup_image(const void* z, int64_t n_vectors, int dim, int64_t inner, int64_t stride_outer,
+                           int64_t stride_inner, int64_t stride_c, const void* image, int with_lo, int fused,
+                           int64_t* indices, int32_t* histogram, void* stream);
+
 /* loss = mse + commitment*mse (:43-45), perplexity = exp(-sum p log(p+1e-10)) (:50-51).
  * out[0] = loss, out[1] = perplexity, out[2] = mse. */
 int melgpt_vq_finalize(const float* sq_err, int n_partials, const int32_t* histogram, int num_codes,

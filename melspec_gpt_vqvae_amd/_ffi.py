@@ -30,6 +30,9 @@ _PROTOS = {
     "melgpt_vq_argmin_fwd": [_p, _i, _l, _i, _l, _l, _l, _l, _p, _i, _p, _p, _p, _p, _p, _p],
     "melgpt_vq_argmin_fwd_ex": [_p, _i, _l, _i, _l, _l, _l, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "melgpt_vq_max_grid": [],
+    "melgpt_vq_image_bytes": [_i],
+    "melgpt_vq_prepare_image": [_p, _i, _i, _p, _p, _i, _p, _p],
+    "melgpt_vq_lookup_image": [_p, _l, _i, _l, _l, _l, _l, _p, _i, _i, _p, _p, _p],
     "melgpt_vq_finalize": [_p, _i, _p, _i, _l, _i, _f, _p, _p],
     "melgpt_vq_gather": [_p, _l, _p, _i, _i, _p, _i, _l, _l, _l, _l, _p],
     "melgpt_vq_onehot": [_p, _l, _i, _p, _p],
@@ -84,7 +87,7 @@ _PROTOS = {
     "melgpt_conv3x3_gn_nhwc_stats": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i, _f, _p, _p, _p, _p],
     "melgpt_groupnorm_finalize": [_p, _i, _i, C.c_double, _f, _p, _p, _p],
 }
-_RESTYPE = {"melgpt_strerror": C.c_char_p}
+_RESTYPE = {"melgpt_strerror": C.c_char_p, "melgpt_vq_image_bytes": C.c_int64}
 
 _lib = None
 

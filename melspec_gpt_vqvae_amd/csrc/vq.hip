@@ -432,6 +432,161 @@ __global__ __launch_bounds__(64 * B16_WAVES, EXTRAS ? 2 : 4) void vq_bf16_kernel
   if (hist && t < VQ_K && hist_s[t]) atomicAdd(&hist[t], hist_s[t]);
 }
 
+// ============================================================================== prepared codebook image
+// Everything the bf16 lookup derives from the codebook on EVERY launch - the bf16 rounding, the swizzled fragment
+// layout, the |e|^2 chain of 256 dependent FMAs per code - depends only on the codebook's values, so it is prepared
+// ONCE per codebook version into a device-resident image and a launch just copies the image to LDS:
+//     [VQ_K][512 B] "hi" fragments (bf16, chunks XOR-swizzled as cb_off) | optional [VQ_K][512 B] "lo" | c[VQ_K] f32
+// Two kinds of image:
+//   plain  : hi = bf16(E), c_k = |bf16(e_k)|^2 (same chain order as vq_bf16_kernel) - the lookup then produces the same
+//            bits as vq_bf16_kernel<true, false>;
+//   fused  : quant_conv (1x1, z = W x + b, big_model_attn_gan.py:578,607) folded in algebraically:
+//            |z - e_k|^2 = |z|^2 + |e_k|^2 - 2 (x . (W^T e_k) + b . e_k), and |z|^2 does not depend on k, so
+//            argmin_k = argmin_k ( c_k - 2 x . E'_k ),  E' = E W  (K x D_in),  c_k = |e_k|^2 - 2 b . e_k  (f32, unrounded).
+//            The lookup then runs on the ENCODER's output x and z is never formed, stored or re-read on the
+//            indices-only path.  E' is kept as hi + lo (two bf16 planes: 2^-17 relative) unless the caller asks for hi
+//            only; the latents x are bf16 in this lane either way.
+constexpr size_t IMG_PLANE = (size_t)VQ_K * 512;
+__host__ __device__ constexpr size_t img_bytes(bool lo) { return (lo ? 2 : 1) * IMG_PLANE + VQ_K * 4; }
+
+__global__ __launch_bounds__(256) void vq_prepare_kernel(const float* __restrict__ codebook, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, char* __restrict__ image,
+                                                         int with_lo) {
+  __shared__ float row[VQ_D];
+  __shared__ float ek[VQ_D];
+  const int k = blockIdx.x, c = threadIdx.x;
+  ek[c] = codebook[(size_t)k * VQ_D + c];
+  __syncthreads();
+  float v = ek[c];
+  if (W) {  // E'[k][c] = sum_j e_k[j] W[j][c]   (W is the Conv2d weight (out j, in c, 1, 1)); ascending j, one FMA chain
+    v = 0.f;
+    for (int j = 0; j < VQ_D; ++j) v = fmaf(ek[j], W[(size_t)j * VQ_D + c], v);
+  }
+  row[c] = v;
+  __syncthreads();
+  const int planes = (W && with_lo) ? 2 : 1;
+  if (c < 32 * planes) {
+    const int pl = c >> 5, q = c & 31;
+    unsigned short h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = row[8 * q + e];
+      const bf16_t hi = f32_to_bf16(x);
+      h[e] = pl == 0 ? hi : f32_to_bf16(x - bf16_to_f32(hi));
+    }
+    *(u32x4*)(image + pl * IMG_PLANE + cb_off(k, q)) =
+        u32x4{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16),
+              (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16)};
+  }
+  if (c == 0) {
+    float p = 0.f;
+    if (W) {
+      float be = 0.f;
+      for (int j = 0; j < VQ_D; ++j) {
+        p = fmaf(ek[j], ek[j], p);
+        if (bias) be = fmaf(ek[j], bias[j], be);
+      }
+      p = p - 2.0f * be;
+    } else {  // |bf16(e)|^2 in vq_bf16_kernel's order (ascending component, one chain)
+      for (int j = 0; j < VQ_D; ++j) {
+        const float r = bf16_to_f32(f32_to_bf16(ek[j]));
+        p = fmaf(r, r, p);
+      }
+    }
+    ((float*)(image + planes * IMG_PLANE))[k] = p;
+  }
+}
+
+// Lean indices-only lookup on a prepared image (the hot path of extract_codes / encode_to_codes): per workgroup the
+// image is copied to LDS with every load in flight at once (no rounding, no |e|^2 pass, ONE barrier), then every wave
+// owns 16 vectors end to end exactly as in vq_bf16_kernel.  XSQ: add |x|^2 (plain images: keeps the reference's
+// evaluation order (|x|^2 + |e|^2) - 2 x.e and the bits of vq_bf16_kernel); fused images skip it.
+template <bool HAS_LO, bool XSQ>
+__global__ __launch_bounds__(64 * B16_WAVES, HAS_LO ? 2 : 4) void vq_image_kernel(const bf16_t* __restrict__ z, VqAddr za,
+                                                                                 long long N, const char* __restrict__ image,
+                                                                                 long long* __restrict__ indices,
+                                                                                 int* __restrict__ hist) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PLANES = HAS_LO ? 2 : 1;
+  char* cbs = smem;
+  float* bsq = (float*)(smem + PLANES * IMG_PLANE);
+  int* hist_s = (int*)(bsq + VQ_K);
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int ntiles = (int)((N + 15) / 16);
+  const int stride = (int)gridDim.x * B16_WAVES;
+  auto load_x = [&](int tile, u32x4 (&dst)[8]) {
+    long long nn = (long long)tile * 16 + r16;
+    if (nn >= N) nn = N - 1;
+    const bf16_t* xp = z + vq_off(za, nn, 8 * g);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) dst[ks] = *(const u32x4*)(xp + 32 * ks);
+  };
+  u32x4 xf[8];
+  int tile = (int)blockIdx.x * B16_WAVES + w;
+  {
+    constexpr int NCH = PLANES * (int)IMG_PLANE / 16 / (64 * B16_WAVES);  // 16-byte chunks per thread (8 or 16)
+    u32x4 v[NCH];
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) v[u] = *(const u32x4*)(image + (size_t)(t + 64 * B16_WAVES * u) * 16);
+    float c4 = 0.f;
+    if (t < VQ_K) c4 = ((const float*)(image + PLANES * IMG_PLANE))[t];
+    if (tile < ntiles) load_x(tile, xf);  // after the image (L2 hits): in-order returns, the image is stored meanwhile
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) *(u32x4*)(cbs + (size_t)(t + 64 * B16_WAVES * u) * 16) = v[u];
+    if (t < VQ_K) {
+      bsq[t] = c4;
+      hist_s[t] = 0;
+    }
+  }
+  __syncthreads();
+
+  for (; tile < ntiles; tile += stride) {
+    const long long n = (long long)tile * 16 + r16;
+    const bool valid = n < N;
+    float A = 0.f;
+    if constexpr (XSQ) A = xsq_mfma(xf, r16);
+    float best = __builtin_inff();
+    int bk = 4 * g;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 b4 = *(const f32x4*)(bsq + 16 * ct + 4 * g);
+      if constexpr (HAS_LO) {  // the small terms first
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const u32x4 cf = *(const u32x4*)(cbs + IMG_PLANE + cb_off(16 * ct + r16, 4 * ks + g));
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, cf), __builtin_bit_cast(s16x8, xf[ks]),
+                                                        acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const u32x4 cf = *(const u32x4*)(cbs + cb_off(16 * ct + r16, 4 * ks + g));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, cf), __builtin_bit_cast(s16x8, xf[ks]),
+                                                      acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const float d = XSQ ? (A + b4[rg]) - 2.0f * acc[rg] : b4[rg] - 2.0f * acc[rg];
+        lexmin_asc(best, bk, d, 16 * ct + 4 * g + rg);
+      }
+    }
+    lexmin_xor(best, bk, 16);
+    lexmin_xor(best, bk, 32);
+    bk &= (VQ_K - 1);
+    if (g == 0 && valid) {
+      indices[n] = (long long)bk;
+      if (hist) atomicAdd(&hist_s[bk], 1);
+    }
+    if (tile + stride < ntiles) load_x(tile + stride, xf);
+  }
+  if (hist) {
+    __syncthreads();
+    if (t < VQ_K && hist_s[t]) atomicAdd(&hist[t], hist_s[t]);
+  }
+}
+
 // ====================================================================================== small kernels
 __global__ void vq_finalize_kernel(const float* sq_err, int n_partials, const int* hist, int K, long long N,
                                    int D, float commitment, float* out) {
@@ -583,6 +738,54 @@ extern "C" int melgpt_vq_argmin_fwd(const void* z, int z_dtype, int64_t n_vector
   return melgpt_vq_argmin_fwd_ex(z, z_dtype, n_vectors, dim, inner, stride_outer, stride_inner, stride_c,
                                  codebook, num_codes, indices, quantized, sq_err, histogram, nullptr,
                                  grid_out, stream);
+}
+
+extern "C" int64_t melgpt_vq_image_bytes(int with_lo) { return (int64_t)img_bytes(with_lo != 0); }
+
+extern "C" int melgpt_vq_prepare_image(const float* codebook, int num_codes, int dim, const float* conv_weight,
+                                       const float* conv_bias, int with_lo, void* image, void* stream) {
+  MELGPT_CHECK(codebook && image, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(dim == VQ_D && num_codes == VQ_K, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK(((uintptr_t)image & 15) == 0, MELGPT_ERR_ALIGN);
+  MELGPT_CHECK(conv_weight || (!conv_bias && !with_lo), MELGPT_ERR_BAD_ARG);  // bias / lo plane only with a folded conv
+  hipLaunchKernelGGL(vq_prepare_kernel, dim3(VQ_K), dim3(256), 0, (hipStream_t)stream, codebook, conv_weight, conv_bias,
+                     (char*)image, with_lo);
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_vq_lookup_image(const void* z, int64_t n_vectors, int dim, int64_t inner, int64_t stride_outer,
+                                      int64_t stride_inner, int64_t stride_c, const void* image, int with_lo, int fused,
+                                      int64_t* indices, int32_t* histogram, void* stream) {
+  MELGPT_CHECK(z && image && indices, MELGPT_ERR_BAD_ARG);
+  int st = validate_addr(n_vectors, dim, inner, VQ_K);
+  if (st != MELGPT_OK) return st;
+  MELGPT_CHECK(!with_lo || fused, MELGPT_ERR_BAD_ARG);
+  // channel-contiguous bf16 latents only (the encoder's NHWC output): everything else goes through melgpt_vq_argmin_fwd
+  MELGPT_CHECK(stride_c == 1 && (stride_inner % 8) == 0 && (stride_outer % 8) == 0, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK((((uintptr_t)z | (uintptr_t)image) & 15) == 0, MELGPT_ERR_ALIGN);
+  MELGPT_CHECK(n_vectors <= (int64_t)16 * 0x7ffffff0, MELGPT_ERR_UNSUPPORTED);
+  VqAddr za = vq_fold(VqAddr{inner, stride_outer, stride_inner, stride_c});
+  const long long wg_tiles = ((n_vectors + 15) / 16 + B16_WAVES - 1) / B16_WAVES;
+  const int per_cu = with_lo ? 1 : 2;  // LDS: 128.5 KB with the lo plane, 64.5 KB without
+  const int grid = (int)(wg_tiles < 256 * per_cu ? wg_tiles : 256 * per_cu);
+  const size_t lds = img_bytes(with_lo != 0) + VQ_K * 4;
+  static bool attr = false;
+  if (!attr) {
+    bool ok = hipFuncSetAttribute((const void*)vq_image_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(img_bytes(false) + VQ_K * 4)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void*)vq_image_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(img_bytes(false) + VQ_K * 4)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void*)vq_image_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(img_bytes(true) + VQ_K * 4)) == hipSuccess;
+    if (!ok) return MELGPT_ERR_LAUNCH;
+    attr = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+#define VQIMG_LAUNCH(L, X)                                                                                              \
+  hipLaunchKernelGGL((vq_image_kernel<L, X>), dim3(grid), dim3(64 * B16_WAVES), lds, s, (const bf16_t*)z, za,           \
+                     (long long)n_vectors, (const char*)image, (long long*)indices, (int*)histogram)
+  if (with_lo) VQIMG_LAUNCH(true, false);
+  else if (fused) VQIMG_LAUNCH(false, false);
+  else VQIMG_LAUNCH(false, true);
+#undef VQIMG_LAUNCH
+  return melgpt_launch_status();
 }
 
 extern "C" int melgpt_vq_finalize(const float* sq_err, int n_partials, const int32_t* histogram,

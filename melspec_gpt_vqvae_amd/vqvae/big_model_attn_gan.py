@@ -496,10 +496,19 @@ class LitVQVAE(_LitBase):
         return _as_nchw(self._decoder._nhwc(_as_nchw(q)))
 
     @torch.no_grad()
-    def encode_to_codes(self, x):
+    def encode_to_codes(self, x, fused=None):
         """mel tiles (B,1,80,848) in [-1,1] -> (B,5,53) int64 codes: the whole of extract_codes.get_codes'
-        device work (feature_extraction/extract_codes.py:48-50) without the quantised tensor, loss or one-hot."""
-        return self._vq_vae.encode_indices(self.encode(x))
+        device work (feature_extraction/extract_codes.py:48-50) without the quantised tensor, loss or one-hot.
+        bf16 lane (fused=None/True): the lookup runs on the encoder's output with quant_conv folded into the prepared
+        codebook image - z is never formed; f32 parity lane (or fused=False): quant_conv, then the reference's
+        (|x|^2 + |e|^2) - 2 x.e on the real z."""
+        _require_cuda(x)
+        h = self._encoder._nhwc(x)
+        if fused is None:
+            fused = h.dtype == torch.bfloat16
+        if fused:
+            return self._vq_vae.encode_indices_fused(_as_nchw(h), self.quant_conv)
+        return self._vq_vae.encode_indices(_as_nchw(_conv(self.quant_conv, h)))
 
     def forward(self, x):
         z = self.encode(x)

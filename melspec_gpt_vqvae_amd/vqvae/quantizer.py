@@ -52,6 +52,59 @@ def vq_lookup(z, codebook, want_quantized=True, want_stats=True, want_distances=
                 addressing=(N, inner, s_outer, s_inner, s_c))
 
 
+class CodebookImage:
+    """Device-resident prepared image of a codebook for the bf16 indices-only lookup (melgpt_vq_prepare_image):
+    rebuilt only when the codebook - or the folded 1x1 quant_conv - changes (tensor version counter / storage), so a
+    launch of the lookup copies 64 KB to LDS instead of rounding the codebook and running its |e|^2 chains."""
+
+    def __init__(self):
+        self._key = None
+        self._buf = None
+
+    @staticmethod
+    def _sig(t):
+        return None if t is None else (t.data_ptr(), t._version, str(t.device))
+
+    def invalidate(self):
+        self._key = None
+
+    def get(self, codebook, conv_weight=None, conv_bias=None, with_lo=False):
+        key = (self._sig(codebook), self._sig(conv_weight), self._sig(conv_bias), bool(with_lo))
+        if key != self._key:
+            L = _ffi.lib()
+            K, D = codebook.shape
+            cb = codebook.detach()
+            if cb.dtype != torch.float32 or not cb.is_contiguous():
+                cb = cb.float().contiguous()
+            w = b = None
+            if conv_weight is not None:
+                w = conv_weight.detach().reshape(conv_weight.shape[0], -1).float().contiguous()   # (out, in)
+                assert w.shape == (D, D), "the folded quant_conv must be a 1x1 convolution D -> D"
+                b = conv_bias.detach().float().contiguous() if conv_bias is not None else None
+            lo = int(bool(with_lo) and w is not None)
+            buf = torch.empty(int(L.melgpt_vq_image_bytes(lo)), dtype=torch.uint8, device=codebook.device)
+            _ffi.call("melgpt_vq_prepare_image", _ffi.ptr(cb), K, D, _ffi.ptr(w), _ffi.ptr(b), lo, _ffi.ptr(buf),
+                      _ffi.stream())
+            self._buf, self._key, self.with_lo, self.fused = buf, key, lo, int(w is not None)
+        return self._buf
+
+
+def vq_lookup_image(z, image: CodebookImage, buf, want_histogram=False):
+    """indices-only lookup of channel-contiguous bf16 latents z (logical (B,D,H,W), channels-last strides) on a
+    prepared image -> (N,) int64 [, (K,) int32 histogram]."""
+    z, N, inner, s_outer, s_inner, s_c = _latent_addressing(z)
+    idx = torch.empty(N, dtype=torch.int64, device=z.device)
+    hist = torch.zeros(128, dtype=torch.int32, device=z.device) if want_histogram else None
+    _ffi.call("melgpt_vq_lookup_image", _ffi.ptr(z), N, z.shape[1], inner, s_outer, s_inner, s_c, _ffi.ptr(buf),
+              image.with_lo, image.fused, _ffi.ptr(idx), _ffi.ptr(hist), _ffi.stream())
+    return (idx, hist) if want_histogram else idx
+
+
+def _image_eligible(z):
+    return (z.dtype == torch.bfloat16 and z.dim() == 4 and z.shape[1] == 256 and z.stride(1) == 1
+            and z.stride(3) % 8 == 0 and z.stride(0) % 8 == 0 and z.data_ptr() % 16 == 0)
+
+
 class _VQ(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inputs, codebook, commitment_cost):
@@ -109,12 +162,39 @@ class VectorQuantizer(nn.Module):
         _ffi.call("melgpt_vq_onehot", _ffi.ptr(idx), N, self._num_embeddings, _ffi.ptr(encodings), _ffi.stream())
         return loss, quantized, (perplexity, encodings, idx)
 
+    def _images(self):
+        im = getattr(self, "_melgpt_images", None)
+        if im is None:
+            im = {"plain": CodebookImage(), "fused": CodebookImage()}
+            object.__setattr__(self, "_melgpt_images", im)
+        return im
+
     @torch.no_grad()
     def encode_indices(self, inputs):
-        """Hot path of feature_extraction/extract_codes.py:48-50: latents -> (B,H,W) int64 codes, nothing else."""
-        r = vq_lookup(inputs, self._embedding.weight, want_quantized=False, want_stats=False)
+        """Hot path of feature_extraction/extract_codes.py:48-50: latents -> (B,H,W) int64 codes, nothing else.
+        bf16 channels-last latents run on the prepared codebook image (same bits as the general kernel's bf16 lane)."""
         B, _, H, W = inputs.shape
+        if _image_eligible(inputs) and self._num_embeddings == 128:
+            im = self._images()["plain"]
+            return vq_lookup_image(inputs, im, im.get(self._embedding.weight)).view(B, H, W)
+        r = vq_lookup(inputs, self._embedding.weight, want_quantized=False, want_stats=False)
         return r["indices"].view(B, H, W)
+
+    @torch.no_grad()
+    def encode_indices_fused(self, h, quant_conv, with_lo=False):
+        """codes of quant_conv(h) WITHOUT forming it: h = the encoder's output, logical (B,256,H,W) bf16 with
+        channels-last strides; the 1x1 quant_conv (big_model_attn_gan.py:578,607) is folded into the prepared image
+        (argmin_k |W h + b - e_k|^2 = argmin_k (|e_k|^2 - 2 b.e_k) - 2 h.(W^T e_k)).  bf16 lane only; the f32 parity
+        lane keeps the reference's evaluation order (encode_indices on the real z).  with_lo=False (default): W^T e_k as
+        one bf16 plane - the same resolution as the bf16 lane's rounding of z and of the codebook (31 of 16 960 codes differ
+        from the f64 argmin, all near-ties within 3e-4 relative distance; agreement with the f32 reference's codes on
+        the full encoder 0.985, the unfused bf16 lane: 0.983); with_lo=True adds the residual plane (0 of 16 960 differ)
+        at twice the MFMA work and LDS (profiles/r02_b_vq_lab.jsonl)."""
+        assert _image_eligible(h) and self._num_embeddings == 128, "fused lookup: bf16 channels-last (B,256,H,W) latents"
+        B, _, H, W = h.shape
+        im = self._images()["fused"]
+        buf = im.get(self._embedding.weight, quant_conv.weight, quant_conv.bias, with_lo=with_lo)
+        return vq_lookup_image(h, im, buf).view(B, H, W)
 
     def get_codebook_entry(self, indices, shape):
         """reference :56-71; shape = (batch, height, width, channel) or None."""

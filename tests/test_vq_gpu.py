@@ -163,3 +163,69 @@ def test_batch_strided_latents_match_packed(dt):
         assert torch.equal(a["indices"], b["indices"])
         if a["quantized"] is not None:
             assert torch.equal(a["quantized"], b["quantized"])
+
+
+# ------------------------------------------------------------------------------ prepared codebook image (bf16 lane)
+@pytest.mark.parametrize("nvec", [16960, 265 * 3, 7])
+def test_prepared_image_lookup_equals_the_general_bf16_kernel_bit_for_bit(nvec):
+    """plain image (no folded conv): rounding, fragment layout and |e|^2 prepared once - same indices as the bf16 lane
+    of melgpt_vq_argmin_fwd on every vector, including ragged tails; a changed codebook rebuilds the image."""
+    from melspec_gpt_vqvae_amd.vqvae.quantizer import CodebookImage, vq_lookup, vq_lookup_image
+
+    z = t(synth.normal(20, (64, 256, 5, 53))).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    z = z.permute(0, 2, 3, 1).reshape(-1, 256)[:nvec].reshape(1, nvec, 1, 256).permute(0, 3, 1, 2)   # (1,256,nvec,1) flat
+    E = t(synth.normal(21, (128, 256)), DEV)
+    ref = vq_lookup(z, E, want_quantized=False, want_stats=False)["indices"]
+    im = CodebookImage()
+    idx, hist = vq_lookup_image(z, im, im.get(E), want_histogram=True)
+    assert torch.equal(idx, ref)
+    assert torch.equal(hist.long(), torch.bincount(ref, minlength=128))
+    buf0 = im.get(E)
+    assert im.get(E) is buf0                       # cached
+    E.mul_(-1.0)                                   # in-place change bumps the version counter -> rebuilt
+    idx2 = vq_lookup_image(z, im, im.get(E))
+    assert im.get(E) is not buf0
+    assert torch.equal(idx2, vq_lookup(z, E, want_quantized=False, want_stats=False)["indices"])
+
+
+@pytest.mark.parametrize("with_lo", [True, False])
+def test_fused_quant_conv_lookup_vs_f64_reference(with_lo):
+    """quant_conv folded into the image: codes of z = W x + b (reference big_model_attn_gan.py:19-33,578,607) computed
+    from x alone.  Oracle: f64 distances |W x + b - e_k|^2 on the same bf16 x.  Every code must be the f64 argmin or a
+    near-tie whose f64 distance exceeds the minimum by less than the lane's resolution; counts are reported."""
+    from melspec_gpt_vqvae_amd.vqvae.quantizer import CodebookImage, vq_lookup_image
+
+    N = 16960
+    x = t(synth.normal(40, (N, 256))).to(torch.bfloat16)
+    W = t(synth.normal(41, (256, 256), 1.0 / 16))
+    b = t(synth.normal(42, (256,), 0.1))
+    E = t(synth.normal(43, (128, 256)))
+    zd = x.double() @ W.double().t() + b.double()
+    d = (zd * zd).sum(1, keepdim=True) + (E.double() ** 2).sum(1) - 2 * zd @ E.double().t()
+    want = d.argmin(1)
+    im = CodebookImage()
+    buf = im.get(E.to(DEV), W.view(256, 256, 1, 1).to(DEV), b.to(DEV), with_lo=with_lo)
+    assert im.fused == 1 and im.with_lo == int(with_lo)
+    xg = x.to(DEV).view(1, N, 1, 256).permute(0, 3, 1, 2)
+    got = vq_lookup_image(xg, im, buf).cpu()
+    miss = got != want
+    excess = (d.gather(1, got[:, None]) - d.gather(1, want[:, None])).squeeze(1) / d.gather(1, want[:, None]).squeeze(1)
+    n_miss, worst = int(miss.sum()), float(excess.max())
+    report("vq_fused_quant_conv_vs_f64", with_lo=int(with_lo), vectors=N, codes_differing_from_f64_argmin=n_miss,
+           worst_relative_distance_excess=worst)
+    if with_lo:      # hi + lo planes: 2^-17 on the folded codebook, f32 accumulation
+        assert n_miss <= 8 and worst < 1e-5
+    else:            # one bf16 plane: 2^-9 per element of W^T e_k
+        assert n_miss <= N // 50 and worst < 5e-3
+
+
+def test_lookup_image_refuses_what_it_does_not_cover():
+    from melspec_gpt_vqvae_amd import _ffi
+    from melspec_gpt_vqvae_amd.vqvae.quantizer import CodebookImage, vq_lookup_image
+
+    im = CodebookImage()
+    E = t(synth.normal(21, (128, 256)), DEV)
+    buf = im.get(E)
+    z = torch.zeros(2, 256, 5, 53, dtype=torch.bfloat16, device=DEV)          # NCHW strides: channels not contiguous
+    with pytest.raises(_ffi.MelgptError):
+        vq_lookup_image(z, im, buf)

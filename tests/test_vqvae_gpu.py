@@ -146,11 +146,19 @@ def test_full_vqvae_bf16_lane_reports_code_agreement():
     set_compute_dtype(m, torch.bfloat16)
     with torch.no_grad():
         z = m.encode(t(g["x"], DEV))
-        codes = m.encode_to_codes(t(g["x"], DEV))
+        codes = m.encode_to_codes(t(g["x"], DEV))                       # quant_conv folded into the codebook image
+        codes_unfused = m.encode_to_codes(t(g["x"], DEV), fused=False)  # quant_conv -> bf16 z -> lookup
+        codes_lo = m._vq_vae.encode_indices_fused(m._encoder._nhwc(t(g["x"], DEV)).permute(0, 3, 1, 2), m.quant_conv,
+                                                  with_lo=True)
     err = rel_err(z.float().cpu().numpy(), g["z"])
-    agree = float((codes.cpu().numpy().ravel() == g["indices"].astype(np.int64)).mean())
-    report("vqvae_full_bf16_lane_vs_f32_reference", latent_rel_to_max_err=err, code_agreement=agree, vectors=530)
-    assert err < 5e-2 and agree > 0.9
+    want = g["indices"].astype(np.int64)
+    agree = float((codes.cpu().numpy().ravel() == want).mean())
+    agree_unfused = float((codes_unfused.cpu().numpy().ravel() == want).mean())
+    agree_lo = float((codes_lo.cpu().numpy().ravel() == want).mean())
+    report("vqvae_full_bf16_lane_vs_f32_reference", latent_rel_to_max_err=err, code_agreement_fused_hi_only=agree,
+           code_agreement_unfused=agree_unfused, code_agreement_fused_hi_lo=agree_lo, vectors=530)
+    assert err < 5e-2 and agree > 0.9 and agree_unfused > 0.9 and agree_lo > 0.9
+    assert agree >= agree_unfused - 0.02       # folding the conv must not cost agreement with the f32 reference
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])

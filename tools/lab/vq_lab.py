@@ -20,11 +20,16 @@ from melspec_gpt_vqvae_amd import _ffi
 DEV = "cuda:0"
 
 
-def run(z, cb, idx, reps):
+def run(z, cb, idx, reps, image=None):
+    """image = None: melgpt_vq_argmin_fwd_ex;  (buf, with_lo, fused): melgpt_vq_lookup_image on a prepared image"""
     N, D = z.shape
     grid = ctypes.c_int(0)
 
     def launch():
+        if image is not None:
+            _ffi.call("melgpt_vq_lookup_image", _ffi.ptr(z), N, D, N, N * D, D, 1, _ffi.ptr(image[0]), image[1], image[2],
+                      _ffi.ptr(idx), None, _ffi.stream())
+            return
         _ffi.call("melgpt_vq_argmin_fwd_ex", _ffi.ptr(z), _ffi.dtype_code(z.dtype), N, D, N, N * D, D, 1, _ffi.ptr(cb), 128,
                   _ffi.ptr(idx), None, None, None, None, ctypes.addressof(grid), _ffi.stream())
 
@@ -66,6 +71,26 @@ def main():
     batches = tuple(int(a) for a in sys.argv[1:]) or (64, 256, 1024, 4096)
     g = torch.Generator(device="cpu").manual_seed(5)
     cb = torch.randn(128, 256, generator=g).to(DEV)
+    if os.environ.get("VQ_LAB_IMAGE"):  # prepared images: plain | fused hi | fused hi+lo (quant_conv folded in)
+        from melspec_gpt_vqvae_amd.vqvae.quantizer import CodebookImage
+
+        W = (torch.randn(256, 256, generator=g) / 16).to(DEV)
+        bias = (0.1 * torch.randn(256, generator=g)).to(DEV)
+        for name, kw in (("image_plain", {}), ("image_fused_hi", dict(conv_weight=W, conv_bias=bias, with_lo=False)),
+                         ("image_fused_hi_lo", dict(conv_weight=W, conv_bias=bias, with_lo=True))):
+            im = CodebookImage()
+            buf = im.get(cb, **kw)
+            for B in batches:
+                n = B * 265
+                z = torch.randn(n, 256, generator=torch.Generator(device="cpu").manual_seed(6 + B)).to(DEV).to(torch.bfloat16)
+                idx = torch.empty(n, dtype=torch.int64, device=DEV)
+                ms, _ = run(z, cb, idx, 50 if B <= 1024 else 20, image=(buf, im.with_lo, im.fused))
+                by = n * (256 * 2 + 8) + (131072 if name != "image_fused_hi_lo" else 2 * 65536) // (1 if name == "image_fused_hi_lo" else 2) + 512
+                h = hashlib.sha1(idx.cpu().numpy().tobytes()).hexdigest()[:12]
+                print(json.dumps(dict(kernel=f"vq_{name}", graph=bool(os.environ.get("VQ_LAB_GRAPH")), batch=B, vectors=n,
+                                      us=round(ms * 1e3, 2), algorithmic_MB=round(by / 1e6, 2), GBps=round(by / ms / 1e6, 1),
+                                      frac_hbm=round(by / ms / 1e6 / 8000.0, 4), idx_sha=h)), flush=True)
+        return
     for dt, es in ((torch.bfloat16, 2), (torch.float32, 4)):
         for B in batches:
             n = B * 265
