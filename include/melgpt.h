@@ -142,11 +142,15 @@ int melgpt_vq_bwd(const void* z, const void* g_quantized, int dtype, int64_t n_v
  * epilogue order: v = alpha*acc + bias[n]; C2 = v (optional pre-activation copy);
  *   act: MELGPT_ACT_GELU -> exact-erf GELU (nn.GELU(), minGPT.py:102);
  *        MELGPT_ACT_GELU_GRAD -> v *= gelu'(R[m,n])  (R is the saved pre-activation, not a residual);
+ *        MELGPT_ACT_GELU_DACT -> as MELGPT_ACT_GELU, but C2 receives gelu'(v) instead of v: the forward pass of
+ *                                Linear -> GELU saves the activation's DERIVATIVE (the exponential is shared with the
+ *                                activation itself), so that the backward epilogue is a multiplication:
+ *        MELGPT_ACT_MUL       -> v *= R[m,n]  (R = the saved derivative, not a residual);
  *   dropout(drop_p) with Philox4x32-10 keyed by (seed, stream_id, element index)  (minGPT.py:88,104);
  *   v += R[m,n] (residual, minGPT.py:115,117);  if accumulate: v += C[m,n];  store as dtype or f32.
  * dtype: MELGPT_F32 -> exact f32 MFMA; MELGPT_BF16 -> bf16 operands, f32 accumulate.  bias is f32.
  * Alignment: all pointers 16 B; N % 4 == 0; K, lda, ldb and batch strides multiples of 16 bytes.   */
-enum { MELGPT_ACT_NONE = 0, MELGPT_ACT_GELU = 1, MELGPT_ACT_GELU_GRAD = 2 };
+enum { MELGPT_ACT_NONE = 0, MELGPT_ACT_GELU = 1, MELGPT_ACT_GELU_GRAD = 2, MELGPT_ACT_GELU_DACT = 3, MELGPT_ACT_MUL = 4 };
 
 int melgpt_gemm(const void* A, int a_kmajor, long long lda, long long strideA, const void* B, int b_kmajor,
                 long long ldb, long long strideB, void* C, long long ldc, long long strideC, int M, int N,

@@ -298,8 +298,9 @@ extern "C" int melgpt_gemm(const void* A, int a_kmajor, long long lda, long long
   MELGPT_CHECK(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0, MELGPT_ERR_BAD_ARG);
   MELGPT_CHECK(dtype == MELGPT_F32 || dtype == MELGPT_BF16, MELGPT_ERR_UNSUPPORTED);
   const int es = dtype == MELGPT_F32 ? 4 : 2, vec = 16 / es;
-  MELGPT_CHECK(act >= MELGPT_ACT_NONE && act <= MELGPT_ACT_GELU_GRAD, MELGPT_ERR_UNSUPPORTED);
-  MELGPT_CHECK(act != MELGPT_ACT_GELU_GRAD || R, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(act >= MELGPT_ACT_NONE && act <= MELGPT_ACT_MUL, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK((act != MELGPT_ACT_GELU_GRAD && act != MELGPT_ACT_MUL) || R, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(act != MELGPT_ACT_GELU_DACT || C2, MELGPT_ERR_BAD_ARG);
   MELGPT_CHECK(drop_p >= 0.f && drop_p < 1.f, MELGPT_ERR_BAD_ARG);
   // 16-byte vector accesses everywhere
   // K only has to be a whole number of 16-byte chunks for operands whose reduction index is contiguous

@@ -442,7 +442,8 @@ int launch_mode(const GemmParams& p, int batch, hipStream_t s) {
 template <int ALAY, int BLAY>
 int launch_lay(const GemmParams& p, int batch, hipStream_t s) {
   if (!p.vec_io) return MELGPT_ERR_UNSUPPORTED;
-  const bool plain = p.act == MELGPT_ACT_NONE && p.drop_scale == 0.f && !p.C2;
+  // MELGPT_ACT_MUL (v *= R: the saved GELU derivative) is a plain mode: same loads and stores as a residual add
+  const bool plain = (p.act == MELGPT_ACT_NONE || p.act == MELGPT_ACT_MUL) && p.drop_scale == 0.f && !p.C2;
   if constexpr (ALAY == LAY_CONV) {  // convolutions: bias + residual, bf16 out - the only form the VQ-VAE uses
     return (plain && !p.out_f32) ? launch_mode<ALAY, BLAY, EPI_PLAIN16>(p, batch, s) : MELGPT_ERR_UNSUPPORTED;
   } else {
@@ -451,6 +452,13 @@ int launch_lay(const GemmParams& p, int batch, hipStream_t s) {
       if (!plain) return MELGPT_ERR_UNSUPPORTED;
       return loads ? launch_mode<ALAY, BLAY, EPI_PLAIN32>(p, batch, s) : launch_mode<ALAY, BLAY, EPI_PLAIN32N>(p, batch, s);
     }
+    if (p.act == MELGPT_ACT_GELU_DACT) {  // forward of Linear -> GELU: its own lean mode, or the generic 128-tile kernel
+      if constexpr (ALAY == LAY_ROW && BLAY == LAY_ROW) {
+        if (p.drop_scale == 0.f && !loads && p.C2) return launch_mode<ALAY, BLAY, EPI_DACT16>(p, batch, s);
+      }
+      return MELGPT_ERR_UNSUPPORTED;
+    }
+    if (p.act == MELGPT_ACT_MUL && !plain) return MELGPT_ERR_UNSUPPORTED;
     if (!plain) return launch_mode<ALAY, BLAY, EPI_FULL16>(p, batch, s);
     return loads ? launch_mode<ALAY, BLAY, EPI_PLAIN16>(p, batch, s) : launch_mode<ALAY, BLAY, EPI_PLAIN16N>(p, batch, s);
   }

@@ -94,6 +94,14 @@ __device__ __forceinline__ f32x4 gelu_exact4(f32x4 v) {
   gelu_parts2(f32x2{v[2], v[3]}, c1, p1);
   return f32x4{v[0] * c0[0], v[1] * c0[1], v[2] * c1[0], v[3] * c1[1]};
 }
+// activation and derivative from ONE evaluation of the shared parts (forward of Linear -> GELU in MELGPT_ACT_GELU_DACT)
+__device__ __forceinline__ void gelu_both4(f32x4 v, f32x4& act, f32x4& der) {
+  f32x2 c0, p0, c1, p1;
+  gelu_parts2(f32x2{v[0], v[1]}, c0, p0);
+  gelu_parts2(f32x2{v[2], v[3]}, c1, p1);
+  act = f32x4{v[0] * c0[0], v[1] * c0[1], v[2] * c1[0], v[3] * c1[1]};
+  der = f32x4{c0[0] + p0[0], c0[1] + p0[1], c1[0] + p1[0], c1[1] + p1[1]};
+}
 __device__ __forceinline__ f32x4 gelu_grad4(f32x4 v) {
   f32x2 c0, p0, c1, p1;
   gelu_parts2(f32x2{v[0], v[1]}, c0, p0);
@@ -130,7 +138,11 @@ enum { EPI_GENERIC = 0, EPI_PLAIN16 = 1, EPI_PLAIN32 = 2, EPI_FULL16 = 3,
        // compiled in (a conditional load the row predicates can skip leaves its registers "pending" in the compiler's
        // wait-count bookkeeping, and the persistent GEMM's next tile then opens with a vmcnt(0) that waits for this
        // tile's output rows to be acknowledged)
-       EPI_PLAIN16N = 4, EPI_PLAIN32N = 5 };
+       EPI_PLAIN16N = 4, EPI_PLAIN32N = 5,
+       // forward of Linear -> GELU alone (MELGPT_ACT_GELU_DACT, bias, bf16 outputs C = gelu(v), C2 = gelu'(v); no R, no
+       // dropout, no accumulation): the full mode's dropout / residual machinery costs 16 spilled VGPRs at 256 rows, whose
+       // reloads sit in the K loop and drain the LDS-DMA ring on every unit (fc1: 9.7 -> 17 ms per step)
+       EPI_DACT16 = 6 };
 //   EPI_GENERIC  everything, decided at run time; slabs unrolled
 //   EPI_PLAIN16  alpha, bias, +R, accumulate; bf16 output; slabs unrolled (a few hundred instructions in all)
 //   EPI_PLAIN32  the same with f32 output (split-K weight gradients)
@@ -159,14 +171,14 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
   constexpr bool ACT = MODE == EPI_GENERIC || MODE == EPI_FULL16;           // activation / dropout / C2 compiled in
   constexpr bool CAN32 = MODE == EPI_GENERIC || MODE == EPI_PLAIN32 || MODE == EPI_PLAIN32N;
   constexpr bool CAN16 = MODE != EPI_PLAIN32 && MODE != EPI_PLAIN32N && ES == 2;
-  constexpr bool LOADS = MODE != EPI_PLAIN16N && MODE != EPI_PLAIN32N;  // R and accumulate compiled in
-  constexpr bool ROLLED = MODE == EPI_FULL16;
+  constexpr bool LOADS = MODE != EPI_PLAIN16N && MODE != EPI_PLAIN32N && MODE != EPI_DACT16;  // R and accumulate compiled in
+  constexpr bool ROLLED = MODE == EPI_FULL16 || MODE == EPI_DACT16;
   static_assert(CAN32 || CAN16, "no output type left");
   using RV = typename std::conditional<ES == 4, f32x4, u32x2>::type;  // one 4-element group of R / C in dtype T
   const int i16 = lane & 15, g = lane >> 4;
   const bool f32out = CAN32 && (!CAN16 || p.out_f32);
   char* Cb = (char*)p.C + (long long)bz * p.sC * (f32out ? 4 : ES);
-  char* C2b = (ACT && p.C2) ? (char*)p.C2 + (long long)bz * p.sC * (f32out ? 4 : ES) : nullptr;
+  char* C2b = ((ACT || MODE == EPI_DACT16) && p.C2) ? (char*)p.C2 + (long long)bz * p.sC * (f32out ? 4 : ES) : nullptr;
   const char* Rb = (LOADS && p.R) ? (const char*)p.R + (long long)bz * p.sR * ES : nullptr;
 
   f32x4 bv[TN];
@@ -191,6 +203,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
         v = gelu_exact4(v);
       } else if (p.act == MELGPT_ACT_GELU_GRAD) {
         v *= gelu_grad4(r4);
+      } else if (MODE == EPI_GENERIC && p.act == MELGPT_ACT_MUL) {  // the 256-wide kernel serves MUL in its plain modes
+        v *= r4;
       }
       if (p.drop_scale != 0.f) {
         const unsigned long long e0 = ((unsigned long long)bz * p.M + m) * (unsigned long long)p.N + n;
@@ -198,9 +212,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (keep >> e & 1) ? v[e] * p.drop_scale : 0.f;
       }
-      if (has_r && p.act != MELGPT_ACT_GELU_GRAD) v += r4;
+      if (has_r && p.act != MELGPT_ACT_GELU_GRAD && p.act != MELGPT_ACT_MUL) v += r4;
     } else {
-      if (has_r) v += r4;
+      if (has_r) v = p.act == MELGPT_ACT_MUL ? v * r4 : v + r4;   // plain modes: residual add, or the saved-derivative product
     }
     return v;
   };
@@ -215,7 +229,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
     // between two uses is waited for at once.  Two batches = two exposed latencies per tile instead of TM.
     // (slabs per batch: half the tile where the registers allow it; the rolled full epilogue is at the 256-VGPR
     // limit with two sets)
-    constexpr int NB = (MODE == EPI_GENERIC || MODE == EPI_FULL16) ? (TM < 2 ? 1 : 2) : (TM + 1) / 2;
+    constexpr int NB = (MODE == EPI_GENERIC || ROLLED) ? (TM < 2 ? 1 : 2) : (TM + 1) / 2;
     u32x4 rin[NB][NR];
     auto fetch_r = [&](long long mr, u32x4 (&dst)[NR]) {
 #pragma clang loop unroll(full)
@@ -244,6 +258,55 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
           else r4[nt] = unpack(*(const u32x2*)(stage + stage_off<IN_ROWB>(i16, 2 * nt + (g >> 1)) + (g & 1) * 8));
         }
       }
+      // MELGPT_ACT_GELU_DACT (forward of Linear -> GELU): activation and derivative come from ONE evaluation of the
+      // shared exponential / reciprocal.  bf16 outputs: both 2 KiB slabs are staged side by side in the wave's 4 KiB
+      // block and written out together - no second copy of the tile in registers (the 256-wide kernel's epilogue is
+      // at the register limit).  f32 outputs (generic mode only): the activation waits in registers for the C pass.
+      // (the full mode does not carry this path: with it the 256-row kernel spills 16 VGPRs into its K loop)
+      const bool dact = MODE == EPI_DACT16 || (MODE == EPI_GENERIC && p.act == MELGPT_ACT_GELU_DACT);
+      if constexpr ((MODE == EPI_GENERIC || MODE == EPI_DACT16) && CAN16) {
+        if (dact && !f32out) {
+          constexpr int ROWB = TN * 32, CPR = ROWB / 16, PER = (16 * CPR) / 64;
+          static_assert(2 * 16 * ROWB <= 4096, "two bf16 slabs must fit the wave's staging block");
+          char* st2 = stage + 16 * ROWB;
+#pragma clang loop unroll(full)
+          for (int nt = 0; nt < TN; ++nt) {
+            f32x4 a, d;
+            gelu_both4(av[nt] * p.alpha + bv[nt], a, d);
+            if constexpr (MODE != EPI_DACT16) a = math(a, Rb ? r4[nt] : a, m, n_base + nt * 16 + g * 4, Rb != nullptr);
+            const int o = stage_off<ROWB>(i16, 2 * nt + (g >> 1)) + (g & 1) * 8;
+            *(u32x2*)(stage + o) = u32x2{pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
+            *(u32x2*)(st2 + o) = u32x2{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
+          }
+#pragma clang loop unroll(full)
+          for (int j = 0; j < PER; ++j) {
+            const int q = lane + 64 * j, row = q / CPR, ch = q % CPR;
+            const long long mm = mr + row;
+            const int nn = n_base + ch * 8;
+            if (mr >= 0 && row < row_limit && mm < p.M && nn < p.N) {
+              *(u32x4*)(C2b + (mm * p.ldc + nn) * 2) = *(const u32x4*)(stage + stage_off<ROWB>(row, ch));
+              *(u32x4*)(Cb + (mm * p.ldc + nn) * 2) = *(const u32x4*)(st2 + stage_off<ROWB>(row, ch));
+            }
+          }
+          return;
+        }
+      }
+      f32x4 actv[MODE == EPI_GENERIC ? TN : 1];
+      auto value = [&](int pass, int nt) -> f32x4 {
+        f32x4 v = av[nt] * p.alpha + bv[nt];
+        if constexpr (MODE == EPI_GENERIC) {
+          if (dact) {
+            if (pass == 0) {
+              f32x4 der;
+              gelu_both4(v, actv[nt], der);
+              return der;
+            }
+            v = actv[nt];
+          }
+        }
+        if (pass == 1) v = math(v, Rb ? r4[nt] : v, m, n_base + nt * 16 + g * 4, Rb != nullptr);
+        return v;
+      };
       // one or two outputs, each staged and written as full rows
 #pragma clang loop unroll(full)
       for (int pass = ACT ? 0 : 1; pass < 2; ++pass) {
@@ -253,11 +316,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
           if constexpr (CAN32) {
             constexpr int ROWB = TN * 64, CPR = ROWB / 16, PER = (16 * CPR) / 64;
 #pragma clang loop unroll(full)
-            for (int nt = 0; nt < TN; ++nt) {
-              f32x4 v = av[nt] * p.alpha + bv[nt];
-              if (pass == 1) v = math(v, Rb ? r4[nt] : v, m, n_base + nt * 16 + g * 4, Rb != nullptr);
-              *(f32x4*)(stage + stage_off<ROWB>(i16, 4 * nt + g)) = v;
-            }
+            for (int nt = 0; nt < TN; ++nt) *(f32x4*)(stage + stage_off<ROWB>(i16, 4 * nt + g)) = value(pass, nt);
 #pragma clang loop unroll(full)
             for (int j = 0; j < PER; ++j) {
               const int q = lane + 64 * j, row = q / CPR, ch = q % CPR;
@@ -276,8 +335,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
             constexpr int ROWB = TN * 32, CPR = ROWB / 16, PER = (16 * CPR) / 64;
 #pragma clang loop unroll(full)
             for (int nt = 0; nt < TN; ++nt) {
-              f32x4 v = av[nt] * p.alpha + bv[nt];
-              if (pass == 1) v = math(v, Rb ? r4[nt] : v, m, n_base + nt * 16 + g * 4, Rb != nullptr);
+              const f32x4 v = value(pass, nt);
               *(u32x2*)(stage + stage_off<ROWB>(i16, 2 * nt + (g >> 1)) + (g & 1) * 8) =
                   u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             }
@@ -406,8 +464,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
         if (mrow[mt] < 0 || i16 >= row_limit || m >= p.M) continue;
         f32x4 v = acc[mt][nt] * p.alpha + bv[nt];
         if (C2b) {
-          if (f32out) *(f32x4*)(C2b + ((long long)m * p.ldc + n) * 4) = v;
-          else *(u32x2*)(C2b + ((long long)m * p.ldc + n) * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          f32x4 c2 = v;
+          if (p.act == MELGPT_ACT_GELU_DACT) gelu_both4(v, v, c2);  // v becomes the activation, C2 its derivative
+          if (f32out) *(f32x4*)(C2b + ((long long)m * p.ldc + n) * 4) = c2;
+          else *(u32x2*)(C2b + ((long long)m * p.ldc + n) * 2) = u32x2{pack_bf16x2(c2[0], c2[1]), pack_bf16x2(c2[2], c2[3])};
         }
         f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
         if (Rb) r4 = unpack(*(const RV*)(Rb + ((long long)m * p.ldr + n) * ES));

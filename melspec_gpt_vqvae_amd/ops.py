@@ -10,7 +10,7 @@ import torch
 from . import _ffi
 from ._ffi import call, dtype_code, ptr, stream
 
-ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_DACT, ACT_MUL = 0, 1, 2, 3, 4
 
 
 class KernelTimer:
@@ -98,8 +98,9 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=None, accu
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
     with _timed(2.0 * M * N * K * batch, f"gemm {'T' if a_kmajor else 'N'}{'N' if b_kmajor else 'T'} {M}x{N}x{K}"
-                + (f" b{batch}" if batch > 1 else "") + (" gelu" if act == ACT_GELU else " dgelu" if act else "")
-                + (" drop" if drop_p > 0 else "") + (" res" if residual is not None and act != ACT_GELU_GRAD else "")):
+                + (f" b{batch}" if batch > 1 else "") + ({ACT_GELU: " gelu", ACT_GELU_GRAD: " dgelu", ACT_GELU_DACT: " gelu+dact", ACT_MUL: " mul"}.get(act, ""))
+                + (" drop" if drop_p > 0 else "")
+                + (" res" if residual is not None and act not in (ACT_GELU_GRAD, ACT_MUL) else "")):
         call("melgpt_gemm", ptr(a), int(a_kmajor), lda, sa, ptr(b), int(b_kmajor), ldb, sb, ptr(out), ldc, sc, M, N, K,
              batch, dtype_code(dt), int(odt == torch.float32 and dt != torch.float32), int(accumulate), float(alpha),
              ptr(bias), int(act), ptr(residual), ldr, sr, ptr(pre_out), float(drop_p), int(seed), int(stream_id),

@@ -156,12 +156,14 @@ class _BlockFn(torch.autograd.Function):
                                        n_unmasked=a.n_unmasked, attn_p=attn_p, resid_p=resid_p, seed=seed, site=site,
                                        residual=x2, want_att=want_att)
         h2, mu2, rs2 = ops.layernorm_fwd(x1, blk.ln2.weight, blk.ln2.bias, blk.ln2.eps)
-        pre = torch.empty(B * T, 4 * C, dtype=dt, device=x.device)
-        act = ops.gemm(h2, W.w_fc1, bias=m[0].bias, act=ops.ACT_GELU, pre_out=pre)
+        # fc1 writes gelu(pre) and gelu'(pre) (one shared exponential); the pre-activation itself is never stored and
+        # the backward GEMM's epilogue is a multiplication instead of a second erf evaluation
+        dact = torch.empty(B * T, 4 * C, dtype=dt, device=x.device)
+        act = ops.gemm(h2, W.w_fc1, bias=m[0].bias, act=ops.ACT_GELU_DACT, pre_out=dact)
         y = ops.gemm(act, W.w_fc2, bias=m[2].bias, drop_p=mlp_p, seed=seed, stream_id=site + 2, residual=x1)
         ctx.blk, ctx.seed, ctx.site = blk, seed, site
         ctx.cfg = (B, T, C, attn_p, resid_p, mlp_p, dt)
-        ctx.save_for_backward(x2, mu1, rs1, h1, sav[0], sav[1], sav[2], x1, mu2, rs2, h2, pre, act)
+        ctx.save_for_backward(x2, mu1, rs1, h1, sav[0], sav[1], sav[2], x1, mu2, rs2, h2, dact, act)
         if att is None:
             att = x.new_zeros(0)
         ctx.mark_non_differentiable(att)
@@ -171,7 +173,7 @@ class _BlockFn(torch.autograd.Function):
     def backward(ctx, dy, _datt):
         blk = ctx.blk
         B, T, C, attn_p, resid_p, mlp_p, dt = ctx.cfg
-        x2, mu1, rs1, h1, qkv, a_out, lse, x1, mu2, rs2, h2, pre, act = ctx.saved_tensors
+        x2, mu1, rs1, h1, qkv, a_out, lse, x1, mu2, rs2, h2, dact, act = ctx.saved_tensors
         fp = ensure_flat(blk)
         W = _BlockWeights(blk, fp, dt)
         a, m = blk.attn, blk.mlp
@@ -188,7 +190,7 @@ class _BlockFn(torch.autograd.Function):
             ops.colsum(d, gb, accumulate=acc)
         gw, acc = fp.grad_target(m[2].weight)
         ops.wgrad(d, act, gw, acc)
-        dpre = ops.gemm(d, W.w_fc2, b_kmajor=True, act=ops.ACT_GELU_GRAD, residual=pre)
+        dpre = ops.gemm(d, W.w_fc2, b_kmajor=True, act=ops.ACT_MUL, residual=dact)
         gw, acc = fp.grad_target(m[0].weight)
         ops.wgrad(dpre, h2, gw, acc)
         gb, acc = fp.grad_target(m[0].bias)

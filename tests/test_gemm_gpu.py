@@ -156,6 +156,46 @@ def test_epilogues(dt):
     assert rel_err(out.cpu().numpy(), torch.bmm(a3c, b3c.transpose(1, 2)).numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(265, 256, 128), (16640, 1536, 256)])
+def test_gelu_with_saved_derivative_and_mul_epilogues(dt, M, N, K):
+    """forward of Linear -> GELU writing gelu(pre) and gelu'(pre) (MELGPT_ACT_GELU_DACT), backward multiplying by the
+    saved derivative (MELGPT_ACT_MUL) == the two-erf form (ACT_GELU + ACT_GELU_GRAD on the stored pre-activation):
+    bit-identical on the f32 lane, within bf16 rounding of the stored tensor on the bf16 lane; small (128-tile kernel)
+    and multi-round persistent-kernel sizes."""
+    from melspec_gpt_vqvae_amd import ops
+
+    a, ac = _rand(50, (M, K), DT[dt], 0.5)
+    b, bc = _rand(51, (N, K), DT[dt], 0.5)
+    bias = t(synth.normal(52, (N,)), DEV)
+    pre_ref = ac @ bc.t() + bias.cpu()
+    x = pre_ref.clone().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    der_ref = x.grad
+    dact = torch.empty(M, N, dtype=DT[dt], device=DEV)
+    act = ops.gemm(a, b, bias=bias, act=ops.ACT_GELU_DACT, pre_out=dact)
+    pre = torch.empty(M, N, dtype=DT[dt], device=DEV)
+    act_old = ops.gemm(a, b, bias=bias, act=ops.ACT_GELU, pre_out=pre)
+    assert torch.equal(act, act_old)
+    tol = 1e-5 if dt == "f32" else 2 ** -8
+    assert rel_err(act.float().cpu().numpy(), F.gelu(pre_ref).numpy()) < tol
+    assert rel_err(dact.float().cpu().numpy(), der_ref.numpy()) < tol
+    d, dc = _rand(53, (M, 192), DT[dt], 0.5)
+    w2, w2c = _rand(54, (192, N), DT[dt], 0.2)                      # (out, in) weight used K-major in the dgrad product
+    g_new = ops.gemm(d, w2, b_kmajor=True, act=ops.ACT_MUL, residual=dact)
+    g_old = ops.gemm(d, w2, b_kmajor=True, act=ops.ACT_GELU_GRAD, residual=pre)
+    if dt == "f32":
+        assert torch.equal(g_new, g_old)
+    ref = (dc @ w2c) * der_ref
+    assert rel_err(g_new.float().cpu().numpy(), ref.numpy()) < (1e-5 if dt == "f32" else 2 ** -7)
+    # dropout + residual after the activation still apply to C (not to the saved derivative)
+    r, rc = _rand(55, (M, N), DT[dt])
+    dact2 = torch.empty_like(dact)
+    y = ops.gemm(a, b, bias=bias, act=ops.ACT_GELU_DACT, pre_out=dact2, residual=r)
+    assert torch.equal(dact2, dact)
+    assert rel_err(y.float().cpu().numpy(), (F.gelu(pre_ref) + rc).numpy()) < (1e-5 if dt == "f32" else 2 ** -7)
+
+
 def test_dropout_epilogue_statistics_and_replay():
     from melspec_gpt_vqvae_amd import ops
 
