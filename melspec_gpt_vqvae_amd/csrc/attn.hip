@@ -17,7 +17,11 @@
 //   in the dK/dV kernel S = Q K^T puts the key on the lane and the accumulators feed dV^T and dK^T.
 // The causal / n_unmasked mask (minGPT.py:65-69) is computed from (row, col, n_unmasked) - the persistent
 // (1,1,bs,bs) `mask` buffer of the reference is never read.  Dropout masks are a counter hash (common.h) keyed by
-// (seed, stream, (b,h)) over the counter q * 128 + key / 4, regenerated bit-identically in the backward kernels.
+// (seed, stream, (b,h)), regenerated bit-identically in the backward kernels: general p - one hash per (query, 4 keys),
+// counter q * 128 + key / 4; p = 1/2 (the reference's attn_pdrop) needs ONE BIT per probability, so one 32-bit hash
+// serves a query's 32 keys {128 kb + 16 t + 4 gk + r : t < 8, r < 4} - the keys ONE LANE of the forward / dQ kernels
+// meets in eight consecutive key tiles - counter q * 16 + 4 gk + kb, bit 4 t + r: one hash per lane per EIGHT tiles
+// instead of one per tile (the hash's two integer multiplies were a third of the per-probability VALU work).
 // T = bf16: v_mfma_f32_16x16x32_bf16;  T = f32: v_mfma_f32_16x16x4_f32 (exact f32) - same code path.
 #include "mma.h"
 
@@ -223,6 +227,7 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kerne
   int* ctr = (int*)(smem + 2 * (size_t)TP * A::ROWB);
 #if ATTN_LAB == 8
   const unsigned long long ts_entry = __builtin_amdgcn_s_memtime();
+  const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();  // 100 MHz, one clock for the whole chip
 #endif
   const T* Kg = (const T*)p.K + (long long)b * Tn * p.ld + h * HS;
   const T* Vg = (const T*)p.V + (long long)b * Tn * p.ld + h * HS;
@@ -288,6 +293,14 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kerne
   const int nfull = vis_keys(q0, Tn, nu) / 16;                         // key tiles EVERY row sees whole: no mask test
   const int nst = (nkt + A::TPS - 1) / A::TPS, nst_full = nfull / A::TPS;
   const unsigned cb = (unsigned)q * 128u + (unsigned)g;                // dropout counter of keys 16 kt + 4 g ..+3: cb + 4 kt
+  // p = 1/2: the lane's hash words for key blocks kb = 0, 1, 2 (128 keys each; T <= 288); bit 4 (kt & 7) + r = key 16 kt + 4 g + r
+  int hblk[3] = {0, 0, 0};
+  if constexpr (DM == DM_HALF) {
+    const unsigned ch = (unsigned)q * 16u + 4u * (unsigned)g + dkeys.k0;
+    hblk[0] = (int)hash32(ch);
+    if (nkt > 8) hblk[1] = (int)hash32(ch + 1u);
+    if (nkt > 16) hblk[2] = (int)hash32(ch + 2u);
+  }
   const f32x4 c2v = splat4(c2);
 
   auto scores = [&](int kt, bool masked) {  // S^T tile: keys 16 kt + 4 g + r of query q, raw (unscaled) logits
@@ -301,7 +314,18 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kerne
     }
     return acc;
   };
-  auto dropped = [&](f32x4 v, int kt) { return drop4<DM>(dkeys, cb + 4u * (unsigned)kt, v); };
+  auto dropped = [&](f32x4 v, int kt) {
+    if constexpr (DM == DM_HALF) {
+      const int kb = kt >> 3, sh = 4 * (kt & 7);                       // wave-uniform
+      const int hsh = kb == 0 ? hblk[0] : (kb == 1 ? hblk[1] : hblk[2]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        v[r] = __uint_as_float(__float_as_uint(v[r]) & (unsigned)__builtin_amdgcn_sbfe(hsh, sh + r, 1));
+      return v;
+    } else {
+      return drop4<DM>(dkeys, cb + 4u * (unsigned)kt, v);
+    }
+  };
 
   f32x4 o[4];
 #pragma unroll
@@ -458,7 +482,7 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kerne
   if (!BWD && t == 0 && bh < 4096) {
     unsigned long long* d = melgpt_attn_dbg + 256 + 4 * bh;
     d[0] = ts_entry; d[1] = ts_k; d[2] = __builtin_amdgcn_s_memtime();
-    d[3] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+    d[3] = (rt_entry << 32) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull);
   }
 #endif
 }
@@ -499,7 +523,7 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_dkv_ker
   const int ntiles = (Tn + 15) / 16;
   const f32x4 c2v = splat4(p.scale * LOG2E);
   const DropKeys dkeys = drop_keys(p.seed, p.stream_id, (unsigned)bh, p.drop_thresh);
-  const int qsh = 8 * (lane & 3);  // this lane's key is element (key & 3) of its counter: byte qsh of the 8-bit hash
+  const int qsh = 8 * (lane & 3);  // (general p) this lane's key is element (key & 3) of its counter: byte qsh of the 8-bit hash
 
  for (;;) {  // ---- this wave's next 16-key tile (key tile 0 is seen by every query: heaviest first); wave-uniform
   int job = 0;
@@ -524,6 +548,9 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_dkv_ker
   // dropout counter of (query q, keys key&~3 ..+3) is q * 128 + key / 4; quad lane j hashes query 16 qt + 4 g + j
   const unsigned cq = (unsigned)(4 * g + (lane & 3)) * 128u + (unsigned)(key >> 2) + dkeys.k0;
   const unsigned ce = (unsigned)(4 * g) * 128u + (unsigned)(key >> 2);
+  // p = 1/2: (query q, this key) is bit 4 ((key >> 4) & 7) + (key & 3) of the hash of q * 16 + 4 ((key & 15) >> 2) + (key >> 7)
+  const unsigned chq = (unsigned)(4 * g + (lane & 3)) * 16u + (unsigned)(((key & 15) >> 2) * 4 + (key >> 7)) + dkeys.k0;
+  const int hbit = 4 * ((key >> 4) & 7) + (key & 3);
 
   auto step = [&](int st, bool masked) {
     f32x4 pd[2], ds[2];
@@ -546,11 +573,11 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_dkv_ker
       }
       f32x4 pk = pr;
       if constexpr (DM == DM_HALF) {
-        const int hq = (int)hash32(cq + (unsigned)qb * 128u);
+        const int hq = (int)hash32(chq + (unsigned)qb * 16u);
         const int hr[4] = {quad_lane<0>(hq), quad_lane<1>(hq), quad_lane<2>(hq), quad_lane<3>(hq)};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const unsigned km = (unsigned)__builtin_amdgcn_sbfe(hr[r], qsh + 7, 1);  // all ones = kept
+          const unsigned km = (unsigned)__builtin_amdgcn_sbfe(hr[r], hbit, 1);  // all ones = kept
           pk[r] = __uint_as_float(__float_as_uint(pr[r]) & km);
           dp[r] = __uint_as_float(__float_as_uint(dp[r]) & km);
         }

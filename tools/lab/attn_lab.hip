@@ -80,7 +80,7 @@ int main(int argc, char** argv) {
     hipMemcpyFromSymbol(w.data(), HIP_SYMBOL(melgpt_attn_dbg), w.size() * 8, 256 * 8);
     FILE* f = fopen("gpurun_out/attn_wg.csv", "w");
     if (f) {
-      fprintf(f, "wg,entry,staged,exit,hw_id,xcc_id\n");
+      fprintf(f, "wg,entry,staged,exit,rt_exit,rt_entry\n");
       for (int i = 0; i < B * H && i < 4096; ++i)
         fprintf(f, "%d,%llu,%llu,%llu,%llu,%llu\n", i, w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3] & 0xFFFFFFFFull, w[4 * i + 3] >> 32);
       fclose(f);
