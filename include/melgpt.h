@@ -38,6 +38,12 @@ enum {
 
 int melgpt_abi_version(void);
 const char* melgpt_strerror(int code);
+/* Compute units the persistent kernels (one workgroup per CU for a whole launch: the 256-wide GEMM, the wide fused
+ * convolution) leave unused, so that RCCL's all-reduce kernels running beside the backward pass of a data-parallel step
+ * (Lightning DDP in the reference, GPT_VAE_train.py:172-174) always find free CUs and never delay a persistent
+ * workgroup's whole tile list.  0 (default) = use every CU; per process. */
+int melgpt_set_reserved_cus(int n);
+int melgpt_get_reserved_cus(void);
 
 /* ===================================================================== mel frontend
  * wav -> log-mel in one kernel = MelSpectrogram.__call__ + TRANSFORMS

@@ -155,3 +155,5 @@ __device__ __forceinline__ Philox4 philox4x32_10(unsigned long long seed, unsign
   }
   return Philox4{c0, c1, c2, c3};
 }
+
+extern "C" int melgpt_get_reserved_cus(void);  // abi.hip: CUs the persistent kernels leave free (data-parallel runs)

@@ -445,7 +445,8 @@ int launch_fused_wide(const FusedConvParams& q0, int B, hipStream_t s) {
   const long long total = (long long)q.tiles_x * q.tiles_y * B;
   if (total > 0x7FFFFFFF) return MELGPT_ERR_UNSUPPORTED;
   const int gy = (q.g.N + 127) / 128;
-  int gx = ncu / gy;
+  const int avail = ncu - melgpt_get_reserved_cus() >= 8 ? ncu - melgpt_get_reserved_cus() : ncu;
+  int gx = avail / gy;
   if (gx < 1) gx = 1;
   if (gx > total) gx = (int)total;
   if (q.stat_part) {

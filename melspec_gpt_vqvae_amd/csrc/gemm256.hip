@@ -418,8 +418,9 @@ static int device_cus() {
 // rounds (3 x 6).
 template <int ALAY, int BLAY, int MODE>
 int launch_mode(const GemmParams& p, int batch, hipStream_t s) {
-  const int ncu = device_cus();
+  int ncu = device_cus();
   if (ncu <= 0) return MELGPT_ERR_LAUNCH;
+  if (ncu - melgpt_get_reserved_cus() >= 8) ncu -= melgpt_get_reserved_cus();  // CUs left to concurrent RCCL kernels
   if constexpr (ALAY != LAY_KMAJ) {
     auto cost = [&](int bm, int tm) {
       const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + 255) / 256) * batch;

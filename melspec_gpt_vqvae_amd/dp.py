@@ -103,7 +103,10 @@ class DataParallel:
     at once while earlier blocks are still in their GEMMs.  finish() is called once per step before the optimizer
     (whose grad_scale = 1/world folds the averaging in)."""
 
-    def __init__(self, module, group=None, overlap=True, max_bucket_elems: int = 64 << 20):
+    def __init__(self, module, group=None, overlap=True, max_bucket_elems: int = 64 << 20, reserve_cus=None):
+        import os
+
+        from . import _ffi
         from .flat import ensure_flat
 
         self.module = module
@@ -111,6 +114,16 @@ class DataParallel:
         self.ex = GradientExchange(self.fp.grad, group, max_bucket_elems=max_bucket_elems)
         self.world = self.ex.world
         self.overlap = bool(overlap)
+        # The persistent GEMM / conv kernels own one CU per workgroup for a whole launch; an RCCL kernel that holds a CU
+        # when such a launch starts would leave one workgroup waiting for another one's ENTIRE tile list.  With early
+        # (overlapped) all-reduces those kernels therefore leave `reserve_cus` CUs to RCCL (default 16 of 256 when the
+        # exchange really runs over RCCL, MELGPT_RESERVE_CUS overrides; 0 for gloo / single rank).
+        if reserve_cus is None:
+            on_rccl = self.world > 1 and self.overlap and dist.get_backend(group) == "nccl"
+            reserve_cus = int(os.environ.get("MELGPT_RESERVE_CUS", "16" if on_rccl else "0"))
+        self.reserve_cus = int(reserve_cus)
+        if self.fp.device.type == "cuda":
+            _ffi.call("melgpt_set_reserved_cus", self.reserve_cus)
         self.hook_calls = 0           # Block hooks fired since construction (tests count them)
         self._segs = {}
         self.blocks = [m for m in module.modules() if hasattr(m, "_layer_index") and hasattr(m, "attn")]

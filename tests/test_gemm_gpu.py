@@ -372,3 +372,30 @@ def test_wide_kernel_is_bit_reproducible(ak, bk, M, N, K):
         assert torch.equal(ops.gemm(a, b, a_kmajor=ak, b_kmajor=bk), ref)
     r32 = (a.float().T if ak else a.float()) @ (b.float() if bk else b.float().T)
     assert float((ref.float() - r32).abs().max() / r32.abs().max()) < 6e-3
+
+
+def test_reserved_cus_leave_room_for_rccl_and_do_not_change_results():
+    """melgpt_set_reserved_cus(n): the persistent GEMM / wide conv run on (CUs - n) workgroups (dp.DataParallel sets it
+    when all-reduces overlap the backward pass); same bits as the full-chip launch."""
+    from melspec_gpt_vqvae_amd import _ffi, ops
+
+    torch.manual_seed(4)
+    a = torch.randn(33920, 1024, device=DEV).bfloat16()
+    b = torch.randn(1024, 1024, device=DEV).bfloat16()
+    x = (torch.randn(8, 80, 848, 128, device=DEV) * 0.5).bfloat16()
+    w = (torch.randn(128, 3, 3, 128, device=DEV) * 0.05).bfloat16()
+    bias = torch.randn(128, device=DEV) * 0.1
+    g, bt = torch.ones(128, device=DEV), torch.zeros(128, device=DEV)
+    mean, rstd = ops.groupnorm_stats(x, 1e-6)
+    ref = ops.gemm(a, b)
+    cref = ops.conv3x3_gn(x, (mean, rstd), g, bt, w, bias)
+    try:
+        _ffi.call("melgpt_set_reserved_cus", 16)
+        assert _ffi.lib().melgpt_get_reserved_cus() == 16
+        assert torch.equal(ops.gemm(a, b), ref)
+        assert torch.equal(ops.conv3x3_gn(x, (mean, rstd), g, bt, w, bias), cref)
+        with pytest.raises(_ffi.MelgptError):
+            _ffi.call("melgpt_set_reserved_cus", -1)
+    finally:
+        _ffi.call("melgpt_set_reserved_cus", 0)
+    assert torch.equal(ops.gemm(a, b), ref)
