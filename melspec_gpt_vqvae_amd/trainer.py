@@ -65,9 +65,17 @@ class Fit:
             self.global_step += 1
             losses.append(loss.detach())
             freq = int(getattr(self.args, "logging_frequency", 200) or 200)
-            if self.rank == 0 and self.global_step % freq == 0:
-                self.log(f"epoch {epoch} step {self.global_step} train/loss {float(losses[-1]):.4f} "
-                         f"({(time.perf_counter() - t0) / (i + 1):.3f} s/step)")
+            if self.global_step % freq == 0:
+                # the step's logged scalars (Lit_GPT_VAE.py:310-313: four `self.log(..., sync_dist=True)` = four
+                # all-reduces per step under DDP) as ONE all-reduce, and only on logging steps
+                names = list(getattr(m, "last_metrics", {}) or {"train/loss": losses[-1]})
+                vals = [getattr(m, "last_metrics", {}).get(k, losses[-1]) for k in names]
+                if self.dp is not None:
+                    vals = self.dp.reduce_metrics(*vals)
+                if self.rank == 0:
+                    txt = "  ".join(f"{k} {float(v):.4f}" for k, v in zip(names, vals))
+                    self.log(f"epoch {epoch} step {self.global_step}  {txt}  "
+                             f"({(time.perf_counter() - t0) / (i + 1):.3f} s/step)")
         out = torch.stack(losses).float() if losses else torch.zeros(0)
         self.history["train_loss"].append([float(v) for v in out.cpu()])
         self.history["steps"] = self.global_step
