@@ -1,6 +1,7 @@
 // Development harness: phase stamps of the persistent fused GroupNorm+swish+conv3x3 kernel (conv3x3_gn_wide_kernel).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCONVW_LAB=1 -I include -I melspec_gpt_vqvae_amd/csrc tools/lab/convw_lab.hip
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include "../../melspec_gpt_vqvae_amd/csrc/conv_fused.hip"
 
@@ -15,7 +16,7 @@ int main() {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(e0, 0);
-    int st = melgpt_conv3x3_gn_nhwc(x, B, H, W, C, mean, rstd, gamma, beta, 1, wp, C, bias, res, y, MELGPT_BF16, 0);
+    int st = melgpt_conv3x3_gn_nhwc(x, B, H, W, C, mean, rstd, gamma, beta, 1, wp, C, bias, getenv("NORES") ? nullptr : res, y, MELGPT_BF16, 0);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("status %d  %.3f ms  %.1f TFLOP/s\n", st, ms, 2.0 * B * H * W * C * 9.0 * C / ms / 1e9);
@@ -27,3 +28,6 @@ int main() {
            h[4 * i + 2] - h[4 * i + 1], h[4 * i + 3] - h[4 * i + 2], h[4 * i + 4] ? (long long)(h[4 * i + 4] - h[4 * i + 3]) : -1LL);
   return 0;
 }
+// stand-ins for the two library entry points conv_fused.hip references (not exercised by this harness)
+extern "C" int melgpt_groupnorm_finalize(const float*, int, int, double, float, float*, float*, void*) { return 0; }
+extern "C" int melgpt_get_reserved_cus(void) { return 0; }
