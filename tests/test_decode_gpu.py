@@ -197,3 +197,29 @@ def test_decode_never_reads_cache_rows_it_has_not_written(dt):
             outs.append(torch.stack(rows).cpu().numpy())
     assert np.isfinite(outs[1]).all()
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_sampling_with_an_unmasked_prefix_does_not_use_a_stale_kv_cache():
+    """n_unmasked > 0 (reference minGPT.py:65-69): positions below n_unmasked attend bidirectionally, so their K / V
+    change as the sequence grows and a cache of them would be stale.  sample(kv_cache=True) must then take the
+    reference's re-forward loop (same samples as kv_cache=False, same as the CPU oracle); decode_begin refuses."""
+    from oracle import gpt as ogpt
+
+    from melspec_gpt_vqvae_amd.transformer.minGPT import Lit_minGPT
+
+    args = synth.gpt_args(n_layer=2, n_head=4, n_embd=256, n_unmasked=12, reconstruct_spec="", device=DEV, batch_size=2,
+                          learning_rate=1e-6)
+    lit = Lit_minGPT(args)
+    sd_np = synth.gpt_state_dict(args, 1)
+    _load(lit.transformer, sd_np)
+    lit.to(DEV).eval()
+    assert not lit.transformer.kv_cacheable()
+    with pytest.raises(AssertionError, match="n_unmasked"):
+        lit.transformer.decode_begin(2)
+    x0 = t(synth.randint(77, 0, 128, (2, 5)), DEV)
+    c = t(synth.randint(78, 0, 8, (2, 1)), DEV)
+    a, _ = lit.sample(x0, c, steps=20, sample=False)                  # default kv_cache=True falls back
+    b, _ = lit.sample(x0, c, steps=20, sample=False, kv_cache=False)
+    assert torch.equal(a, b)
+    ref, _ = ogpt.sample_class_gpt(ogpt.as_torch_sd(sd_np), x0.cpu(), c.cpu(), 20, 2, 4, n_unmasked=12)
+    assert np.array_equal(a.cpu().numpy(), ref.numpy())
