@@ -290,12 +290,15 @@ def main():
     ap.add_argument("--workload", default="class_gpt", choices=["class_gpt", "gpt_vae_xl"],
                     help="class_gpt = BASELINE configs[1]+[2] (the metric's configuration); gpt_vae_xl = configs[3]")
     ap.add_argument("--batch", type=int, default=128, help="sequences per GPU per step (BASELINE configs 3 and 4: 128)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "f32"],
+                    help="bf16 (default, the metric's lane) | fp16 (the library's IEEE-half flavour) | f32 (parity lane)")
     ap.add_argument("--layers", type=int, default=24, help="debug only; anything but the configuration's depth is flagged")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print per-phase timings to stderr")
     a = ap.parse_args()
 
+    if a.dtype == "fp16":  # the 16-bit format is a property of the library flavour: choose it before the package loads
+        os.environ["MELGPT_HALF"] = "fp16"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -319,7 +322,7 @@ def main():
 
     from melspec_gpt_vqvae_amd import ops
 
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}[a.dtype]
     job = (ClassGPTStep if a.workload == "class_gpt" else GPTVAEXLStep)(a, device, dtype, rank, world)
 
     phases = {"encode": 0.0, "fwd": 0.0, "bwd": 0.0, "opt": 0.0}
@@ -379,7 +382,7 @@ def main():
             "metric": job.metric,
             "value": round(value, 3), "unit": "seq/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
+            "dtype": a.dtype, "data": "synthetic",
             "config": {
                 "workload": job.workload,
                 "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": job.seq_len,

@@ -46,6 +46,7 @@ def init_config(argv=None):
 
 
 def main(args):
+    from . import _ffi
     from .checkpoint import warm_start_encoder
     from .trainer import Fit
     from .transformer.Lit_GPT_VAE import GPT_VAE
@@ -57,7 +58,7 @@ def main(args):
     vae = GPT_VAE(args)
     if args.load_path:
         warm_start_encoder(vae, args.load_path)
-    set_compute_dtype(vae, torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    set_compute_dtype(vae, _ffi.HALF_DTYPE if args.dtype in ("bf16", "fp16") else torch.float32)
     fit = Fit(vae, args)
     hist = None
     if args.train:

@@ -35,7 +35,7 @@ def _common_flags(parser):
         parser.add_argument("--" + name, type=typ, default=None)
     parser.add_argument('--splits_dir', type=str, default='./data')
     parser.add_argument('--log_root', type=str, default='lightning_logs')
-    parser.add_argument('--dtype', choices=["f32", "bf16"], default="f32", help="kernel numerics lane")
+    parser.add_argument('--dtype', choices=["f32", "bf16", "fp16"], default="f32", help="kernel numerics lane")
     parser.add_argument('--max_steps_per_epoch', type=int, default=None)
 
 
@@ -83,6 +83,7 @@ def init_distributed(args):
 
 
 def main(args):
+    from . import _ffi
     from .trainer import Fit
     from .transformer.minGPT import Lit_minGPT, set_compute_dtype
 
@@ -90,7 +91,7 @@ def main(args):
     if not args.cuda:
         raise SystemExit("melspec_gpt_vqvae_amd runs on an MI355X only (there is no CPU path)")
     gpt = Lit_minGPT(args)
-    set_compute_dtype(gpt.transformer, torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    set_compute_dtype(gpt.transformer, _ffi.HALF_DTYPE if args.dtype in ("bf16", "fp16") else torch.float32)
     fit = Fit(gpt, args)
     hist = None
     if args.train:

@@ -11,7 +11,13 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libmelgpt_hip.so")
+# The 16-bit lane's storage format is a property of the LIBRARY (csrc/common.h): bfloat16 (libmelgpt_hip.so, default)
+# or IEEE half (libmelgpt_hip_fp16.so, MELGPT_HALF=fp16 - BASELINE configs[4] names fp16).  One format per process.
+HALF = os.environ.get("MELGPT_HALF", "bf16").lower()
+if HALF not in ("bf16", "fp16"):
+    raise ImportError(f"MELGPT_HALF={HALF!r}: expected bf16 or fp16")
+HALF_DTYPE = torch.float16 if HALF == "fp16" else torch.bfloat16
+LIB_PATH = os.path.join(_PKG, "lib", "libmelgpt_hip_fp16.so" if HALF == "fp16" else "libmelgpt_hip.so")
 
 F32, BF16 = 0, 1
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -137,6 +143,9 @@ def stream():
 def dtype_code(dt):
     if dt == torch.float32:
         return F32
-    if dt == torch.bfloat16:
-        return BF16
-    raise MelgptError(f"unsupported dtype {dt}: the kernels are built for float32 and bfloat16")
+    if dt == HALF_DTYPE:
+        return BF16          # "the library's 16-bit format" (include/melgpt.h)
+    if dt in (torch.bfloat16, torch.float16):
+        raise MelgptError(f"{dt} tensors need the other library flavour: this process loaded the {HALF} one "
+                          f"(MELGPT_HALF={HALF}); set MELGPT_HALF before importing the package")
+    raise MelgptError(f"unsupported dtype {dt}: the kernels are built for float32 and a 16-bit format")

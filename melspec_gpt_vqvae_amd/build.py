@@ -1,6 +1,7 @@
-"""Build libmelgpt_hip.so: every csrc/*.hip compiled for gfx950 with hipcc and linked in-tree
-(melspec_gpt_vqvae_amd/lib/).  hipcc cross-compiles without a GPU, so this runs in the build
-container; the resulting .so travels to the GPU box with the tree."""
+"""Build libmelgpt_hip.so (+ libmelgpt_hip_fp16.so): every csrc/*.hip compiled for gfx950 with hipcc and linked
+in-tree (melspec_gpt_vqvae_amd/lib/).  hipcc cross-compiles without a GPU, so this runs in the build
+container; the resulting .so files travel to the GPU box with the tree.  Two flavours of the same sources: the
+16-bit lane as bfloat16 (default) and as IEEE half (-DMELGPT_HALF_FP16; csrc/common.h)."""
 from __future__ import annotations
 
 import concurrent.futures as cf
@@ -46,12 +47,20 @@ def _headers():
     return sorted(hs)
 
 
-def _compile(src, stamp, verbose):
-    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+FLAVOURS = {"bf16": ([], "libmelgpt_hip.so", ""), "fp16": (["-DMELGPT_HALF_FP16"], "libmelgpt_hip_fp16.so", "_fp16")}
+
+
+def lib_path(flavour="bf16"):
+    return os.path.join(LIBDIR, FLAVOURS[flavour][1])
+
+
+def _compile(src, stamp, verbose, flavour="bf16"):
+    extra, _, suffix = FLAVOURS[flavour]
+    obj = os.path.join(OBJ + suffix, os.path.basename(src)[:-4] + ".o")
     tag = obj + ".sha"
     if os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == stamp:
         return obj, False
-    cmd = [_hipcc(), *FLAGS, "-c", src, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *extra, "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -64,25 +73,28 @@ def _compile(src, stamp, verbose):
     return obj, True
 
 
-def build(verbose=False, force=False, jobs=None):
-    os.makedirs(OBJ, exist_ok=True)
+def build(verbose=False, force=False, jobs=None, flavours=("bf16", "fp16")):
+    """-> path of the default (bf16) library; builds every flavour in `flavours`."""
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = sources()
     hdr = _headers()
-    if force:
-        shutil.rmtree(OBJ)
-        os.makedirs(OBJ)
     stamps = {s: _digest([s] + hdr) for s in srcs}
     jobs = jobs or min(6, max(1, (os.cpu_count() or 2) - 1))
-    with cf.ThreadPoolExecutor(jobs) as ex:
-        res = list(ex.map(lambda s: _compile(s, stamps[s], verbose), srcs))
-    objs = [o for o, _ in res]
-    if any(ch for _, ch in res) or not os.path.exists(LIB):
-        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB + ".tmp", *objs]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        os.replace(LIB + ".tmp", LIB)
+    for fl in flavours:
+        objdir = OBJ + FLAVOURS[fl][2]
+        if force and os.path.isdir(objdir):
+            shutil.rmtree(objdir)
+        os.makedirs(objdir, exist_ok=True)
+        with cf.ThreadPoolExecutor(jobs) as ex:
+            res = list(ex.map(lambda s: _compile(s, stamps[s], verbose, fl), srcs))
+        objs = [o for o, _ in res]
+        lib = lib_path(fl)
+        if any(ch for _, ch in res) or not os.path.exists(lib):
+            cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib + ".tmp", *objs]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            os.replace(lib + ".tmp", lib)
     return LIB
 
 

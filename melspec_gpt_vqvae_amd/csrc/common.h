@@ -27,13 +27,33 @@ static inline int melgpt_launch_status() {
   return e == hipSuccess ? MELGPT_OK : MELGPT_ERR_LAUNCH;
 }
 
-// ---------------------------------------------------------------- bf16 <-> f32 (RNE; NaN stays NaN via cast)
+// ---------------------------------------------------------------- 16-bit storage format <-> f32
+// The 16-bit lane of every kernel is written against `bf16_t` = 16 raw bits and the handful of helpers below; the
+// library is built in two flavours from the same sources: bfloat16 (default: libmelgpt_hip.so) and IEEE half
+// (-DMELGPT_HALF_FP16: libmelgpt_hip_fp16.so - BASELINE configs[4] names fp16).  Same MFMA rate either way
+// (v_mfma_f32_16x16x32_{bf16,f16}); dtype code MELGPT_BF16 means "the library's 16-bit format".
+// Conversions are round-to-nearest-even; a NaN stays a NaN (plain casts).
+#ifdef MELGPT_HALF_FP16
+typedef _Float16 melgpt_half_native;
+typedef __attribute__((ext_vector_type(8))) _Float16 melgpt_half8;
+#define MELGPT_MFMA_16x16x32(a, b, c) \
+  __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(melgpt_half8, a), __builtin_bit_cast(melgpt_half8, b), c, 0, 0, 0)
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }
+__device__ __forceinline__ float half_lo(unsigned v) { return bf16_to_f32((bf16_t)(v & 0xFFFFu)); }
+__device__ __forceinline__ float half_hi(unsigned v) { return bf16_to_f32((bf16_t)(v >> 16)); }
+#else
+#define MELGPT_MFMA_16x16x32(a, b, c) \
+  __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0)
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   // plain cast semantic (round-to-nearest-even); hipcc lowers __bf16 casts to v_cvt_pk_bf16_f32 on gfx950
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(bf16_t, b);
 }
+__device__ __forceinline__ float half_lo(unsigned v) { return __uint_as_float(v << 16); }          // element 0 of a packed pair
+__device__ __forceinline__ float half_hi(unsigned v) { return __uint_as_float(v & 0xFFFF0000u); }  // element 1
+#endif
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
 }

@@ -99,8 +99,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
         for (int c = 0; c < ROWCH; ++c)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            acc = fmaf(__uint_as_float(kr[i][c][e] << 16), qs[8 * c + 2 * e], acc);
-            acc = fmaf(__uint_as_float(kr[i][c][e] & 0xFFFF0000u), qs[8 * c + 2 * e + 1], acc);
+            acc = fmaf(half_lo(kr[i][c][e]), qs[8 * c + 2 * e], acc);
+            acc = fmaf(half_hi(kr[i][c][e]), qs[8 * c + 2 * e + 1], acc);
           }
       } else {
 #pragma unroll
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        o[2 * e] = fmaf(p, __uint_as_float(vr[i][e] << 16), o[2 * e]);
-        o[2 * e + 1] = fmaf(p, __uint_as_float(vr[i][e] & 0xFFFF0000u), o[2 * e + 1]);
+        o[2 * e] = fmaf(p, half_lo(vr[i][e]), o[2 * e]);
+        o[2 * e + 1] = fmaf(p, half_hi(vr[i][e]), o[2 * e + 1]);
       }
     } else {
 #pragma unroll
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
             if (ok[j]) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                if constexpr (sizeof(T) == 2) s1 += __uint_as_float(xv[j][m][e] << 16) + __uint_as_float(xv[j][m][e] & 0xFFFF0000u);
+                if constexpr (sizeof(T) == 2) s1 += half_lo(xv[j][m][e]) + half_hi(xv[j][m][e]);
                 else s1 += __uint_as_float(xv[j][m][e]);
               }
             }
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 if constexpr (sizeof(T) == 2) {
-                  const float d0 = __uint_as_float(xv[j][m][e] << 16) - mean, d1 = __uint_as_float(xv[j][m][e] & 0xFFFF0000u) - mean;
+                  const float d0 = half_lo(xv[j][m][e]) - mean, d1 = half_hi(xv[j][m][e]) - mean;
                   s2 = fmaf(d0, d0, s2);
                   s2 = fmaf(d1, d1, s2);
                 } else {
@@ -339,8 +339,8 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
             if constexpr (sizeof(T) == 2) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const float h0 = (__uint_as_float(xv[j][m][e] << 16) - mean) * rstd * gv[j][e >> 1][(2 * e) & 3] + bv[j][e >> 1][(2 * e) & 3];
-                const float h1 = (__uint_as_float(xv[j][m][e] & 0xFFFF0000u) - mean) * rstd * gv[j][e >> 1][(2 * e + 1) & 3] +
+                const float h0 = (half_lo(xv[j][m][e]) - mean) * rstd * gv[j][e >> 1][(2 * e) & 3] + bv[j][e >> 1][(2 * e) & 3];
+                const float h1 = (half_hi(xv[j][m][e]) - mean) * rstd * gv[j][e >> 1][(2 * e + 1) & 3] +
                                  bv[j][e >> 1][(2 * e + 1) & 3];
                 xv[j][m][e] = pack_bf16x2(h0, h1);
               }
@@ -362,8 +362,8 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
               if constexpr (sizeof(T) == 2) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                  acc[r][m] = fmaf(__uint_as_float(wv[j][r][e] << 16), __uint_as_float(xv[j][m][e] << 16), acc[r][m]);
-                  acc[r][m] = fmaf(__uint_as_float(wv[j][r][e] & 0xFFFF0000u), __uint_as_float(xv[j][m][e] & 0xFFFF0000u), acc[r][m]);
+                  acc[r][m] = fmaf(half_lo(wv[j][r][e]), half_lo(xv[j][m][e]), acc[r][m]);
+                  acc[r][m] = fmaf(half_hi(wv[j][r][e]), half_hi(xv[j][m][e]), acc[r][m]);
                 }
               } else {
 #pragma unroll
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
           const u32x4 xv = *(const u32x4*)(xr + (long long)c * VEC);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            if constexpr (sizeof(T) == 2) s1 += __uint_as_float(xv[e] << 16) + __uint_as_float(xv[e] & 0xFFFF0000u);
+            if constexpr (sizeof(T) == 2) s1 += half_lo(xv[e]) + half_hi(xv[e]);
             else s1 += __uint_as_float(xv[e]);
           }
         }
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if constexpr (sizeof(T) == 2) {
-              const float d0 = __uint_as_float(xv[e] << 16) - mean, d1 = __uint_as_float(xv[e] & 0xFFFF0000u) - mean;
+              const float d0 = half_lo(xv[e]) - mean, d1 = half_hi(xv[e]) - mean;
               s2 = fmaf(d0, d0, s2);
               s2 = fmaf(d1, d1, s2);
             } else {
@@ -428,8 +428,8 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int k = c * VEC + 2 * e;
-              const float h0 = (__uint_as_float(xv[e] << 16) - mu[m]) * rs[m] * ln_g[k] + ln_b[k];
-              const float h1 = (__uint_as_float(xv[e] & 0xFFFF0000u) - mu[m]) * rs[m] * ln_g[k + 1] + ln_b[k + 1];
+              const float h0 = (half_lo(xv[e]) - mu[m]) * rs[m] * ln_g[k] + ln_b[k];
+              const float h1 = (half_hi(xv[e]) - mu[m]) * rs[m] * ln_g[k + 1] + ln_b[k + 1];
               xv[e] = pack_bf16x2(h0, h1);
             }
           } else {
@@ -445,8 +445,8 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
           if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              acc[r][m] = fmaf(__uint_as_float(wv[r][e] << 16), __uint_as_float(xv[e] << 16), acc[r][m]);
-              acc[r][m] = fmaf(__uint_as_float(wv[r][e] & 0xFFFF0000u), __uint_as_float(xv[e] & 0xFFFF0000u), acc[r][m]);
+              acc[r][m] = fmaf(half_lo(wv[r][e]), half_lo(xv[e]), acc[r][m]);
+              acc[r][m] = fmaf(half_hi(wv[r][e]), half_hi(xv[e]), acc[r][m]);
             }
           } else {
 #pragma unroll
@@ -541,8 +541,7 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const bf16_t* __rest
     for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, a[s]), __builtin_bit_cast(s16x8, b[s][mt]),
-                                                          acc[mt], 0, 0, 0);
+        acc[mt] = MELGPT_MFMA_16x16x32(a[s], b[s][mt], acc[mt]);
   };
   if constexpr (LN) {
     // host: K % 512 == 0 and K <= 1024, so 1 <= nst <= 2 for every wave (KS = 4: MT <= 4)

@@ -21,8 +21,7 @@ struct Tr<float> {
 template <typename T>
 __device__ __forceinline__ void mma(f32x4& acc, u32x4 a, u32x4 b) {
   if constexpr (Tr<T>::ES == 2) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), acc,
-                                                  0, 0, 0);
+    acc = MELGPT_MFMA_16x16x32(a, b, acc);
   } else {
     f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
 #pragma unroll
@@ -30,5 +29,5 @@ __device__ __forceinline__ void mma(f32x4& acc, u32x4 a, u32x4 b) {
   }
 }
 
-__device__ __forceinline__ float bf16lo(unsigned v) { return __uint_as_float(v << 16); }
-__device__ __forceinline__ float bf16hi(unsigned v) { return __uint_as_float(v & 0xFFFF0000u); }
+__device__ __forceinline__ float bf16lo(unsigned v) { return half_lo(v); }
+__device__ __forceinline__ float bf16hi(unsigned v) { return half_hi(v); }

@@ -27,8 +27,8 @@ struct V16<bf16_t> {
     u32x4 v = *(const u32x4*)p;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      o[2 * i] = __uint_as_float(v[i] << 16);
-      o[2 * i + 1] = __uint_as_float(v[i] & 0xFFFF0000u);
+      o[2 * i] = half_lo(v[i]);
+      o[2 * i + 1] = half_hi(v[i]);
     }
   }
   static __device__ __forceinline__ void st(bf16_t* p, const float* o) {
@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        o[2 * i] = __uint_as_float(v[i] << 16);
-        o[2 * i + 1] = __uint_as_float(v[i] & 0xFFFF0000u);
+        o[2 * i] = half_lo(v[i]);
+        o[2 * i + 1] = half_hi(v[i]);
       }
     } else {
 #pragma unroll
@@ -579,8 +579,8 @@ __global__ __launch_bounds__(256) void embed_bwd_table_kernel(const T* __restric
             d[0] = q[0]; d[1] = q[1]; d[2] = q[2]; d[3] = q[3];
           } else {
             u32x2 q = *(const u32x2*)((const bf16_t*)dx + row * C + c);
-            d[0] = __uint_as_float(q[0] << 16); d[1] = __uint_as_float(q[0] & 0xFFFF0000u);
-            d[2] = __uint_as_float(q[1] << 16); d[3] = __uint_as_float(q[1] & 0xFFFF0000u);
+            d[0] = half_lo(q[0]); d[1] = half_hi(q[0]);
+            d[2] = half_lo(q[1]); d[3] = half_hi(q[1]);
           }
           if (drop_scale != 0.f) keep_mask(seed, sid, (unsigned long long)row * C + c, 4, thresh, drop_scale, d);
           acc[i] += f32x4{d[0], d[1], d[2], d[3]};

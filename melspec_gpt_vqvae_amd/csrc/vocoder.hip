@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void pad1d_act_kernel(const T* __restrict__ x,
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xFFFF0000u);
+            float lo = half_lo(v[e]), hi = half_hi(v[e]);
             lo = lo >= 0.f ? lo : lo * slope;
             hi = hi >= 0.f ? hi : hi * slope;
             v[e] = pack_bf16x2(lo, hi);

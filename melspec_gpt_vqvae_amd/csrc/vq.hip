@@ -31,8 +31,8 @@ inline VqAddr vq_fold(VqAddr a) {
   return a;
 }
 
-__device__ __forceinline__ float bf16lo(unsigned v) { return __uint_as_float(v << 16); }
-__device__ __forceinline__ float bf16hi(unsigned v) { return __uint_as_float(v & 0xFFFF0000u); }
+__device__ __forceinline__ float bf16lo(unsigned v) { return half_lo(v); }
+__device__ __forceinline__ float bf16hi(unsigned v) { return half_hi(v); }
 
 // lexicographic (distance, code) minimum == torch.argmin's first-minimal-index rule
 // Branch-free on purpose: written with `if`, each call became an exec-mask region (s_and_saveexec ... s_or exec) and
@@ -254,8 +254,7 @@ __device__ __forceinline__ float xsq_mfma(const u32x4 (&xf)[8], int r16) {
   f32x4 gg = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks)
-    gg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, xf[ks]), __builtin_bit_cast(s16x8, xf[ks]), gg,
-                                                 0, 0, 0);
+    gg = MELGPT_MFMA_16x16x32(xf[ks], xf[ks], gg);
   const int slot = r16 & 3;
   const float lo = (slot & 1) ? gg[1] : gg[0], hi = (slot & 1) ? gg[3] : gg[2];
   return __shfl((slot & 2) ? hi : lo, r16 + 16 * (r16 >> 2), 64);
@@ -361,8 +360,7 @@ __global__ __launch_bounds__(64 * B16_WAVES, EXTRAS ? 2 : 4) void vq_bf16_kernel
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const u32x4 cf = *(const u32x4*)(cbs + cb_off(16 * ct + r16, 4 * ks + g));
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, cf), __builtin_bit_cast(s16x8, xf[ks]),
-                                                      acc, 0, 0, 0);
+        acc = MELGPT_MFMA_16x16x32(cf, xf[ks], acc);
       }
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
@@ -556,15 +554,13 @@ __global__ __launch_bounds__(64 * B16_WAVES, HAS_LO ? 2 : 4) void vq_image_kerne
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
           const u32x4 cf = *(const u32x4*)(cbs + IMG_PLANE + cb_off(16 * ct + r16, 4 * ks + g));
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, cf), __builtin_bit_cast(s16x8, xf[ks]),
-                                                        acc, 0, 0, 0);
+          acc = MELGPT_MFMA_16x16x32(cf, xf[ks], acc);
         }
       }
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const u32x4 cf = *(const u32x4*)(cbs + cb_off(16 * ct + r16, 4 * ks + g));
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, cf), __builtin_bit_cast(s16x8, xf[ks]),
-                                                      acc, 0, 0, 0);
+        acc = MELGPT_MFMA_16x16x32(cf, xf[ks], acc);
       }
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {

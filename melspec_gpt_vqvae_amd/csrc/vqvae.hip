@@ -27,8 +27,8 @@ struct V16<bf16_t> {
     u32x4 v = *(const u32x4*)p;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      o[2 * i] = __uint_as_float(v[i] << 16);
-      o[2 * i + 1] = __uint_as_float(v[i] & 0xFFFF0000u);
+      o[2 * i] = half_lo(v[i]);
+      o[2 * i + 1] = half_hi(v[i]);
     }
   }
   static __device__ __forceinline__ void st(bf16_t* p, const float* o) {

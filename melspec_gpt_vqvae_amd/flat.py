@@ -14,7 +14,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _ffi, ops
 
 ALIGN = 8  # elements: keeps every view 16-byte aligned in both the f32 buffer and the bf16 shadow
 
@@ -108,10 +108,10 @@ class FlatParams:
             return self.data
         key = sum(p._version for p in self.params)
         if self.shadow is None:
-            self.shadow = torch.empty(self.total, dtype=torch.bfloat16, device=self.device)
+            self.shadow = torch.empty(self.total, dtype=_ffi.HALF_DTYPE, device=self.device)
             self._shadow_key = None
         if key != self._shadow_key:
-            ops.cast(self.data, torch.bfloat16, out=self.shadow)
+            ops.cast(self.data, _ffi.HALF_DTYPE, out=self.shadow)
             self._shadow_key = key
         return self.shadow
 

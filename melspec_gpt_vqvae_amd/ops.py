@@ -231,7 +231,7 @@ def _wgrad_split(M, N, K, dtype):
     rounds of 256 tiles (cost = rounds x rows per batch, plus the pass that sums the f32 partials);
     otherwise: ~3 workgroups of the 128x128 kernel per CU."""
     t256 = ((N + 255) // 256) * ((K + 255) // 256)
-    if dtype == torch.bfloat16 and t256 >= 12:
+    if dtype == _ffi.HALF_DTYPE and t256 >= 12:
         best, best_cost = 1, None
         for ns in range(1, 33):
             if M % ns or (M // ns) % 8 or (ns > 1 and M // ns < 512):
@@ -411,7 +411,7 @@ def linear_rows(x, w, *, bias=None, act=ACT_NONE, residual=None, out_dtype=None,
     assert K == K2 and x.dtype == w.dtype and x.stride(1) == 1 and w.stride(1) == 1
     odt = out_dtype or x.dtype
     assert odt in (x.dtype, torch.float32)
-    skinny = x.dtype == torch.bfloat16 and 4 < M <= 128 and N % 16 == 0 and K % 128 == 0
+    skinny = x.dtype == _ffi.HALF_DTYPE and 4 < M <= 128 and N % 16 == 0 and K % 128 == 0
     skinny_ln = skinny and ln is not None and M <= SKINNY_LN_MAX_ROWS and K in (512, 1024)
     if ln is not None and M > 4 and not skinny_ln:
         # the weight-streaming kernels re-derive the row statistics in every workgroup: that pays for a few rows (one
@@ -528,7 +528,7 @@ def conv3x3_gn_with_out_stats(x, stats, gamma, beta, wpack, bias, out_eps, *, sw
     not run on the persistent fused kernel (bf16, Cout 128, no residual) - nothing has been launched then."""
     B, H, W, Cin = x.shape
     Cout = wpack.shape[0]
-    if x.dtype != torch.bfloat16 or Cout != 128:
+    if x.dtype != _ffi.HALF_DTYPE or Cout != 128:
         return None
     assert x.is_contiguous() and wpack.is_contiguous() and wpack.shape[1:] == (3, 3, Cin) and wpack.dtype == x.dtype
     L = _ffi.lib()

@@ -72,7 +72,7 @@ def _compute_dtype(module):
 
 def set_compute_dtype(module, dtype):
     """torch.float32 (parity lane) or torch.bfloat16 (throughput lane) for `module` and all its children."""
-    assert dtype in (torch.float32, torch.bfloat16)
+    assert dtype in (torch.float32, _ffi.HALF_DTYPE), f"compute dtype: float32 or {_ffi.HALF_DTYPE} (MELGPT_HALF)"
     for m in module.modules():
         object.__setattr__(m, "compute_dtype", dtype)
     return module

@@ -31,7 +31,7 @@ def _cdtype(module):
 
 
 def set_compute_dtype(module, dtype):
-    assert dtype in (torch.float32, torch.bfloat16)
+    assert dtype in (torch.float32, _ffi.HALF_DTYPE), f"compute dtype: float32 or {_ffi.HALF_DTYPE} (MELGPT_HALF)"
     for m in module.modules():
         object.__setattr__(m, "compute_dtype", dtype)
     return module
@@ -72,7 +72,7 @@ def nonlinearity(x):
     implemented as a plain elementwise launch through the GELU-free cast+apply path)."""
     _require_cuda(x)
     # x * sigmoid(x) == GroupNorm-apply with mean 0, rstd 1, gamma 1, beta 0 and swish on
-    h = ops.to_nhwc(x, x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32)
+    h = ops.to_nhwc(x, x.dtype if x.dtype in (torch.float32, _ffi.HALF_DTYPE) else torch.float32)
     B, H, W, C = h.shape
     pad_c = (-C) % 32
     if pad_c:
@@ -292,7 +292,7 @@ class Encoder(nn.Module):
             xin = x.reshape(B, H, W)
             if not xin.is_contiguous():
                 xin = xin.contiguous()
-            if xin.dtype not in (torch.float32, torch.bfloat16):
+            if xin.dtype not in (torch.float32, _ffi.HALF_DTYPE):
                 xin = xin.float()
             h = ops.conv_in_c1(xin, self.conv_in.weight.detach(), _f32(self.conv_in.bias), dt)
         else:
@@ -505,7 +505,7 @@ class LitVQVAE(_LitBase):
         _require_cuda(x)
         h = self._encoder._nhwc(x)
         if fused is None:
-            fused = h.dtype == torch.bfloat16
+            fused = h.dtype == _ffi.HALF_DTYPE
         if fused:
             return self._vq_vae.encode_indices_fused(_as_nchw(h), self.quant_conv)
         return self._vq_vae.encode_indices(_as_nchw(_conv(self.quant_conv, h)))

@@ -101,7 +101,7 @@ def vq_lookup_image(z, image: CodebookImage, buf, want_histogram=False):
 
 
 def _image_eligible(z):
-    return (z.dtype == torch.bfloat16 and z.dim() == 4 and z.shape[1] == 256 and z.stride(1) == 1
+    return (z.dtype == _ffi.HALF_DTYPE and z.dim() == 4 and z.shape[1] == 256 and z.stride(1) == 1
             and z.stride(3) % 8 == 0 and z.stride(0) % 8 == 0 and z.data_ptr() % 16 == 0)
 
 

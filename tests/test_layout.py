@@ -26,6 +26,9 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/melgpt.h but not exported"
     assert _ffi.lib().melgpt_abi_version() == 1
+    # the fp16 flavour (same sources, -DMELGPT_HALF_FP16) exports the same ABI
+    L16 = ctypes.CDLL(build.lib_path("fp16"))
+    assert all(hasattr(L16, s) for s in syms) and L16.melgpt_abi_version() == 1
     # every bound prototype is declared in the header and vice versa
     assert sorted(_ffi._PROTOS) == syms
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""End-to-end generation chain on one GPU (BASELINE.json configs[4]), bf16 lane, random-init
+"""End-to-end generation chain on one GPU (BASELINE.json configs[4]), 16-bit lane (bf16, or fp16 with `--dtype fp16`), random-init
 weights, synthetic audio:
 
     raw wav (22 050 Hz, 10 s) -> HIP STFT / log-mel tile -> VQ-VAE encode + 128-code argmin -> class-GPT samples 265
@@ -17,6 +17,8 @@ import warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
 warnings.filterwarnings("ignore")
+if "--dtype" in sys.argv and sys.argv[sys.argv.index("--dtype") + 1] == "fp16":
+    os.environ["MELGPT_HALF"] = "fp16"   # the library's IEEE-half flavour (BASELINE configs[4] names fp16); before the imports
 import torch
 
 import synth
@@ -25,21 +27,24 @@ from melspec_gpt_vqvae_amd.transformer.minGPT import Lit_minGPT, set_compute_dty
 from melspec_gpt_vqvae_amd.vocoder import Generator
 from melspec_gpt_vqvae_amd.vqvae import big_model_attn_gan as vq
 
+from melspec_gpt_vqvae_amd import _ffi
+
 DEV = "cuda:0"
+HALF = _ffi.HALF_DTYPE  # torch.bfloat16, or torch.float16 under --dtype fp16
 
 
 def main():
     torch.manual_seed(0)
     vqvae = vq.LitVQVAE(num_embeddings=128, embedding_dim=256).to(DEV).eval()
-    vq.set_compute_dtype(vqvae, torch.bfloat16)
+    vq.set_compute_dtype(vqvae, HALF)
     args = synth.gpt_args(n_layer=24, n_head=16, n_embd=1024, reconstruct_spec="", device=DEV, batch_size=2,
                           learning_rate=1e-6)  # config/config_GPT_vas.py:1-18
     lit = Lit_minGPT(args).to(DEV).eval()
-    set_compute_dtype(lit.transformer, torch.bfloat16)
+    set_compute_dtype(lit.transformer, HALF)
     lit.first_stage_model = vqvae
     voc = Generator(80, 32, 3).to(DEV).eval()
     for m in voc.modules():
-        object.__setattr__(m, "compute_dtype", torch.bfloat16)
+        object.__setattr__(m, "compute_dtype", HALF)
 
     def sync():
         torch.cuda.synchronize()
@@ -49,7 +54,7 @@ def main():
     def run(wav, c):
         B = wav.shape[0]
         t = [sync()]
-        _, tile = TRANSFORMS.run(wav, want_mel=False, tile_dtype=torch.bfloat16)        # (B,1,80,848) in [-1,1]
+        _, tile = TRANSFORMS.run(wav, want_mel=False, tile_dtype=HALF)        # (B,1,80,848) in [-1,1]
         t.append(sync())
         codes = vqvae.encode_to_codes(tile)                                            # (B,5,53) int64
         seq = lit.code_reader(codes.reshape(B, -1))                                    # time-major (B,265)
@@ -78,7 +83,7 @@ def main():
         p50 = totals[len(totals) // 2]
         p95 = totals[min(len(totals) - 1, int(round(0.95 * (len(totals) - 1))))]
         print(json.dumps({
-            "bench": "wav -> mel -> VQ encode -> GPT sample 265 -> VQ decode -> MelGAN, bf16, one MI355X", "batch": B,
+            "bench": f"wav -> mel -> VQ encode -> GPT sample 265 -> VQ decode -> MelGAN, {_ffi.HALF}, one MI355X", "batch": B,
             "stage_ms_median": {n: round(v, 2) for n, v in zip(names, med)},
             "latency_ms": {"p50": round(p50, 1), "p95": round(p95, 1), "runs": reps},
             "clips_per_s": round(B / (p50 * 1e-3), 2),
