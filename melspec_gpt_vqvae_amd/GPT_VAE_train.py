@@ -8,34 +8,40 @@ import argparse
 
 import torch
 
-from .GPT_train import _common_flags, init_distributed, merge_config, seed_all
+from .GPT_train import _common_flags, add_flags, init_distributed, merge_config, seed_all
+
+
+# (flag, type, default, help): the reference's extra command line for the VAE (GPT_VAE_train.py:33-97)
+VAE_FLAGS = [
+    ("num_nodes", int, 1, "kept for command-line compatibility (one node here)"),
+    ("momentum", float, 0, "unused by AdamW; kept"),
+    ("lr", float, 1.0, "unused (learning_rate comes from the config set); kept"),
+    ("nsamples", int, 1, "latent samples per sequence in training"),
+    ("iw_train_nsamples", int, -1, "importance-weighted training samples (-1: off)"),
+    ("iw_train_ns", int, 1, "kept"),
+    ("iw_nsamples", int, 500, "kept"),
+    ("load_path", str, "", "stage-1 checkpoint whose encoder weights warm-start this model"),
+    ("reconstruct_from", str, "", "kept"),
+    ("reconstruct_to", str, "decoding.txt", "kept"),
+    ("warm_up", int, 10, "epochs over which the KL weight anneals to 1"),
+    ("kl_start", float, 1.0, "initial KL weight"),
+    ("seed", int, 783435, "random seed"),
+    ("save_latent", int, 0, "kept"),
+    ("fix_var", float, -1, "fixed posterior variance (> 0 enables)"),
+    ("freeze_epoch", int, -1, "kept"),
+    ("beta", float, 1.0, "0 = plain autoencoder objective"),
+    ("fb", int, 0, "free bits: 0 off, 1 per sequence, 2 per latent dimension, 3 on the batch mean"),
+    ("target_kl", float, -1, "free-bits threshold"),
+]
 
 
 def init_config(argv=None):
     parser = argparse.ArgumentParser(description='VAE mode collapse study')
     _common_flags(parser)
-    parser.add_argument('--gpus', nargs='+', type=int, default=[0], help='GPU device IDs (the launcher decides here)')
-    parser.add_argument('--num_nodes', type=int, default=1)
-    parser.add_argument('--momentum', type=float, default=0)
-    parser.add_argument('--opt', type=str, choices=["sgd", "adam"], default="sgd")
-    parser.add_argument('--lr', type=float, default=1.0)
-    parser.add_argument('--nsamples', type=int, default=1, help='number of iw samples for training')
-    parser.add_argument('--iw_train_nsamples', type=int, default=-1)
-    parser.add_argument('--iw_train_ns', type=int, default=1)
-    parser.add_argument('--iw_nsamples', type=int, default=500)
-    parser.add_argument('--load_path', type=str, default='')
-    parser.add_argument('--reconstruct_from', type=str, default='')
-    parser.add_argument('--reconstruct_to', type=str, default="decoding.txt")
-    parser.add_argument('--decoding_strategy', type=str, choices=["greedy", "beam", "sample"], default="greedy")
-    parser.add_argument('--warm_up', type=int, default=10, help="number of annealing epochs")
-    parser.add_argument('--kl_start', type=float, default=1.0, help="starting KL weight")
-    parser.add_argument('--seed', type=int, default=783435)
-    parser.add_argument("--save_latent", type=int, default=0)
-    parser.add_argument("--fix_var", type=float, default=-1)
-    parser.add_argument("--freeze_epoch", type=int, default=-1)
-    parser.add_argument("--beta", type=float, default=1.0, help="0 = plain autoencoder")
-    parser.add_argument("--fb", type=int, default=0, help="0: no fb; 1: fb; 2: max(target_kl, kl) for each dimension")
-    parser.add_argument("--target_kl", type=float, default=-1, help="target kl of the free bits trick")
+    add_flags(parser, VAE_FLAGS)
+    parser.add_argument('--gpus', nargs='+', type=int, default=[0], help='kept (the launcher decides which GPUs)')
+    parser.add_argument('--opt', choices=['sgd', 'adam'], default='sgd', help='kept (AdamW is used, as in the reference)')
+    parser.add_argument('--decoding_strategy', choices=['greedy', 'beam', 'sample'], default='greedy')
     parser.set_defaults(logging_frequency=500)
     args = parser.parse_args(argv)
     args.cuda = torch.cuda.is_available()

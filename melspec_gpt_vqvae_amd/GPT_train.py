@@ -17,26 +17,42 @@ from . import config as _config
 SEED = 783435
 
 
+REQUIRED = object()
+# (flag, type, default, help) - names and defaults are the reference's command line (GPT_train.py:25-50); the ints that
+# act as switches (train / eval / test) default to False there, kept
+REFERENCE_FLAGS = [
+    ("dataset", str, REQUIRED, "config set GPT_<dataset> / GPT_VAE_<dataset>"),
+    ("experiment", str, REQUIRED, "run name: logs and checkpoints go under <log_root>/<experiment>-<dataset>"),
+    ("train", int, False, "1 = run the training loop"),
+    ("resume", str, None, "checkpoint to continue from"),
+    ("workers", int, 1, "DataLoader worker processes"),
+    ("eval", int, False, "1 = run validation and print val/loss"),
+    ("test", int, False, "kept for command-line compatibility"),
+    ("logging_frequency", int, 200, "steps between text log lines"),
+    ("test_interpolation", int, False, "kept for command-line compatibility"),
+    ("reconstruct_spec", str, "", "VQ-VAE checkpoint (LitVQVAE state_dict) for decode_to_img"),
+    ("vocoder", str, "", "MelGAN checkpoint for audio reconstruction"),
+]
+# not in the reference: overrides of config entries, where split lists / logs live, numerics lane, smoke-run cap
+LOCAL_FLAGS = [(n, t, None, "override of the config entry") for n, t in
+               (("epochs", int), ("batch_size", int), ("n_layer", int), ("n_head", int), ("n_embd", int),
+                ("spec_dir_path", str), ("learning_rate", float))] + [
+    ("splits_dir", str, "./data", "directory of the vas_*/vggsound_* split lists"),
+    ("log_root", str, "lightning_logs", "root of logs and checkpoints"),
+    ("max_steps_per_epoch", int, None, "cap on steps per epoch (smoke runs)"),
+]
+
+
+def add_flags(parser, table):
+    for name, typ, default, text in table:
+        kw = {"required": True} if default is REQUIRED else {"default": default}
+        parser.add_argument("--" + name, type=typ, help=text, **kw)
+
+
 def _common_flags(parser):
-    parser.add_argument('--dataset', type=str, required=True, help='dataset to use')
-    parser.add_argument('--experiment', type=str, required=True, help='experiment name')
-    parser.add_argument('--train', type=int, default=False, help='start training process')
-    parser.add_argument('--resume', type=str, default=None, help='resume_from the checkpoint')
-    parser.add_argument('--workers', type=int, default=1, help='number of workers for data')
-    parser.add_argument('--eval', type=int, default=False, help='evaluate model')
-    parser.add_argument('--test', type=int, default=False, help='test model')
-    parser.add_argument('--logging_frequency', type=int, default=200, help='number of steps for text logging')
-    parser.add_argument('--test_interpolation', type=int, default=False)
-    parser.add_argument('--reconstruct_spec', type=str, default='', help="model ckpt for mel-spectrograms reconstuction")
-    parser.add_argument('--vocoder', type=str, default='', help="model ckpt for vocoder for audio reconstuction")
-    # not in the reference: overrides of config entries + where the split lists and logs live
-    for name, typ in (("epochs", int), ("batch_size", int), ("n_layer", int), ("n_head", int), ("n_embd", int),
-                      ("spec_dir_path", str), ("learning_rate", float)):
-        parser.add_argument("--" + name, type=typ, default=None)
-    parser.add_argument('--splits_dir', type=str, default='./data')
-    parser.add_argument('--log_root', type=str, default='lightning_logs')
-    parser.add_argument('--dtype', choices=["f32", "bf16", "fp16"], default="f32", help="kernel numerics lane")
-    parser.add_argument('--max_steps_per_epoch', type=int, default=None)
+    add_flags(parser, REFERENCE_FLAGS)
+    add_flags(parser, LOCAL_FLAGS)
+    parser.add_argument("--dtype", choices=["f32", "bf16", "fp16"], default="f32", help="kernel numerics lane")
 
 
 def merge_config(args, set_name):
