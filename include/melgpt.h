@@ -44,6 +44,12 @@ const char* melgpt_strerror(int code);
  * workgroup's whole tile list.  0 (default) = use every CU; per process. */
 int melgpt_set_reserved_cus(int n);
 int melgpt_get_reserved_cus(void);
+/* Claimed tiles: with 1 the persistent GEMM's workgroups draw every tile from a per-launch counter (scalar-memory atomic
+ * at L2, ticket handed to the workgroup's other waves through a mailbox in global memory) instead of walking static
+ * lists, so a workgroup that starts late or runs slowly - its CU shared with an RCCL kernel - does not strand work;
+ * same results bit for bit.  Default 0 (MELGPT_DYNAMIC_TILES=1 in the environment turns it on); per process. */
+int melgpt_set_dynamic_tiles(int on);
+int melgpt_get_dynamic_tiles(void);
 
 /* ===================================================================== mel frontend
  * wav -> log-mel in one kernel = MelSpectrogram.__call__ + TRANSFORMS

@@ -35,6 +35,8 @@ _PROTOS = {
     "melgpt_strerror": [_i],
     "melgpt_set_reserved_cus": [_i],
     "melgpt_get_reserved_cus": [],
+    "melgpt_set_dynamic_tiles": [_i],
+    "melgpt_get_dynamic_tiles": [],
     "melgpt_vq_argmin_fwd": [_p, _i, _l, _i, _l, _l, _l, _l, _p, _i, _p, _p, _p, _p, _p, _p],
     "melgpt_vq_argmin_fwd_ex": [_p, _i, _l, _i, _l, _l, _l, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "melgpt_vq_max_grid": [],

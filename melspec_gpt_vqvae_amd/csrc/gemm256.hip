@@ -103,8 +103,8 @@ __device__ __forceinline__ void wait_vm_barrier() {
 //
 // Tile order: the 32 workgroups of one XCD (blockIdx & 7, round-robin dispatch) take an RM x RN block of tiles, so
 // one L2 serves RM row panels of A and RN column panels of B instead of 1 + 32.
-template <int ALAY, int BLAY, int MODE, int TM>
-__global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m, int tiles_n, int batch, int RN) {
+template <int ALAY, int BLAY, int MODE, int TM, bool DYN = false>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m, int tiles_n, int batch, int RN, int* sched) {
   constexpr int WN = 4, TN = 4, NW = 8, BM = 32 * TM, BN = 256;  // TM = 8: 256 x 256; TM = 6: 192 x 256 (A row-major only)
   constexpr int HALF = 256 * 128, NSLOT = 5;
   constexpr int PER = HALF / 1024 / NW;   // LDS-DMA pieces per wave per B half-unit (4)
@@ -121,14 +121,72 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
   const int total = rows_m * tiles_n;
 
   // ---- this workgroup's tile list: item r -> (batch, m0, n0) or "not a tile"
-  const int RM = RN > 0 ? (G >> 3) / RN : 0;
-  const int blocks_n = RN > 0 ? (tiles_n + RN - 1) / RN : 0;
-  const int nblocks = RN > 0 ? ((rows_m + RM - 1) / RM) * blocks_n : 0;
+  const int RM = !DYN && RN > 0 ? (G >> 3) / RN : 0;
+  const int blocks_n = !DYN && RN > 0 ? (tiles_n + RN - 1) / RN : 0;
+  const int nblocks = !DYN && RN > 0 ? ((rows_m + RM - 1) / RM) * blocks_n : 0;
   const int xcd = blockIdx.x & 7, jslot = blockIdx.x >> 3;
-  auto live = [&](int r) { return RN > 0 ? r * 8 + xcd < nblocks : r * G + (int)blockIdx.x < total; };
+  // CLAIMED TILES (sched != nullptr; the host passes RN = 0): instead of a static list every tile is drawn from one
+  // counter, so a workgroup that starts late - its CU was held by an RCCL kernel overlapped with the backward pass -
+  // or runs slowly does not leave a whole list undone: the others take the work.  Tickets are drawn by wave 0 with a
+  // scalar-memory atomic (executed at L2, does not touch vmcnt) TWO items ahead and handed to the other seven waves
+  // through a two-slot mailbox in global memory (the ring leaves no LDS byte free): written with s_atomic_swap, read
+  // with s_atomic_or 0 - both at L2, no cache to go stale - and always at least one workgroup barrier apart.  sched[0] =
+  // counter, sched[16 + 2 blockIdx + (item & 1)]
+  // = ticket of that item.  Item j of a workgroup is tile `ticket_j`; a ticket >= total ends the list.  Every workgroup
+  // draws exactly one dead ticket (it stops drawing then), so a launch makes total + G draws: the one that returns
+  // total + G - 1 is the last and puts the counter back to 0 for the cell's next launch.
+  constexpr bool dyn = DYN;  // a kernel variant of its own: the static-list kernels keep their register budget
+  int tk0 = 0x3FFFFFFF, tk1 = 0x3FFFFFFF;  // tickets of this workgroup's even / odd items (wave-uniform)
+  bool drawing = true;                      // wave 0: no dead ticket drawn yet
+  auto satomic = [](int* addr, int v, auto op_c) -> int {
+    constexpr int OP = decltype(op_c)::value;  // 0 add, 1 swap, 2 or
+    // (operands pinned to SGPRs: everything here is wave-uniform, but the compiler cannot always prove it)
+    const unsigned long long a64 = (unsigned long long)addr;
+    // (the builtin returns int: without the casts a low word with bit 31 set sign-extends over the high word)
+    addr = (int*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a64 >> 32)) << 32) |
+                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a64));
+    v = __builtin_amdgcn_readfirstlane(v);
+    if constexpr (OP == 0) asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(addr) : "memory");
+    else if constexpr (OP == 1) asm volatile("s_atomic_swap %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(addr) : "memory");
+    else asm volatile("s_atomic_or %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(addr) : "memory");
+    return v;
+  };
+  using op_add = std::integral_constant<int, 0>;
+  using op_swap = std::integral_constant<int, 1>;
+  using op_or = std::integral_constant<int, 2>;
+  int* mail = sched + 16 + 2 * (int)blockIdx.x;
+  auto draw = [&](int item) {  // wave 0: ticket for `item` into its mailbox slot
+    int tkt = 0x3FFFFFFF;
+    if (drawing) {
+      tkt = satomic(sched, 1, op_add{});
+      if (tkt == total + G - 1) satomic(sched, 0, op_swap{});  // the launch's last draw: counter back to 0
+      drawing = tkt < total;
+    }
+    satomic(mail + (item & 1), tkt, op_swap{});
+  };
+  auto take = [&](int item) {  // every wave: ticket of `item` out of the mailbox (written at least one barrier ago)
+    const int tkt = satomic(mail + (item & 1), 0, op_or{});
+    if (item & 1) tk1 = tkt;
+    else tk0 = tkt;
+  };
+  // (both tickets read, then chosen by mask: written as `r & 1 ? tk1 : tk0` the compiler selects between the two
+  // ADDRESSES inside the closure, which keeps closure and tickets in scratch memory)
+  auto ticket = [&](int r) {
+    const int a = tk0, b = tk1, odd = -(r & 1);
+    return __builtin_amdgcn_readfirstlane((b & odd) | (a & ~odd));  // wave-uniform by construction: say so
+  };
+  auto live = [&](int r) {
+    if constexpr (dyn) return ticket(r) < total;
+    else return RN > 0 ? r * 8 + xcd < nblocks : r * G + (int)blockIdx.x < total;
+  };
   auto decode = [&](int r, int& bz, int& m0, int& n0) -> bool {
     int tm, tn;
-    if (RN > 0) {
+    if constexpr (dyn) {
+      const int tl = ticket(r);
+      if (tl >= total) return false;
+      tm = tl / tiles_n;
+      tn = tl - tm * tiles_n;
+    } else if (RN > 0) {
       const int blk = r * 8 + xcd;
       tm = (blk / blocks_n) * RM + jslot / RN;
       tn = (blk % blocks_n) * RN + jslot % RN;
@@ -145,11 +203,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
     return true;
   };
   auto next_item = [&](int r) {  // first item after r that is a tile, or the first dead one
-    int bz, m0, n0;
-    do ++r;
-    while (live(r) && !decode(r, bz, m0, n0));
-    return r;
+    if constexpr (dyn) {
+      return r + 1;  // (its ticket was taken out of the mailbox at the top of the K unit that gets here)
+    } else {
+      int bz, m0, n0;
+      do ++r;
+      while (live(r) && !decode(r, bz, m0, n0));
+      return r;
+    }
   };
+  if constexpr (dyn) {  // items 0 and 1 drawn up front; a barrier between the mailbox writes and the first read
+    if (w == 0) {
+      draw(0);
+      draw(1);
+    }
+    asm volatile("s_barrier" ::: "memory");
+    take(0);
+  }
 
   // ---- issue cursor: source plan of the tile whose half-units are being requested.  Piece j of a wave is piece
   // w + 8 j of the half-unit; its rows are 64 j rows (ROW) / 16 j k-rows (K-major) below piece 0's, and the swizzled
@@ -171,6 +241,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
     pok = live(r) && decode(r, bz, pm0, pn0);  // dead: every request is out of bounds (zero fills nobody reads)
     ra = make_rsrc4((const char*)p.A + (long long)bz * p.sA * 2, p.a_bytes);
     rb = make_rsrc4((const char*)p.B + (long long)bz * p.sB * 2, p.b_bytes);
+    if constexpr (DYN) {  // wave-uniform by construction (the ticket is): pinned to SGPRs for the LDS-DMA asm blocks
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ra[e] = __builtin_amdgcn_readfirstlane(ra[e]);
+        rb[e] = __builtin_amdgcn_readfirstlane(rb[e]);
+      }
+    }
     if constexpr (ALAY == LAY_KMAJ) {
       a_base0 = (pok && pm0 + k_lc * 8 < p.M) ? (unsigned)(((long long)k_row0 * p.lda + pm0) * 2) + k_lc * 16 : OOB;
     } else if constexpr (ALAY == LAY_CONV) {
@@ -231,13 +308,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
   };
 
   int first_item = -1;
-  first_item = next_item(first_item);
+  first_item = next_item(first_item);  // (claimed tiles: item 0, ticket taken above)
   // Issue cursor.  The stream of half-units is A(0) B(0) A(1) | B(1) A(2) | B(2) A(3) | ... : three up front, then
   // every K-unit iteration requests the B half of unit `iu` and the A half of the unit after it.
   int ir = first_item, iu = 0;  // item and K-unit of the next B half to request
   int fill = 0;                 // slot of the next half-unit to request
   plan(ir);
   auto next_slot = [&]() { fill = fill + 1 == NSLOT ? 0 : fill + 1; };
+  // claimed tiles: called (by every wave) before the cursor moves from item `ir` to `ir + 1`, no LDS read in flight:
+  // takes that item's ticket; wave 0 then draws the one after it into the slot item `ir` no longer needs
+  auto claim_ahead = [&]() {
+    take(ir + 1);
+    if (w == 0) draw(ir + 2);
+  };
   auto next_unit = [&]() {      // the B half of unit iu is out: move on (possibly to the next tile)
     if (++iu == nu) {
       iu = 0;
@@ -245,6 +328,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
       plan(ir);
     }
   };
+  if constexpr (dyn) if (nu == 1) {  // the prologue's next_unit() below already moves to item 1
+    asm volatile("s_barrier" ::: "memory");  // every wave has taken item 0 out of the slot item 2 is drawn into
+    claim_ahead();
+  }
 #pragma unroll
   for (int j = 0; j < PER_A; ++j) issue_a_piece(0, smem, j);           // A(0) -> slot 0
 #pragma unroll
@@ -272,6 +359,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
       // requested before the previous tile's epilogue were drained there (vmcnt(0)): barrier only.
       if (first || u > 0) wait_vm_barrier<PER_A>();
       else asm volatile("s_barrier" ::: "memory");
+      if constexpr (dyn) if (iu + 1 == nu) claim_ahead();  // this unit's next_unit() moves the cursor to the next item
       // The eight LDS-DMA pieces of this iteration (B of unit iu, then A of the unit after) are issued ONE AT A TIME
       // between groups of MFMAs: a piece occupies the issuing wave for 60-180 cycles, and all 64 of a workgroup's
       // pieces issued together right after the barrier stall every wave for as long as the whole K-unit's MFMAs
@@ -399,7 +487,25 @@ int launch_tm(const GemmParams& p, int batch, int ncu, hipStream_t s) {
     for (int c = 1; c * c <= per; ++c)
       if (per % c == 0 && c <= tiles_n) RN = c;  // most square block whose width fits the tile grid
   }
-  hipLaunchKernelGGL((gemm256_kernel<ALAY, BLAY, MODE, TM>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n, batch, RN);
+  int* sched = nullptr;
+  if (melgpt_get_dynamic_tiles() && 16 + 2 * grid <= MELGPT_TILE_CELL_INTS) {
+    sched = melgpt_tile_cell();  // claimed tiles: this launch's counter + mailboxes (abi.hip); nullptr -> static lists
+    if (sched) RN = 0;
+  }
+  if (sched) {
+    static bool attr_dyn = false;
+    if (!attr_dyn) {
+      if (hipFuncSetAttribute((const void*)gemm256_kernel<ALAY, BLAY, MODE, TM, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        return MELGPT_ERR_LAUNCH;
+      attr_dyn = true;
+    }
+    hipLaunchKernelGGL((gemm256_kernel<ALAY, BLAY, MODE, TM, true>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n,
+                       batch, 0, sched);
+  } else {
+    hipLaunchKernelGGL((gemm256_kernel<ALAY, BLAY, MODE, TM, false>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n,
+                       batch, RN, sched);
+  }
   return melgpt_launch_status();
 }
 

@@ -399,3 +399,42 @@ def test_reserved_cus_leave_room_for_rccl_and_do_not_change_results():
     finally:
         _ffi.call("melgpt_set_reserved_cus", 0)
     assert torch.equal(ops.gemm(a, b), ref)
+
+
+def test_claimed_tiles_give_the_same_bits_as_static_tile_lists():
+    """melgpt_set_dynamic_tiles(1): the persistent GEMM's workgroups draw every tile from a per-launch counter (scalar
+    atomics + a global-memory mailbox) instead of walking static lists - what dp.DataParallel turns on when RCCL kernels
+    share the chip with the backward pass.  Same tiles, same arithmetic: results must be bit-identical, launch after
+    launch (the counter cell resets itself), for every operand layout / epilogue family / tile height."""
+    from melspec_gpt_vqvae_amd import _ffi, ops
+
+    torch.manual_seed(8)
+    a = torch.randn(33920, 1024, device=DEV).bfloat16()
+    w = (torch.randn(4096, 1024, device=DEV) * 0.1).bfloat16()
+    w2 = (torch.randn(1024, 4096, device=DEV) * 0.1).bfloat16()
+    bias = torch.randn(4096, device=DEV) * 0.1
+    r = torch.randn(33920, 1024, device=DEV).bfloat16()
+    dy = (torch.randn(33920, 1024, device=DEV) * 0.1).bfloat16()
+
+    def run():
+        dact = torch.empty(33920, 4096, dtype=torch.bfloat16, device=DEV)
+        act = ops.gemm(a, w, bias=bias, act=ops.ACT_GELU_DACT, pre_out=dact)                    # NT, EPI_DACT16
+        y = ops.gemm(act, w2, bias=bias[:1024].contiguous(), residual=r, drop_p=0.5, seed=3, stream_id=1)  # NT, full mode
+        g = ops.gemm(dy, w2, b_kmajor=True, act=ops.ACT_MUL, residual=dact)                     # NN, plain + R, 192 rows
+        gw = torch.empty(4096, 1024, device=DEV)
+        ops.wgrad(g, a, gw, False)                                                              # TN split-K, f32 out
+        lg = ops.gemm(a, w[:128].contiguous(), out_dtype=torch.float32)                         # few tiles (< one round)
+        return act, dact, y, g, gw, lg
+
+    ref = run()
+    try:
+        _ffi.call("melgpt_set_dynamic_tiles", 1)
+        assert _ffi.lib().melgpt_get_dynamic_tiles() == 1
+        for _ in range(3):
+            got = run()
+            for x, y in zip(got, ref):
+                assert torch.equal(x, y)
+    finally:
+        _ffi.call("melgpt_set_dynamic_tiles", 0)
+    for x, y in zip(run(), ref):
+        assert torch.equal(x, y)
