@@ -121,25 +121,32 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
   const int total = rows_m * tiles_n;
 
   // ---- this workgroup's tile list: item r -> (batch, m0, n0) or "not a tile"
-  const int RM = !DYN && RN > 0 ? (G >> 3) / RN : 0;
-  const int blocks_n = !DYN && RN > 0 ? (tiles_n + RN - 1) / RN : 0;
-  const int nblocks = !DYN && RN > 0 ? ((rows_m + RM - 1) / RM) * blocks_n : 0;
+  const int RM = RN > 0 ? (G >> 3) / RN : 0;
+  const int blocks_n = RN > 0 ? (tiles_n + RN - 1) / RN : 0;
+  const int nblocks = RN > 0 ? ((rows_m + RM - 1) / RM) * blocks_n : 0;
   const int xcd = blockIdx.x & 7, jslot = blockIdx.x >> 3;
-  // CLAIMED TILES (sched != nullptr; the host passes RN = 0): instead of a static list every tile is drawn from one
-  // counter, so a workgroup that starts late - its CU was held by an RCCL kernel overlapped with the backward pass -
-  // or runs slowly does not leave a whole list undone: the others take the work.  Tickets are drawn by wave 0 with a
-  // scalar-memory atomic (executed at L2, does not touch vmcnt) TWO items ahead and handed to the other seven waves
-  // through a two-slot mailbox in global memory (the ring leaves no LDS byte free): written with s_atomic_swap, read
-  // with s_atomic_or 0 - both at L2, no cache to go stale - and always at least one workgroup barrier apart.  sched[0] =
-  // counter, sched[16 + 2 blockIdx + (item & 1)]
-  // = ticket of that item.  Item j of a workgroup is tile `ticket_j`; a ticket >= total ends the list.  Every workgroup
-  // draws exactly one dead ticket (it stops drawing then), so a launch makes total + G draws: the one that returns
-  // total + G - 1 is the last and puts the counter back to 0 for the cell's next launch.
+  // CLAIMED TILES (the DYN variant, sched != nullptr): instead of a static list every tile is drawn from a counter, so a
+  // workgroup that starts late - its CU was held by an RCCL kernel overlapped with the backward pass - or runs slowly
+  // does not leave a whole list undone: the others take the work.  With XCD blocks (RN > 0) each XCD has its OWN counter
+  // over its own blocks (ticket t of XCD x = slot t % per of its block number t / per, per = G / 8 workgroups), so the
+  // tickets a chip's 32 workgroups draw one after the other are the tiles of one RM x RN block and its L2 serves the
+  // same few panels as with the static lists; without blocks there is one counter over the linear tile order.
+  // Tickets are drawn by wave 0 with a scalar-memory atomic (executed at L2, does not touch vmcnt) TWO items ahead and
+  // handed to the other seven waves through a two-slot mailbox in global memory (the ring leaves no LDS byte free):
+  // written with s_atomic_swap, read with s_atomic_or 0 - both at L2, no cache to go stale - and always at least one
+  // workgroup barrier apart.  Cell layout: counter of queue q at sched[32 q] (a 128-byte line each), mailbox of
+  // workgroup b at sched[256 + 2 b + (item & 1)].  A ticket >= qtotal ends the list.  Every workgroup draws exactly one
+  // dead ticket (it stops drawing then), so a queue sees qtotal + qgroups draws: the one that returns
+  // qtotal + qgroups - 1 is the last and puts the counter back to 0 for the cell's next launch.
   constexpr bool dyn = DYN;  // a kernel variant of its own: the static-list kernels keep their register budget
+  const int per = G >> 3;    // workgroups per XCD (RN > 0 implies G % 8 == 0)
+  const int qgroups = RN > 0 ? per : G;
+  const int qtotal = RN > 0 ? per * (nblocks > xcd ? (nblocks - xcd + 7) >> 3 : 0) : total;
   int tk0 = 0x3FFFFFFF, tk1 = 0x3FFFFFFF;  // tickets of this workgroup's even / odd items (wave-uniform)
+  int own0 = 0x3FFFFFFF, own1 = 0x3FFFFFFF;  // wave 0: the tickets it drew (it does not read its own mail)
   bool drawing = true;                      // wave 0: no dead ticket drawn yet
   auto satomic = [](int* addr, int v, auto op_c) -> int {
-    constexpr int OP = decltype(op_c)::value;  // 0 add, 1 swap, 2 or
+    constexpr int OP = decltype(op_c)::value;  // 0 add, 1 swap, 2 or (returned value waited for); 3 swap, posted
     // (operands pinned to SGPRs: everything here is wave-uniform, but the compiler cannot always prove it)
     const unsigned long long a64 = (unsigned long long)addr;
     // (the builtin returns int: without the casts a low word with bit 31 set sign-extends over the high word)
@@ -148,24 +155,48 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
     v = __builtin_amdgcn_readfirstlane(v);
     if constexpr (OP == 0) asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(addr) : "memory");
     else if constexpr (OP == 1) asm volatile("s_atomic_swap %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(addr) : "memory");
-    else asm volatile("s_atomic_or %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(addr) : "memory");
+    else if constexpr (OP == 2) asm volatile("s_atomic_or %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(addr) : "memory");
+    else asm volatile("s_atomic_swap %0, %1, 0x0" : : "s"(v), "s"(addr) : "memory");  // performed at L2 by the next lgkmcnt(0)
     return v;
   };
   using op_add = std::integral_constant<int, 0>;
   using op_swap = std::integral_constant<int, 1>;
   using op_or = std::integral_constant<int, 2>;
-  int* mail = sched + 16 + 2 * (int)blockIdx.x;
+  using op_post = std::integral_constant<int, 3>;
+  int* counter = sched + (RN > 0 ? 32 * xcd : 0);
+  int* mail = sched + 256 + 2 * (int)blockIdx.x;
+  // ticket -> tile row / column over all batches; false: a slot of a block that hangs over the edge of the tile grid
+  auto ticket_tile = [&](int tl, int& tm, int& tn) -> bool {
+    if (RN > 0) {
+      const int lb = tl / per, j = tl - lb * per, blk = lb * 8 + xcd;
+      const int bm = blk / blocks_n, jm = j / RN;
+      tm = bm * RM + jm;
+      tn = (blk - bm * blocks_n) * RN + (j - jm * RN);
+      return tm < rows_m && tn < tiles_n;
+    }
+    tm = tl / tiles_n;
+    tn = tl - tm * tiles_n;
+    return true;
+  };
   auto draw = [&](int item) {  // wave 0: ticket for `item` into its mailbox slot
     int tkt = 0x3FFFFFFF;
     if (drawing) {
-      tkt = satomic(sched, 1, op_add{});
-      if (tkt == total + G - 1) satomic(sched, 0, op_swap{});  // the launch's last draw: counter back to 0
-      drawing = tkt < total;
+      int tm, tn;
+      do {  // (tickets of overhanging slots are drawn and dropped)
+        tkt = satomic(counter, 1, op_add{});
+        if (tkt == qtotal + qgroups - 1) satomic(counter, 0, op_swap{});  // the queue's last draw: counter back to 0
+      } while (tkt < qtotal && !ticket_tile(tkt, tm, tn));
+      drawing = tkt < qtotal;
     }
-    satomic(mail + (item & 1), tkt, op_swap{});
+    if (item & 1) own1 = tkt;
+    else own0 = tkt;
+    // posted: wave 0 waits for it (lgkmcnt(0)) in front of the next workgroup barrier, and the others read the slot
+    // at least one barrier later
+    satomic(mail + (item & 1), tkt, op_post{});
   };
   auto take = [&](int item) {  // every wave: ticket of `item` out of the mailbox (written at least one barrier ago)
-    const int tkt = satomic(mail + (item & 1), 0, op_or{});
+    const int o0 = own0, o1 = own1, odd = -(item & 1);  // (chosen by mask, as in ticket() below)
+    const int tkt = w == 0 ? ((o1 & odd) | (o0 & ~odd)) : satomic(mail + (item & 1), 0, op_or{});
     if (item & 1) tk1 = tkt;
     else tk0 = tkt;
   };
@@ -176,16 +207,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
     return __builtin_amdgcn_readfirstlane((b & odd) | (a & ~odd));  // wave-uniform by construction: say so
   };
   auto live = [&](int r) {
-    if constexpr (dyn) return ticket(r) < total;
+    if constexpr (dyn) return ticket(r) < qtotal;
     else return RN > 0 ? r * 8 + xcd < nblocks : r * G + (int)blockIdx.x < total;
   };
   auto decode = [&](int r, int& bz, int& m0, int& n0) -> bool {
     int tm, tn;
     if constexpr (dyn) {
       const int tl = ticket(r);
-      if (tl >= total) return false;
-      tm = tl / tiles_n;
-      tn = tl - tm * tiles_n;
+      if (tl >= qtotal) return false;
+      ticket_tile(tl, tm, tn);  // (draw() only hands out tickets of real tiles)
     } else if (RN > 0) {
       const int blk = r * 8 + xcd;
       tm = (blk / blocks_n) * RM + jslot / RN;
@@ -212,12 +242,29 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
       return r;
     }
   };
-  if constexpr (dyn) {  // items 0 and 1 drawn up front; a barrier between the mailbox writes and the first read
+  // WHEN a ticket is drawn.  Needed: when the load cursor enters item ir + 1, during the last K unit but one of item
+  // ir; the others take it at the top of that unit (iu + 1 == nu), so wave 0 must have drawn it by the top of the unit
+  // before (iu + 2 == nu) - the LATE draw, a claim held for under three K units.  Drawing late costs every tile a second
+  // L2 round trip in front of a barrier (measured: + 3 % on the step's GEMMs), so while MORE THAN ONE ROUND of tickets
+  // is left in the queue (qtotal - last ticket > qgroups: nobody can be left without work by it) wave 0 draws item
+  // ir + 2 EARLY, in the same unit top in which item ir + 1 is taken.  Drawn early without that test, the first
+  // workgroups to start took two tiles each of a 240-tile launch and left the rest of the chip idle (8.1 ms against 4.3).
+  // Launches with fewer than three K units per tile have no room for the late draw: always two items ahead.
+  const bool early = nu < 3;
+  int drawn = -1, t_last = 0;  // wave 0: last item drawn for, and its ticket
+  auto plenty = [&]() { return early || qtotal - t_last > qgroups; };
+  auto draw_next = [&]() {
+    ++drawn;
+    draw(drawn);
+    const int o0 = own0, o1 = own1, odd = -(drawn & 1);
+    t_last = (o1 & odd) | (o0 & ~odd);
+  };
+  if constexpr (dyn) {  // first draws; a barrier between the mailbox writes and the first read
     if (w == 0) {
-      draw(0);
-      draw(1);
+      draw_next();
+      if (plenty()) draw_next();
     }
-    asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     take(0);
   }
 
@@ -315,11 +362,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
   int fill = 0;                 // slot of the next half-unit to request
   plan(ir);
   auto next_slot = [&]() { fill = fill + 1 == NSLOT ? 0 : fill + 1; };
-  // claimed tiles: called (by every wave) before the cursor moves from item `ir` to `ir + 1`, no LDS read in flight:
-  // takes that item's ticket; wave 0 then draws the one after it into the slot item `ir` no longer needs
-  auto claim_ahead = [&]() {
-    take(ir + 1);
-    if (w == 0) draw(ir + 2);
+  // claimed tiles: called (by every wave) at the top of a K unit, no LDS read in flight, the cursor in item `ir`
+  auto claim = [&]() {
+    if (iu + 2 == nu) {
+      if (w == 0 && drawn < ir + 1) draw_next();  // late (into the slot of item ir - 1)
+    } else if (iu + 1 == nu) {
+      take(ir + 1);
+      if (w == 0 && drawn < ir + 2 && plenty()) draw_next();  // early (into the slot of item ir)
+    }
   };
   auto next_unit = [&]() {      // the B half of unit iu is out: move on (possibly to the next tile)
     if (++iu == nu) {
@@ -330,7 +380,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
   };
   if constexpr (dyn) if (nu == 1) {  // the prologue's next_unit() below already moves to item 1
     asm volatile("s_barrier" ::: "memory");  // every wave has taken item 0 out of the slot item 2 is drawn into
-    claim_ahead();
+    claim();
   }
 #pragma unroll
   for (int j = 0; j < PER_A; ++j) issue_a_piece(0, smem, j);           // A(0) -> slot 0
@@ -357,9 +407,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
       // H(2u), H(2u+1) must have landed for every wave and every wave must be past its reads of unit u-1, whose two
       // slots are refilled now.  One younger half-unit (an A half: PER_A operations) may still be in flight.  The half-units
       // requested before the previous tile's epilogue were drained there (vmcnt(0)): barrier only.
+      if constexpr (dyn) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave 0's posted mailbox write (no LDS read is pending here)
       if (first || u > 0) wait_vm_barrier<PER_A>();
       else asm volatile("s_barrier" ::: "memory");
-      if constexpr (dyn) if (iu + 1 == nu) claim_ahead();  // this unit's next_unit() moves the cursor to the next item
+      if constexpr (dyn) claim();  // (iu + 1 == nu: this unit's next_unit() moves the cursor to the next item)
       // The eight LDS-DMA pieces of this iteration (B of unit iu, then A of the unit after) are issued ONE AT A TIME
       // between groups of MFMAs: a piece occupies the issuing wave for 60-180 cycles, and all 64 of a workgroup's
       // pieces issued together right after the barrier stall every wave for as long as the whole K-unit's MFMAs
@@ -460,7 +511,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
     }
 #endif
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
 static int device_cus();
@@ -488,10 +539,8 @@ int launch_tm(const GemmParams& p, int batch, int ncu, hipStream_t s) {
       if (per % c == 0 && c <= tiles_n) RN = c;  // most square block whose width fits the tile grid
   }
   int* sched = nullptr;
-  if (melgpt_get_dynamic_tiles() && 16 + 2 * grid <= MELGPT_TILE_CELL_INTS) {
-    sched = melgpt_tile_cell();  // claimed tiles: this launch's counter + mailboxes (abi.hip); nullptr -> static lists
-    if (sched) RN = 0;
-  }
+  if (melgpt_get_dynamic_tiles() && 256 + 2 * grid <= MELGPT_TILE_CELL_INTS)
+    sched = melgpt_tile_cell();  // claimed tiles: this launch's counters + mailboxes (abi.hip); nullptr -> static lists
   if (sched) {
     static bool attr_dyn = false;
     if (!attr_dyn) {
@@ -501,7 +550,7 @@ int launch_tm(const GemmParams& p, int batch, int ncu, hipStream_t s) {
       attr_dyn = true;
     }
     hipLaunchKernelGGL((gemm256_kernel<ALAY, BLAY, MODE, TM, true>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n,
-                       batch, 0, sched);
+                       batch, RN, sched);
   } else {
     hipLaunchKernelGGL((gemm256_kernel<ALAY, BLAY, MODE, TM, false>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n,
                        batch, RN, sched);

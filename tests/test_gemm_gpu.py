@@ -402,7 +402,7 @@ def test_reserved_cus_leave_room_for_rccl_and_do_not_change_results():
 
 
 def test_claimed_tiles_give_the_same_bits_as_static_tile_lists():
-    """melgpt_set_dynamic_tiles(1): the persistent GEMM's workgroups draw every tile from a per-launch counter (scalar
+    """melgpt_set_dynamic_tiles(1): the persistent GEMM's workgroups draw every tile from per-launch counters (one per XCD, or one for all; scalar
     atomics + a global-memory mailbox) instead of walking static lists - what dp.DataParallel turns on when RCCL kernels
     share the chip with the backward pass.  Same tiles, same arithmetic: results must be bit-identical, launch after
     launch (the counter cell resets itself), for every operand layout / epilogue family / tile height."""
@@ -424,17 +424,20 @@ def test_claimed_tiles_give_the_same_bits_as_static_tile_lists():
         gw = torch.empty(4096, 1024, device=DEV)
         ops.wgrad(g, a, gw, False)                                                              # TN split-K, f32 out
         lg = ops.gemm(a, w[:128].contiguous(), out_dtype=torch.float32)                         # few tiles (< one round)
-        return act, dact, y, g, gw, lg
+        sq = ops.gemm(a[:3584], w[:3584].contiguous())            # 196 tiles < 256 workgroups: one counter, linear order
+        return act, dact, y, g, gw, lg, sq
 
     ref = run()
     try:
         _ffi.call("melgpt_set_dynamic_tiles", 1)
         assert _ffi.lib().melgpt_get_dynamic_tiles() == 1
-        for _ in range(3):
+        for reserve in (0, 0, 0, 16, 16):   # 16: 240 workgroups, 30 per XCD queue (what dp.DataParallel sets with it)
+            _ffi.call("melgpt_set_reserved_cus", reserve)
             got = run()
             for x, y in zip(got, ref):
                 assert torch.equal(x, y)
     finally:
         _ffi.call("melgpt_set_dynamic_tiles", 0)
+        _ffi.call("melgpt_set_reserved_cus", 0)
     for x, y in zip(run(), ref):
         assert torch.equal(x, y)
