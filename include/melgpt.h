@@ -347,15 +347,16 @@ int melgpt_conv3x3_gn_nhwc(const void* x, int B, int H, int W, int Cin, const fl
                            const float* bias, const void* residual, void* y, int dtype, void* stream);
 
 /* The same launch that ALSO yields the GroupNorm(32) statistics (eps out_eps) of its own output y - what the block's next
- * Normalize (:124) would otherwise read y again for: per-tile partial sums leave the conv's epilogue (values as stored:
- * bias added, rounded to bf16), melgpt_groupnorm_finalize adds them per image in tile order.  bf16, Cout == 128, no
- * residual, shapes that run on the persistent kernel; anything else: MELGPT_ERR_UNSUPPORTED before any launch (callers
- * then use melgpt_conv3x3_gn_nhwc + melgpt_groupnorm_stats).  workspace: melgpt_conv3x3_gn_stats_workspace(B,H,W) floats. */
+ * Normalize (:124), or the next ResnetBlock's norm1 (:117) after conv2 + shortcut, would otherwise read y again for:
+ * per-tile partial sums leave the conv's epilogue (values as stored: bias and residual added, rounded to bf16),
+ * melgpt_groupnorm_finalize adds them per image in tile order.  bf16, Cout == 128, shapes that run on the persistent
+ * kernel; anything else: MELGPT_ERR_UNSUPPORTED before any launch (callers then use melgpt_conv3x3_gn_nhwc +
+ * melgpt_groupnorm_stats).  residual may be null.  workspace: melgpt_conv3x3_gn_stats_workspace(B,H,W) floats. */
 int melgpt_conv3x3_gn_stats_workspace(int B, int H, int W);
 int melgpt_conv3x3_gn_nhwc_stats(const void* x, int B, int H, int W, int Cin, const float* mean, const float* rstd,
                                  const float* gamma, const float* beta, int swish, const void* wpack, int Cout,
-                                 const float* bias, void* y, int dtype, float out_eps, float* out_mean, float* out_rstd,
-                                 float* workspace, void* stream);
+                                 const float* bias, const void* residual, void* y, int dtype, float out_eps,
+                                 float* out_mean, float* out_rstd, float* workspace, void* stream);
 /* second stage of melgpt_groupnorm_stats on its own: partial (B, nchunks, 32, 2) sums -> mean / rstd (B*32);
  * count = elements per (image, group) */
 int melgpt_groupnorm_finalize(const float* partial, int nchunks, int B, double count, float eps, float* mean, float* rstd,

@@ -32,6 +32,7 @@ struct FusedConvParams {
   const float* beta;
   int H, W, Cin, swish, tiles_x, tiles_y;
   unsigned x_bytes;      // addressable bytes of x (persistent kernel: patch loads through a buffer resource)
+  unsigned r_bytes;      // ... of the residual (persistent kernel: fetched in accumulator layout, see there)
   float* stat_part;      // persistent kernel, optional: (B, tiles_y*tiles_x, 32, 2) sum / sum of squares of the OUTPUT
 };
 
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
   char* wring = smem + (size_t)WNPIX * pix_bytes;            // [4][128 rows x 128 B]
   float* ab = (float*)(wring + WNST * 16384);                // [Cin][2]
   float* stp = ab + 2 * Cin;                                 // [4 wm][32 groups][2]: output statistics of a tile
+  char* rturn = (char*)(stp + 256) + (threadIdx.x >> 6) * 1024;  // per wave: 8 residual rows on their way into accumulator layout
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w >> 1, wn = w & 1;
   const int i16 = lane & 15, g = lane >> 4;
@@ -247,6 +249,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
   const int cshift = __builtin_ctz(cpp), ch = t & (cpp - 1), ppi = 512 >> cshift;  // pixels advanced per trip
   u32x4 raw[MAXCH];
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(q.x, q.x_bytes);
+  const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.R, p.R ? q.r_bytes : 0u);
   auto fetch_patch = [&](int tile) {
     const int tx = tile % q.tiles_x, ty = (tile / q.tiles_x) % q.tiles_y, b = tile / (q.tiles_x * q.tiles_y);
     const int y0 = ty * WTH, x0 = tx * WTW;
@@ -278,6 +281,32 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
         ab[2 * c + 1] = q.beta[c] - q.mean[b * 32 + c / cg] * a;
       }
     }
+    // The accumulators START from bias + residual instead of zero, and the epilogue is left with rounding and stores.
+    // (Fetched by the epilogue - two batches of row slabs through the LDS staging block - the residual cost a tile 7 500
+    // of its 60 000 cycles, the bias round trip another ~2 000: tools/lab/convw_lab.hip.)  The residual is requested
+    // here as full rows - 8 lanes per 128-byte row of the wave's 64 channels, 8 pixels per load: requested in
+    // accumulator layout (8 bytes per lane, neighbouring lanes 256 bytes apart) every lane is a memory request of its
+    // own and the 128 loads of a tile take as long to issue as they save - lands under the staging pass below and is
+    // turned into accumulator layout through a 1 KiB block of LDS per wave when the accumulators are initialised.
+    // Requested AFTER the normalisation constants above: those loads are waited for with vmcnt(0), which would wait for
+    // these as well.
+    u32x4 rrow[4][2];
+    f32x4 bv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + wn * 64 + nt * 16 + g * 4;
+      bv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias && n < p.N) bv[nt] = *(const f32x4*)(p.bias + n);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int hp = 0; hp < 2; ++hp) {
+        const int y = y0 + wm * 4 + mt, x = x0 + hp * 8 + (lane >> 3), n = n0 + wn * 64 + (lane & 7) * 8;
+        const bool ok = p.R && y < q.H && x < q.W && n < p.N;
+        const unsigned off = ok ? (unsigned)(((((long long)b * q.H + y) * q.W + x) * p.ldr + n) * ES) : OOB;
+        rrow[mt][hp] = buf_load16(rres, off);
+      }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ab visible; previous tile's epilogue is out of the patch
     // ---- stage the input patch (normalise + swish on the fly; out-of-image pixels are zeros AFTER the normalisation)
     f32x4 sc[4];  // (a, b) of channels 8 ch .. 8 ch + 7, interleaved
@@ -315,9 +344,25 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
 
     f32x4 acc[4][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a) {
+      u32x2 rr[4] = {u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}};
+      if (p.R) {
+        // 8 pixel rows of 128 bytes at a time through the wave's block (16-byte chunk index XOR-ed with the row); the LDS
+        // executes one wave's operations in order: no wait between a pass's reads and the next pass's write
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int hp = 0; hp < 2; ++hp) {
+          *(u32x4*)(rturn + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4)) = rrow[a][hp];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const u32x2 v = *(const u32x2*)(rturn + (i16 & 7) * 128 + (((2 * c + (g >> 1)) ^ (i16 & 7)) << 4) + (g & 1) * 8);
+            if ((i16 >> 3) == hp) rr[c] = v;
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        acc[a][c] = f32x4{bf16lo(rr[c][0]), bf16hi(rr[c][0]), bf16lo(rr[c][1]), bf16hi(rr[c][1])} + bv[c];
+    }
 
     // Two K-steps per barrier (nk is even: the launcher checks): the ring's four stages are two pairs - while pair p is
     // multiplied pair p + 1 lands in the stages pair p - 1 was read from.  At one barrier per 64-wide step the SIMD's two
@@ -359,22 +404,19 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
     asm volatile("s_barrier" ::: "memory");  // everybody is done reading the patch: it becomes the epilogue's staging
     if constexpr (STATS) {
       // GroupNorm(32) statistics of THIS conv's output (Cout = 128: a lane's four consecutive channels are one group),
-      // taken on the values as they are stored (bias added, rounded to bf16): the next ResnetBlock norm then needs no
+      // taken on the values as they are stored (bias and residual added, rounded to bf16): the next ResnetBlock norm then needs no
       // pass over the 2.2 GB tensor.  Per tile a (32, 2) partial, summed across the four pixel-row waves in wave
       // order; melgpt_groupnorm_finalize adds the tiles of an image in tile order.
       float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
       const bool xin = x0 + i16 < q.W;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wn * 64 + nt * 16 + g * 4;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bv = *(const f32x4*)(p.bias + n);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           if (xin && y0 + wm * 4 + mt < q.H) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float v = bf16_to_f32(f32_to_bf16(acc[mt][nt][e] + bv[e]));
+              const float v = bf16_to_f32(f32_to_bf16(acc[mt][nt][e]));  // (bias and residual are in the accumulators)
               s1[nt] += v;
               s2[nt] = fmaf(v, v, s2[nt]);
             }
@@ -410,7 +452,10 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
     }
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));  // keep the epilogue's per-lane offsets out of the tile loop's live range
-    epilogue_rows<T, 4, 4, EPI_PLAIN16>(p, acc, mrow, min(WTW, q.W - x0), n0 + wn * 64, 0, lane_e, smem + w * 4096);
+    GemmParams pe = p;  // (bias and residual are in the accumulators: the loadless plain mode)
+    pe.bias = nullptr;
+    pe.R = nullptr;
+    epilogue_rows<T, 4, 4, EPI_PLAIN16N>(pe, acc, mrow, min(WTW, q.W - x0), n0 + wn * 64, 0, lane_e, smem + w * 4096);
 #if CONVW_LAB
     if (blockIdx.x == 7 && t == 0) {
       const int k = (tile - 7) / gridDim.x;
@@ -428,7 +473,7 @@ int launch_fused_wide(const FusedConvParams& q0, int B, hipStream_t s) {
   FusedConvParams q = q0;
   q.tiles_x = (q.W + WTW - 1) / WTW;
   q.tiles_y = (q.H + WTH - 1) / WTH;
-  const size_t lds = (size_t)WNPIX * q.Cin * 2 + WNST * 16384 + (size_t)q.Cin * 8 + 1024;
+  const size_t lds = (size_t)WNPIX * q.Cin * 2 + WNST * 16384 + (size_t)q.Cin * 8 + 1024 + 8 * 1024;
   static int ncu = 0;
   if (!ncu) {
     int dev = 0, n = 0;
@@ -507,10 +552,10 @@ static int conv3x3_gn_impl(const void* x, int B, int H, int W, int Cin, const fl
   q.tiles_x = (W + TW - 1) / TW; q.tiles_y = (H + TH - 1) / TH;
   hipStream_t s = (hipStream_t)stream;
   q.stat_part = stat_part;
-  if (stat_part && (dtype != MELGPT_BF16 || Cout != 128 || residual)) return MELGPT_ERR_UNSUPPORTED;
+  if (stat_part && (dtype != MELGPT_BF16 || Cout != 128)) return MELGPT_ERR_UNSUPPORTED;
   if (dtype == MELGPT_F32) return launch_fused<float>(q, B, s);
   // narrow bf16 layers with plenty of 16 x 16 tiles: the persistent kernel with the weight ring
-  const size_t wide_lds = (size_t)WNPIX * Cin * 2 + WNST * 16384 + (size_t)Cin * 8 + 1024;
+  const size_t wide_lds = (size_t)WNPIX * Cin * 2 + WNST * 16384 + (size_t)Cin * 8 + 1024 + 8 * 1024;
   const long long wide_tiles = (long long)((W + WTW - 1) / WTW) * ((H + WTH - 1) / WTH) * B;
   static int wide_off = -1;
   if (wide_off < 0) wide_off = getenv("MELGPT_CONV_WIDE") && atoi(getenv("MELGPT_CONV_WIDE")) == 0;
@@ -518,8 +563,9 @@ static int conv3x3_gn_impl(const void* x, int B, int H, int W, int Cin, const fl
   const long long wide_px = wide_tiles * WTH * WTW, narrow_px = (long long)q.tiles_x * q.tiles_y * B * TH * TW;
   if (!wide_off && wide_lds <= 160 * 1024 && wide_tiles >= 512 && wide_px * 4 <= narrow_px * 5 && q.g.vec_io &&
       (9 * (Cin / 64)) % 2 == 0 &&
-      M * Cin * 2 < 0xFFFFFF00LL) {
+      M * Cin * 2 < 0xFFFFFF00LL && (!residual || M * Cout * 2 < 0xFFFFFF00LL)) {
     q.x_bytes = (unsigned)(M * Cin * 2);
+    q.r_bytes = residual ? (unsigned)(M * Cout * 2) : 0u;
     return launch_fused_wide(q, B, s);
   }
   if (stat_part) return MELGPT_ERR_UNSUPPORTED;
@@ -539,12 +585,12 @@ extern "C" int melgpt_conv3x3_gn_stats_workspace(int B, int H, int W) {
 
 extern "C" int melgpt_conv3x3_gn_nhwc_stats(const void* x, int B, int H, int W, int Cin, const float* mean,
                                             const float* rstd, const float* gamma, const float* beta, int swish,
-                                            const void* wpack, int Cout, const float* bias, void* y, int dtype,
-                                            float out_eps, float* out_mean, float* out_rstd, float* workspace,
-                                            void* stream) {
+                                            const void* wpack, int Cout, const float* bias, const void* residual,
+                                            void* y, int dtype, float out_eps, float* out_mean, float* out_rstd,
+                                            float* workspace, void* stream) {
   MELGPT_CHECK(out_mean && out_rstd && workspace, MELGPT_ERR_BAD_ARG);
-  int st = conv3x3_gn_impl(x, B, H, W, Cin, mean, rstd, gamma, beta, swish, wpack, Cout, bias, nullptr, y, dtype, workspace,
-                           stream);
+  int st = conv3x3_gn_impl(x, B, H, W, Cin, mean, rstd, gamma, beta, swish, wpack, Cout, bias, residual, y, dtype,
+                           workspace, stream);
   if (st != MELGPT_OK) return st;
   const int nchunks = ((W + WTW - 1) / WTW) * ((H + WTH - 1) / WTH);
   return melgpt_groupnorm_finalize(workspace, nchunks, B, (double)H * W * (Cout / 32), out_eps, out_mean, out_rstd, stream);

@@ -522,10 +522,10 @@ def conv3x3_gn(x, stats, gamma, beta, wpack, bias, *, swish=True, residual=None)
     return out
 
 
-def conv3x3_gn_with_out_stats(x, stats, gamma, beta, wpack, bias, out_eps, *, swish=True):
-    """conv3x3_gn that also returns the GroupNorm(32) statistics (mean, rstd) of its OUTPUT, accumulated in the conv's
-    epilogue (the next norm of a ResnetBlock then needs no pass over the tensor).  Returns None when this shape does
-    not run on the persistent fused kernel (bf16, Cout 128, no residual) - nothing has been launched then."""
+def conv3x3_gn_with_out_stats(x, stats, gamma, beta, wpack, bias, out_eps, *, swish=True, residual=None):
+    """conv3x3_gn that also returns the GroupNorm(32) statistics (mean, rstd) of its OUTPUT (residual included),
+    accumulated in the conv's epilogue (the next norm then needs no pass over the tensor).  Returns None when this
+    shape does not run on the persistent fused kernel (bf16, Cout 128) - nothing has been launched then."""
     B, H, W, Cin = x.shape
     Cout = wpack.shape[0]
     if x.dtype != _ffi.HALF_DTYPE or Cout != 128:
@@ -539,8 +539,8 @@ def conv3x3_gn_with_out_stats(x, stats, gamma, beta, wpack, bias, out_eps, *, sw
     mean, rstd = stats if stats is not None else (None, None)
     with _timed(2.0 * B * H * W * Cout * 9 * Cin, f"conv3x3+gn {H}x{W} {Cin}->{Cout}"):
         code = L.melgpt_conv3x3_gn_nhwc_stats(ptr(x), B, H, W, Cin, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), int(swish),
-                                              ptr(wpack), Cout, ptr(bias), ptr(out), dtype_code(x.dtype), float(out_eps),
-                                              ptr(omean), ptr(orstd), ptr(ws), stream())
+                                              ptr(wpack), Cout, ptr(bias), ptr(residual), ptr(out), dtype_code(x.dtype),
+                                              float(out_eps), ptr(omean), ptr(orstd), ptr(ws), stream())
     if code == _ffi.ERR_UNSUPPORTED:
         return None
     _ffi.check(code, "melgpt_conv3x3_gn_nhwc_stats")

@@ -105,8 +105,8 @@ def _gn_swish_conv3x3(norm, conv, h, residual=None, stats=None, next_norm=None):
             stats = ops.groupnorm_stats(h, norm.eps)
         args = (h, stats, _f32(norm.weight), _f32(norm.bias), _packed_weight(conv, h.dtype), _f32(conv.bias))
         y = None
-        if next_norm is not None and residual is None:
-            r = ops.conv3x3_gn_with_out_stats(*args, next_norm.eps, swish=True)
+        if next_norm is not None:
+            r = ops.conv3x3_gn_with_out_stats(*args, next_norm.eps, swish=True, residual=residual)
             if r is not None:
                 y, out_stats = r
         if y is None:
@@ -114,6 +114,23 @@ def _gn_swish_conv3x3(norm, conv, h, residual=None, stats=None, next_norm=None):
     else:
         y = _conv(conv, _gn(norm, h, True), residual=residual)
     return (y, out_stats) if next_norm is not None else y
+
+
+def _block_chain(lvl, n_blocks, h):
+    """the ResnetBlocks (+ AttnBlocks) of one resolution level (reference :263-267 / :377-381).  Between two ResnetBlocks
+    with nothing in between, the first one's conv2 launch also takes the GroupNorm statistics the second one's norm1
+    needs (its epilogue holds the finished tile, residual included)."""
+    stats = None
+    for i_block in range(n_blocks):
+        chained = len(lvl.attn) == 0 and i_block + 1 < n_blocks
+        if chained:
+            h, stats = lvl.block[i_block]._nhwc(h, stats=stats, next_norm=lvl.block[i_block + 1].norm1)
+        else:
+            h = lvl.block[i_block]._nhwc(h, stats=stats)
+            stats = None
+        if len(lvl.attn) > 0:
+            h = lvl.attn[i_block]._nhwc(h)
+    return h
 
 
 class ResnetBlock(nn.Module):
@@ -136,14 +153,16 @@ class ResnetBlock(nn.Module):
             else:
                 self.nin_shortcut = torch.nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
 
-    def _nhwc(self, h):
-        """reference :114-135 on an NHWC tensor (temb is None on this path, dropout p = 0)."""
-        t, t_stats = _gn_swish_conv3x3(self.norm1, self.conv1, h, next_norm=self.norm2)
+    def _nhwc(self, h, stats=None, next_norm=None):
+        """reference :114-135 on an NHWC tensor (temb is None on this path, dropout p = 0).  stats: GroupNorm statistics
+        of h if the launch that produced h already took them; next_norm: the GroupNorm the caller applies to this
+        block's output next (the following ResnetBlock's norm1) - returns (out, its statistics or None) then."""
+        t, t_stats = _gn_swish_conv3x3(self.norm1, self.conv1, h, stats=stats, next_norm=self.norm2)
         if self.in_channels != self.out_channels:
             sc = _conv(self.conv_shortcut if self.use_conv_shortcut else self.nin_shortcut, h)
         else:
             sc = h
-        return _gn_swish_conv3x3(self.norm2, self.conv2, t, residual=sc, stats=t_stats)
+        return _gn_swish_conv3x3(self.norm2, self.conv2, t, residual=sc, stats=t_stats, next_norm=next_norm)
 
     def forward(self, x, temb):
         assert temb is None, "the mel VQ-VAE has no timestep embedding (temb_ch = 0, reference :196)"
@@ -299,10 +318,7 @@ class Encoder(nn.Module):
             h = _conv(self.conv_in, ops.to_nhwc(x, dt))
         for i_level in range(self.num_resolutions):
             lvl = self.down[i_level]
-            for i_block in range(self.num_res_blocks):
-                h = lvl.block[i_block]._nhwc(h)
-                if len(lvl.attn) > 0:
-                    h = lvl.attn[i_block]._nhwc(h)
+            h = _block_chain(lvl, self.num_res_blocks, h)
             if i_level != self.num_resolutions - 1:
                 h = lvl.downsample._nhwc(h)
         h = self.mid.block_1._nhwc(h)
@@ -376,10 +392,7 @@ class Decoder(nn.Module):
         h = self.mid.block_2._nhwc(h)
         for i_level in reversed(range(self.num_resolutions)):
             lvl = self.up[i_level]
-            for i_block in range(self.num_res_blocks + 1):
-                h = lvl.block[i_block]._nhwc(h)
-                if len(lvl.attn) > 0:
-                    h = lvl.attn[i_block]._nhwc(h)
+            h = _block_chain(lvl, self.num_res_blocks + 1, h)
             if i_level != 0:
                 h = lvl.upsample._nhwc(h)
         if self.give_pre_end:

@@ -191,11 +191,12 @@ def test_fused_groupnorm_swish_conv3x3(dt, H, W, Cin, Cout, B):
     assert rel_err(y2.float().cpu().numpy(), ref2.numpy()) < (2e-5 if dt == "f32" else 8e-3)
 
 
+@pytest.mark.parametrize("with_res", [False, True])
 @pytest.mark.parametrize("H,W,B", [(80, 848, 8), (40, 424, 9), (37, 250, 16)])
-def test_fused_conv_also_yields_groupnorm_stats_of_its_output(H, W, B):
-    """bf16, 128 -> 128, no residual: the persistent fused conv accumulates the GroupNorm(32) statistics of its own
-    output in its epilogue (melgpt_conv3x3_gn_nhwc_stats).  Same tensor as the plain call, statistics equal to a
-    separate melgpt_groupnorm_stats pass over it (edge tiles and padded rows included)."""
+def test_fused_conv_also_yields_groupnorm_stats_of_its_output(H, W, B, with_res):
+    """bf16, 128 -> 128, with and without the shortcut operand: the persistent fused conv accumulates the GroupNorm(32)
+    statistics of its own output in its epilogue (melgpt_conv3x3_gn_nhwc_stats).  Same tensor as the plain call,
+    statistics equal to a separate melgpt_groupnorm_stats pass over it (edge tiles and padded rows included)."""
     from melspec_gpt_vqvae_amd import ops
 
     C = 128
@@ -205,8 +206,9 @@ def test_fused_conv_also_yields_groupnorm_stats_of_its_output(H, W, B):
     gm, bt = t(synth.normal(14, (C,), 0.1, 1.0)).to(DEV), t(synth.normal(15, (C,), 0.1)).to(DEV)
     wp = w.permute(0, 2, 3, 1).contiguous().to(DEV)
     stats = ops.groupnorm_stats(x, 1e-6)
-    r = ops.conv3x3_gn_with_out_stats(x, stats, gm, bt, wp, bias, 1e-6, swish=True)
-    y0 = ops.conv3x3_gn(x, stats, gm, bt, wp, bias, swish=True)
+    res = t(synth.normal(16, (B, H, W, C), 0.7)).to(torch.bfloat16).to(DEV) if with_res else None
+    r = ops.conv3x3_gn_with_out_stats(x, stats, gm, bt, wp, bias, 1e-6, swish=True, residual=res)
+    y0 = ops.conv3x3_gn(x, stats, gm, bt, wp, bias, swish=True, residual=res)
     if r is None:
         pytest.skip("this shape does not run on the persistent fused kernel")
     y, (mean, rstd) = r
