@@ -192,6 +192,11 @@ def xl_args(**kw):
     return SimpleNamespace(**d)  # config/config_GPT_VAE_vggsound.py:43-58 + GPT_VAE_train.py flag defaults
 
 
+# debug aid (1-GPU boxes): MELGPT_BENCH_FORCE_DP=1 runs the one rank through dp.DataParallel over a real RCCL process group
+# of size 1 - the exchange's launches, streams and the reserved CUs as an N-GPU run has them, minus the wire
+FORCE_DP = os.environ.get("MELGPT_BENCH_FORCE_DP") == "1"
+
+
 class ClassGPTStep:
     """BASELINE configs[2] (+ the VQ-encode of configs[1]): the default workload, the one `metric` is quoted on."""
     name = "class_gpt"
@@ -207,7 +212,7 @@ class ClassGPTStep:
         self.x_mel, self.c = synthetic_batch(a.batch, rank, device)
         self.opt = FusedAdamW(self.gpt, lr=gargs.learning_rate, betas=(0.9, 0.95), weight_decay=0.01)
         self.opt.grad_scale = 1.0 / world
-        self.dp = DataParallel(self.gpt) if world > 1 else None
+        self.dp = DataParallel(self.gpt) if world > 1 or FORCE_DP else None
         self.full = a.layers == 24
         self.workload = ("VQ-encode (LitVQVAE encoder + 128-code L2 argmin on 80x848 mel tiles) + class-GPT VAS "
                          f"({a.layers} L, 1024, 16 H, T=265, V=128, dropout 0.5) fwd/bwd + AdamW")
@@ -259,7 +264,7 @@ class GPTVAEXLStep:
         self.x = torch.randint(0, 1024, (a.batch, 265), generator=g).to(device)
         self.opt = FusedAdamW(self.vae, lr=args.learning_rate, betas=(0.9, 0.95), weight_decay=0.01)
         self.opt.grad_scale = 1.0 / world
-        self.dp = DataParallel(self.vae) if world > 1 else None
+        self.dp = DataParallel(self.vae) if world > 1 or FORCE_DP else None
         self.full = layers == 40
         self.n_params = sum(p.numel() for p in self.vae.parameters())
         self.workload = (f"GPT-VAE XL (encoder + decoder GPT, {layers}+{layers} L, 1472, 23 H, T=265, V=1024, "
@@ -312,8 +317,13 @@ def main():
     device = torch.device("cuda", dev_index)
     import torch.distributed as dist
 
-    if world > 1:
+    if world > 1 or FORCE_DP:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if FORCE_DP and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if share:
             dist.init_process_group("gloo")
         else:
@@ -414,7 +424,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline and job.name == "class_gpt":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

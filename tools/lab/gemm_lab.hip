@@ -110,3 +110,16 @@ int main(int argc, char** argv) {
   }
   return 0;
 }
+// stand-ins for the library entry points gemm256.hip references (abi.hip is not linked into this harness)
+extern "C" int melgpt_get_reserved_cus(void) { return 0; }
+extern "C" int melgpt_get_dynamic_tiles(void) { return getenv("DYN") != nullptr; }
+extern "C" int* melgpt_tile_cell(void) {
+  static int* pool = nullptr;
+  static unsigned seq = 0;
+  if (!pool) {
+    (void)hipMalloc(&pool, (size_t)64 * MELGPT_TILE_CELL_INTS * sizeof(int));
+    (void)hipMemset(pool, 0, (size_t)64 * MELGPT_TILE_CELL_INTS * sizeof(int));
+    (void)hipDeviceSynchronize();
+  }
+  return pool + (size_t)(seq++ % 64) * MELGPT_TILE_CELL_INTS;
+}
