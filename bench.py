@@ -195,6 +195,8 @@ def xl_args(**kw):
 # debug aid (1-GPU boxes): MELGPT_BENCH_FORCE_DP=1 runs the one rank through dp.DataParallel over a real RCCL process group
 # of size 1 - the exchange's launches, streams and the reserved CUs as an N-GPU run has them, minus the wire
 FORCE_DP = os.environ.get("MELGPT_BENCH_FORCE_DP") == "1"
+if FORCE_DP:
+    os.environ.setdefault("MELGPT_DP_FORCE_EXCHANGE", "1")  # dp.GradientExchange: launch the all-reduces of a 1-rank group
 
 
 class ClassGPTStep:

@@ -15,6 +15,8 @@ sharing one GPU in tests/test_dp_gpu.py.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -27,13 +29,16 @@ class GradientExchange:
         self.grad = grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # a group of ONE rank has nothing to exchange; MELGPT_DP_FORCE_EXCHANGE=1 (debug aid, 1-GPU boxes) launches the
+        # all-reduces anyway, so that a single rank drives RCCL exactly as a rank of an N-GPU run does
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("MELGPT_DP_FORCE_EXCHANGE") == "1")
         self.max_bucket = int(max_bucket_elems)
         self._works = []
         self._done = []  # (lo, hi) already launched this step
 
     def launch(self, lo: int, hi: int):
         """start reducing grad[lo:hi] (asynchronously on GPU backends); safe to call from a backward hook."""
-        if self.world == 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return
         if (lo, hi) in self._done:
             # a block's backward ran twice before finish() (gradient accumulation / two backward passes): the first
@@ -51,7 +56,7 @@ class GradientExchange:
 
     def finish(self):
         """reduce everything not launched yet, then make the current stream wait for all of it."""
-        if self.world > 1:
+        if self.active:
             covered = sorted(self._done)
             pos = 0
             for lo, hi in covered:
@@ -103,9 +108,8 @@ class DataParallel:
     at once while earlier blocks are still in their GEMMs.  finish() is called once per step before the optimizer
     (whose grad_scale = 1/world folds the averaging in)."""
 
-    def __init__(self, module, group=None, overlap=True, max_bucket_elems: int = 64 << 20, reserve_cus=None):
-        import os
-
+    def __init__(self, module, group=None, overlap=True, max_bucket_elems: int = 64 << 20, reserve_cus=None,
+                 dynamic_tiles=None):
         from . import _ffi
         from .flat import ensure_flat
 
@@ -115,34 +119,57 @@ class DataParallel:
         self.world = self.ex.world
         self.overlap = bool(overlap)
         # The persistent GEMM / conv kernels own one CU per workgroup for a whole launch; an RCCL kernel that holds a CU
-        # when such a launch starts would leave one workgroup waiting for another one's ENTIRE tile list.  With early
-        # (overlapped) all-reduces those kernels therefore leave `reserve_cus` CUs to RCCL (default 16 of 256 when the
-        # exchange really runs over RCCL, MELGPT_RESERVE_CUS overrides; 0 for gloo / single rank).
+        # when such a launch starts would leave one workgroup waiting for another one's ENTIRE static tile list.  While an
+        # (overlapped) all-reduce can be in flight - from the first Block's early launch to finish() - the persistent GEMM
+        # therefore draws its tiles from counters (`dynamic_tiles`, csrc/gemm256.hip: whoever has a CU takes the next tile;
+        # default when the exchange really runs over RCCL), and/or leaves `reserve_cus` CUs free (default 0:
+        # reserving 16 of 256 costs the weight-gradient GEMMs, whose 256 tiles are one round on 256 CUs, a second round).
+        # MELGPT_DP_DYNAMIC_TILES / MELGPT_RESERVE_CUS override.  The forward pass, the head's and the last Block's
+        # backward and the optimizer run on the whole chip with static lists.
+        active = self.ex.active
+        on_rccl = active and self.overlap and dist.get_backend(group) == "nccl"
         if reserve_cus is None:
-            on_rccl = self.world > 1 and self.overlap and dist.get_backend(group) == "nccl"
-            reserve_cus = int(os.environ.get("MELGPT_RESERVE_CUS", "16" if on_rccl else "0"))
+            reserve_cus = int(os.environ.get("MELGPT_RESERVE_CUS", "0"))
+        if dynamic_tiles is None:
+            dynamic_tiles = int(os.environ.get("MELGPT_DP_DYNAMIC_TILES", "1" if on_rccl else "0")) != 0
         self.reserve_cus = int(reserve_cus)
-        if self.fp.device.type == "cuda":
-            _ffi.call("melgpt_set_reserved_cus", self.reserve_cus)
+        self.dynamic_tiles = bool(dynamic_tiles)
+        self._reserved = False
+        self._on_gpu = self.fp.device.type == "cuda"
+        if self._on_gpu:
+            _ffi.call("melgpt_set_reserved_cus", 0)
         self.hook_calls = 0           # Block hooks fired since construction (tests count them)
         self._segs = {}
         self.blocks = [m for m in module.modules() if hasattr(m, "_layer_index") and hasattr(m, "attn")]
-        if self.world > 1 and self.overlap:
+        if active and self.overlap:
             for blk in self.blocks:
                 self._segs[id(blk)] = block_segments(self.fp, blk)
                 object.__setattr__(blk, "_grad_ready_hook", self._on_block_done)
 
+    def _reserve(self, on):
+        """enter / leave the part of a step in which RCCL kernels may share the chip with the compute kernels"""
+        if self._on_gpu and on != self._reserved and (self.reserve_cus > 0 or self.dynamic_tiles):
+            from . import _ffi
+
+            if self.reserve_cus > 0:
+                _ffi.call("melgpt_set_reserved_cus", self.reserve_cus if on else 0)
+            if self.dynamic_tiles:
+                _ffi.call("melgpt_set_dynamic_tiles", 1 if on else 0)
+            self._reserved = on
+
     def _on_block_done(self, blk):
         self.hook_calls += 1
+        self._reserve(True)   # the launches from here on share the chip with RCCL kernels
         for lo, hi in self._segs[id(blk)]:
             self.ex.launch(lo, hi)
 
     def finish(self):
         """all-reduce whatever the Block hooks have not launched (stem, head, ln_f, parameters without a gradient this
         step - zeroed first so that no stale slice is summed), then wait for every launched piece."""
-        if self.world > 1:
+        if self.ex.active:
             self.fp.zero_missing_grads()
         self.ex.finish()
+        self._reserve(False)  # everything launched after this is stream-ordered behind the last all-reduce
 
     def detach(self):
         for blk in self.blocks:

@@ -225,18 +225,31 @@ def _split_count(rows, target=32):
     return 1
 
 
+_CUS = None
+
+
+def _persistent_workgroups():
+    """workgroups a persistent-kernel launch gets right now: the device's CUs minus melgpt_set_reserved_cus()"""
+    global _CUS
+    if _CUS is None:
+        _CUS = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    left = _CUS - _ffi.lib().melgpt_get_reserved_cus()
+    return left if left >= 8 else _CUS
+
+
 def _wgrad_split(M, N, K, dtype):
     """split-K factor for the weight-gradient GEMM (a divisor of the M reduction rows).
     bf16, big outputs: the persistent 256x256 kernel runs one workgroup per CU, so the factor is chosen to fill whole
-    rounds of 256 tiles (cost = rounds x rows per batch, plus the pass that sums the f32 partials);
+    rounds of that many tiles (cost = rounds x rows per batch, plus the pass that sums the f32 partials);
     otherwise: ~3 workgroups of the 128x128 kernel per CU."""
     t256 = ((N + 255) // 256) * ((K + 255) // 256)
     if dtype == _ffi.HALF_DTYPE and t256 >= 12:
         best, best_cost = 1, None
+        wgs = _persistent_workgroups()
         for ns in range(1, 33):
             if M % ns or (M // ns) % 8 or (ns > 1 and M // ns < 512):
                 continue
-            rounds = -(-(t256 * ns) // 256)
+            rounds = -(-(t256 * ns) // wgs)
             if t256 * ns < 192:          # the dispatcher keeps such launches on the 128x128 kernel
                 continue
             cost = rounds * (M // ns) * 33e-9 + (ns > 1) * (ns + 1) * N * K * 4 / 3e12
