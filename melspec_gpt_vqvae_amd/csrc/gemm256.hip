@@ -534,9 +534,21 @@ int launch_tm(const GemmParams& p, int batch, int ncu, hipStream_t s) {
   // XCD blocks need every XCD to own the same number of workgroups; otherwise the linear order is used
   int RN = 0;
   if (grid == ncu && ncu % 8 == 0) {
+    // block shape RM x RN with RM * RN = workgroups per XCD: the one that pads the tile grid least (a 3-wide block on a
+    // 4-column grid leaves a third of the workgroups of every second block without a tile - 240 workgroups, 30 per XCD,
+    // N = 1024: + 18 % on the step), the most square among equals
     const int per = ncu / 8;
-    for (int c = 1; c * c <= per; ++c)
-      if (per % c == 0 && c <= tiles_n) RN = c;  // most square block whose width fits the tile grid
+    const long long rows_m = (long long)tiles_m * batch;
+    long long best = 0;
+    for (int c = 1; c * c <= per; ++c) {
+      if (per % c != 0 || c > tiles_n) continue;
+      const int rm = per / c;
+      const long long slots = ((tiles_n + c - 1) / c) * (long long)c * (((rows_m + rm - 1) / rm) * rm);
+      if (RN == 0 || slots <= best) {
+        best = slots;
+        RN = c;
+      }
+    }
   }
   int* sched = nullptr;
   if (melgpt_get_dynamic_tiles() && 256 + 2 * grid <= MELGPT_TILE_CELL_INTS)
