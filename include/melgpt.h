@@ -170,6 +170,19 @@ int melgpt_gemm(const void* A, int a_kmajor, long long lda, long long strideA, c
                 int act, const void* R, long long ldr, long long strideR, void* C2, float drop_p,
                 unsigned long long seed, unsigned stream_id, void* stream);
 
+/* Weight gradient AND bias gradient of y = x W^T + b in one launch (torch.nn.Linear backward, the c_attn / c_proj / mlp
+ * sites of transformer/minGPT.py:61-66,99-104): dW_part[z] (M x N, f32) = dY_z^T X_z over batch z's K reduction rows
+ * (both operands K-major: dY is (K, M), X is (K, N), element strides lda / ldb, batch strides strideA / strideB), and
+ * rowsum_part (melgpt_wgrad_rowsum_rows(N, batch) rows of M floats, row stride ld_rowsum) = partial sums over the
+ * reduction rows of dY - one more MFMA per A fragment in the same K loop instead of a pass of its own over dY.  The caller
+ * adds the batches of dW_part and ALL rows of rowsum_part in fixed order (melgpt_reduce_rows).  16-bit lane, shapes that
+ * run on the persistent kernel; otherwise MELGPT_ERR_UNSUPPORTED before any launch (callers then use melgpt_gemm +
+ * melgpt_colsum). */
+int melgpt_wgrad_rowsum_rows(int N, int batch);
+int melgpt_wgrad_rowsum(const void* dY, long long lda, long long strideA, const void* X, long long ldb, long long strideB,
+                        float* dW_part, long long ldc, long long strideC, int M, int N, int K, int batch, int dtype,
+                        float* rowsum_part, long long ld_rowsum, void* stream);
+
 /* 3x3 / 1x1 convolution as implicit GEMM over an NHWC activation (torch.nn.Conv2d sites of
  * vqvae/big_model_attn_gan.py:85-99,108-112,151-159,176-186,247-251,313-317,403-422,578-579).
  *   x (B,H,W,Cin) dtype; wpack (Cout, KH, KW, Cin) dtype (repacked from the reference's OIHW f32);

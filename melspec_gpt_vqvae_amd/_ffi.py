@@ -49,6 +49,8 @@ _PROTOS = {
     "melgpt_vq_bwd": [_p, _p, _i, _l, _i, _l, _l, _l, _l, _p, _i, _p, _p, _f, _p, _p, _p],
     "melgpt_gemm": [_p, _i, _l, _l, _p, _i, _l, _l, _p, _l, _l, _i, _i, _i, _i, _i, _i, _i, _f, _p, _i, _p, _l, _l,
                     _p, _f, _u64, C.c_uint, _p],
+    "melgpt_wgrad_rowsum_rows": [_i, _i],
+    "melgpt_wgrad_rowsum": [_p, _l, _l, _p, _l, _l, _p, _l, _l, _i, _i, _i, _i, _i, _p, _l, _p],
     "melgpt_conv2d_nhwc": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],
     "melgpt_attn_fwd": [_p, _p, _p, _l, _p, _l, _p, _p, _i, _i, _i, _i, _i, _f, _u64, C.c_uint, _i, _p],
     "melgpt_attn_decode": [_p, _l, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],

@@ -289,12 +289,12 @@ int pick_tile(const GemmParams& p, int batch) {
 
 }  // namespace
 
-extern "C" int melgpt_gemm(const void* A, int a_kmajor, long long lda, long long strideA, const void* B,
-                           int b_kmajor, long long ldb, long long strideB, void* C, long long ldc,
-                           long long strideC, int M, int N, int K, int batch, int dtype, int out_f32,
-                           int accumulate, float alpha, const float* bias, int act, const void* R,
-                           long long ldr, long long strideR, void* C2, float drop_p,
-                           unsigned long long seed, unsigned stream_id, void* stream) {
+static int gemm_impl(const void* A, int a_kmajor, long long lda, long long strideA, const void* B,
+                     int b_kmajor, long long ldb, long long strideB, void* C, long long ldc,
+                     long long strideC, int M, int N, int K, int batch, int dtype, int out_f32,
+                     int accumulate, float alpha, const float* bias, int act, const void* R,
+                     long long ldr, long long strideR, void* C2, float drop_p,
+                     unsigned long long seed, unsigned stream_id, float* a_rowsum, long long ld_rowsum, void* stream) {
   MELGPT_CHECK(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0, MELGPT_ERR_BAD_ARG);
   MELGPT_CHECK(dtype == MELGPT_F32 || dtype == MELGPT_BF16, MELGPT_ERR_UNSUPPORTED);
   const int es = dtype == MELGPT_F32 ? 4 : 2, vec = 16 / es;
@@ -339,6 +339,13 @@ extern "C" int melgpt_gemm(const void* A, int a_kmajor, long long lda, long long
   p.seed = seed; p.stream_id = stream_id;
   hipStream_t s = (hipStream_t)stream;
   const int alay = a_kmajor ? LAY_KMAJ : LAY_ROW, blay = b_kmajor ? LAY_KMAJ : LAY_ROW;
+  if (a_rowsum) {  // only the persistent kernel's weight-gradient instantiation carries it: nothing is launched otherwise
+    MELGPT_CHECK(dtype == MELGPT_BF16 && ld_rowsum >= M, MELGPT_ERR_UNSUPPORTED);
+    if (pick_tile(p, batch) != 3) return MELGPT_ERR_UNSUPPORTED;
+    p.a_rowsum = a_rowsum;
+    p.ld_rowsum = ld_rowsum;
+    return launch_gemm256(p, alay, blay, batch, 3, s);
+  }
   if (dtype == MELGPT_F32) return dispatch<float>(p, alay, blay, batch, s);
   const int cfg = pick_tile(p, batch);
   if (cfg != 1) {
@@ -346,6 +353,26 @@ extern "C" int melgpt_gemm(const void* A, int a_kmajor, long long lda, long long
     if (st != MELGPT_ERR_UNSUPPORTED) return st;
   }
   return dispatch<bf16_t>(p, alay, blay, batch, s);
+}
+
+extern "C" int melgpt_gemm(const void* A, int a_kmajor, long long lda, long long strideA, const void* B,
+                           int b_kmajor, long long ldb, long long strideB, void* C, long long ldc,
+                           long long strideC, int M, int N, int K, int batch, int dtype, int out_f32,
+                           int accumulate, float alpha, const float* bias, int act, const void* R,
+                           long long ldr, long long strideR, void* C2, float drop_p,
+                           unsigned long long seed, unsigned stream_id, void* stream) {
+  return gemm_impl(A, a_kmajor, lda, strideA, B, b_kmajor, ldb, strideB, C, ldc, strideC, M, N, K, batch, dtype, out_f32,
+                   accumulate, alpha, bias, act, R, ldr, strideR, C2, drop_p, seed, stream_id, nullptr, 0, stream);
+}
+
+extern "C" int melgpt_wgrad_rowsum_rows(int N, int batch) { return batch * ((N + 255) / 256); }
+
+extern "C" int melgpt_wgrad_rowsum(const void* dY, long long lda, long long strideA, const void* X, long long ldb,
+                                   long long strideB, float* dW_part, long long ldc, long long strideC, int M, int N,
+                                   int K, int batch, int dtype, float* rowsum_part, long long ld_rowsum, void* stream) {
+  MELGPT_CHECK(rowsum_part, MELGPT_ERR_BAD_ARG);
+  return gemm_impl(dY, 1, lda, strideA, X, 1, ldb, strideB, dW_part, ldc, strideC, M, N, K, batch, dtype, 1, 0, 1.0f,
+                   nullptr, MELGPT_ACT_NONE, nullptr, 0, 0, nullptr, 0.f, 0ULL, 0u, rowsum_part, ld_rowsum, stream);
 }
 
 extern "C" int melgpt_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, const void* wpack, int Cout, int KH,

@@ -402,6 +402,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
     for (int a = 0; a < TM; ++a)
 #pragma unroll
       for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ROW SUMS OF A (p.a_rowsum, weight-gradient instantiation only): the bias gradient is the sum over the reduction
+    // rows of the same dY the K loop streams through LDS anyway - one more MFMA per A fragment against a fragment of
+    // ones (every output row then holds sum_k A[m][k]) instead of a pass of its own over the tensor.  The tiles of one
+    // tile row share the work: tile column tn takes K units tn, tn + tiles_n, ... (each of the four waves of a row group
+    // two of its eight 16-row fragments: 8 registers - with all eight in one wave the kernel spilled 31), and writes its
+    // partial sums as row (batch, tn) of p.a_rowsum; the host adds the rows in fixed order.
+    constexpr bool CS = ALAY == LAY_KMAJ && BLAY == LAY_KMAJ && MODE == EPI_PLAIN32N && TM == 8;
+    constexpr int CSN = TM / WN;
+    f32x4 cs[CS ? CSN : 1];
+    int cs_next = 0x7FFFFFFF;
+    if constexpr (CS) {
+#pragma unroll
+      for (int a = 0; a < CSN; ++a) cs[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.a_rowsum) cs_next = n0 >> 8;
+    }
 
     auto unit = [&](int u) {
       // H(2u), H(2u+1) must have landed for every wave and every wave must be past its reads of unit u-1, whose two
@@ -456,6 +471,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+        if constexpr (CS) {
+          if (u == cs_next) {  // (wave-uniform)
+            const unsigned one2 = pack_bf16x2(1.0f, 1.0f);
+            const u32x4 ones = {one2, one2, one2, one2};
+            static_for<WN>([&](auto wn_c) {  // (wave-uniform: one copy of the two MFMAs per wave column)
+              constexpr int W0 = decltype(wn_c)::value;
+              if (wn == W0) {
+#pragma unroll
+                for (int a = 0; a < CSN; ++a) mma<bf16_t>(cs[a], ones, fa[W0 * CSN + a]);
+              }
+            });
+            if (ks == 1) cs_next += tiles_n;
+          }
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (DMA_ON && ks == 0) next_unit();
@@ -504,6 +533,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
       continue;
     }
     epilogue<bf16_t, TM, TN, MODE>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, bz, lane_e, smem + fill * HALF + w * 4096);
+    if constexpr (CS) {
+      if (p.a_rowsum && (lane_e >> 4) == 0) {  // every tile writes its slice, zeros when it took no K unit
+        float* dst = p.a_rowsum + ((long long)bz * tiles_n + (n0 >> 8)) * p.ld_rowsum;
+#pragma unroll
+        for (int a = 0; a < CSN; ++a) {
+          const int m = m0 + wm * TM * 16 + (wn * CSN + a) * 16 + (lane_e & 15);
+          if (m < p.M) dst[m] = cs[a][0];
+        }
+      }
+    }
 #if G256_LAB & 8
     if (blockIdx.x == 17 && t == 0) {
       unsigned long long* dbg = g256_dbg + 4 * (r - first_item);
@@ -612,6 +651,10 @@ int launch_lay(const GemmParams& p, int batch, hipStream_t s) {
   if (!p.vec_io) return MELGPT_ERR_UNSUPPORTED;
   // MELGPT_ACT_MUL (v *= R: the saved GELU derivative) is a plain mode: same loads and stores as a residual add
   const bool plain = (p.act == MELGPT_ACT_NONE || p.act == MELGPT_ACT_MUL) && p.drop_scale == 0.f && !p.C2;
+  if (p.a_rowsum) {  // row sums of A ride on the weight-gradient instantiation only (K-major x K-major, f32 out, no loads)
+    if constexpr (!(ALAY == LAY_KMAJ && BLAY == LAY_KMAJ)) return MELGPT_ERR_UNSUPPORTED;
+    if (!p.out_f32 || !plain || p.R || p.accumulate || p.act != MELGPT_ACT_NONE) return MELGPT_ERR_UNSUPPORTED;
+  }
   if constexpr (ALAY == LAY_CONV) {  // convolutions: bias + residual, bf16 out - the only form the VQ-VAE uses
     return (plain && !p.out_f32) ? launch_mode<ALAY, BLAY, EPI_PLAIN16>(p, batch, s) : MELGPT_ERR_UNSUPPORTED;
   } else {

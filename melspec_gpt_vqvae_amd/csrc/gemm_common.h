@@ -40,6 +40,10 @@ struct GemmParams {
   unsigned stream_id;
   // implicit-GEMM convolution (A = NHWC input)
   int cH, cW, cC, OH, OW, cstride, pad_t, pad_l, ups, KW;
+  // optional (persistent kernel, both operands K-major, f32 output: the weight-gradient GEMM): partial sums over K of the
+  // rows of A - the bias gradient when A = dY - as (batch * ceil(N / 256)) rows of M floats, row stride ld_rowsum
+  float* a_rowsum;
+  long long ld_rowsum;
 };
 
 constexpr unsigned OOB = 0xFFFFFFF0u;

@@ -262,16 +262,37 @@ def _wgrad_split(M, N, K, dtype):
     return _split_count(M, want) if want > 1 else 1
 
 
-def wgrad(dy, x, out, accumulate):
+def wgrad(dy, x, out, accumulate, bias_out=None, bias_accumulate=None):
     """out (N,K) f32 (+)= dy^T (N x M) @ x (M x K): the weight gradient of y = x W^T.  The reduction runs over
     M = B*T rows (tens of thousands) while the output has only a few dozen to a few hundred tiles, so the rows are
-    split into batches (_wgrad_split); partial products are summed in fixed order (deterministic)."""
+    split into batches (_wgrad_split); partial products are summed in fixed order (deterministic).
+    bias_out (N,) f32: also (+)= the column sums of dy - the bias gradient - taken in the same launch when the shape
+    runs on the persistent kernel (melgpt_wgrad_rowsum), by melgpt_colsum otherwise."""
     M, N = dy.shape
     K = x.shape[1]
+    if bias_accumulate is None:
+        bias_accumulate = accumulate
     ns = _wgrad_split(M, N, K, dy.dtype)
     if ns == 1 or dy.stride(1) != 1 or x.stride(1) != 1 or (M // ns) < 512:
+        if bias_out is not None:
+            colsum(dy, bias_out, accumulate=bias_accumulate)
         return gemm(dy, x, a_kmajor=True, b_kmajor=True, out=out, accumulate=accumulate)
     rows = M // ns
+    if bias_out is not None and dy.dtype == _ffi.HALF_DTYPE and dy.dtype == x.dtype:
+        L = _ffi.lib()
+        nrs = L.melgpt_wgrad_rowsum_rows(K, ns)
+        part = torch.empty(ns, N, K, dtype=torch.float32, device=dy.device)
+        rpart = torch.empty(nrs, N, dtype=torch.float32, device=dy.device)
+        with _timed(2.0 * M * N * K, f"gemm TN {N}x{K}x{rows} b{ns} +rowsum"):
+            code = L.melgpt_wgrad_rowsum(ptr(dy), dy.stride(0), rows * dy.stride(0), ptr(x), x.stride(0), rows * x.stride(0),
+                                         ptr(part), K, N * K, N, K, rows, ns, dtype_code(dy.dtype), ptr(rpart), N, stream())
+        if code != _ffi.ERR_UNSUPPORTED:
+            _ffi.check(code, "melgpt_wgrad_rowsum")
+            call("melgpt_reduce_rows", ptr(part), ns, N * K, N * K, ptr(out), int(accumulate), 1.0, stream())
+            call("melgpt_reduce_rows", ptr(rpart), nrs, N, N, ptr(bias_out), int(bias_accumulate), 1.0, stream())
+            return out
+    if bias_out is not None:
+        colsum(dy, bias_out, accumulate=bias_accumulate)
     a3 = torch.as_strided(dy, (ns, rows, N), (rows * dy.stride(0), dy.stride(0), 1), dy.storage_offset())
     b3 = torch.as_strided(x, (ns, rows, K), (rows * x.stride(0), x.stride(0), 1), x.storage_offset())
     part = gemm(a3, b3, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)     # (ns, N, K)

@@ -113,23 +113,19 @@ def _attention_core_bwd(dy, x2d, saved, w_qkv, w_proj, fp, blkw_params, *, B, T,
     qkv, a, lse = saved
     C = x2d.shape[1]
     (qkv_p, qkvb_p, proj_w, proj_b) = blkw_params
-    gb, acc = fp.grad_target(proj_b)
-    if resid_p > 0:   # mask replay and the bias gradient (column sums of the masked gradient) in one pass
-        d = ops.dropout_apply_colsum(dy, resid_p, seed, site + 1, gb, accumulate=acc)
-    else:
-        d = dy
-        ops.colsum(d, gb, accumulate=acc)
+    d = ops.dropout_apply(dy, resid_p, seed, site + 1) if resid_p > 0 else dy   # mask replay
+    gb, accb = fp.grad_target(proj_b)
     gw, acc = fp.grad_target(proj_w)
-    ops.wgrad(d, a, gw, acc)         # dW_proj = d^T a
+    # dW_proj = d^T a; the bias gradient (column sums of d) rides in the same GEMM's K loop
+    ops.wgrad(d, a, gw, acc, bias_out=gb, bias_accumulate=accb)
     da = ops.gemm(d, w_proj, b_kmajor=True)
     dqkv = torch.empty_like(qkv)
     k, q, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     ops.attn_bwd(q, k, v, a, da, lse, n_head, B=B, T=T, dqkv=(dqkv[:, C:2 * C], dqkv[:, :C], dqkv[:, 2 * C:]),
                  n_unmasked=n_unmasked, drop_p=attn_p, seed=seed, stream_id=site)
     gw, acc = fp.packed_grad_target(qkv_p)
-    ops.wgrad(dqkv, x2d, gw, acc)    # dW_qkv = dqkv^T x
-    gb, acc = fp.packed_grad_target(qkvb_p)
-    ops.colsum(dqkv, gb, accumulate=acc)
+    gb, accb = fp.packed_grad_target(qkvb_p)
+    ops.wgrad(dqkv, x2d, gw, acc, bias_out=gb, bias_accumulate=accb)    # dW_qkv = dqkv^T x, db_qkv = column sums
     return ops.gemm(dqkv, w_qkv, b_kmajor=True) if need_dx else None
 
 
@@ -182,19 +178,14 @@ class _BlockFn(torch.autograd.Function):
         if dy2.dtype != dt or not dy2.is_contiguous():
             dy2 = ops.cast(dy2.contiguous(), dt)
         # ---- MLP branch: y = x1 + drop(fc2(gelu(fc1(ln2(x1)))))
-        gb, acc = fp.grad_target(m[2].bias)
-        if mlp_p > 0:
-            d = ops.dropout_apply_colsum(dy2, mlp_p, seed, site + 2, gb, accumulate=acc)
-        else:
-            d = dy2
-            ops.colsum(d, gb, accumulate=acc)
+        d = ops.dropout_apply(dy2, mlp_p, seed, site + 2) if mlp_p > 0 else dy2
+        gb, accb = fp.grad_target(m[2].bias)
         gw, acc = fp.grad_target(m[2].weight)
-        ops.wgrad(d, act, gw, acc)
+        ops.wgrad(d, act, gw, acc, bias_out=gb, bias_accumulate=accb)
         dpre = ops.gemm(d, W.w_fc2, b_kmajor=True, act=ops.ACT_MUL, residual=dact)
+        gb, accb = fp.grad_target(m[0].bias)
         gw, acc = fp.grad_target(m[0].weight)
-        ops.wgrad(dpre, h2, gw, acc)
-        gb, acc = fp.grad_target(m[0].bias)
-        ops.colsum(dpre, gb, accumulate=acc)
+        ops.wgrad(dpre, h2, gw, acc, bias_out=gb, bias_accumulate=accb)
         dh2 = ops.gemm(dpre, W.w_fc1, b_kmajor=True)
         g2, accg = fp.grad_target(blk.ln2.weight)
         b2, accb = fp.grad_target(blk.ln2.bias)

@@ -442,3 +442,29 @@ def test_claimed_tiles_give_the_same_bits_as_static_tile_lists():
     finally:
         _ffi.call("melgpt_set_dynamic_tiles", 0)
         _ffi.call("melgpt_set_reserved_cus", 0)
+
+
+@pytest.mark.parametrize("N,K,M", [(1024, 1024, 33920), (4096, 1024, 33920), (1024, 4096, 33920), (3072, 1024, 16960),
+                                    (256, 192, 2120)])
+def test_weight_gradient_launch_also_yields_the_bias_gradient(N, K, M):
+    """ops.wgrad(dy, x, dW, acc, bias_out=db): on the persistent kernel the column sums of dy (the bias gradient of
+    y = x W^T + b) come out of the weight-gradient GEMM's own K loop (melgpt_wgrad_rowsum: one more MFMA per A fragment
+    against a fragment of ones); dW is bit-identical to the launch without it, db equals the f64 column sums to f32
+    accumulation accuracy, accumulate flags are honoured separately.  The small shape takes the melgpt_colsum path."""
+    from melspec_gpt_vqvae_amd import ops
+
+    torch.manual_seed(N + K)
+    dy = (torch.randn(M, N, device=DEV) * 0.1 + 0.01).bfloat16()
+    x = torch.randn(M, K, device=DEV).bfloat16()
+    ref_w = torch.empty(N, K, device=DEV)
+    ops.wgrad(dy, x, ref_w, False)
+    w = torch.empty(N, K, device=DEV)
+    b = torch.full((N,), 3.0, device=DEV)
+    ops.wgrad(dy, x, w, False, bias_out=b, bias_accumulate=True)
+    assert torch.equal(w, ref_w)
+    want = dy.double().sum(0).cpu().numpy()
+    got = (b - 3.0).double().cpu().numpy()
+    assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+    ops.wgrad(dy, x, w, True, bias_out=b, bias_accumulate=False)        # weights accumulate, bias overwritten
+    assert rel_err(w.cpu().numpy(), (2 * ref_w).cpu().numpy()) < 1e-6
+    assert np.abs(b.double().cpu().numpy() - want).max() < 2e-5 * max(1.0, np.abs(want).max())
