@@ -731,17 +731,35 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const long long step = (long long)gridDim.x * blockDim.x * 4;
   const float step_size = lr / bc1;
+  auto update4 = [&](f32x4& pp, f32x4 gg, f32x4& mm, f32x4& vv) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pp[e] *= (1.f - lr * wd);
+      mm[e] = beta1 * mm[e] + (1.f - beta1) * gg[e];
+      vv[e] = beta2 * vv[e] + (1.f - beta2) * gg[e] * gg[e];
+      const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+      pp[e] -= step_size * (mm[e] / denom);
+    }
+  };
+  // two sweeps' chunks per trip: eight 16-byte loads in flight per lane instead of four (30 bytes move per element:
+  // the kernel is a pure stream)
+  for (; i + step + 3 < n; i += 2 * step) {
+    const long long j = i + step;
+    f32x4 p0 = *(f32x4*)(p + i), g0 = *(const f32x4*)(g + i) * grad_scale, m0 = *(f32x4*)(m + i), v0 = *(f32x4*)(v + i);
+    f32x4 p1 = *(f32x4*)(p + j), g1 = *(const f32x4*)(g + j) * grad_scale, m1 = *(f32x4*)(m + j), v1 = *(f32x4*)(v + j);
+    update4(p0, g0, m0, v0);
+    update4(p1, g1, m1, v1);
+    *(f32x4*)(p + i) = p0; *(f32x4*)(m + i) = m0; *(f32x4*)(v + i) = v0;
+    *(f32x4*)(p + j) = p1; *(f32x4*)(m + j) = m1; *(f32x4*)(v + j) = v1;
+    if (p_bf16) {
+      *(u32x2*)(p_bf16 + i) = u32x2{pack_bf16x2(p0[0], p0[1]), pack_bf16x2(p0[2], p0[3])};
+      *(u32x2*)(p_bf16 + j) = u32x2{pack_bf16x2(p1[0], p1[1]), pack_bf16x2(p1[2], p1[3])};
+    }
+  }
   for (; i < n; i += step) {
     if (i + 3 < n) {
       f32x4 pp = *(f32x4*)(p + i), gg = *(const f32x4*)(g + i) * grad_scale, mm = *(f32x4*)(m + i), vv = *(f32x4*)(v + i);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        pp[e] *= (1.f - lr * wd);
-        mm[e] = beta1 * mm[e] + (1.f - beta1) * gg[e];
-        vv[e] = beta2 * vv[e] + (1.f - beta2) * gg[e] * gg[e];
-        const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
-        pp[e] -= step_size * (mm[e] / denom);
-      }
+      update4(pp, gg, mm, vv);
       *(f32x4*)(p + i) = pp; *(f32x4*)(m + i) = mm; *(f32x4*)(v + i) = vv;
       if (p_bf16) *(u32x2*)(p_bf16 + i) = u32x2{pack_bf16x2(pp[0], pp[1]), pack_bf16x2(pp[2], pp[3])};
     } else {
