@@ -48,6 +48,8 @@ def test_two_ranks_share_one_gpu_gradients_equal_single_process(which, tmp_path)
     for r in res:
         assert r["names"] == fp.names and r["offsets"] == fp.offsets
         assert r["hook_calls"] == n_blocks and r["launched_early"] == 2 * n_blocks     # two slices per Block, before finish()
+        # claimed tiles / reserved CUs are on exactly while an all-reduce can be in flight (first hook .. finish())
+        assert [tuple(w) for w in r["window"]] == [(0, 0), (1, 8), (0, 0)]
         got = r["grad"] / world                                                        # the optimizer's grad_scale
         err = float((got - want).abs().max() / want.abs().max())
         assert err < 1e-6, err
