@@ -210,7 +210,8 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
   const int i16 = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.y * 128;
   const bool norm = q.mean != nullptr;
-  const int kpt = Cin / KSTEP, nk = 9 * kpt;
+  const int nk = 9 * (Cin / KSTEP);  // 18: Cin = 128, the launcher checks (a run-time value on purpose: with the trip
+                                     // count known the compiler re-pipelines the pair loop into 22 spilled VGPRs)
 
   // weight ring: stage s <- K-step (kg % nk); 16 pieces of 1 KiB per stage, two per wave
   // (the pieces are issued by an asm block, not the builtin: hipcc completes the builtin's LDS write only at vmcnt(0) and
@@ -225,8 +226,10 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
     b_base[i] = (n0 + row < p.N) ? (unsigned)(((long long)(n0 + row) * p.ldb) * ES) + ch * 16 : OOB;
   }
   int kg_issue = 0;  // next K-step (global, over all tiles) to request
+  int kt_issue = 0;  // ... within its tile (a running counter: `kg_issue % nk` is a 30-instruction division per request)
   auto issue_w = [&]() {
-    const int kt = kg_issue % nk, st = kg_issue & (WNST - 1);
+    const int kt = kt_issue, st = kg_issue & (WNST - 1);
+    kt_issue = kt_issue + 1 == nk ? 0 : kt_issue + 1;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const unsigned m0v = (unsigned)(size_t)LDS_PTR(char, wring + st * 16384 + (w + 8 * i) * 1024);
@@ -367,7 +370,11 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
     // Two K-steps per barrier (nk is even: the launcher checks): the ring's four stages are two pairs - while pair p is
     // multiplied pair p + 1 lands in the stages pair p - 1 was read from.  At one barrier per 64-wide step the SIMD's two
     // waves spent as long waiting (barrier skew + the fragment reads right behind it) as multiplying.
+    // (Cin = 128, the only width this kernel is launched for: a pair of K-steps is one filter tap, its two steps the tap's
+    // two 64-channel halves - written with a run-time `kpt` the tap / channel split cost the scalar unit two divisions per
+    // step, in front of the step's first fragment reads)
     for (int pr = 0; pr < nk / 2; ++pr) {
+      const int ky = pr / 3, kx = pr - 3 * ky;
       // this wave's pieces of the pair have landed; after the barrier everybody's have, and everybody is past the
       // previous pair, whose two stages are refilled now.  (The next tile's MAXCH patch loads were issued just before
       // this loop: younger than the first pair's pieces - they stay in flight - and older than all later ones.)
@@ -377,9 +384,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
       issue_w();
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh, ++kg) {
-        const int kt = 2 * pr + hh;
-        const int tap = kt / kpt, kc = kt - tap * kpt;
-        const int ky = tap / 3, kx = tap - ky * 3;
+        const int kc = hh;
         const char* sb = wring + (kg & (WNST - 1)) * 16384;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -562,7 +567,7 @@ static int conv3x3_gn_impl(const void* x, int B, int H, int W, int Cin, const fl
   // 16-row tiles pay for the rows they pad: take them only while they compute at most 1/4 more pixels than 8-row tiles
   const long long wide_px = wide_tiles * WTH * WTW, narrow_px = (long long)q.tiles_x * q.tiles_y * B * TH * TW;
   if (!wide_off && wide_lds <= 160 * 1024 && wide_tiles >= 512 && wide_px * 4 <= narrow_px * 5 && q.g.vec_io &&
-      (9 * (Cin / 64)) % 2 == 0 &&
+      Cin == 128 &&
       M * Cin * 2 < 0xFFFFFF00LL && (!residual || M * Cout * 2 < 0xFFFFFF00LL)) {
     q.x_bytes = (unsigned)(M * Cin * 2);
     q.r_bytes = residual ? (unsigned)(M * Cout * 2) : 0u;
