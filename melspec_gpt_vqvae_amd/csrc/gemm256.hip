@@ -529,10 +529,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
     if (G256_LAB == 4) {  // full epilogue arithmetic + staging, stores predicated off at run time
       GemmParams q = p;
       q.N = p.alpha == 1.f ? 0 : p.N;
-      epilogue<bf16_t, TM, TN, MODE>(q, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, bz, lane_e, smem + fill * HALF + w * 4096);
+      epilogue<bf16_t, TM, TN, MODE, ALAY != LAY_CONV>(q, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, bz, lane_e, smem + fill * HALF + w * 4096);
       continue;
     }
-    epilogue<bf16_t, TM, TN, MODE>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, bz, lane_e, smem + fill * HALF + w * 4096);
+    epilogue<bf16_t, TM, TN, MODE, ALAY != LAY_CONV>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, bz, lane_e, smem + fill * HALF + w * 4096);
     if constexpr (CS) {
       if (p.a_rowsum && (lane_e >> 4) == 0) {  // every tile writes its slice, zeros when it took no K unit
         float* dst = p.a_rowsum + ((long long)bz * tiles_n + (n0 >> 8)) * p.ld_rowsum;

@@ -153,22 +153,22 @@ enum { EPI_GENERIC = 0, EPI_PLAIN16 = 1, EPI_PLAIN32 = 2, EPI_FULL16 = 3,
 //   EPI_FULL16   activation / dropout / second output as well, bf16 output; ONE copy of the slab body in a rolled
 //                loop (unrolled it is ~100 KiB of code, which a persistent kernel would re-fetch on every tile)
 // EPI_PLAIN* / EPI_FULL16 require p.vec_io.
-template <typename T, int TM, int TN, int MODE = EPI_GENERIC>
+template <typename T, int TM, int TN, int MODE = EPI_GENERIC, bool RALL = false>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[TM][TN], const long long (&mrow)[TM],
                                               int row_limit, int n_base, int bz, int lane, char* stage);
 
-template <typename T, int TM, int TN, int MODE = EPI_GENERIC>
+template <typename T, int TM, int TN, int MODE = EPI_GENERIC, bool RALL = false>
 __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[TM][TN], int m_base, int n_base, int bz,
                                          int lane, char* stage) {
   long long mrow[TM];
 #pragma unroll
   for (int mt = 0; mt < TM; ++mt) mrow[mt] = m_base + mt * 16;
-  epilogue_rows<T, TM, TN, MODE>(p, acc, mrow, 16, n_base, bz, lane, stage);
+  epilogue_rows<T, TM, TN, MODE, RALL>(p, acc, mrow, 16, n_base, bz, lane, stage);
 }
 
 // mrow[mt] = output row (in C) of the first of the 16 consecutive rows held by accumulator slab mt, or < 0 when the
 // slab is entirely out of range; rows mrow[mt] + r with r >= row_limit (or >= p.M) are skipped.
-template <typename T, int TM, int TN, int MODE>
+template <typename T, int TM, int TN, int MODE, bool RALL>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[TM][TN], const long long (&mrow)[TM],
                                               int row_limit, int n_base, int bz, int lane, char* stage) {
   constexpr int ES = Tr<T>::ES;
@@ -233,7 +233,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
     // between two uses is waited for at once.  Two batches = two exposed latencies per tile instead of TM.
     // (slabs per batch: half the tile where the registers allow it; the rolled full epilogue is at the 256-VGPR
     // limit with two sets)
-    constexpr int NB = (MODE == EPI_GENERIC || ROLLED) ? (TM < 2 ? 1 : 2) : (TM + 1) / 2;
+    // (RALL: the plain bf16 mode requests ALL its slabs up front: the loads are ordinary, counted loads - the persistent
+    // kernel's LDS-DMA is invisible to the compiler since round 2 - so only the first slab's latency is exposed; the
+    // implicit-GEMM convolution's 256-row instantiation has no registers for it)
+    constexpr int NB = (MODE == EPI_GENERIC || ROLLED) ? (TM < 2 ? 1 : 2) : (RALL && MODE == EPI_PLAIN16 ? TM : (TM + 1) / 2);
     u32x4 rin[NB][NR];
     auto fetch_r = [&](long long mr, u32x4 (&dst)[NR]) {
 #pragma clang loop unroll(full)
