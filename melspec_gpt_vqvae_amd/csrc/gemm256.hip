@@ -131,10 +131,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
   // over its own blocks (ticket t of XCD x = slot t % per of its block number t / per, per = G / 8 workgroups), so the
   // tickets a chip's 32 workgroups draw one after the other are the tiles of one RM x RN block and its L2 serves the
   // same few panels as with the static lists; without blocks there is one counter over the linear tile order.
-  // Tickets are drawn by wave 0 with a scalar-memory atomic (executed at L2, does not touch vmcnt) TWO items ahead and
-  // handed to the other seven waves through a two-slot mailbox in global memory (the ring leaves no LDS byte free):
-  // written with s_atomic_swap, read with s_atomic_or 0 - both at L2, no cache to go stale - and always at least one
-  // workgroup barrier apart.  Cell layout: counter of queue q at sched[32 q] (a 128-byte line each), mailbox of
+  // Tickets are drawn by wave 0 with a scalar-memory atomic (executed at L2, does not touch vmcnt), one or two items ahead
+  // (see "WHEN a ticket is drawn" below), and handed to the other seven waves through a two-slot mailbox in global memory
+  // (the ring leaves no LDS byte free): written with a posted s_atomic_swap, read with s_atomic_or 0 - both at L2, no cache
+  // to go stale - and always at least one workgroup barrier apart (wave 0 waits for its write in front of that barrier).  Cell layout: counter of queue q at sched[32 q] (a 128-byte line each), mailbox of
   // workgroup b at sched[256 + 2 b + (item & 1)].  A ticket >= qtotal ends the list.  Every workgroup draws exactly one
   // dead ticket (it stops drawing then), so a queue sees qtotal + qgroups draws: the one that returns
   // qtotal + qgroups - 1 is the last and puts the counter back to 0 for the cell's next launch.
