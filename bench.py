@@ -68,6 +68,26 @@ def synthetic_batch(batch, rank, device):
     return x, c
 
 
+def vq_encode_b64(job, device, reps=5):
+    """BASELINE configs[1] beside the metric (outside the timed region, a few launches' worth of time): VQ-encode + 128-code
+    argmin of 64 mel tiles on the step's own frozen VQ-VAE - milliseconds per batch with a device synchronisation around
+    each repetition, median of `reps`; the encoder's convolutions are 142.57 GFLOP per tile."""
+    x, _ = synthetic_batch(64, 1000, device)
+    with torch.no_grad():
+        job.vqvae.encode_to_codes(x)
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            codes = job.vqvae.encode_to_codes(x)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+    ms = 1e3 * sorted(ts)[len(ts) // 2]
+    return {"workload": "VQ-encode + argmin, 64 tiles (1,80,848), 16-bit lane", "ms": round(ms, 3),
+            "tiles_per_s": round(64 / (ms * 1e-3), 1), "encoder_tflops": round(64 * 142.57e9 / (ms * 1e-3) / 1e12, 1),
+            "codes_shape": list(codes.shape)}
+
+
 def pmc_summary(workload="class_gpt"):
     """The newest committed rocprofv3 PMC summary OF THIS WORKLOAD's training step (profiles/*_summary.json written by
     tools/profile_round.sh; bench.py itself cannot collect PMC counters): HBM bytes per step of the GEMM-family kernels
@@ -423,6 +443,8 @@ def main():
             for r in rows[:40]:
                 print(f"  {r['shape']:44s} n/step={r['calls_per_step']:6.1f} ms/step={r['ms_per_step']:8.3f} "
                       f"TFLOP/s={r['tflops']:7.1f}", file=sys.stderr)
+        if world == 1 and job.name == "class_gpt":
+            out["config2_vq_encode"] = vq_encode_b64(job, device)
         if world == 1 and not a.no_cpu_baseline and job.name == "class_gpt":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
