@@ -66,6 +66,12 @@ int melgpt_mel_frontend_fwd(const float* wav, int n_clips, long long n_samples, 
                             float min_val, float mult, float sub, float add, float div, float clip_lo,
                             float clip_hi, float* mel_out, int n_keep, void* tile_out, int tile_dtype, int crop0,
                             int crop_len, void* stream);
+/* The transform tail alone = TRANSFORMS.transforms[1:] (feature_extraction/extract_mel_spectrogram.py:143-150:
+ * LowerThresh, Log10, Multiply, Subtract, Add, Divide, Clip, TrimSpec) on mel magnitudes already in memory,
+ * mel_in (n_clips, n_mels, n_frames) f32: the same device function the fused kernel ends with; outputs as above. */
+int melgpt_mel_transforms_fwd(const float* mel_in, int n_clips, int n_mels, int n_frames, float min_val, float mult,
+                              float sub, float add, float div, float clip_lo, float clip_hi, float* mel_out,
+                              int n_keep, void* tile_out, int tile_dtype, int crop0, int crop_len, void* stream);
 
 /* ===================================================================== VQ codebook
  * Nearest-neighbour lookup = VectorQuantizer.forward, vqvae/big_model_attn_gan.py:19-54

@@ -94,6 +94,7 @@ _PROTOS = {
     "melgpt_reduce_rows": [_p, _i, _l, _l, _p, _i, _f, _p],
     "melgpt_mel_frontend_fwd": [_p, _i, _l, _i, _i, _p, _p, _p, _i, _f, _f, _f, _f, _f, _f, _f, _p, _i, _p, _i, _i, _i,
                                 _p],
+    "melgpt_mel_transforms_fwd": [_p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _p, _i, _p, _i, _i, _i, _p],
     "melgpt_conv3x3_gn_nhwc": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _p],
     "melgpt_conv3x3_gn_stats_workspace": [_i, _i, _i],
     "melgpt_conv3x3_gn_nhwc_stats": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _f, _p, _p, _p, _p],

@@ -67,6 +67,34 @@ __device__ __forceinline__ cplx cis(float turns) {  // exp(2 pi i turns)
   return cplx{c, s};
 }
 
+// TRANSFORMS[1:] of the reference (LowerThresh, Log10, Multiply, Subtract, Add, Divide, Clip; :141-150) on one value and
+// its two destinations: mel[clip][m][f] for f < n_keep (TrimSpec) and the VQ-VAE tile 2 v - 1 of the cropped columns
+__device__ __forceinline__ void mel_emit(const MelParams& p, float inv_div, int clip, int m, int f, float acc) {
+  float v = fmaxf(p.min_val, acc);  // > 0: v_log_f32 (1 ulp) is enough for log10
+  v = ((__builtin_amdgcn_logf(v) * 0.30102999566398120f * p.mult - p.sub) + p.add) * inv_div;
+  v = fminf(fmaxf(v, p.clip_lo), p.clip_hi);
+  if (p.mel && f < p.n_keep) p.mel[((long long)clip * p.n_mels + m) * p.n_keep + f] = v;
+  const int fc = f - p.crop0;
+  if (p.tile && fc >= 0 && fc < p.crop_len) {
+    const long long o = ((long long)clip * p.n_mels + m) * p.crop_len + fc;
+    const float x = 2.0f * v - 1.0f;
+    if (p.tile_bf16) ((bf16_t*)p.tile)[o] = f32_to_bf16(x);
+    else ((float*)p.tile)[o] = x;
+  }
+}
+
+// the tail alone on mel magnitudes already in memory, (n_clips, n_mels, n_frames) f32: the same mel_emit the fused kernel
+// ends with - the operator form of the reference's TRANSFORMS.transforms[1:] (melgpt_mel_transforms_fwd)
+__global__ __launch_bounds__(256) void mel_tail_kernel(MelParams p, const float* mag) {
+  const long long total = (long long)p.n_clips * p.n_mels * p.n_frames;
+  const float inv_div = 1.0f / p.div;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int f = (int)(e % p.n_frames);
+    const long long r = e / p.n_frames;
+    mel_emit(p, inv_div, (int)(r / p.n_mels), (int)(r % p.n_mels), f, mag[e]);
+  }
+}
+
 // forward 8-point DFT in place: a[k] <- sum_n a[n] exp(-2 pi i n k / 8)
 __device__ __forceinline__ void dft8(cplx (&a)[8]) {
   const float h = 0.70710678118654752440f;
@@ -218,19 +246,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES) void mel_block_kernel(MelParams p) 
   };
   // log compression and the two outputs of one value
   const float inv_div = 1.0f / p.div;
-  auto emit = [&](int clip, int m, int f, float acc) {
-    float v = fmaxf(p.min_val, acc);  // > 0: v_log_f32 (1 ulp) is enough for log10
-    v = ((__builtin_amdgcn_logf(v) * 0.30102999566398120f * p.mult - p.sub) + p.add) * inv_div;
-    v = fminf(fmaxf(v, p.clip_lo), p.clip_hi);
-    if (p.mel && f < p.n_keep) p.mel[((long long)clip * p.n_mels + m) * p.n_keep + f] = v;
-    const int fc = f - p.crop0;
-    if (p.tile && fc >= 0 && fc < p.crop_len) {
-      const long long o = ((long long)clip * p.n_mels + m) * p.crop_len + fc;
-      const float x = 2.0f * v - 1.0f;
-      if (p.tile_bf16) ((bf16_t*)p.tile)[o] = f32_to_bf16(x);
-      else ((float*)p.tile)[o] = x;
-    }
-  };
+  auto emit = [&](int clip, int m, int f, float acc) { mel_emit(p, inv_div, clip, m, f, acc); };
 
 #if MEL_LAB
   unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
@@ -376,6 +392,26 @@ __global__ __launch_bounds__(64 * MEL_WAVES) void mel_block_kernel(MelParams p) 
 }
 
 }  // namespace
+
+extern "C" int melgpt_mel_transforms_fwd(const float* mel_in, int n_clips, int n_mels, int n_frames, float min_val,
+                                         float mult, float sub, float add, float div, float clip_lo, float clip_hi,
+                                         float* mel_out, int n_keep, void* tile_out, int tile_dtype, int crop0,
+                                         int crop_len, void* stream) {
+  MELGPT_CHECK(mel_in && n_clips > 0 && n_mels > 0 && n_frames > 0, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(mel_out || tile_out, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(!tile_out || tile_dtype == MELGPT_F32 || tile_dtype == MELGPT_BF16, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK(n_keep >= 0 && crop0 >= 0 && (!mel_out || n_keep <= n_frames) && (!tile_out || crop0 + crop_len <= n_frames),
+               MELGPT_ERR_BAD_ARG);
+  MelParams p{};
+  p.n_frames = n_frames; p.n_mels = n_mels; p.n_clips = n_clips;
+  p.min_val = min_val; p.mult = mult; p.sub = sub; p.add = add; p.div = div; p.clip_lo = clip_lo; p.clip_hi = clip_hi;
+  p.mel = mel_out; p.n_keep = n_keep; p.tile = tile_out; p.tile_bf16 = tile_dtype == MELGPT_BF16;
+  p.crop0 = crop0; p.crop_len = crop_len;
+  const long long total = (long long)n_clips * n_mels * n_frames;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(mel_tail_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, mel_in);
+  return melgpt_launch_status();
+}
 
 extern "C" int melgpt_mel_frontend_fwd(const float* wav, int n_clips, long long n_samples, int n_fft, int hop,
                                        const float* mel_basis, const int* band_lo, const int* band_hi, int n_mels,

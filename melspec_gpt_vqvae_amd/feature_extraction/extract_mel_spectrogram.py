@@ -149,6 +149,23 @@ class FusedTransforms(object):
                   _ffi.dtype_code(tile_dtype) if tile_dtype is not None else 0, crop0, crop_len, _ffi.stream())
         return mel, tile
 
+    def tail(self, mel_mag, *, tile_dtype=None, crop0=6, crop_len=848):
+        """`Compose(TRANSFORMS.transforms[1:])` of the reference (:143-150) on mel magnitudes (n, n_mels, n_frames) f32
+        that are already on the GPU -> (mel (n, n_mels, max_len) f32, tile | None): the kernel's own last stage."""
+        if not mel_mag.is_cuda:
+            raise _ffi.MelgptError("the mel frontend runs on the GPU only (no CPU fallback)")
+        _, lt, _, mul, sub, add, div, clip, trim = self.transforms
+        mel_mag = mel_mag.contiguous().float()
+        n, nm, nf = mel_mag.shape
+        keep = min(trim.max_len, nf)
+        mel = torch.empty(n, nm, keep, dtype=torch.float32, device=mel_mag.device)
+        tile = torch.empty(n, 1, nm, crop_len, dtype=tile_dtype, device=mel_mag.device) if tile_dtype is not None else None
+        _ffi.call("melgpt_mel_transforms_fwd", _ffi.ptr(mel_mag), n, nm, nf, float(lt.min_val), float(mul.val),
+                  float(sub.val), float(add.val), float(div.val), float(clip.min_val), float(clip.max_val), _ffi.ptr(mel),
+                  keep, _ffi.ptr(tile), _ffi.dtype_code(tile_dtype) if tile_dtype is not None else 0, crop0, crop_len,
+                  _ffi.stream())
+        return mel, tile
+
     def __call__(self, y):
         """y: 1-D waveform (numpy or torch) -> (80, 860) numpy array, like the reference's TRANSFORMS(y)."""
         yt = torch.as_tensor(np.asarray(y, dtype=np.float32) if not torch.is_tensor(y) else y.float())
@@ -203,6 +220,10 @@ def get_spectrogram(audio_path, save_dir, length, folder_name='melspec_10s_22050
     if folder_name != 'melspec_10s_22050hz':
         raise NotImplementedError
     mel_spec = TRANSFORMS(y)
+    if len(wav) < length:
+        # reference :169-171: a zero-padded clip is a float64 array and so is everything computed from it (the saved
+        # `_mel.npy` is float64); a truncated clip keeps librosa.load's float32.  The kernel computes in f32 either way.
+        y, mel_spec = y.astype(np.float64), mel_spec.astype(np.float64)
     if save_results:
         os.makedirs(save_dir, exist_ok=True)
         audio_name = os.path.basename(audio_path).split('.')[0]

@@ -1,9 +1,13 @@
 """Oracle: wav -> log-mel tile, numpy restatement.  TEST INFRASTRUCTURE - see oracle/__init__.py.
 
-PARITY UNPINNED: the arithmetic of this stage lives in librosa==0.8.1 (pinned in the
+PINNED (tests/golden/mel_transforms.npz, recorded from the real reference by make_golden.gen_mel): the transform
+tail `transform_tail` (= TRANSFORMS.transforms[1:], :143-150), the two numpy lines of MelSpectrogram.__call__
+(`mel_project`, :36-37), get_spectrogram's pad / truncate + dtype rule (`fit_length`, :169-173), the keyword arguments
+the reference hands to librosa, and the saved file's name / shape / dtype - bit for bit, f32 and f64.
+PARITY UNPINNED: `stft_mag` and `mel_filterbank`, i.e. the arithmetic INSIDE librosa==0.8.1 (pinned in the
 reference's requirements.txt:2 / MSGVenv.yml:84) which is neither vendored under
 /root/reference nor installed here, and the reference has no test at this boundary.
-This file restates the *published* librosa-0.8.1 algorithm for the exact call sites
+These two restate the *published* librosa-0.8.1 algorithm for the exact call sites
   feature_extraction/extract_mel_spectrogram.py:26   librosa.filters.mel(sr, n_fft, fmin, fmax, n_mels)
   feature_extraction/extract_mel_spectrogram.py:36   np.abs(librosa.stft(x, n_fft, hop_length)) ** power
   feature_extraction/extract_mel_spectrogram.py:37   np.dot(mel_basis, spec)
@@ -91,16 +95,31 @@ def fit_length(wav, length=220500):
     return wav[:length]
 
 
-def log_mel(y, mel_basis=None):
-    """TRANSFORMS :141-151 on a waveform that already has its final length -> (80, 860) in [0,1]."""
-    if mel_basis is None:
-        mel_basis = mel_filterbank()
-    m = np.dot(mel_basis, stft_mag(y))
+def mel_project(mel_basis, spec, power=1):
+    """MelSpectrogram.__call__ :36-37 around librosa.stft's result: np.abs(spec) ** spec_power, then np.dot."""
+    return np.dot(mel_basis, np.abs(spec) ** power)
+
+
+def transform_tail(m):
+    """TRANSFORMS.transforms[1:] :143-150, stage by stage in the reference's order and dtype (f32 stays f32):
+    LowerThresh(1e-5), Log10, Multiply(20), Subtract(20), Add(100), Divide(100), Clip(0, 1), TrimSpec(860)."""
     m = np.maximum(1e-5, m)
-    m = np.log10(m) * 20
-    m = (m - 20 + 100) / 100
+    m = np.log10(m)
+    m = m * 20
+    m = m - 20
+    m = m + 100
+    m = m / 100
     m = np.clip(m, 0, 1.0)
     return m[:, :SPEC_LEN]
+
+
+def log_mel(y, mel_basis=None, stft=None):
+    """TRANSFORMS :141-151 on a waveform that already has its final length -> (80, 860) in [0,1].  `stft` (complex
+    spectrum of y) and `mel_basis` default to the restatements of librosa above."""
+    if mel_basis is None:
+        mel_basis = mel_filterbank()
+    mag = stft_mag(y) if stft is None else np.abs(stft(y))
+    return transform_tail(np.dot(mel_basis, mag))
 
 
 def crop_and_scale(mel):

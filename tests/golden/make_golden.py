@@ -38,6 +38,19 @@ def _stub(name, **attrs):
     return m
 
 
+class _Sequential(object):
+    """what torchvision.transforms.Compose does with a list of callables (the package is not installed): apply
+    them in order; `.transforms` is the list, as the reference's inv_transforms reads it (:157)."""
+
+    def __init__(self, transforms):
+        self.transforms = transforms
+
+    def __call__(self, x):
+        for f in self.transforms:
+            x = f(x)
+        return x
+
+
 def import_reference():
     class LightningModule(nn.Module):
         def log(self, *a, **k):
@@ -49,7 +62,7 @@ def import_reference():
     _stub("pytorch_lightning", LightningModule=LightningModule, LightningDataModule=object,
           Callback=object, seed_everything=lambda *a, **k: None)
     tv = _stub("torchvision")
-    tv.transforms = _stub("torchvision.transforms", Compose=object)
+    tv.transforms = _stub("torchvision.transforms", Compose=_Sequential)
     tv.utils = _stub("torchvision.utils")
     _stub("albumentations")
     ds = _stub("datasets")
@@ -557,13 +570,82 @@ def gen_melgan():
          sd_keys=np.array(list(sd.keys())))
 
 
+def gen_mel():
+    """M2 + the host half of M3 from the REAL reference (feature_extraction/extract_mel_spectrogram.py).  librosa
+    0.8.1 is absent, so its three entry points are stand-ins that do NOT pretend to be librosa: `filters.mel` and
+    `stft` return seeded arrays (recorded), `load` returns a seeded f32 waveform.  Everything else executes the
+    reference's own code: the eight small transform classes :40-127 chained by TRANSFORMS :141-151, `np.abs(.)**1`
+    and `np.dot(mel_basis, spec)` of MelSpectrogram.__call__ :36-37, and get_spectrogram's pad / truncate + dtype
+    rule :166-173 with the file naming of :183-187."""
+    print("mel transforms / get_spectrogram host rule")
+    import tempfile
+
+    calls = {}
+    basis = synth.standin_mel_basis()
+
+    def fake_mel(**kw):
+        calls["mel_kwargs"] = kw
+        return basis
+
+    def fake_stft(x, **kw):
+        calls["stft_x"] = x
+        calls["stft_kwargs"] = kw
+        return synth.standin_stft(x, kw["hop_length"])
+
+    def fake_load(path, sr="unset"):
+        calls["load_sr"] = sr
+        return synth.standin_wav(os.path.basename(path).split("_")[0]), 22050
+
+    lib = _stub("librosa", stft=fake_stft, load=fake_load)
+    lib.filters = _stub("librosa.filters", mel=fake_mel)
+    sys.path.insert(0, REF)
+    sys.modules.pop("feature_extraction.extract_mel_spectrogram", None)
+    import feature_extraction.extract_mel_spectrogram as ref_mel
+
+    out = {"mel_kwargs": np.array(sorted(f"{k}={v}" for k, v in calls["mel_kwargs"].items()))}
+    out["chain"] = np.array([type(f).__name__ for f in ref_mel.TRANSFORMS.transforms])
+    # (1) M2: the tail TRANSFORMS.transforms[1:] on synthetic mel matrices, f32 and f64, 1e-8 .. 1e3 with exact zeros
+    tail = _Sequential(ref_mel.TRANSFORMS.transforms[1:])
+    m64 = synth.mel_matrix()
+    o64, o32 = tail(m64), tail(m64.astype(np.float32))
+    out.update(mel_matrix_seed=910, out64=o64, out32=o32)
+    out["out_dtypes"] = np.array([str(o64.dtype), str(o32.dtype)])
+    # (2) M1's own two numpy lines + the tail, on the recorded stand-in STFT / basis (whole TRANSFORMS)
+    for tag in ("short", "long", "exact"):
+        y, mel = ref_mel.get_spectrogram(f"/nowhere/{tag}_clip.wav", None, 220500, save_results=False)
+        wav = synth.standin_wav(tag)
+        assert calls["stft_x"] is y
+        out[f"{tag}.wav_len"] = len(wav)
+        out[f"{tag}.y_dtype"] = str(y.dtype)
+        out[f"{tag}.y_equals_wav_prefix"] = bool(np.array_equal(y[:min(len(wav), 220500)], wav[:220500]))
+        out[f"{tag}.y_tail_abs_max"] = float(np.abs(y[len(wav):]).max()) if len(wav) < 220500 else 0.0
+        out[f"{tag}.mel"] = mel
+        out[f"{tag}.mel_dtype"] = str(mel.dtype)
+    out["stft_kwargs"] = np.array(sorted(f"{k}={v}" for k, v in calls["stft_kwargs"].items()))
+    out["load_sr"] = str(calls["load_sr"])
+    # (3) save_results=True: the file the reference writes
+    with tempfile.TemporaryDirectory() as d:
+        r = ref_mel.get_spectrogram("/nowhere/short_clip.wav", os.path.join(d, "melspec_10s_22050hz"), 220500)
+        assert r is None
+        names = sorted(os.listdir(os.path.join(d, "melspec_10s_22050hz")))
+        saved = np.load(os.path.join(d, "melspec_10s_22050hz", names[0]))
+        out["saved_names"] = np.array(names)
+        out["saved_shape"] = np.array(saved.shape)
+        out["saved_dtype"] = str(saved.dtype)
+        assert np.array_equal(saved, out["short.mel"])
+    save("mel_transforms", **out)
+
+
 def main():
     torch.manual_seed(synth.SEED)
     torch.set_num_threads(8)
     ref_gpt, ref_enc, ref_dec, ref_vq = import_reference()
-    which = set(sys.argv[1:]) or {"vq", "attn", "gpt", "lit", "vae", "vae_steps", "vae_xl", "vqvae", "melgan"}
-    if which == {"melgan"}:
-        gen_melgan()
+    which = set(sys.argv[1:]) or {"vq", "attn", "gpt", "lit", "vae", "vae_steps", "vae_xl", "vqvae", "melgan", "mel"}
+    if which <= {"melgan", "mel"}:
+        if "melgan" in which:
+            gen_melgan()
+        if "mel" in which:
+            gen_mel()
         assert not any("__pycache__" in d for d, _, _ in os.walk(REF)), "bytecode leaked into reference"
         return
     if "vq" in which:
@@ -584,6 +666,8 @@ def main():
         gen_vqvae(ref_vq)
     if "melgan" in which:
         gen_melgan()
+    if "mel" in which:
+        gen_mel()
     assert not any("__pycache__" in d for d, _, _ in os.walk(REF)), "bytecode leaked into reference"
 
 

@@ -216,6 +216,39 @@ def mel_tiles(seed, batch, n_mels=80, length=860):
     return np.clip(x, 0.0, 1.0).astype(np.float32)
 
 
+def mel_matrix(seed=910):
+    """synthetic (80, 862) f64 mel-magnitude matrix for the transform tail (M2): columns sweep 1e-8 .. 1e3, with exact
+    zeros, a run exactly on LowerThresh's floor and a run exactly on the upper clip edge."""
+    m = np.abs(normal(seed, (80, 862), 1.0).astype(np.float64)) * np.logspace(-8, 3, 862)[None, :]
+    m[::9, ::5] = 0.0
+    m[3, 10:20] = 1e-5
+    m[4, 10:20] = 10.0
+    return m
+
+
+def standin_mel_basis(seed=900):
+    """NOT librosa's filterbank: a seeded non-negative (80, 513) f32 matrix standing where librosa.filters.mel's result
+    stands when the reference's own numpy lines are recorded (make_golden.gen_mel)."""
+    return np.abs(normal(seed, (80, 513), 0.05)).astype(np.float32)
+
+
+def standin_stft(x, hop_length=256, seeds=(901, 902)):
+    """NOT an STFT: a seeded complex (513, 1 + len(x)//hop) matrix with librosa's output dtype rule (complex64 for f32
+    input, complex128 otherwise), magnitudes sweeping 1e-9 .. 1e2 with exact zeros."""
+    n_frames = 1 + len(x) // hop_length
+    re_ = normal(seeds[0], (513, n_frames), 1.0).astype(np.float64)
+    im_ = normal(seeds[1], (513, n_frames), 1.0).astype(np.float64)
+    re_[:, ::7] = 0.0
+    im_[:, ::7] = 0.0
+    z = (re_ + 1j * im_) * np.logspace(-9, 2, n_frames)[None, :]
+    return z.astype(np.complex64 if x.dtype == np.float32 else np.complex128)
+
+
+def standin_wav(tag, seed=903):
+    n = {"short": 100000, "long": 300000, "exact": 220500}[tag]
+    return normal(seed, (n,), 0.1).astype(np.float32)
+
+
 def waveform(seed, n=220500, sr=22050):
     """0.1*N(0,1) + a sine mix."""
     t = np.arange(n, dtype=np.float64) / sr

@@ -68,3 +68,49 @@ def test_many_clips_odd_length_and_wide_filter_fallback():
         ref = np.clip((np.log10(np.maximum(1e-5, m)) * 20 - 20 + 100) / 100, 0, 1.0)[:, :128]
         assert got.shape[1:] == ref.shape
         assert np.abs(got[0].cpu().numpy() - ref).max() < 1e-4
+
+
+def test_transform_tail_against_the_real_reference_1e4():
+    """M2 pinned: the kernel's last stage (melgpt_mel_transforms_fwd = the device function the fused kernel ends with)
+    against TRANSFORMS.transforms[1:] of the REAL reference recorded in tests/golden/mel_transforms.npz."""
+    from melspec_gpt_vqvae_amd.feature_extraction.extract_mel_spectrogram import TRANSFORMS
+    from util import golden
+
+    g = golden("mel_transforms")
+    assert [type(f).__name__ for f in TRANSFORMS.transforms] == list(g["chain"])
+    m32 = synth.mel_matrix(int(g["mel_matrix_seed"])).astype(np.float32)
+    x = torch.from_numpy(np.stack([m32, m32[::-1].copy()])).cuda()
+    mel, tile = TRANSFORMS.tail(x, tile_dtype=torch.float32)
+    assert mel.shape == (2, 80, 860) and tile.shape == (2, 1, 80, 848)
+    got = mel.cpu().numpy()
+    assert np.abs(got[0] - g["out32"]).max() < 1e-4 and np.abs(got[1] - g["out32"][::-1]).max() < 1e-4
+    assert np.abs(got[0] - g["out64"]).max() < 1e-4
+    assert np.all(got[0][g["out32"] == 0.0] == 0.0) and np.all(got[0][g["out32"] == 1.0] == 1.0)   # clip edges exact
+    assert np.abs(tile[0, 0].cpu().numpy() - (2 * g["out32"][:, 6:854] - 1)).max() < 2e-4
+
+
+def test_get_spectrogram_host_rule_matches_the_reference(tmp_path):
+    """M3's host half pinned: pad / truncate, dtypes, file name and shape as the real reference produced them."""
+    import wave
+
+    from melspec_gpt_vqvae_amd.feature_extraction import extract_mel_spectrogram as fe
+    from util import golden
+
+    g = golden("mel_transforms")
+    for tag in ("short", "long"):
+        wav = synth.standin_wav(tag)
+        pcm = np.clip(np.round(wav * 32768.0), -32768, 32767).astype("<i2")
+        path = str(tmp_path / f"{tag}_clip.wav")
+        with wave.open(path, "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(22050); f.writeframes(pcm.tobytes())
+        y, mel = fe.get_spectrogram(path, None, 220500, save_results=False)
+        assert str(y.dtype) == str(g[f"{tag}.y_dtype"]) and str(mel.dtype) == str(g[f"{tag}.mel_dtype"])
+        n = min(len(wav), 220500)
+        assert len(y) == 220500 and np.array_equal(y[:n], (pcm[:n].astype(np.float32) / 32768.0))
+        assert np.all(y[n:] == 0.0) and mel.shape == (80, 860)
+    out = tmp_path / "melspec_10s_22050hz"
+    assert fe.get_spectrogram(str(tmp_path / "short_clip.wav"), str(out), 220500) is None
+    import os
+    assert sorted(os.listdir(out)) == list(g["saved_names"])
+    saved = np.load(out / "short_clip_mel.npy")
+    assert list(saved.shape) == list(g["saved_shape"]) and str(saved.dtype) == str(g["saved_dtype"])

@@ -292,3 +292,38 @@ def test_vqvae_full_tile_to_codes():
         rec = ovq.vqvae_decode(sd, ovq.vq_forward(z[:1], sd["_vq_vae._embedding.weight"])[1])
     assert rel_err(rec.numpy(), g["rec"]) < 1e-5
     assert n_near == 0
+
+
+# --------------------------------------------------------------------- mel transforms (M2) + get_spectrogram host rule (M3)
+def test_mel_transform_tail_equals_reference_bit_for_bit():
+    from oracle import mel as om
+
+    g = golden("mel_transforms")
+    assert list(g["chain"]) == ["MelSpectrogram", "LowerThresh", "Log10", "Multiply", "Subtract", "Add", "Divide", "Clip",
+                                "TrimSpec"]
+    m64 = synth.mel_matrix(int(g["mel_matrix_seed"]))
+    o64, o32 = om.transform_tail(m64), om.transform_tail(m64.astype(np.float32))
+    assert [str(o64.dtype), str(o32.dtype)] == list(g["out_dtypes"])
+    assert np.array_equal(o64, g["out64"]) and np.array_equal(o32, g["out32"])
+    assert o64.shape == (80, 860) and o64.min() == 0.0 and o64.max() == 1.0
+    assert np.all(o64[::9, ::5] == 0.0) and np.all(o64[3, 10:20] == 0.0) and np.all(o64[4, 10:20] == 1.0)
+
+
+@pytest.mark.parametrize("tag", ["short", "long", "exact"])
+def test_get_spectrogram_host_rule_and_numpy_lines(tag):
+    """the reference's get_spectrogram with librosa's three entry points replaced by recorded stand-ins: pad -> f64 /
+    truncate keeps f32, then abs, np.dot and the tail - the oracle reproduces every array bit for bit."""
+    from oracle import mel as om
+
+    g = golden("mel_transforms")
+    assert list(g["mel_kwargs"]) == ["fmax=7600", "fmin=125", "n_fft=1024", "n_mels=80", "sr=22050"]
+    assert list(g["stft_kwargs"]) == ["hop_length=256", "n_fft=1024"] and str(g["load_sr"]) == "None"
+    wav = synth.standin_wav(tag)
+    y = om.fit_length(wav, 220500)
+    assert str(y.dtype) == str(g[f"{tag}.y_dtype"]) and len(y) == 220500
+    assert bool(g[f"{tag}.y_equals_wav_prefix"]) and np.array_equal(y[:min(len(wav), 220500)], wav[:220500])
+    assert float(g[f"{tag}.y_tail_abs_max"]) == 0.0 and (len(wav) >= 220500 or np.all(y[len(wav):] == 0.0))
+    mel = om.log_mel(y, mel_basis=synth.standin_mel_basis(), stft=synth.standin_stft)
+    assert str(mel.dtype) == str(g[f"{tag}.mel_dtype"]) and mel.shape == (80, 860)
+    assert np.array_equal(mel, g[f"{tag}.mel"])
+    assert list(g["saved_names"]) == ["short_clip_mel.npy"] and list(g["saved_shape"]) == [80, 860]
