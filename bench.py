@@ -82,10 +82,83 @@ def vq_encode_b64(job, device, reps=5):
             codes = job.vqvae.encode_to_codes(x)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
+        # the codebook lookup alone (north_star's ">= 60 % of HBM at batch 64" kernel): the encoder's output is kept and
+        # the fused lookup launched back to back, timed with HIP events on the launch stream (torch's current stream)
+        from melspec_gpt_vqvae_amd.vqvae.big_model_attn_gan import _as_nchw
+        h = _as_nchw(job.vqvae._encoder._nhwc(x))
+        n_vec = h.shape[0] * h.shape[2] * h.shape[3]
+        job.vqvae._vq_vae.encode_indices_fused(h, job.vqvae.quant_conv)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_l = 50
+        e0.record()
+        for _ in range(n_l):
+            job.vqvae._vq_vae.encode_indices_fused(h, job.vqvae.quant_conv)
+        e1.record()
+        e1.synchronize()
+        lookup_us = 1e3 * e0.elapsed_time(e1) / n_l
+    lookup_bytes = n_vec * 520 + 66048      # 512 B bf16 latent + 8 B index per vector, + the prepared image
     ms = 1e3 * sorted(ts)[len(ts) // 2]
     return {"workload": "VQ-encode + argmin, 64 tiles (1,80,848), 16-bit lane", "ms": round(ms, 3),
             "tiles_per_s": round(64 / (ms * 1e-3), 1), "encoder_tflops": round(64 * 142.57e9 / (ms * 1e-3) / 1e12, 1),
-            "codes_shape": list(codes.shape)}
+            "codes_shape": list(codes.shape), "lookup_us": round(lookup_us, 2), "lookup_vectors": n_vec,
+            "lookup_bytes": lookup_bytes, "lookup_frac_hbm": round(lookup_bytes / (lookup_us * 1e-6) / 8e12, 4),
+            "lookup_note": "in-stream average of 50 back-to-back launches incl. the Python launch path; 8.9 MB is 1.1 us "
+                           "at 8 TB/s - below any stand-alone launch (DESIGN 4)"}
+
+
+def gpt_vae_xl_rank(a, device, dtype, steps=3):
+    """BASELINE configs[3] beside the metric: ONE rank's work of the 8-GPU GPT-VAE XL job (2.09 B parameters, batch 128
+    per GPU), `steps` timed steps after one warm-up, outside the metric's timed region (the class-GPT job is freed
+    first: this one peaks at 168 GB)."""
+    from types import SimpleNamespace
+
+    from melspec_gpt_vqvae_amd import ops
+    job = GPTVAEXLStep(SimpleNamespace(layers=40, batch=128), device, dtype, 0, 1)
+    job.step(time.perf_counter)
+    torch.cuda.synchronize()
+    ops.TIMER = ops.KernelTimer()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = job.step(time.perf_counter)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    timer, ops.TIMER = ops.TIMER, None
+    ks = timer.summary()
+    out = {"workload": job.workload, "steps": steps, "ms_per_step": round(1e3 * dt, 2), "seq_per_s": round(128 / dt, 2),
+           "gemm_family_tflops": round(ks["flops"] / (ks["total_ms"] * 1e-3) / 1e12, 1) if ks["total_ms"] > 0 else None,
+           "step_tflops_3416_gflop_per_seq": round(128 * 3.416e12 / dt / 1e12, 1), "final_loss": round(float(loss.detach()), 4),
+           "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1),
+           "note": "one rank of the dp8 job; the 8.37 GB f32 gradient exchange of the other seven ranks is not in it"}
+    del job
+    return out
+
+
+def e2e_fp16_child(timeout=420):
+    """BASELINE configs[4] beside the metric: the end-to-end chain in the library's fp16 flavour - a CHILD process
+    (MELGPT_HALF is a property of the process; started after this one's GPU work is done, never replacing it): batch 1
+    latency percentiles and batch 64 clips/s with per-stage milliseconds (tools/bench_e2e.py)."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_e2e.py"), "--dtype", "fp16", "--batches", "1,64"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MELGPT_HALF")}
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": f"tools/bench_e2e.py did not finish in {timeout} s"}
+    rows = []
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{"):
+            try:
+                rows.append(json.loads(ln))
+            except ValueError:
+                pass
+    if r.returncode != 0 or len(rows) < 2:
+        return {"error": f"rc {r.returncode}", "stderr_tail": r.stderr[-400:]}
+    b1, b64 = rows[0], rows[1]
+    return {"workload": "wav -> HIP STFT/mel -> VQ encode -> GPT sample 265 (KV-cached) -> VQ decode -> MelGAN, fp16 flavour, one GPU",
+            "batch1_latency_ms": b1["latency_ms"], "batch1_stage_ms": b1["stage_ms_median"],
+            "batch64_clips_per_s": b64["clips_per_s"], "batch64_latency_ms": b64["latency_ms"],
+            "batch64_stage_ms": b64["stage_ms_median"], "x_realtime_batch64": b64["x_realtime"]}
 
 
 def pmc_summary(workload="class_gpt"):
@@ -321,11 +394,20 @@ def main():
                     help="bf16 (default, the metric's lane) | fp16 (the library's IEEE-half flavour) | f32 (parity lane)")
     ap.add_argument("--layers", type=int, default=24, help="debug only; anything but the configuration's depth is flagged")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip config4_gpt_vae_xl_rank / config5_e2e_fp16 (BASELINE configs[3], [4] beside the metric)")
     ap.add_argument("--breakdown", action="store_true", help="print per-phase timings to stderr")
     a = ap.parse_args()
 
     if a.dtype == "fp16":  # the 16-bit format is a property of the library flavour: choose it before the package loads
         os.environ["MELGPT_HALF"] = "fp16"
+    share = os.environ.get("MELGPT_BENCH_SHARE_GPU") == "1"
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N` (no torch.distributed.run around it): start the N ranks here, BEFORE this
+        # process makes any GPU call; rank 0 prints the JSON line on the inherited stdout, the exit status is the ranks'
+        from melspec_gpt_vqvae_amd.launch import spawn_ranks
+
+        raise SystemExit(spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], a.gpus, share_gpu=share))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -333,7 +415,6 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # debug aid (1-GPU boxes): MELGPT_BENCH_SHARE_GPU=1 lets several ranks share cuda:0 over gloo to exercise the
     # multi-rank control flow; the numbers of such a run mean nothing and the JSON line says so
-    share = os.environ.get("MELGPT_BENCH_SHARE_GPU") == "1"
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -445,7 +526,19 @@ def main():
                       f"TFLOP/s={r['tflops']:7.1f}", file=sys.stderr)
         if world == 1 and job.name == "class_gpt":
             out["config2_vq_encode"] = vq_encode_b64(job, device)
-        if world == 1 and not a.no_cpu_baseline and job.name == "class_gpt":
+        extras = world == 1 and job.name == "class_gpt" and job.full and a.batch == 128 and not a.no_extras
+        if extras:
+            # BASELINE configs[3] and [4] in the same driver-run line, outside the timed region; the class-GPT job is freed
+            # first (the XL rank step needs 168 GB)
+            del job
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["config4_gpt_vae_xl_rank"] = gpt_vae_xl_rank(a, device, dtype)
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["config5_e2e_fp16"] = e2e_fp16_child()
+        if world == 1 and not a.no_cpu_baseline and out["metric"].startswith("mel-token seqs/sec training step (VQ"):
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist.is_initialized():

@@ -1,6 +1,7 @@
 """Entry point with the flags of the reference's GPT_VAE_train.py (:28-116): the GPT-VAE (GPTEncoder + GPTDecoder) on
 VQ-code sequences, the one script the reference runs under DDP (:166-190, strategy "ddp_find_unused_parameters_false").
-Here: one process per GPU started by torch.distributed.run, gradients exchanged by dp.DataParallel over RCCL.
+Here: one process per GPU - `--gpus 0 1 2 3` starts them itself (launch.spawn_ranks, where Lightning's DDP launcher
+stands), or torch.distributed.run does - and gradients are exchanged by dp.DataParallel over RCCL.
 `--load_path CKPT` warm-starts the encoder from a stage-1 checkpoint (the `"encoder" in k` filter of :131-144)."""
 from __future__ import annotations
 
@@ -8,7 +9,7 @@ import argparse
 
 import torch
 
-from .GPT_train import _common_flags, add_flags, init_distributed, merge_config, seed_all
+from .GPT_train import _common_flags, add_flags, init_distributed, merge_config, seed_all, select_half
 
 
 # (flag, type, default, help): the reference's extra command line for the VAE (GPT_VAE_train.py:33-97)
@@ -44,6 +45,13 @@ def init_config(argv=None):
     parser.add_argument('--decoding_strategy', choices=['greedy', 'beam', 'sample'], default='greedy')
     parser.set_defaults(logging_frequency=500)
     args = parser.parse_args(argv)
+    from .launch import launched_by_a_launcher, spawn_ranks
+    if len(args.gpus) > 1 and not launched_by_a_launcher():
+        # `devices=args.gpus` of the reference's pl.Trainer (:172): one fresh rank per listed GPU, started before this
+        # process touches a GPU; rank r drives args.gpus[r] (init_distributed)
+        import sys
+        raise SystemExit(spawn_ranks(["-m", __spec__.name] + list(sys.argv[1:] if argv is None else argv), len(args.gpus)))
+    select_half(args.dtype)
     args.cuda = torch.cuda.is_available()
     seed_all(args.seed)
     args = merge_config(args, "GPT_VAE_%s" % args.dataset)

@@ -64,6 +64,22 @@ def merge_config(args, set_name):
     return argparse.Namespace(**merged)
 
 
+def select_half(dtype):
+    """`--dtype bf16|fp16`: the 16-bit format is a property of the LIBRARY flavour a process loads (_ffi.HALF, fixed at
+    import from MELGPT_HALF).  Called by init_config before anything imports `_ffi`: sets MELGPT_HALF from the flag, or
+    refuses when the process already holds the other flavour (silently training in the wrong format is not an option)."""
+    import sys
+
+    if dtype not in ("bf16", "fp16"):
+        return
+    loaded = sys.modules.get(__package__ + "._ffi")
+    if loaded is None:
+        os.environ["MELGPT_HALF"] = dtype
+    elif loaded.HALF != dtype:
+        raise SystemExit(f"--dtype {dtype}: this process already loaded the {loaded.HALF} flavour of the library "
+                         f"(MELGPT_HALF={loaded.HALF}); start a fresh process or export MELGPT_HALF={dtype}")
+
+
 def seed_all(seed):
     np.random.seed(seed)
     torch.manual_seed(seed)
@@ -75,6 +91,7 @@ def init_config(argv=None):
     parser = argparse.ArgumentParser(description='GPT transformer for VQVAE_spec')
     _common_flags(parser)
     args = parser.parse_args(argv)
+    select_half(args.dtype)
     args.cuda = torch.cuda.is_available()
     args.seed = SEED
     seed_all(args.seed)
@@ -88,6 +105,9 @@ def init_distributed(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.cuda:
+        gpus = getattr(args, "gpus", None)          # GPT_VAE_train's `--gpus 0 1 ...`: rank r drives the r-th listed GPU
+        if isinstance(gpus, (list, tuple)) and world > 1 and len(gpus) == world:
+            local = int(gpus[local])
         torch.cuda.set_device(local)
         args.device = f"cuda:{local}"
     else:

@@ -181,7 +181,8 @@ class DataParallel:
         seeds identically)."""
         if self.world > 1:
             dist.broadcast(self.fp.data, src=src, group=self.ex.group)
-            self.fp._shadow_key = None      # the bf16 shadow is refreshed from the received master copy
+            self.fp.generation += 1         # a write through the flat buffer: the bf16 shadow and every cache derived
+            self.fp._shadow_key = None      # from a parameter (flat.tensor_version) are rebuilt from the received copy
 
     def reduce_metrics(self, *values):
         """C4 of SURVEY §2b: the logged scalars of a step (Lit_GPT_VAE.py:310-313 logs loss / kl_weight / rec / KL with

@@ -58,12 +58,16 @@ class FlatParams:
         self.shadow = None
         self._shadow_key = None
         self._index = {}
+        # writes that go THROUGH the flat buffer (the fused optimizer, dp.broadcast_parameters) do not bump the
+        # parameters' tensor version counters: they bump this instead, and tensor_version() folds it into every cache key
+        self.generation = 0
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             v = self.data[o:o + p.numel()].view(p.shape)
             with torch.no_grad():
                 ops.cast(p.data.contiguous(), torch.float32, out=v)
             old_grad = p.grad
             p.data = v
+            p._melgpt_fp = self
             self._index[id(p)] = i
             p.grad = None
             if old_grad is not None:
@@ -106,7 +110,7 @@ class FlatParams:
         one cast launch whenever any parameter was modified in place)."""
         if dtype == torch.float32:
             return self.data
-        key = sum(p._version for p in self.params)
+        key = (sum(p._version for p in self.params), self.generation)
         if self.shadow is None:
             self.shadow = torch.empty(self.total, dtype=_ffi.HALF_DTYPE, device=self.device)
             self._shadow_key = None
@@ -117,7 +121,7 @@ class FlatParams:
 
     def mark_shadow_fresh(self):
         """called by the fused optimizer, which writes the bf16 shadow itself."""
-        self._shadow_key = sum(p._version for p in self.params)
+        self._shadow_key = (sum(p._version for p in self.params), self.generation)
 
     # ------------------------------------------------------------------ gradients
     def grad_target(self, p):
@@ -151,11 +155,21 @@ class FlatParams:
         unused branch, frozen sub-module, class embedder when no class token is fed).  The fused optimizer and the
         data-parallel exchange run over the whole buffer, so a stale slice would otherwise be applied / summed;
         torch.optim.AdamW in the reference skips such parameters - a zero gradient with zero moments is the same
-        no-op for them apart from weight decay, which the caller masks by `missing` if it needs to."""
+        no-op only while their moments are zero and without weight decay: FusedAdamW.step() therefore puts such
+        parameters (and their moments) back after its launches, using the list returned here."""
         missing = [p for p in self.params if p.grad is None]
         for p in missing:
             self._slice(self.grad, p).zero_()
         return missing
+
+
+def tensor_version(t):
+    """Cache key component for anything derived from a parameter (packed / repacked weights, the prepared codebook
+    image): storage, in-place version, and the generation of the flat store that owns it (see FlatParams.generation)."""
+    if t is None:
+        return None
+    fp = getattr(t, "_melgpt_fp", None)
+    return (t.data_ptr(), t._version, fp.generation if fp is not None else 0)
 
 
 def ensure_flat(module: nn.Module) -> FlatParams:

@@ -50,8 +50,12 @@ class _timed:
             self.s.record()
         return self
 
+    def cancel(self):
+        """the call was refused before any launch (MELGPT_ERR_UNSUPPORTED): its FLOPs belong to the fallback's record"""
+        self.flops = None
+
     def __exit__(self, *a):
-        if TIMER is not None:
+        if TIMER is not None and self.flops is not None:
             self.e.record()
             TIMER.records.append((self.s, self.e, self.flops, self.tag))
         return False
@@ -283,9 +287,11 @@ def wgrad(dy, x, out, accumulate, bias_out=None, bias_accumulate=None):
         nrs = L.melgpt_wgrad_rowsum_rows(K, ns)
         part = torch.empty(ns, N, K, dtype=torch.float32, device=dy.device)
         rpart = torch.empty(nrs, N, dtype=torch.float32, device=dy.device)
-        with _timed(2.0 * M * N * K, f"gemm TN {N}x{K}x{rows} b{ns} +rowsum"):
+        with _timed(2.0 * M * N * K, f"gemm TN {N}x{K}x{rows} b{ns} +rowsum") as tm:
             code = L.melgpt_wgrad_rowsum(ptr(dy), dy.stride(0), rows * dy.stride(0), ptr(x), x.stride(0), rows * x.stride(0),
                                          ptr(part), K, N * K, N, K, rows, ns, dtype_code(dy.dtype), ptr(rpart), N, stream())
+            if code == _ffi.ERR_UNSUPPORTED:
+                tm.cancel()
         if code != _ffi.ERR_UNSUPPORTED:
             _ffi.check(code, "melgpt_wgrad_rowsum")
             call("melgpt_reduce_rows", ptr(part), ns, N * K, N * K, ptr(out), int(accumulate), 1.0, stream())
@@ -571,10 +577,12 @@ def conv3x3_gn_with_out_stats(x, stats, gamma, beta, wpack, bias, out_eps, *, sw
     omean = torch.empty(B * 32, dtype=torch.float32, device=x.device)
     orstd = torch.empty(B * 32, dtype=torch.float32, device=x.device)
     mean, rstd = stats if stats is not None else (None, None)
-    with _timed(2.0 * B * H * W * Cout * 9 * Cin, f"conv3x3+gn {H}x{W} {Cin}->{Cout}"):
+    with _timed(2.0 * B * H * W * Cout * 9 * Cin, f"conv3x3+gn {H}x{W} {Cin}->{Cout}") as tm:
         code = L.melgpt_conv3x3_gn_nhwc_stats(ptr(x), B, H, W, Cin, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), int(swish),
                                               ptr(wpack), Cout, ptr(bias), ptr(residual), ptr(out), dtype_code(x.dtype),
                                               float(out_eps), ptr(omean), ptr(orstd), ptr(ws), stream())
+        if code == _ffi.ERR_UNSUPPORTED:
+            tm.cancel()
     if code == _ffi.ERR_UNSUPPORTED:
         return None
     _ffi.check(code, "melgpt_conv3x3_gn_nhwc_stats")

@@ -28,20 +28,37 @@ class Fit:
         self.best_val = float("inf")
         self.dp = None
         module.to(self.device)
+        # what is trained = what the reference's configure_optimizers walks: `self.transformer` of a Lit_minGPT (a loaded
+        # first_stage_model stays frozen, minGPT.py:632), the whole GPT_VAE (Lit_GPT_VAE.py:908).  The flat store, the
+        # gradient exchange and the optimizer all cover exactly this sub-tree, at every world size.
+        target = self.target = module.transformer if hasattr(module, "transformer") else module
         if self.world > 1:
             from .dp import DataParallel
 
             assert dist.is_initialized(), "initialise torch.distributed (backend nccl = RCCL) before Fit under WORLD_SIZE > 1"
-            self.dp = DataParallel(module)
+            if not (fused_optimizer and self.device.type == "cuda"):
+                raise RuntimeError("data-parallel training uses the fused optimizer (it folds the 1/world averaging in)")
+            self.dp = DataParallel(target)
+            self.dp.broadcast_parameters(0)     # C1 of SURVEY 2b: ranks start from rank 0's weights, whatever their seeds
             if getattr(module, "data", None) is not None:
                 module.data.rank, module.data.world = self.rank, self.world
-        target = module.transformer if hasattr(module, "transformer") else module
+        # fp16 flavour of the library: a 5-bit exponent - the mean cross entropy's dlogits (1e-7 .. 3e-5 at 128 x 265
+        # tokens) are subnormal or zero in fp16 - so the loss is scaled before backward and the optimizer's grad_scale
+        # takes the factor out again; a step whose gradient is not finite is skipped and the scale halved (dynamic loss
+        # scaling).  bf16 / f32 lanes: scale 1, no check.
+        from . import _ffi
+        self.fp16 = getattr(args, "dtype", "f32") == "fp16" and _ffi.HALF == "fp16"
+        self.loss_scale = 4096.0 if self.fp16 else 1.0
+        self._good_steps = 0
+        self.skipped_steps = 0
         if fused_optimizer and self.device.type == "cuda":
             from .optim import FusedAdamW
 
             self.opt = FusedAdamW(target, lr=args.learning_rate, betas=(0.9, 0.95), weight_decay=0.01)
-            self.opt.grad_scale = 1.0 / self.world
+            self.opt.grad_scale = 1.0 / (self.world * self.loss_scale)
         else:
+            if self.fp16:
+                raise RuntimeError("the fp16 lane needs the fused optimizer (loss scaling lives in its grad_scale)")
             self.opt = module.configure_optimizers()
 
     # ------------------------------------------------------------------------------------------------ one epoch
@@ -58,10 +75,11 @@ class Fit:
             batch = _to_device(batch, self.device)
             loss = m.training_step(batch, i)
             self.opt.zero_grad()
-            loss.backward()
+            (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
             if self.dp is not None:
                 self.dp.finish()
-            self.opt.step()
+            if self._step_ok():
+                self.opt.step()
             self.global_step += 1
             losses.append(loss.detach())
             freq = int(getattr(self.args, "logging_frequency", 200) or 200)
@@ -80,6 +98,29 @@ class Fit:
         self.history["train_loss"].append([float(v) for v in out.cpu()])
         self.history["steps"] = self.global_step
         return out
+
+    def _step_ok(self):
+        """fp16 lane only: is the (scaled, reduced) gradient finite?  One fused sum over the flat buffer and one host
+        read per step; an overflow skips the step and halves the scale, 200 clean steps double it (up to 65 536)."""
+        if not self.fp16:
+            return True
+        from . import ops
+        from .flat import ensure_flat
+
+        fp = ensure_flat(self.target)
+        fp.zero_missing_grads()
+        ok = bool(torch.isfinite(ops.sum_f32(fp.grad)).item())
+        if ok:
+            self._good_steps += 1
+            if self._good_steps >= 200 and self.loss_scale < 65536.0:
+                self.loss_scale *= 2.0
+                self._good_steps = 0
+        else:
+            self.skipped_steps += 1
+            self._good_steps = 0
+            self.loss_scale = max(1.0, self.loss_scale / 2.0)
+        self.opt.grad_scale = 1.0 / (self.world * self.loss_scale)
+        return ok
 
     @torch.no_grad()
     def validate(self):
@@ -117,9 +158,12 @@ class Fit:
         ck = {"state_dict": {k: v.detach().cpu().clone() for k, v in self.module.state_dict().items()}, "epoch": epoch,
               "global_step": self.global_step, "best_val_loss": self.best_val}
         if hasattr(self.opt, "state_dict"):
+            # torch.optim.AdamW's layout from both optimizers (FusedAdamW.state_dict writes it per parameter, in the
+            # reference's group order): what Lightning stores under `optimizer_states`
             sd = self.opt.state_dict()
-            ck["optimizer_states"] = [{k: (v.detach().cpu().clone() if isinstance(v, torch.Tensor) else v)
-                                       for k, v in sd.items()}] if "exp_avg" in sd else [sd]
+            sd["state"] = {i: {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in st.items()}
+                           for i, st in sd["state"].items()}
+            ck["optimizer_states"] = [sd]
         if hasattr(self.module, "on_save_checkpoint"):
             self.module.on_save_checkpoint(ck)
         path = os.path.join(d, name)
@@ -128,15 +172,22 @@ class Fit:
 
     def resume(self, path):
         ck = torch.load(path, map_location="cpu", weights_only=False)
-        self.module.load_state_dict(ck["state_dict"], strict=False)
+        res = self.module.load_state_dict(ck["state_dict"], strict=False)
+        # a checkpoint that does not fit must not resume from random weights: only the constant `attn.mask` buffers
+        # (checkpoint ABI, never read) and a frozen first-stage VQ-VAE / vocoder the file did not carry may be absent
+        optional = ("first_stage_model.", "vocoder.")
+        missing = [k for k in res.missing_keys if not k.endswith("attn.mask") and not k.startswith(optional)]
+        unexpected = [k for k in res.unexpected_keys if not k.startswith(optional)]
+        if missing or unexpected:
+            raise RuntimeError(f"{path} does not fit {type(self.module).__name__}: missing {missing[:6]} "
+                               f"({len(missing)}), unexpected {unexpected[:6]} ({len(unexpected)})")
         self.global_step = int(ck.get("global_step", 0))
         self.best_val = float(ck.get("best_val_loss", float("inf")))
         st = ck.get("optimizer_states")
-        if st and "exp_avg" in st[0] and hasattr(self.opt, "_state"):
-            self.opt._state()
-            self.opt.load_state_dict({k: (v.to(self.device) if isinstance(v, torch.Tensor) else v) for k, v in st[0].items()})
-        elif st:
-            self.opt.load_state_dict(st[0])
+        if st:
+            self.opt.load_state_dict(st[0])     # torch.optim.AdamW's layout (ours and the reference's), or the old flat one
+        if self.dp is not None:
+            self.dp.fp.generation += 1          # load_state_dict wrote the parameters in place: refresh shadow and caches
         if hasattr(self.module, "on_load_checkpoint") and "kl_weight" in ck:
             self.module.on_load_checkpoint(ck)
         return int(ck.get("epoch", -1)) + 1

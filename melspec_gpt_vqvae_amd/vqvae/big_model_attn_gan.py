@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from .. import _ffi, ops
+from ..flat import tensor_version
 from .quantizer import VectorQuantizer  # noqa: F401  (re-exported under the reference's module path)
 
 
@@ -40,7 +41,7 @@ def set_compute_dtype(module, dtype):
 def _packed_weight(conv, dtype):
     """(Cout,KH,KW,Cin) copy of a Conv2d weight in the compute dtype, rebuilt only when the parameter changes."""
     w = conv.weight
-    key = (w._version, w.data_ptr(), dtype)
+    key = (tensor_version(w), dtype)
     cached = getattr(conv, "_melgpt_pack", None)
     if cached is None or cached[0] != key:
         cached = (key, ops.repack_conv_weight(w, dtype))
@@ -219,7 +220,7 @@ class AttnBlock(nn.Module):
 
     def _qkv_weights(self, dtype):
         ws = (self.q.weight, self.k.weight, self.v.weight, self.q.bias, self.k.bias, self.v.bias)
-        key = tuple((w._version, w.data_ptr()) for w in ws) + (dtype,)
+        key = tuple(tensor_version(w) for w in ws) + (dtype,)
         cached = getattr(self, "_melgpt_qkv", None)
         if cached is None or cached[0] != key:
             C = self.in_channels
@@ -375,7 +376,7 @@ class Decoder(nn.Module):
 
     def _conv_out_weight(self):
         w = self.conv_out.weight
-        key = (w._version, w.data_ptr())
+        key = tensor_version(w)
         cached = getattr(self, "_melgpt_cout", None)
         if cached is None or cached[0] != key:
             cached = (key, ops.repack_conv_weight(w, torch.float32).reshape(9, w.shape[1]))

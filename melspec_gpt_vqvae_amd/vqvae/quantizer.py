@@ -63,7 +63,9 @@ class CodebookImage:
 
     @staticmethod
     def _sig(t):
-        return None if t is None else (t.data_ptr(), t._version, str(t.device))
+        from ..flat import tensor_version
+
+        return None if t is None else tensor_version(t) + (str(t.device),)
 
     def invalidate(self):
         self._key = None

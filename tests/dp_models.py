@@ -8,6 +8,26 @@ BATCH = 4
 
 
 def build(which, dev):
+    if which == "gptclass_vas16":
+        # 2 layers at the VAS width in the 16-bit lane, 12 sequences = 3 180 rows: fc1 / fc2 / their dgrads are 208-tile
+        # problems, i.e. they run on the persistent 256 x 256 kernel (csrc/gemm.hip pick_tile) - the one that draws claimed
+        # tiles while an all-reduce can be in flight
+        from melspec_gpt_vqvae_amd import _ffi
+        from melspec_gpt_vqvae_amd.transformer.minGPT import GPTClass, cross_entropy, set_compute_dtype
+
+        args = synth.gpt_args(n_layer=2, n_head=16, n_embd=1024)
+        m = GPTClass(args)
+        m.load_state_dict({k: t(v) for k, v in synth.gpt_state_dict(args, 3).items()}, strict=False)
+        m.to(dev).train()
+        set_compute_dtype(m, _ffi.HALF_DTYPE)
+        batch = {"x": t(synth.randint(920, 0, 128, (12, 265)), dev), "c": t(synth.randint(921, 0, 8, (12, 1)), dev)}
+
+        def loss_fn(model, b):
+            with model.discard_att():
+                logits, _, _ = model(b["x"][:, :-1], b["c"])
+            return cross_entropy(logits.reshape(-1, logits.size(-1)), b["x"].reshape(-1))
+
+        return m, batch, loss_fn
     if which == "gptclass":
         from melspec_gpt_vqvae_amd.transformer.minGPT import GPTClass, cross_entropy
 

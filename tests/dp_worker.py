@@ -1,6 +1,8 @@
 """Child rank of tests/test_dp_gpu.py (test infrastructure): several ranks share cuda:0, rendezvous over gloo, run one
-forward/backward of a small model through dp.DataParallel and dump the reduced flat gradient.
-usage: python tests/dp_worker.py <gptclass|vae> <outdir>     (RANK / WORLD_SIZE / MASTER_* in the environment)"""
+forward/backward of a small model through dp.DataParallel and dump the reduced flat gradient.  DP_BACKEND=nccl: ONE rank
+over a real RCCL process group (RCCL refuses two ranks on one device) with MELGPT_DP_FORCE_EXCHANGE=1, so that the
+all-reduces are really issued on RCCL's stream beside the backward GEMMs, with DataParallel's RCCL defaults.
+usage: python tests/dp_worker.py <gptclass|vae|gptclass_vas16> <outdir>     (RANK / WORLD_SIZE / MASTER_* in the environment)"""
 import os
 import sys
 
@@ -17,20 +19,29 @@ import dp_models
 def main():
     which, outdir = sys.argv[1], sys.argv[2]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)          # before anything touches the GPU
-    torch.cuda.set_device(0)
+    backend = os.environ.get("DP_BACKEND", "gloo")
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)      # before anything touches the GPU
+        torch.cuda.set_device(0)
     from melspec_gpt_vqvae_amd.dp import DataParallel
 
     model, batch, loss_fn = dp_models.build(which, "cuda:0")
     from melspec_gpt_vqvae_amd import _ffi
 
-    # the window in which RCCL kernels may share the chip (claimed tiles + reserved CUs on) is what an RCCL run gets by
-    # default; asked for explicitly here because this rendezvous is gloo
-    dp = DataParallel(model, dynamic_tiles=True, reserve_cus=8)
+    # the window in which RCCL kernels may share the chip (claimed tiles + reserved CUs on): claimed tiles are what an
+    # RCCL run gets by default (checked below); asked for explicitly when this rendezvous is gloo
+    if backend == "nccl":
+        dp = DataParallel(model)      # no reserved CUs: they change the weight gradients' split-K factor, hence the bits
+        assert dp.ex.active and dp.dynamic_tiles, "over RCCL the exchange is live and claimed tiles are the default"
+    else:
+        dp = DataParallel(model, dynamic_tiles=True, reserve_cus=8)
     L = _ffi.lib()
     window = [(L.melgpt_get_dynamic_tiles(), L.melgpt_get_reserved_cus())]        # before the backward pass: (0, 0)
-    assert dp.world == world and len(dp.blocks) == (2 if which == "gptclass" else 4)
-    n = dp_models.BATCH // world
+    assert dp.world == world and len(dp.blocks) == (4 if which == "vae" else 2)
+    n = next(iter(batch.values())).shape[0] // world
     local = {k: v[rank * n:(rank + 1) * n] for k, v in batch.items()}
     loss = loss_fn(model, local)
     loss.backward()
@@ -42,7 +53,7 @@ def main():
     m = dp.reduce_metrics(loss, float(rank), 3.0)
     torch.save({"grad": dp.fp.grad.cpu(), "hook_calls": dp.hook_calls, "launched_early": launched_early,
                 "loss": float(loss), "metrics": [float(v) for v in m], "names": dp.fp.names, "window": window,
-                "offsets": dp.fp.offsets}, os.path.join(outdir, f"rank{rank}.pt"))
+                "offsets": dp.fp.offsets, "backend": dist.get_backend(), "n_works": len(dp.ex._done)}, os.path.join(outdir, f"rank{rank}.pt"))
     # a second backward without finish() in between must be refused (partial sums would be reduced twice)
     refused = False
     loss2 = loss_fn(model, local)

@@ -153,3 +153,29 @@ def test_gradient_exchange_two_process_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ------------------------------------------------------------------------------------------ launch.spawn_ranks
+def _run_launcher(extra):
+    import subprocess
+    import sys as _sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path.insert(0, %r); from melspec_gpt_vqvae_amd.launch import spawn_ranks; "
+            "raise SystemExit(spawn_ranks([%r] + %r, 2, share_gpu=True, timeout=120))"
+            % (os.path.dirname(here), os.path.join(here, "launch_worker.py"), extra))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    return subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_spawn_ranks_starts_one_process_per_rank_and_relays_rank0():
+    """what `python bench.py --gpus N` (no launcher around it) does: N fresh ranks with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, rank 0's stdout passed through, exit status 0."""
+    r = _run_launcher([])
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip().splitlines()[-1] == "LAUNCH_OK world=2 local_rank=0 sum=3"   # gloo may print a line first
+
+
+def test_spawn_ranks_propagates_a_failing_rank_instead_of_hanging():
+    r = _run_launcher(["--fail-rank", "1"])
+    assert r.returncode == 7, (r.returncode, r.stderr)

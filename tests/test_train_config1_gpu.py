@@ -79,7 +79,21 @@ def test_config1_vas_plumbing_one_epoch(tmp_path):
     fit2 = Fit(lit2, args)
     assert fit2.resume(os.path.join(ck_dir, "last.ckpt")) == 1 and fit2.global_step == 8
     assert abs(fit2.validate() - val1) < 1e-5
-    assert torch.equal(fit2.opt._m.cpu(), ck["optimizer_states"][0]["exp_avg"])
+    assert torch.equal(fit2.opt._m, fit.opt._m) and torch.equal(fit2.opt._v, fit.opt._v) and fit2.opt.step_count == 8
+    # `optimizer_states` is torch.optim.AdamW's layout (what Lightning stores for the reference): it loads into the
+    # reference-style optimizer of configure_optimizers as it stands
+    ost = ck["optimizer_states"][0]
+    assert set(ost) >= {"state", "param_groups"} and len(ost["param_groups"]) == 2
+    topt = lit2.configure_optimizers()
+    topt.load_state_dict(ost)
+    name0 = ost["param_names"][0]
+    p0 = dict(lit2.transformer.named_parameters())[name0]
+    assert torch.equal(topt.state[p0]["exp_avg"].cpu(), ost["state"][0]["exp_avg"])
+    # a checkpoint that does not fit is refused instead of resuming from random weights
+    bad = dict(ck, state_dict={k: v for k, v in ck["state_dict"].items() if "blocks.1." not in k})
+    torch.save(bad, os.path.join(str(tmp_path), "bad.ckpt"))
+    with pytest.raises(RuntimeError, match="does not fit"):
+        Fit(Lit_minGPT(args), args).resume(os.path.join(str(tmp_path), "bad.ckpt"))
 
 
 def test_entry_point_main_runs_bf16(tmp_path):

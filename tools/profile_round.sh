@@ -11,7 +11,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline $EXTRA"
+CMD="python3 $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras $EXTRA"
 export PROFILE_CMD="$CMD"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- $CMD > "$OUT/trace.log" 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/fetch" -o fetch --output-format csv -- $CMD > "$OUT/fetch.log" 2>&1
