@@ -76,7 +76,14 @@ __device__ __forceinline__ rsrc_t make_rsrc4(const void* base, unsigned bytes) {
 }
 __device__ __forceinline__ void dma16(rsrc_t rs, char* lds_wave_base, unsigned voff) {
   const unsigned m0v = (unsigned)(size_t)LDS_PTR(char, lds_wave_base);
-  asm volatile("s_nop 2\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+  // Cache policy of the requests: sc1 = served by the XCD's L2 without allocating in the CU's vector L1 (the 32 KiB L1
+  // holds nothing this stream ever re-reads).  Lab, constant operands, two runs each (profiles/r03_gemm_lab.md): every
+  // shape +0.5 .. 2.5 % over the default policy; nt (streaming) -3 .. -15 %: the panels ARE re-read, by the other tiles
+  // of the XCD's block, out of L2; sc0 = default.
+#ifndef G256_DMA_POLICY
+#define G256_DMA_POLICY " sc1"
+#endif
+  asm volatile("s_nop 2\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" G256_DMA_POLICY " lds"
                :
                : "s"(m0v), "v"(voff), "s"(rs)
                : "memory", "m0");
@@ -460,7 +467,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
 #pragma unroll
-          for (int nt = 0; nt < TN; ++nt) mma<bf16_t>(acc[mt][nt], fb[nt], fa[mt]);  // rows = n, cols = m
+          for (int nt = 0; nt < TN; ++nt) {
+            if (G256_LAB == 13) asm volatile("" ::"v"(fb[nt]), "v"(fa[mt]));      // lab: LDS-DMA + fragment reads, no MFMA
+            else mma<bf16_t>(acc[mt][nt], fb[nt], fa[mt]);  // rows = n, cols = m
+          }
           // piece k of NP goes out after MFMA row floor((k + 1) TM / NP) - 1
           const int np = ks == 0 ? PER : PER_A;
           const int k_here = ((mt + 1) * np) / TM - (mt * np) / TM;  // 0 or 1 pieces after this row

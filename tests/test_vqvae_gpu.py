@@ -157,7 +157,10 @@ def test_full_vqvae_bf16_lane_reports_code_agreement():
     agree_lo = float((codes_lo.cpu().numpy().ravel() == want).mean())
     report("vqvae_full_bf16_lane_vs_f32_reference", latent_rel_to_max_err=err, code_agreement_fused_hi_only=agree,
            code_agreement_unfused=agree_unfused, code_agreement_fused_hi_lo=agree_lo, vectors=530)
-    assert err < 5e-2 and agree > 0.9 and agree_unfused > 0.9 and agree_lo > 0.9
+    # gate = the measured agreement (0.987 / 0.983 / 0.987 of 530 codes, profiles/r02_h_parity_report.jsonl) minus a
+    # margin of two or three flips, not a loose bound: north_star's "indices bit-exact" is the f32 lane's property, the
+    # 16-bit lane's is reported and held at >= 0.98
+    assert err < 5e-2 and agree >= 0.98 and agree_unfused >= 0.975 and agree_lo >= 0.98
     assert agree >= agree_unfused - 0.02       # folding the conv must not cost agreement with the f32 reference
 
 
