@@ -239,6 +239,23 @@ int melgpt_linear_skinny(const void* x, long long ldx, const void* W, long long 
                          const void* residual, long long ldr, void* y, long long ldy, int M, int N, int K, int act,
                          int dtype, int out_f32, const float* ln_gamma, const float* ln_beta, float ln_eps,
                          void* stream);
+/* The same product for 9 .. 128 rows with every byte a workgroup needs requested up front (decode steps at batch 16 ..
+ * 128, transformer/minGPT.py:293-360 with a KV cache): a workgroup owns 16 output columns x one 1024-wide slice of K;
+ * its rows of x go to LDS by LDS-DMA, its weights to registers, one wait, then MFMAs on on-chip operands.  K must be a
+ * multiple of 1024; K > 1024 runs as K / 1024 slices whose f32 partial tiles (melgpt_linear_lds_workspace bytes) are
+ * summed in slice order by a second launch that applies bias / GELU / residual.
+ * Pre-LayerNorm folded in (ln_c1 / ln_c2 non-NULL, K = 1024): W is then the PREPARED weight W' of melgpt_ln_fold_prepare
+ * and y = rstd (W' x - mu c1) + c2 = W LN(x) + b with the row statistics taken inside the launch; `bias` is ignored. */
+long long melgpt_linear_lds_workspace(int M, int N, int K);
+int melgpt_linear_lds(const void* x, long long ldx, const void* W, long long ldw, const float* bias, const void* residual,
+                      long long ldr, void* y, long long ldy, int M, int N, int K, int act, int dtype, int out_f32,
+                      const float* ln_c1, const float* ln_c2, float ln_eps, void* workspace, void* stream);
+/* once per (weight, LayerNorm, bias) version: W' (N, K) = W diag(gamma) in the 16-bit format, c1[n] = sum_k W'[n][k],
+ * c2[n] = sum_k W[n][k] beta[k] + bias[n] (bias may be NULL) - the block's pre-LN (transformer/minGPT.py:108-117: ln1
+ * before attn's key/query/value, ln2 before mlp[0]; ln_f before head :187-188) folded into the Linear that follows it. */
+int melgpt_ln_fold_prepare(const void* W, long long ldw, const float* bias, const float* gamma, const float* beta, int N,
+                           int K, int dtype, void* W_folded, float* c1, float* c2, void* stream);
+
 /* graph-replayed decoding helpers: x[b,:] = tok_emb[idx[b]] + pos_emb[*pos_dev] (minGPT.py:170-180 for one position);
  * *counter += 1 */
 int melgpt_embed_decode(const long long* idx, const float* tok_emb, const float* pos_emb, const int* pos_dev, int B,

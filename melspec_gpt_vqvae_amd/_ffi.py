@@ -60,6 +60,9 @@ _PROTOS = {
     "melgpt_conv1d_out1": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "melgpt_gemv_rows": [_p, _l, _p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p],
     "melgpt_linear_skinny": [_p, _l, _p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p],
+    "melgpt_linear_lds_workspace": [_i, _i, _i],
+    "melgpt_linear_lds": [_p, _l, _p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p, _p],
+    "melgpt_ln_fold_prepare": [_p, _l, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p],
     "melgpt_attn_bwd": [_p, _p, _p, _l, _p, _p, _l, _p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _f, _u64, C.c_uint,
                         _i, _p],
     "melgpt_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _l, _i, _f, _i, _p],
@@ -100,7 +103,7 @@ _PROTOS = {
     "melgpt_conv3x3_gn_nhwc_stats": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _f, _p, _p, _p, _p],
     "melgpt_groupnorm_finalize": [_p, _i, _i, C.c_double, _f, _p, _p, _p],
 }
-_RESTYPE = {"melgpt_strerror": C.c_char_p, "melgpt_vq_image_bytes": C.c_int64}
+_RESTYPE = {"melgpt_strerror": C.c_char_p, "melgpt_vq_image_bytes": C.c_int64, "melgpt_linear_lds_workspace": C.c_int64}
 
 _lib = None
 

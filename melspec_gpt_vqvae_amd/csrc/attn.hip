@@ -637,10 +637,13 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_dkv_ker
  }  // tile loop
 }
 
+#ifndef ATTN_LAB_LDSPAD
+#define ATTN_LAB_LDSPAD 0  // lab: extra dynamic LDS per workgroup (90000 forces ONE workgroup per CU: what a persistent
+#endif                     // workgroup with double-buffered K/V would run at - profiles/r03_attn_lab.md)
 template <typename T>
 size_t lds_bytes(int Tn, bool with_stats) {
   const int TP = (Tn + 31) / 32 * 32;
-  return 2 * (size_t)TP * AT<T>::ROWB + (with_stats ? 2 * (size_t)TP * 4 : 0) + 16;
+  return 2 * (size_t)TP * AT<T>::ROWB + (with_stats ? 2 * (size_t)TP * 4 : 0) + 16 + ATTN_LAB_LDSPAD;
 }
 
 int validate(const AttnParams& p, int hs, int dtype) {

@@ -40,7 +40,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
   if (pos_dev) pos = *pos_dev;  // graph-replayed decoding: the position lives on the device
   if (pos >= Tmax) return;
   const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  __shared__ float prob[MAXT];
   __shared__ float qs[HS];
   __shared__ float vnew[HS];
   __shared__ float red[2][4];
@@ -50,21 +49,21 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
   T* kb = kc + ((long long)b * Tmax) * C + h * HS;
   T* vb = vc + ((long long)b * Tmax) * C + h * HS;
   const int len = pos + 1;
-  // the cache rows this thread will need do not depend on the new token: request them first
-  u32x4 kr[2][ROWCH];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int t = min(tid + NT * i, pos);  // clamped: always a valid row (row `pos` may hold anything: not used)
-    if (i == 0 || pos >= NT) {             // uniform
-#pragma unroll
-      for (int c = 0; c < ROWCH; ++c) kr[i][c] = *(const u32x4*)(kb + (long long)t * C + c * VEC);
-    }
-  }
+  // the cache rows this thread will need do not depend on the new token: request them first.  BOTH caches are read the
+  // same way: thread = (position group g, 16-byte chunk c of the head dimension), rows g + G i - the ROWCH lanes of a
+  // row cover its 128 / 256 contiguous bytes, one full line per 8 / 16 lanes.  (One whole K row per thread - the first
+  // version - made every load instruction touch 64 different lines, 16 bytes of each: 8 x the requests for the same
+  // bytes; at batch 64 the step took 14.4 us against 6 us of cache bytes at the HBM rate, profiles/r03_decode_lab.md.)
   const int g = tid / ROWCH, cch = tid % ROWCH;
-  u32x4 vr[NIT];
+  u32x4 kr[NIT], vr[NIT];
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
-    const int t = min(g + G * i, max(pos - 1, 0));  // clamped to rows that exist; weight 0 beyond the end
+    const int t = min(g + G * i, max(pos - 1, 0));  // clamped to rows that exist (their scores are masked below)
+    kr[i] = *(const u32x4*)(kb + (long long)t * C + cch * VEC);
+  }
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int t = min(g + G * i, max(pos - 1, 0));  // weight 0 beyond the end
     vr[i] = *(const u32x4*)(vb + (long long)t * C + cch * VEC);
   }
   // append this token's key / value (wave 0: lane = head dimension); q and v stay in LDS, the newest key's score comes
@@ -84,66 +83,64 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
     if (lane == 0) s_new_sh = sn;
   }
   __syncthreads();
-  float s[2];
-  float mx = -INFINITY;
+  // scores of rows g + G i: the lane's chunk of the dot product, summed over the ROWCH lanes of the row (DPP butterflies:
+  // every lane of the row ends up with the whole dot product, bit-identical)
+  float qv[VEC];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int t = tid + NT * i;
-    s[i] = -INFINITY;
-    if (t < len) {
-      float acc = 0.f;
-      if (t == pos) {
-        acc = s_new_sh;
-      } else if constexpr (sizeof(T) == 2) {
+  for (int e = 0; e < VEC; ++e) qv[e] = qs[cch * VEC + e];
+  const float s_new = s_new_sh * scale;
+  float s[NIT];
+  float mx = s_new;  // (position `pos` itself is always visible)
 #pragma unroll
-        for (int c = 0; c < ROWCH; ++c)
+  for (int i = 0; i < NIT; ++i) {
+    float acc = 0.f;
+    if constexpr (sizeof(T) == 2) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            acc = fmaf(half_lo(kr[i][c][e]), qs[8 * c + 2 * e], acc);
-            acc = fmaf(half_hi(kr[i][c][e]), qs[8 * c + 2 * e + 1], acc);
-          }
-      } else {
-#pragma unroll
-        for (int c = 0; c < ROWCH; ++c)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc = fmaf(__uint_as_float(kr[i][c][e]), qs[4 * c + e], acc);
+      for (int e = 0; e < 4; ++e) {
+        acc = fmaf(half_lo(kr[i][e]), qv[2 * e], acc);
+        acc = fmaf(half_hi(kr[i][e]), qv[2 * e + 1], acc);
       }
-      s[i] = acc * scale;
-      mx = fmaxf(mx, s[i]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = fmaf(__uint_as_float(kr[i][e]), qv[e], acc);
     }
+    acc += dpp_move<0xB1>(acc);   // lane ^ 1
+    acc += dpp_move<0x4E>(acc);   // lane ^ 2
+    acc += dpp_move<0x141>(acc);  // the other quad of the 8 (mirror inside 8 lanes)
+    if constexpr (ROWCH == 16) acc += dpp_move<0x140>(acc);  // f32: 16 lanes per row (mirror inside 16)
+    s[i] = (g + G * i < pos) ? acc * scale : -INFINITY;
+    mx = fmaxf(mx, s[i]);
   }
   mx = wave_max(mx);
   if (lane == 0) red[0][wave] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+  // every row's exponential is held by its ROWCH lanes: lane chunk 0 of each row contributes it to the sum
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-    if (tid + NT * i < len) {
-      s[i] = __expf(s[i] - mx);
-      sum += s[i];
-    }
+  for (int i = 0; i < NIT; ++i) {
+    s[i] = (g + G * i < pos) ? __expf(s[i] - mx) : 0.f;
+    if (cch == 0) sum += s[i];
+  }
+  const float e_new = __expf(s_new - mx);
   sum = wave_sum(sum);
   if (lane == 0) red[1][wave] = sum;
   __syncthreads();
-  const float inv = 1.0f / ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+  const float inv = 1.0f / (((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) + e_new);
+  if (att_row) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int t = tid + NT * i;
-    if (t < len) {
-      prob[t] = s[i] * inv;
-      if (att_row) att_row[((long long)b * gridDim.x + h) * Tmax + t] = s[i] * inv;
-    }
+    for (int i = 0; i < NIT; ++i)
+      if (cch == 0 && g + G * i < pos) att_row[((long long)b * gridDim.x + h) * Tmax + g + G * i] = s[i] * inv;
+    if (tid == 0) att_row[((long long)b * gridDim.x + h) * Tmax + pos] = e_new * inv;
   }
-  __syncthreads();
+  // output: the lane's rows weighted by their probabilities (already in its registers), chunk c of the head dimension
   float o[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) o[e] = 0.f;
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
-    const int t = g + G * i;
-    if (t >= pos) continue;  // the newest position is added from LDS below; a clamped load may hold anything (NaN)
-    const float p = prob[t];
+    const float p = s[i] * inv;  // 0 for rows at and beyond `pos` (a clamped load may hold anything: select, not multiply)
+    if (g + G * i >= pos) continue;
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -167,7 +164,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
   }
   __syncthreads();
   if (tid < HS) {
-    const float v = (osum[0][tid] + osum[1][tid]) + (osum[2][tid] + osum[3][tid]) + prob[pos] * vnew[tid];
+    const float v = (osum[0][tid] + osum[1][tid]) + (osum[2][tid] + osum[3][tid]) + (e_new * inv) * vnew[tid];
     stf(out + (long long)b * C + h * HS + tid, v);
   }
 }
@@ -660,6 +657,219 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const bf16_t* __rest
   }
 }
 
+
+// ------------------------------------------------------------------------------------ LDS-resident skinny linear
+// The same product for 9 .. 128 rows with EVERY byte a workgroup needs requested up front.  linear_skinny_kernel keeps two
+// register sets of loads in flight (~10 KB per workgroup): at 64 rows its 192-256 workgroups each walk K = 1024 in 16
+// dependent round trips and a launch takes 13-15 us for 6-8 MB of weights (profiles/r03_decode_lab.md) - latency, not
+// bandwidth.  Here a workgroup owns 16 output columns x ONE 1024-wide slice of K x up to 64 rows:
+//   * its slice of x (rows x 2 KB, up to 128 KB) goes to LDS by LDS-DMA - 1 KB pieces, all issued at once, no registers -
+//     with the 16-byte chunk index XOR-ed with the row on the SOURCE side and again on the fragment read (conflict-free
+//     ds_read_b128 across the 16 rows of an MFMA operand);
+//   * its 32 KB of weights go straight to registers as MFMA A fragments (8 x 16 bytes per lane: wave w takes k in
+//     [256 w, 256 w + 256) of the slice), requested behind the DMA pieces;
+//   * ONE wait, one barrier, then 8 k-steps x (rows / 16) MFMAs per wave on operands that are all on chip;
+//   * the four waves' partial tiles are summed through LDS in wave order (deterministic), wave w finishing row tile w.
+// K > 1024 (fc2: 4096): gridDim.y slices, each writing an f32 partial tile to `part` (slice-major); the host sums them
+// with splitk_epilogue_kernel (fixed order) which also applies bias / residual.  K = 1024: the epilogue runs here.
+// LN: the block's pre-LayerNorm folded in ALGEBRAICALLY (K = 1024 only; melgpt_ln_fold_prepare, once per weight version):
+//   W LN(x) + b = rstd (W' x - mu c1) + c2,   W' = W diag(gamma),  c1 = W' 1,  c2 = W beta + b
+// so the kernel multiplies the RAW rows by the prepared W' and the epilogue applies the two per-row scalars; mu and
+// sum x^2 come off the matrix pipe too (ones . x and the diagonal of x x^T on the fragments already in registers).
+// Normalising the rows in place in LDS first (four lanes per row, 1 600 VALU instructions per lane on one wave per SIMD)
+// cost 8 of such a launch's 14 us (profiles/r03_decode_lab.md).
+typedef u32x4 dec_rsrc_t;
+__device__ __forceinline__ void dec_dma16(dec_rsrc_t rs, char* lds_wave_base, unsigned voff) {
+  // (inline asm for the reasons given at dma16 in gemm256.hip: hipcc would complete the builtin only at vmcnt(0))
+  const unsigned m0v = (unsigned)(size_t)LDS_PTR(char, lds_wave_base);
+  asm volatile("s_nop 2\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :
+               : "s"(m0v), "v"(voff), "s"(rs)
+               : "memory", "m0");
+}
+__device__ __forceinline__ int xl_off(int row, int chunk) {  // 2 KB rows of 128 chunks; low 4 chunk bits XOR row
+  return row * 2048 + ((chunk ^ (row & 15)) << 4);
+}
+
+template <int MT, bool LN>  // MT 16-row tiles of x per workgroup (1, 2 or 4)
+__global__ __launch_bounds__(256) void linear_lds_kernel(const bf16_t* __restrict__ x, long long ldx, unsigned x_bytes,
+                                                         const bf16_t* __restrict__ W, long long ldw,
+                                                         const float* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                         long long ldr, void* __restrict__ y, long long ldy,
+                                                         float* __restrict__ part, int M, int N, int act, int out_f32,
+                                                         const float* ln_c1, const float* ln_c2, float ln_eps) {
+  constexpr int KSL = 1024, NW = 4, ROWS = 16 * MT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xl = smem;                                        // [ROWS][2 KB] swizzled
+  f32x4* psum = (f32x4*)(smem + ROWS * 2048);             // [NW][MT][64]
+  float* pst = (float*)(psum + NW * MT * 64);             // LN: [NW][MT][64][2] partial sum x, sum x^2 of the lane's row
+  const int t = threadIdx.x, lane = t & 63, r16 = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int n0 = blockIdx.x * 16, k0 = blockIdx.y * KSL, m_base = blockIdx.z * ROWS;
+  const int mrows = min(ROWS, M - m_base);
+  // ---- x slice -> LDS: piece p = (row p >> 1, half p & 1), 2 * ROWS pieces over 4 waves; rows past M read zeros (OOB)
+  {
+    const unsigned long long a64 = (unsigned long long)x;
+    dec_rsrc_t rs = {(unsigned)a64, (unsigned)(a64 >> 32) & 0xFFFFu, x_bytes, 0x00020000u};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rs[e] = __builtin_amdgcn_readfirstlane(rs[e]);
+#pragma unroll
+    for (int j = 0; j < 2 * ROWS / NW; ++j) {
+      const int p = w + NW * j, row = p >> 1, cp = 64 * (p & 1) + lane;   // physical chunk this lane fills
+      const int cl = cp ^ (row & 15);                                       // ... holds logical chunk cl
+      const unsigned off = row < mrows ? (unsigned)(((long long)(m_base + row) * ldx + k0 + 8 * cl) * 2) : 0xFFFFFFF0u;
+      dec_dma16(rs, xl + p * 1024, off);
+    }
+  }
+  // ---- weights -> registers (A fragments: output column n0 + r16, k = k0 + 256 w + 32 ks + 8 g ..+7)
+  u32x4 a[8];
+  {
+    const bf16_t* wp = W + (long long)(n0 + r16) * ldw + k0 + 256 * w + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) a[ks] = *(const u32x4*)(wp + 32 * ks);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces (and, in order behind them, its weights) have landed
+  __syncthreads();
+  // ---- 8 k-steps x MT row tiles: B fragment = x rows 16 mt + r16, logical chunk (256 w + 32 ks) / 8 + g
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 s1t[LN ? MT : 1], s2t[LN ? MT : 1];  // LN: ones . x (every row = sum_k x[m][k]) and x x^T (diagonal = sum_k x[m][k]^2)
+  if constexpr (LN) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) s1t[mt] = s2t[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const unsigned one2 = pack_bf16x2(1.0f, 1.0f);
+  const u32x4 ones = {one2, one2, one2, one2};
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    u32x4 b[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) b[mt] = *(const u32x4*)(xl + xl_off(16 * mt + r16, 32 * w + 4 * ks + g));
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      acc[mt] = MELGPT_MFMA_16x16x32(a[ks], b[mt], acc[mt]);
+      if constexpr (LN) {
+        s1t[mt] = MELGPT_MFMA_16x16x32(ones, b[mt], s1t[mt]);
+        s2t[mt] = MELGPT_MFMA_16x16x32(b[mt], b[mt], s2t[mt]);
+      }
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    psum[(w * MT + mt) * 64 + lane] = acc[mt];
+    if constexpr (LN) {
+      // D[i][j] of x x^T sits in lane (j = r16, g = i >> 2) element i & 3: the diagonal of column r16 is in the lane
+      // with g == r16 >> 2; the other three lanes of the column contribute 0 and read the total back by shuffle below
+      const float dg = (g == (r16 >> 2)) ? (((r16 & 3) == 0) ? s2t[mt][0] : ((r16 & 3) == 1) ? s2t[mt][1]
+                                                              : ((r16 & 3) == 2) ? s2t[mt][2] : s2t[mt][3])
+                                         : 0.f;
+      pst[((w * MT + mt) * 64 + lane) * 2] = s1t[mt][0];
+      pst[((w * MT + mt) * 64 + lane) * 2 + 1] = dg;
+    }
+  }
+  __syncthreads();
+  // ---- wave w finishes row tiles w, w + 4, ..: sum of the four waves' partials in wave order, then the epilogue.
+  // v[e] = y[m_base + 16 mt + r16][n0 + 4 g + e]
+  for (int mt = w; mt < MT; mt += NW) {
+    f32x4 v = psum[(0 * MT + mt) * 64 + lane];
+#pragma unroll
+    for (int q = 1; q < NW; ++q) v += psum[(q * MT + mt) * 64 + lane];
+    const int m = m_base + 16 * mt + r16, n = n0 + 4 * g;
+    if constexpr (LN) {  // (before the row predicate: the shuffle needs every lane)
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        s1 += pst[((q * MT + mt) * 64 + lane) * 2];
+        s2 += pst[((q * MT + mt) * 64 + lane) * 2 + 1];
+      }
+      s2 = __shfl(s2, r16 + 16 * (r16 >> 2), 64);
+      const float mu = s1 * (1.0f / KSL);
+      const float rstd = rsqrtf(fmaxf(s2 * (1.0f / KSL) - mu * mu, 0.f) + ln_eps);
+      const f32x4 c1 = *(const f32x4*)(ln_c1 + n), c2 = *(const f32x4*)(ln_c2 + n);
+      v = (v - c1 * mu) * rstd + c2;   // = W LN(x) + b
+    }
+    if (m >= M) continue;
+    if (part) {  // one K slice of several: raw partial sums, slice-major
+      *(f32x4*)(part + ((long long)blockIdx.y * M + m) * N + n) = v;
+      continue;
+    }
+    if (!LN && bias) v += *(const f32x4*)(bias + n);   // (LN: the bias is inside c2)
+    if (act == MELGPT_ACT_GELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+    }
+    if (res) {
+      const u32x2 rv = *(const u32x2*)(res + (long long)m * ldr + n);
+      v += f32x4{bf16lo(rv[0]), bf16hi(rv[0]), bf16lo(rv[1]), bf16hi(rv[1])};
+    }
+    if (out_f32) *(f32x4*)((float*)y + (long long)m * ldy + n) = v;
+    else *(u32x2*)((bf16_t*)y + (long long)m * ldy + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  }
+}
+
+// melgpt_ln_fold_prepare: W' = bf16(W gamma) (N, K), c1[n] = sum_k W'[n][k] (of the ROUNDED values), c2[n] = sum_k W[n][k]
+// beta[k] + bias[n] - one wave per output row, fixed summation order
+__global__ __launch_bounds__(256) void ln_fold_prepare_kernel(const bf16_t* __restrict__ W, long long ldw,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int N, int K,
+                                                              bf16_t* __restrict__ Wf, float* __restrict__ c1,
+                                                              float* __restrict__ c2) {
+  const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float a1 = 0.f, a2 = 0.f;
+  for (int k = 8 * lane; k < K; k += 512) {
+    const u32x4 wv = *(const u32x4*)(W + (long long)n * ldw + k);
+    const f32x4 g0 = *(const f32x4*)(gamma + k), g1 = *(const f32x4*)(gamma + k + 4);
+    const f32x4 b0 = *(const f32x4*)(beta + k), b1 = *(const f32x4*)(beta + k + 4);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float wl = bf16lo(wv[e]), wh = bf16hi(wv[e]);
+      const float gl = e < 2 ? g0[2 * e] : g1[2 * e - 4], gh = e < 2 ? g0[2 * e + 1] : g1[2 * e - 3];
+      const float bl = e < 2 ? b0[2 * e] : b1[2 * e - 4], bh = e < 2 ? b0[2 * e + 1] : b1[2 * e - 3];
+      o[e] = pack_bf16x2(wl * gl, wh * gh);
+      a1 += bf16lo(o[e]) + bf16hi(o[e]);
+      a2 = fmaf(wl, bl, a2);
+      a2 = fmaf(wh, bh, a2);
+    }
+    *(u32x4*)(Wf + (long long)n * K + k) = o;
+  }
+  a1 = wave_sum(a1);
+  a2 = wave_sum(a2);
+  if (lane == 0) {
+    c1[n] = a1;
+    c2[n] = a2 + (bias ? bias[n] : 0.f);
+  }
+}
+
+// y = epi(sum over the K slices of part (slices, M, N) f32, in slice order) - bias, GELU, residual as linear_lds_kernel
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ part, int slices, int M, int N,
+                                                              const float* __restrict__ bias,
+                                                              const bf16_t* __restrict__ res, long long ldr,
+                                                              void* __restrict__ y, long long ldy, int act, int out_f32) {
+  const long long quads = (long long)M * (N / 4);
+  const long long stride = (long long)M * N;
+  for (long long qd = (long long)blockIdx.x * 256 + threadIdx.x; qd < quads; qd += (long long)gridDim.x * 256) {
+    const int m = (int)(qd / (N / 4)), n = 4 * (int)(qd % (N / 4));
+    const float* p = part + (long long)m * N + n;
+    f32x4 v = *(const f32x4*)p;
+    for (int sl = 1; sl < slices; ++sl) v += *(const f32x4*)(p + sl * stride);
+    if (bias) v += *(const f32x4*)(bias + n);
+    if (act == MELGPT_ACT_GELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+    }
+    if (res) {
+      const u32x2 rv = *(const u32x2*)(res + (long long)m * ldr + n);
+      v += f32x4{bf16lo(rv[0]), bf16hi(rv[0]), bf16lo(rv[1]), bf16hi(rv[1])};
+    }
+    if (out_f32) *(f32x4*)((float*)y + (long long)m * ldy + n) = v;
+    else *(u32x2*)((bf16_t*)y + (long long)m * ldy + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  }
+}
+
 }  // namespace
 
 extern "C" int melgpt_linear_skinny(const void* x, long long ldx, const void* W, long long ldw, const float* bias,
@@ -740,5 +950,75 @@ extern "C" int melgpt_gemv_rows(const void* x, long long ldx, const void* W, lon
   }
 #undef MELGPT_GEMV_LAUNCH
 #undef MELGPT_GEMV_LAUNCH_LN
+  return melgpt_launch_status();
+}
+
+extern "C" long long melgpt_linear_lds_workspace(int M, int N, int K) {
+  return K > 1024 ? (long long)(K / 1024) * M * N * 4 : 0;  // bytes of f32 partial tiles (K slices of 1024)
+}
+
+extern "C" int melgpt_linear_lds(const void* x, long long ldx, const void* W, long long ldw, const float* bias,
+                                 const void* residual, long long ldr, void* y, long long ldy, int M, int N, int K, int act,
+                                 int dtype, int out_f32, const float* ln_c1, const float* ln_c2, float ln_eps,
+                                 void* workspace, void* stream) {
+  MELGPT_CHECK(x && W && y && M > 0 && N > 0 && K > 0, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(dtype == MELGPT_BF16 && M <= 128 && K % 1024 == 0 && K <= 8192, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK(act == MELGPT_ACT_NONE || act == MELGPT_ACT_GELU, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK(N % 16 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldy % 4 == 0 && (!residual || ldr % 4 == 0), MELGPT_ERR_ALIGN);
+  MELGPT_CHECK((((uintptr_t)x | (uintptr_t)W | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)bias | (uintptr_t)workspace) & 15) == 0,
+               MELGPT_ERR_ALIGN);
+  MELGPT_CHECK((ln_c1 == nullptr) == (ln_c2 == nullptr), MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(!ln_c1 || (K == 1024 && ((((uintptr_t)ln_c1 | (uintptr_t)ln_c2) & 15) == 0)), MELGPT_ERR_UNSUPPORTED);
+  const int slices = K / 1024;
+  MELGPT_CHECK(slices == 1 || workspace, MELGPT_ERR_BAD_ARG);
+  const long long xb = ((long long)(M - 1) * ldx + K) * 2;
+  MELGPT_CHECK(xb < 0xFFFFFF00LL, MELGPT_ERR_UNSUPPORTED);
+  hipStream_t s = (hipStream_t)stream;
+  float* part = slices > 1 ? (float*)workspace : nullptr;
+  const int mt_all = (M + 15) / 16;
+  const int MTsel = mt_all <= 1 ? 1 : (mt_all <= 2 ? 2 : 4);
+  const int zb = (mt_all + MTsel - 1) / MTsel;
+#define MELGPT_LDS_LAUNCH(MT, LN)                                                                                      \
+  do {                                                                                                                 \
+    const size_t lds = (size_t)16 * MT * 2048 + (size_t)4 * MT * 64 * 16 + (LN ? (size_t)4 * MT * 64 * 8 : 0);                                \
+    static bool attr = false;                                                                                          \
+    if (!attr) {                                                                                                       \
+      if (hipFuncSetAttribute((const void*)linear_lds_kernel<MT, LN>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                              (int)lds) != hipSuccess)                                                                 \
+        return MELGPT_ERR_LAUNCH;                                                                                      \
+      attr = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((linear_lds_kernel<MT, LN>), dim3(N / 16, slices, zb), dim3(256), lds, s, (const bf16_t*)x, ldx, \
+                       (unsigned)xb, (const bf16_t*)W, ldw, bias, (const bf16_t*)residual, ldr, y, ldy, part, M, N, act, \
+                       out_f32, ln_c1, ln_c2, ln_eps);                                                                 \
+  } while (0)
+  if (ln_c1) {
+    if (MTsel == 1) MELGPT_LDS_LAUNCH(1, true);
+    else if (MTsel == 2) MELGPT_LDS_LAUNCH(2, true);
+    else MELGPT_LDS_LAUNCH(4, true);
+  } else {
+    if (MTsel == 1) MELGPT_LDS_LAUNCH(1, false);
+    else if (MTsel == 2) MELGPT_LDS_LAUNCH(2, false);
+    else MELGPT_LDS_LAUNCH(4, false);
+  }
+#undef MELGPT_LDS_LAUNCH
+  if (slices > 1) {
+    const long long quads = (long long)M * (N / 4);
+    const int grid = (int)((quads + 255) / 256 < 1024 ? (quads + 255) / 256 : 1024);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, s, part, slices, M, N, bias,
+                       (const bf16_t*)residual, ldr, y, ldy, act, out_f32);
+  }
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_ln_fold_prepare(const void* W, long long ldw, const float* bias, const float* gamma,
+                                      const float* beta, int N, int K, int dtype, void* W_folded, float* c1, float* c2,
+                                      void* stream) {
+  MELGPT_CHECK(W && gamma && beta && W_folded && c1 && c2 && N > 0 && K > 0, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(dtype == MELGPT_BF16, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK(K % 8 == 0 && ldw % 8 == 0, MELGPT_ERR_ALIGN);
+  MELGPT_CHECK((((uintptr_t)W | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)W_folded) & 15) == 0, MELGPT_ERR_ALIGN);
+  hipLaunchKernelGGL(ln_fold_prepare_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W, ldw,
+                     bias, gamma, beta, N, K, (bf16_t*)W_folded, c1, c2);
   return melgpt_launch_status();
 }

@@ -17,6 +17,8 @@ import torch.nn as nn
 from . import _ffi, ops
 
 ALIGN = 8  # elements: keeps every view 16-byte aligned in both the f32 buffer and the bf16 shadow
+SHADOW_EPOCH = [0]  # bumped whenever ANY 16-bit shadow is rewritten: views of a shadow carry no version of their own, so
+                    # whatever is derived from such a view (ops._ln_folded) keys on this
 
 
 def _is_decay(module, pname):
@@ -117,11 +119,13 @@ class FlatParams:
         if key != self._shadow_key:
             ops.cast(self.data, _ffi.HALF_DTYPE, out=self.shadow)
             self._shadow_key = key
+            SHADOW_EPOCH[0] += 1
         return self.shadow
 
     def mark_shadow_fresh(self):
         """called by the fused optimizer, which writes the bf16 shadow itself."""
         self._shadow_key = (sum(p._version for p in self.params), self.generation)
+        SHADOW_EPOCH[0] += 1
 
     # ------------------------------------------------------------------ gradients
     def grad_target(self, p):

@@ -440,6 +440,30 @@ def attn_decode(qkv, kcache, vcache, n_head, pos, att_row=None, pos_dev=None, ou
 
 
 SKINNY_LN_MAX_ROWS = int(os.environ.get("MELGPT_SKINNY_LN_MAX_ROWS", "64"))  # lab switch (0: never fuse)
+LDS_LINEAR_MIN_ROWS = int(os.environ.get("MELGPT_LDS_LINEAR_MIN_ROWS", "17"))  # lab switch (999: never; default from
+# profiles/r03_decode_lab.md: at <= 16 rows the register-pipelined kernel is as fast and needs no second launch for K = 4096)
+
+
+_LN_FOLD = {}   # (weight, bias, gamma, beta versions) -> (W' bf16, c1, c2): melgpt_ln_fold_prepare, rebuilt when any changes
+
+
+def _ln_folded(w, bias, gamma, beta):
+    from .flat import SHADOW_EPOCH, tensor_version
+
+    key = (w.data_ptr(), tuple(w.shape), w.stride(0))
+    ver = (tensor_version(w), SHADOW_EPOCH[0], tensor_version(bias), tensor_version(gamma), tensor_version(beta))
+    hit = _LN_FOLD.get(key)
+    if hit is None or hit[0] != ver:
+        N, K = w.shape
+        wf = torch.empty(N, K, dtype=w.dtype, device=w.device)
+        c1 = torch.empty(N, dtype=torch.float32, device=w.device)
+        c2 = torch.empty(N, dtype=torch.float32, device=w.device)
+        call("melgpt_ln_fold_prepare", ptr(w), w.stride(0), ptr(bias), ptr(gamma.detach()), ptr(beta.detach()), N, K,
+             dtype_code(w.dtype), ptr(wf), ptr(c1), ptr(c2), stream())
+        if len(_LN_FOLD) > 256:
+            _LN_FOLD.clear()
+        hit = _LN_FOLD[key] = (ver, wf, c1, c2)
+    return hit[1], hit[2], hit[3]
 
 
 def linear_rows(x, w, *, bias=None, act=ACT_NONE, residual=None, out_dtype=None, ln=None):
@@ -452,6 +476,22 @@ def linear_rows(x, w, *, bias=None, act=ACT_NONE, residual=None, out_dtype=None,
     odt = out_dtype or x.dtype
     assert odt in (x.dtype, torch.float32)
     skinny = x.dtype == _ffi.HALF_DTYPE and 4 < M <= 128 and N % 16 == 0 and K % 128 == 0
+    if skinny and M >= LDS_LINEAR_MIN_ROWS and K % 1024 == 0 and K <= 8192 and (ln is None or K == 1024):
+        # 17 .. 128 rows: x through LDS by LDS-DMA, weights to registers, everything requested up front (melgpt_linear_lds)
+        y = torch.empty(M, N, dtype=odt, device=x.device)
+        if residual is not None:
+            assert residual.shape == (M, N) and residual.dtype == x.dtype and residual.stride(1) == 1
+        c1 = c2 = None
+        eps = 0.0
+        if ln is not None:   # the pre-LN folded into the weight (prepared once per version of weight / LayerNorm / bias)
+            w, c1, c2 = _ln_folded(w, bias, ln[0], ln[1])
+            eps = ln[2]
+        nws = int(_ffi.lib().melgpt_linear_lds_workspace(M, N, K))
+        ws = workspace((nws + 3) // 4, x.device) if nws else None
+        call("melgpt_linear_lds", ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(residual),
+             residual.stride(0) if residual is not None else 0, ptr(y), N, M, N, K, int(act), dtype_code(x.dtype),
+             int(odt == torch.float32), ptr(c1), ptr(c2), float(eps), ptr(ws), stream())
+        return y
     skinny_ln = skinny and ln is not None and M <= SKINNY_LN_MAX_ROWS and K in (512, 1024)
     if ln is not None and M > 4 and not skinny_ln:
         # the weight-streaming kernels re-derive the row statistics in every workgroup: that pays for a few rows (one
