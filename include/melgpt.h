@@ -363,6 +363,13 @@ int melgpt_groupnorm_apply(const void* x, const float* mean, const float* rstd, 
 /* Encoder.conv_in (:203-207): 3x3, pad 1, ONE input channel; x (B,H,W) x_dtype; w (Cout,1,3,3) f32 as stored. */
 int melgpt_conv_in_c1(const void* x, int x_dtype, const float* w, const float* bias, void* y, int dtype, int B,
                       int H, int W, int Cout, void* stream);
+/* The same stem conv AND the GroupNorm(32) statistics (mean, rstd: (B*32,) f32, eps as torch.nn.GroupNorm) of its
+ * output in one pass - what the first ResnetBlock's norm1 (vqvae/big_model_attn_gan.py:117 on conv_in's output, :259-263)
+ * needs; statistics of the values as stored.  Cout == 128 (32 groups of 4).  workspace: melgpt_conv_in_c1_stats_workspace
+ * floats. */
+int melgpt_conv_in_c1_stats_workspace(int B, int H, int W);
+int melgpt_conv_in_c1_stats(const void* x, int x_dtype, const float* w, const float* bias, void* y, int dtype, int B,
+                            int H, int W, int Cout, float eps, float* mean, float* rstd, float* workspace, void* stream);
 /* Decoder.conv_out (:355-359): 3x3, pad 1, ONE output channel; w tap-major (9, C) f32; y (B,H,W). */
 int melgpt_conv_out_c1(const void* x, int dtype, const float* w_tap_major, const float* bias, void* y,
                        int y_dtype, int B, int H, int W, int C, void* stream);

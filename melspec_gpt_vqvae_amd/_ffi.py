@@ -88,6 +88,8 @@ _PROTOS = {
     "melgpt_groupnorm_stats": [_p, _i, _i, _i, _f, _p, _p, _p, _i, _p],
     "melgpt_groupnorm_apply": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "melgpt_conv_in_c1": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "melgpt_conv_in_c1_stats_workspace": [_i, _i, _i],
+    "melgpt_conv_in_c1_stats": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p],
     "melgpt_conv_out_c1": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "melgpt_softmax_rows": [_p, _l, _i, _l, _f, _p, _l, _i, _p],
     "melgpt_repack_conv_weight": [_p, _p, _i, _i, _i, _i, _i, _p],

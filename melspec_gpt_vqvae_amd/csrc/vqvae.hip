@@ -264,6 +264,90 @@ __global__ __launch_bounds__(256) void conv_in_c1_kernel(const TI* __restrict__ 
   }
 }
 
+// The stem conv AND the GroupNorm(32) statistics of its output in one pass (COUT = 128: a thread's 8 channels are two
+// groups of 4): the first ResnetBlock's norm1 otherwise re-reads the 2.2 GB the kernel above has just written
+// (gn_partial: 0.37 ms of a 128-tile VQ-encode).  One workgroup = STEM_CHUNK pixels of ONE image, 16 pixels per trip;
+// per workgroup a (32, 2) partial of sums / sums of squares of the values AS STORED (rounded to the output format),
+// added over the 16 pixel lanes in lane order; melgpt_groupnorm_finalize adds the chunks of an image in chunk order.
+constexpr int STEM_CHUNK = 2048;
+template <typename TI, typename T>
+__global__ __launch_bounds__(256) void conv_in_c1_stats_kernel(const TI* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, T* __restrict__ y, int H,
+                                                               int W, float* __restrict__ partial) {
+  constexpr int COUT = 128;
+  __shared__ float wsh[COUT * 10];
+  __shared__ float red[16][16][4];  // [pixel lane][channel group of 8][s lo, ss lo, s hi, ss hi]
+  for (int i = threadIdx.x; i < COUT * 9; i += 256) wsh[i] = w[i];
+  for (int i = threadIdx.x; i < COUT; i += 256) wsh[COUT * 9 + i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  const int cgp = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t wr[4][9], br[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = cgp * 8 + 2 * e;
+    br[e] = f32x2_t{wsh[COUT * 9 + c], wsh[COUT * 9 + c + 1]};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[e][k] = f32x2_t{wsh[c * 9 + k], wsh[(c + 1) * 9 + k]};
+  }
+  const int b = blockIdx.y, HW = H * W;
+  const int p0 = blockIdx.x * STEM_CHUNK, p1 = min(p0 + STEM_CHUNK, HW);
+  const TI* xb = x + (long long)b * HW;
+  float s[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
+  int p = p0 + pl;
+  int yh = p / W, xw = p - yh * W;
+  for (; p < p1; p += 16, xw += 16) {
+    if (xw >= W) {
+      xw -= W;
+      ++yh;
+    }
+    float in[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = yh + ky - 1, ix = xw + kx - 1;
+        const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+        const float v = Elem<TI>::ld(xb + cy * W + cx);
+        in[ky * 3 + kx] = (iy == cy && ix == cx) ? v : 0.f;
+      }
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f32x2_t a = br[e];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a = __builtin_elementwise_fma(f32x2_t{in[k], in[k]}, wr[e][k], a);
+      o[2 * e] = a[0];
+      o[2 * e + 1] = a[1];
+    }
+    T* dst = y + ((long long)b * HW + p) * COUT + cgp * 8;
+    if constexpr (sizeof(T) == 2) {
+      V16<bf16_t>::st((bf16_t*)dst, o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = bf16_to_f32(f32_to_bf16(o[e]));  // statistics of the stored values
+    } else {
+      V16<float>::st((float*)dst, o);
+      V16<float>::st((float*)dst + 4, o + 4);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s[e >> 2] += o[e];
+      ss[e >> 2] = fmaf(o[e], o[e], ss[e >> 2]);
+    }
+  }
+  red[pl][cgp][0] = s[0];
+  red[pl][cgp][1] = ss[0];
+  red[pl][cgp][2] = s[1];
+  red[pl][cgp][3] = ss[1];
+  __syncthreads();
+  if (threadIdx.x < 64) {  // (group g = 2 cgp + half, statistic st): 32 x 2 values per workgroup
+    const int g = threadIdx.x >> 1, st = threadIdx.x & 1;
+    float a = 0.f;
+    for (int r = 0; r < 16; ++r) a += red[r][g >> 1][2 * (g & 1) + st];
+    partial[(((long long)b * gridDim.x + blockIdx.x) * GN_GROUPS + g) * 2 + st] = a;
+  }
+}
+
 // 3x3 convolution of a C-channel NHWC tensor into ONE channel: 16 lanes per pixel, shuffle reduction.
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void conv_out_c1_kernel(const T* __restrict__ x, const float* __restrict__ w,
@@ -432,6 +516,32 @@ extern "C" int melgpt_conv_in_c1(const void* x, int x_dtype, const float* w, con
   else return MELGPT_ERR_UNSUPPORTED;
 #undef CI_LAUNCH
   return melgpt_launch_status();
+}
+
+extern "C" int melgpt_conv_in_c1_stats_workspace(int B, int H, int W) {
+  return B * ((H * W + STEM_CHUNK - 1) / STEM_CHUNK) * GN_GROUPS * 2;
+}
+
+extern "C" int melgpt_groupnorm_finalize(const float* partial, int nchunks, int B, double count, float eps, float* mean,
+                                         float* rstd, void* stream);
+
+extern "C" int melgpt_conv_in_c1_stats(const void* x, int x_dtype, const float* w, const float* bias, void* y, int dtype,
+                                       int B, int H, int W, int Cout, float eps, float* mean, float* rstd,
+                                       float* workspace, void* stream) {
+  MELGPT_CHECK(x && w && y && mean && rstd && workspace && B > 0 && H > 0 && W > 0, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(Cout == 128 && (long long)H * W < 0x7FFFFFFF / 2, MELGPT_ERR_UNSUPPORTED);
+  const int nchunks = (H * W + STEM_CHUNK - 1) / STEM_CHUNK;
+  hipStream_t s = (hipStream_t)stream;
+#define CIS_LAUNCH(TI, T)                                                                                             \
+  hipLaunchKernelGGL((conv_in_c1_stats_kernel<TI, T>), dim3(nchunks, B), dim3(256), 0, s, (const TI*)x, w, bias, (T*)y, \
+                     H, W, workspace)
+  if (x_dtype == MELGPT_F32 && dtype == MELGPT_F32) CIS_LAUNCH(float, float);
+  else if (x_dtype == MELGPT_F32 && dtype == MELGPT_BF16) CIS_LAUNCH(float, bf16_t);
+  else if (x_dtype == MELGPT_BF16 && dtype == MELGPT_BF16) CIS_LAUNCH(bf16_t, bf16_t);
+  else if (x_dtype == MELGPT_BF16 && dtype == MELGPT_F32) CIS_LAUNCH(bf16_t, float);
+  else return MELGPT_ERR_UNSUPPORTED;
+#undef CIS_LAUNCH
+  return melgpt_groupnorm_finalize(workspace, nchunks, B, (double)H * W * (Cout / GN_GROUPS), eps, mean, rstd, stream);
 }
 
 extern "C" int melgpt_conv_out_c1(const void* x, int dtype, const float* w_tap_major, const float* bias, void* y,

@@ -639,15 +639,23 @@ def groupnorm(x, gamma, beta, eps=1e-6, swish=True):
     return y
 
 
-def conv_in_c1(x, w, bias, dtype):
-    """x (B,H,W) f32/bf16 single-channel image; w (Cout,1,3,3) f32 -> (B,H,W,Cout) in dtype."""
+def conv_in_c1(x, w, bias, dtype, stats_eps=None):
+    """x (B,H,W) f32/bf16 single-channel image; w (Cout,1,3,3) f32 -> (B,H,W,Cout) in dtype.  stats_eps (Cout = 128):
+    also the GroupNorm(32) statistics of the output from the same pass -> (y, (mean, rstd)); else (y, None)."""
     B, H, W = x.shape
     Cout = w.shape[0]
     assert x.is_contiguous() and w.is_contiguous() and w.dtype == torch.float32
     y = torch.empty(B, H, W, Cout, dtype=dtype, device=x.device)
+    if stats_eps is not None and Cout == 128:
+        ws = workspace(_ffi.lib().melgpt_conv_in_c1_stats_workspace(B, H, W), x.device)
+        mean = torch.empty(B * 32, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(B * 32, dtype=torch.float32, device=x.device)
+        call("melgpt_conv_in_c1_stats", ptr(x), dtype_code(x.dtype), ptr(w), ptr(bias), ptr(y), dtype_code(dtype), B, H, W,
+             Cout, float(stats_eps), ptr(mean), ptr(rstd), ptr(ws), stream())
+        return y, (mean, rstd)
     call("melgpt_conv_in_c1", ptr(x), dtype_code(x.dtype), ptr(w), ptr(bias), ptr(y), dtype_code(dtype), B, H, W, Cout,
          stream())
-    return y
+    return y, None
 
 
 def conv_out_c1(x, w_tap_major, bias, out_dtype=torch.float32):

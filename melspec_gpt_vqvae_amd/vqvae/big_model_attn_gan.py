@@ -117,11 +117,11 @@ def _gn_swish_conv3x3(norm, conv, h, residual=None, stats=None, next_norm=None):
     return (y, out_stats) if next_norm is not None else y
 
 
-def _block_chain(lvl, n_blocks, h):
+def _block_chain(lvl, n_blocks, h, stats=None):
     """the ResnetBlocks (+ AttnBlocks) of one resolution level (reference :263-267 / :377-381).  Between two ResnetBlocks
     with nothing in between, the first one's conv2 launch also takes the GroupNorm statistics the second one's norm1
-    needs (its epilogue holds the finished tile, residual included)."""
-    stats = None
+    needs (its epilogue holds the finished tile, residual included).  stats: GroupNorm statistics of h for the first
+    block's norm1 when the launch that produced h took them."""
     for i_block in range(n_blocks):
         chained = len(lvl.attn) == 0 and i_block + 1 < n_blocks
         if chained:
@@ -314,12 +314,16 @@ class Encoder(nn.Module):
                 xin = xin.contiguous()
             if xin.dtype not in (torch.float32, _ffi.HALF_DTYPE):
                 xin = xin.float()
-            h = ops.conv_in_c1(xin, self.conv_in.weight.detach(), _f32(self.conv_in.bias), dt)
+            # the stem launch also takes the GroupNorm statistics the first ResnetBlock's norm1 needs (its output is the
+            # largest tensor of the model: 2.2 GB at 128 tiles - no second pass over it just for 64 numbers per image)
+            first_norm = self.down[0].block[0].norm1
+            h, stats0 = ops.conv_in_c1(xin, self.conv_in.weight.detach(), _f32(self.conv_in.bias), dt,
+                                       stats_eps=first_norm.eps if self.conv_in.out_channels == 128 else None)
         else:
-            h = _conv(self.conv_in, ops.to_nhwc(x, dt))
+            h, stats0 = _conv(self.conv_in, ops.to_nhwc(x, dt)), None
         for i_level in range(self.num_resolutions):
             lvl = self.down[i_level]
-            h = _block_chain(lvl, self.num_res_blocks, h)
+            h = _block_chain(lvl, self.num_res_blocks, h, stats=stats0 if i_level == 0 else None)
             if i_level != self.num_resolutions - 1:
                 h = lvl.downsample._nhwc(h)
         h = self.mid.block_1._nhwc(h)

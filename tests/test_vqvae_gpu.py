@@ -49,9 +49,19 @@ def test_conv_in_out_single_channel_and_permute(dt):
     x = t(2 * synth.mel_tiles(5, B)[:, :, 6:854] - 1)
     w = t(synth.uniform(6, (C, 1, 3, 3), -0.3, 0.3))
     b = t(synth.uniform(7, (C,), -0.3, 0.3))
-    y = ops.conv_in_c1(x.to(DEV), w.to(DEV), b.to(DEV), DT[dt])
+    y, none = ops.conv_in_c1(x.to(DEV), w.to(DEV), b.to(DEV), DT[dt])
+    assert none is None
     ref = F.conv2d(x[:, None], w, b, padding=1).permute(0, 2, 3, 1)
     assert rel_err(y.float().cpu().numpy(), ref.numpy()) < (1e-6 if dt == "f32" else 8e-3)
+    # the same launch taking the GroupNorm(32) statistics of its output (what the first ResnetBlock's norm1 needs):
+    # identical tensor, statistics = those of the stored values (the two-pass kernel's, to summation order)
+    y2, (mean, rstd) = ops.conv_in_c1(x.to(DEV), w.to(DEV), b.to(DEV), DT[dt], stats_eps=1e-6)
+    assert torch.equal(y2, y)
+    m_ref, r_ref = ops.groupnorm_stats(y, 1e-6)
+    assert rel_err(mean.cpu().numpy(), m_ref.cpu().numpy()) < 1e-5 and rel_err(rstd.cpu().numpy(), r_ref.cpu().numpy()) < 1e-5
+    g = y.float().cpu().reshape(B, H * W, 32, 4).permute(0, 2, 1, 3).reshape(B * 32, -1).double()
+    assert rel_err(mean.cpu().numpy(), g.mean(1).numpy()) < 1e-5
+    assert rel_err(rstd.cpu().numpy(), (1.0 / torch.sqrt(g.var(1, unbiased=False) + 1e-6)).numpy()) < 1e-5
     # 128 -> 1
     h = t(synth.normal(8, (B, 20, 53, C))).to(DT[dt])
     wo = t(synth.uniform(9, (1, C, 3, 3), -0.05, 0.05))
