@@ -18,6 +18,8 @@ if HALF not in ("bf16", "fp16"):
     raise ImportError(f"MELGPT_HALF={HALF!r}: expected bf16 or fp16")
 HALF_DTYPE = torch.float16 if HALF == "fp16" else torch.bfloat16
 LIB_PATH = os.path.join(_PKG, "lib", "libmelgpt_hip_fp16.so" if HALF == "fp16" else "libmelgpt_hip.so")
+if os.environ.get("MELGPT_LAB_LIB"):          # lab A/B builds of the same ABI (tools/lab): never set in production
+    LIB_PATH = os.environ["MELGPT_LAB_LIB"]
 
 F32, BF16 = 0, 1
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float

@@ -76,12 +76,12 @@ __device__ __forceinline__ rsrc_t make_rsrc4(const void* base, unsigned bytes) {
 }
 __device__ __forceinline__ void dma16(rsrc_t rs, char* lds_wave_base, unsigned voff) {
   const unsigned m0v = (unsigned)(size_t)LDS_PTR(char, lds_wave_base);
-  // Cache policy of the requests: sc1 = served by the XCD's L2 without allocating in the CU's vector L1 (the 32 KiB L1
-  // holds nothing this stream ever re-reads).  Lab, constant operands, two runs each (profiles/r03_gemm_lab.md): every
-  // shape +0.5 .. 2.5 % over the default policy; nt (streaming) -3 .. -15 %: the panels ARE re-read, by the other tiles
-  // of the XCD's block, out of L2; sc0 = default.
+  // Cache policy of the requests (lab switch): " sc1" (served by L2 without allocating in the CU's vector L1) measured
+  // +0.5 .. 2.5 % per shape on constant operands and NEUTRAL in the training step (GEMM family 88.8-89.4 ms per step
+  // either way, three alternating runs) while FETCH_SIZE read 15 % more bytes per step; " nt" -3 .. -15 % (the panels are
+  // re-read out of L2 by the other tiles of the XCD's block).  Default policy kept.  profiles/r03_gemm_lab.md
 #ifndef G256_DMA_POLICY
-#define G256_DMA_POLICY " sc1"
+#define G256_DMA_POLICY ""
 #endif
   asm volatile("s_nop 2\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" G256_DMA_POLICY " lds"
                :
