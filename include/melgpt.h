@@ -268,6 +268,10 @@ int melgpt_attn_bwd(const void* q, const void* k, const void* v, long long ld, c
                     const void* dout, long long ldo, const float* lse, float* delta, void* dq, void* dk,
                     void* dv, long long ldg, int B, int H, int T, int head_size, int n_unmasked, float drop_p,
                     unsigned long long seed, unsigned stream_id, int dtype, void* stream);
+/* 16-bit lane, causal mask (n_unmasked == 0), T <= 272: melgpt_attn_bwd runs as ONE launch that evaluates the
+ * probabilities once (dK / dV in registers, dS through LDS for dQ).  on != 0 keeps the two-kernel path (dQ, then dK / dV)
+ * that every other case uses; returns the previous setting.  MELGPT_ATTN_BWD_TWO_PASS=1 in the environment does the same. */
+int melgpt_set_attn_bwd_two_pass(int on);
 
 /* ===================================================================== row kernels
  * nn.LayerNorm(C, eps) (minGPT.py:97-98,141): y = (x-mean)*rstd*gamma+beta; mean/rstd (M,) f32 saved. */

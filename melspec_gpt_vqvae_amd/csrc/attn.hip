@@ -23,6 +23,8 @@
 // meets in eight consecutive key tiles - counter q * 16 + 4 gk + kb, bit 4 t + r: one hash per lane per EIGHT tiles
 // instead of one per tile (the hash's two integer multiplies were a third of the per-probability VALU work).
 // T = bf16: v_mfma_f32_16x16x32_bf16;  T = f32: v_mfma_f32_16x16x4_f32 (exact f32) - same code path.
+#include <cstdlib>
+
 #include "mma.h"
 
 #ifndef ATTN_LAB
@@ -711,6 +713,284 @@ int launch_dkv_mode(const AttnParams& p, hipStream_t s) {
   }
 }
 
+// ======================================================================================= single-pass backward
+// dQ, dK and dV of one (batch, head) from ONE evaluation of S, P, dP and dS (16-bit lane, causal mask: n_unmasked == 0).
+// The two kernels above each recompute the probabilities (exp2, dropout hash, mask: the VALU work these kernels are
+// bound by) and each stage two 34 KB tiles; here
+//   phase 1 = attn_dkv_kernel's loop (Q and dO in LDS, a wave owns 16 keys, dK^T / dV^T in its accumulators) which ALSO
+//             leaves every dS tile in LDS - bf16, key-major 16 x 16 tiles of 512 bytes, one per causal (key tile, query
+//             tile) pair: 153 pairs = 78 KB at T = 265 - written straight from the packed dK operand (one ds_write_b64);
+//   phase 2 = dQ^T[d][q] = sum_keys K^T[d][key] dS^T[key][q]: K re-staged over Q's tile (L2-hot), the B operand read
+//             back with ds_read_b64_tr_b16 (a 4-key x 16-query block per 16 lanes = exactly the fragment), 4 MFMAs per
+//             32 keys, no VALU; query tiles pulled from a second work counter.
+// delta = rowsum(dO * O) is taken while Q / dO / O are staged (the same 8-lanes-per-row loads).  152 KB of LDS: one
+// workgroup per CU (the two-kernel path runs two), 256 registers per lane.  Falls back to the two kernels when the dS tiles
+// do not fit (T > 272) or the mask is not plain causal.  Measured: profiles/r03_attn_lab.md.
+__device__ __forceinline__ int ds_pair(int kt, int qt, int nt) { return kt * nt - (kt * (kt - 1)) / 2 + (qt - kt); }
+
+template <int DM>
+__global__ __launch_bounds__(NTHREADS, 2) void attn_bwd1_kernel(AttnParams p) {
+  typedef bf16_t T;
+  using A = AT<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, i16 = lane & 15, g = lane >> 4;
+  const int Tn = p.T;
+  const int TP = rup(Tn, 32), ntiles = (Tn + 15) / 16;
+  char* Qt = smem;                                   // Q (phase 1), K (phase 2)
+  char* Dt = smem + (size_t)TP * A::ROWB;            // dO
+  float* lse_s = (float*)(smem + 2 * (size_t)TP * A::ROWB);  // lse * log2(e)
+  float* del_s = lse_s + TP;                                  // delta * (1 - p)
+  int* ctr = (int*)(del_s + TP);                              // [0] phase 1, [1] phase 2
+  char* dsb = (char*)(ctr + 4);                               // dS tiles (16-byte aligned: TP is a multiple of 32)
+  const float dsc = DM != DM_NONE ? p.drop_scale : 1.f;
+  const f32x4 c2v = splat4(p.scale * LOG2E);
+  const int qsh = 8 * (lane & 3);
+  // PERSISTENT: gridDim.x workgroups (one per CU: 152 KB of LDS) walk the (batch, head) items.  With one workgroup per CU
+  // nothing else on the CU hides the staging phase, so the NEXT item's Q / dO / O rows are requested into registers
+  // (60 of the ~70 this kernel leaves free) as soon as the current item's are in LDS, and land under its two phases.
+  constexpr int NIT = (MAXT * 8 + NTHREADS - 1) / NTHREADS;
+  const int nitems = p.B * p.H;
+  u32x4 vq[NIT], vd[NIT], vo[NIT];
+  auto request = [&](int it) {  // 8 lanes per 128-byte row: every request a full line; rows past T re-read the last one
+    const int bb = it / p.H, hh = it - bb * p.H;
+    const T* Qg = (const T*)p.Q + (long long)bb * Tn * p.ld + hh * HS;
+    const T* Dg = (const T*)p.dO + (long long)bb * Tn * p.ldo + hh * HS;
+    const T* Og = (const T*)p.O + (long long)bb * Tn * p.ldo + hh * HS;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int q = t + i * NTHREADS, row = min(q >> 3, Tn - 1), c = q & 7;
+      vq[i] = *(const u32x4*)(Qg + (long long)row * p.ld + c * 8);
+      vd[i] = *(const u32x4*)(Dg + (long long)row * p.ldo + c * 8);
+      vo[i] = *(const u32x4*)(Og + (long long)row * p.ldo + c * 8);
+    }
+  };
+  request(blockIdx.x);
+ for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  const int b = item / p.H, h = item - b * p.H;
+  const long long bh = item;
+  const T* Kg = (const T*)p.K + (long long)b * Tn * p.ld + h * HS;
+  // ---- Q and dO into LDS; delta = rowsum(dO * O) on the way
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int q = t + i * NTHREADS, row = q >> 3, c = q & 7;
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      d = fmaf(bf16lo(vd[i][e]), bf16lo(vo[i][e]), d);
+      d = fmaf(bf16hi(vd[i][e]), bf16hi(vo[i][e]), d);
+    }
+    d += dpp_move<0xB1>(d);
+    d += dpp_move<0x4E>(d);
+    d += dpp_move<0x141>(d);
+    if (q < TP * 8) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      *(u32x4*)(Qt + offK<T>(row, c)) = row < Tn ? vq[i] : z;
+      *(u32x4*)(Dt + offK<T>(row, c)) = row < Tn ? vd[i] : z;
+      if (c == 0) {
+        del_s[row] = row < Tn ? d / dsc : 0.f;
+        if (row < Tn) p.delta[bh * Tn + row] = d;
+      }
+    }
+  }
+  for (int j = t; j < TP; j += NTHREADS) lse_s[j] = j < Tn ? p.lse[bh * Tn + j] * LOG2E : 0.f;
+  if (t < 2) ctr[t] = 0;
+  __syncthreads();
+  request(min(item + (int)gridDim.x, nitems - 1));  // (past the end: a redundant reload instead of a branch around loads)
+  const DropKeys dkeys = drop_keys(p.seed, p.stream_id, (unsigned)bh, p.drop_thresh);
+
+  // ---- phase 1: this wave's next 16-key tile (key tile 0 is seen by every query: heaviest first); wave-uniform
+  for (;;) {
+    int job = 0;
+    if (lane == 0) job = atomicAdd(ctr, 1);
+    job = __builtin_amdgcn_readfirstlane(job);
+    if (job >= ntiles) break;
+    const int key0 = 16 * job, key = key0 + i16, kc = min(key, Tn - 1);
+    u32x4 kf[A::NKS], vf[A::NKS];
+    {
+      const T* kp = Kg + (long long)kc * p.ld;
+      const T* vp = (const T*)p.V + ((long long)b * Tn + kc) * p.ld + h * HS;
+#pragma unroll
+      for (int ks = 0; ks < A::NKS; ++ks) {
+        kf[ks] = *(const u32x4*)(kp + (4 * ks + g) * A::VEC);
+        vf[ks] = *(const u32x4*)(vp + (4 * ks + g) * A::VEC);
+      }
+    }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned cq = (unsigned)(4 * g + (lane & 3)) * 128u + (unsigned)(key >> 2) + dkeys.k0;
+    const unsigned ce = (unsigned)(4 * g) * 128u + (unsigned)(key >> 2);
+    const unsigned chq = (unsigned)(4 * g + (lane & 3)) * 16u + (unsigned)(((key & 15) >> 2) * 4 + (key >> 7)) + dkeys.k0;
+    const int hbit = 4 * ((key >> 4) & 7) + (key & 3);
+    char* ds_row = dsb + (size_t)ds_pair(job, job, ntiles) * 512 + i16 * 32 + g * 8;  // pair (job, qt): + (qt - job) * 512
+
+    auto step = [&](int st, bool masked) {
+      f32x4 pd[2], ds[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int qt = 2 * st + tt, qb = 16 * qt;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < A::NKS; ++ks) mma<T>(acc, frag_row<T, false>(Qt, qt, ks, lane), kf[ks]);
+#pragma unroll
+        for (int ks = 0; ks < A::NKS; ++ks) mma<T>(dp, frag_row<T, false>(Dt, qt, ks, lane), vf[ks]);
+        const f32x4 l4 = *(const f32x4*)(lse_s + qb + 4 * g), d4 = *(const f32x4*)(del_s + qb + 4 * g);
+        f32x4 pr = exp2_4(acc * c2v - l4);
+        if (masked) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = qb + 4 * g + r;
+            pr[r] = (q < Tn && key < Tn && key <= q) ? pr[r] : 0.f;
+          }
+        }
+        f32x4 pk = pr;
+        if constexpr (DM == DM_HALF) {
+          const int hq = (int)hash32(chq + (unsigned)qb * 16u);
+          const int hr[4] = {quad_lane<0>(hq), quad_lane<1>(hq), quad_lane<2>(hq), quad_lane<3>(hq)};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned km = (unsigned)__builtin_amdgcn_sbfe(hr[r], hbit, 1);  // all ones = kept
+            pk[r] = __uint_as_float(__float_as_uint(pr[r]) & km);
+            dp[r] = __uint_as_float(__float_as_uint(dp[r]) & km);
+          }
+        } else if constexpr (DM == DM_ANY) {
+          if (dkeys.b8) {
+            const int hq = (int)hash32(cq + (unsigned)qb * 128u);
+            const int hr[4] = {quad_lane<0>(hq), quad_lane<1>(hq), quad_lane<2>(hq), quad_lane<3>(hq)};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const bool keep = __builtin_amdgcn_ubfe((unsigned)hr[r], (unsigned)qsh, 8u) >= dkeys.t;
+              pk[r] = keep ? pr[r] : 0.f;
+              dp[r] = keep ? dp[r] : 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              bool k4[4];
+              drop_keep4(dkeys, ce + (unsigned)(qb + r) * 128u, k4);
+              const bool keep = (key & 2) ? ((key & 1) ? k4[3] : k4[2]) : ((key & 1) ? k4[1] : k4[0]);
+              pk[r] = keep ? pr[r] : 0.f;
+              dp[r] = keep ? dp[r] : 0.f;
+            }
+          }
+        }
+        pd[tt] = pk;
+        ds[tt] = pr * (dp - d4);
+      }
+      const u32x4 bp = pack_operand<T>(pd[0], pd[1]);
+      const u32x4 bs = pack_operand<T>(ds[0], ds[1]);
+      // dS tiles of this step for phase 2: lane = key, its 4 consecutive queries are 8 contiguous bytes of the key's row
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int qt = 2 * st + tt;  // (wave-uniform)
+        if (qt >= job && qt < ntiles) *(u32x2*)(ds_row + (qt - job) * 512) = u32x2{bs[2 * tt], bs[2 * tt + 1]};
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        mma<T>(dv[dt], frag_tr<T, false>(Dt, st, dt, lane), bp);
+        mma<T>(dk[dt], frag_tr<T, false>(Qt, st, dt, lane), bs);
+      }
+    };
+    // query tiles that can see these keys: from the diagonal.  A tile is seen whole - no mask test - when it lies
+    // below the diagonal tile and holds no padded row or key.
+    const int st0 = job / 2;
+    const int st1 = (ntiles + 1) / 2;
+    const int stf0 = key0 + 16 <= Tn ? min(st1, (job + 2) / 2) : st1;  // first whole step ..
+    const int stf1 = max(stf0, (Tn / 16) / 2);                          // .. and one past the last
+    for (int st = st0; st < stf0; ++st) step(st, true);
+    for (int st = stf0; st < stf1; ++st) step(st, false);  // (two steps in flight: measured the same)
+    for (int st = stf1; st < st1; ++st) step(st, true);
+
+    if (key < Tn) {
+      T* kp = (T*)p.dK + ((long long)b * Tn + key) * p.ldg + h * HS;
+      T* vp = (T*)p.dV + ((long long)b * Tn + key) * p.ldg + h * HS;
+      const float ksc = p.scale * dsc;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        store4<T>(kp + 16 * dt + 4 * g, dk[dt] * ksc);
+        store4<T>(vp + 16 * dt + 4 * g, dv[dt] * dsc);
+      }
+    }
+  }
+  __syncthreads();  // every dS tile is in LDS; nobody reads Q any more
+  // ---- phase 2: K over Q's tile, then dQ^T = K^T dS^T per 16-query tile
+  {
+    constexpr int NIT = (MAXT * 8 + NTHREADS - 1) / NTHREADS;
+    u32x4 vk[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int q = t + i * NTHREADS, row = min(q >> 3, Tn - 1), c = q & 7;
+      vk[i] = *(const u32x4*)(Kg + (long long)row * p.ld + c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int q = t + i * NTHREADS, row = q >> 3, c = q & 7;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      if (q < TP * 8) *(u32x4*)(Qt + offK<T>(row, c)) = row < Tn ? vk[i] : z;
+    }
+  }
+  __syncthreads();
+  const float oscale = p.scale * dsc;
+  for (;;) {
+    int job = 0;
+    if (lane == 0) job = atomicAdd(ctr + 1, 1);
+    job = __builtin_amdgcn_readfirstlane(job);
+    if (job >= ntiles) break;
+    const int qt = ntiles - 1 - job;  // latest query tiles (most key tiles) first
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tr_off = (4 * g + (i16 >> 2)) * 32 + (i16 & 3) * 8;  // this lane's address inside a 4-key x 16-query block
+    for (int st = 0; 2 * st <= qt; ++st) {
+      const int kt0 = 2 * st, kt1 = 2 * st + 1;
+      const char* a0 = dsb + (size_t)ds_pair(kt0, qt, ntiles) * 512 + tr_off;
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a0));
+      s16x4 hi = {0, 0, 0, 0};
+      if (kt1 <= qt) {  // (wave-uniform) the odd key tile of the pair lies beyond the diagonal otherwise: dS = 0
+        const char* a1 = dsb + (size_t)ds_pair(kt1, qt, ntiles) * 512 + tr_off;
+        hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
+      }
+      const s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      const u32x4 bop = __builtin_bit_cast(u32x4, f);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) mma<T>(o[dt], frag_tr<T, false>(Qt, st, dt, lane), bop);
+    }
+    const int q = 16 * qt + i16;
+    if (q < Tn) {
+      T* op = (T*)p.dQ + ((long long)b * Tn + q) * p.ldg + h * HS;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store4<T>(op + 16 * dt + 4 * g, o[dt] * oscale);
+    }
+  }
+  __syncthreads();  // the next item's rows replace K / dO / the statistics / the counters
+ }  // item loop
+}
+
+static size_t bwd1_lds_bytes(int Tn) {
+  const int TP = (Tn + 31) / 32 * 32, nt = (Tn + 15) / 16;
+  return 2 * (size_t)TP * 128 + 2 * (size_t)TP * 4 + 16 + (size_t)(nt * (nt + 1) / 2) * 512;
+}
+
+template <int DM>
+int launch_bwd1(const AttnParams& p, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    if (set_lds(attn_bwd1_kernel<DM>, 160 * 1024) != MELGPT_OK) return MELGPT_ERR_LAUNCH;
+    attr = true;
+  }
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        n <= 0)
+      n = 256;
+    ncu = n;
+  }
+  const int items = p.B * p.H;
+  hipLaunchKernelGGL((attn_bwd1_kernel<DM>), dim3(items < ncu ? items : ncu), dim3(NTHREADS), bwd1_lds_bytes(p.T), s, p);
+  return MELGPT_OK;
+}
+
 }  // namespace
 
 extern "C" int melgpt_attn_fwd(const void* q, const void* k, const void* v, long long ld, void* out, long long ldo,
@@ -731,6 +1011,13 @@ extern "C" int melgpt_attn_fwd(const void* q, const void* k, const void* v, long
   return st != MELGPT_OK ? st : melgpt_launch_status();
 }
 
+static int g_bwd_two_pass = -1;
+extern "C" int melgpt_set_attn_bwd_two_pass(int on) {
+  const int prev = g_bwd_two_pass > 0;
+  g_bwd_two_pass = on != 0;
+  return prev;
+}
+
 extern "C" int melgpt_attn_bwd(const void* q, const void* k, const void* v, long long ld, const void* out,
                                const void* dout, long long ldo, const float* lse, float* delta, void* dq, void* dk,
                                void* dv, long long ldg, int B, int H, int T, int head_size, int n_unmasked,
@@ -749,6 +1036,19 @@ extern "C" int melgpt_attn_bwd(const void* q, const void* k, const void* v, long
                MELGPT_ERR_ALIGN);
   set_dropout(p, drop_p, seed, stream_id);
   hipStream_t s = (hipStream_t)stream;
+  // 16-bit lane, plain causal mask, dS tiles fit LDS: ONE launch that evaluates the probabilities once (attn_bwd1_kernel)
+  if (g_bwd_two_pass < 0) {  // MELGPT_ATTN_BWD_TWO_PASS=1 / melgpt_set_attn_bwd_two_pass(1) keep the two-kernel path
+    const char* e = getenv("MELGPT_ATTN_BWD_TWO_PASS");
+    g_bwd_two_pass = e ? atoi(e) != 0 : 0;
+  }
+  if (ATTN_LAB == 0 && !g_bwd_two_pass && dtype == MELGPT_BF16 && n_unmasked == 0 && bwd1_lds_bytes(T) <= 160 * 1024) {
+    switch (drop_mode(p)) {
+      case DM_NONE: st = launch_bwd1<DM_NONE>(p, s); break;
+      case DM_HALF: st = launch_bwd1<DM_HALF>(p, s); break;
+      default: st = launch_bwd1<DM_ANY>(p, s); break;
+    }
+    return st != MELGPT_OK ? st : melgpt_launch_status();
+  }
   if (ATTN_LAB != 4) {  // dQ (writes delta, which the dK/dV kernel reads)
     st = dtype == MELGPT_F32 ? launch_q_mode<float, true>(p, s) : launch_q_mode<bf16_t, true>(p, s);
     if (st != MELGPT_OK) return st;
