@@ -395,7 +395,9 @@ def main():
     ap.add_argument("--layers", type=int, default=24, help="debug only; anything but the configuration's depth is flagged")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip config4_gpt_vae_xl_rank / config5_e2e_fp16 (BASELINE configs[3], [4] beside the metric)")
+                    help="skip config2_vq_encode / config4_gpt_vae_xl_rank / config5_e2e_fp16 (BASELINE configs[1], [3], [4] "
+                         "beside the metric): the profiled runs of tools/profile_round.sh, so that every kernel of the "
+                         "trace belongs to a training step")
     ap.add_argument("--breakdown", action="store_true", help="print per-phase timings to stderr")
     a = ap.parse_args()
 
@@ -524,7 +526,7 @@ def main():
             for r in rows[:40]:
                 print(f"  {r['shape']:44s} n/step={r['calls_per_step']:6.1f} ms/step={r['ms_per_step']:8.3f} "
                       f"TFLOP/s={r['tflops']:7.1f}", file=sys.stderr)
-        if world == 1 and job.name == "class_gpt":
+        if world == 1 and job.name == "class_gpt" and not a.no_extras:
             out["config2_vq_encode"] = vq_encode_b64(job, device)
         extras = world == 1 and job.name == "class_gpt" and job.full and a.batch == 128 and not a.no_extras
         if extras:

@@ -29,10 +29,11 @@
 
 #ifndef ATTN_LAB
 #define ATTN_LAB 0  // tools/lab/attn_lab.hip ablations: 1 staging only, 2 no staging, 3 dQ kernel only, 4 dK/dV kernel only,
-// forward only: 5 no row-maximum pass, 6 no P V MFMAs, 7 no softmax arithmetic, 8 phase stamps of one wave
+// forward only: 5 no row-maximum pass, 6 no P V MFMAs, 7 no softmax arithmetic, 8 phase stamps of one wave;
+// 9 single-pass backward: phase stamps of the 8 waves of workgroup 17 over its first items
 #endif
 
-#if ATTN_LAB == 8
+#if ATTN_LAB == 8 || ATTN_LAB == 9
 __device__ unsigned long long melgpt_attn_dbg[256 + 4 * 4096];  // lab build only: phase stamps of one wave of one workgroup
 #endif
 
@@ -745,34 +746,54 @@ __global__ __launch_bounds__(NTHREADS, 2) void attn_bwd1_kernel(AttnParams p) {
   const float dsc = DM != DM_NONE ? p.drop_scale : 1.f;
   const f32x4 c2v = splat4(p.scale * LOG2E);
   const int qsh = 8 * (lane & 3);
-  // PERSISTENT: gridDim.x workgroups (one per CU: 152 KB of LDS) walk the (batch, head) items.  With one workgroup per CU
-  // nothing else on the CU hides the staging phase, so the NEXT item's Q / dO / O rows are requested into registers
-  // (60 of the ~70 this kernel leaves free) as soon as the current item's are in LDS, and land under its two phases.
+  // PERSISTENT: gridDim.x workgroups (one per CU: 152 KB of LDS) walk the (batch, head) items.  The workgroups run in
+  // lockstep (same work each), so un-overlapped staging is the whole chip pulling 26 MB at once and then leaving HBM
+  // idle: 10-15 k of an item's 53 k cycles (stamps: profiles/r03_attn_lab.md).  The NEXT item's Q / dO / O rows are
+  // therefore requested into 60 spare registers under the current item's phase 1.
   constexpr int NIT = (MAXT * 8 + NTHREADS - 1) / NTHREADS;
   const int nitems = p.B * p.H;
   u32x4 vq[NIT], vd[NIT], vo[NIT];
+  float vl = 0.f;
+  // (32-bit element offsets from wave-uniform bases: 64-bit per-lane addresses for the 15 requests cost 30 registers and
+  // pushed the staging code into scratch - whose reloads sit in the same in-order queue as the requests.)
   auto request = [&](int it) {  // 8 lanes per 128-byte row: every request a full line; rows past T re-read the last one
     const int bb = it / p.H, hh = it - bb * p.H;
     const T* Qg = (const T*)p.Q + (long long)bb * Tn * p.ld + hh * HS;
     const T* Dg = (const T*)p.dO + (long long)bb * Tn * p.ldo + hh * HS;
     const T* Og = (const T*)p.O + (long long)bb * Tn * p.ldo + hh * HS;
+    const unsigned ld = (unsigned)p.ld, ldo = (unsigned)p.ldo;
+    unsigned tl = t;
+    asm volatile("" : "+v"(tl));  // (offsets recomputed per item: hoisted out of the item loop they hold 15 registers)
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int q = t + i * NTHREADS, row = min(q >> 3, Tn - 1), c = q & 7;
-      vq[i] = *(const u32x4*)(Qg + (long long)row * p.ld + c * 8);
-      vd[i] = *(const u32x4*)(Dg + (long long)row * p.ldo + c * 8);
-      vo[i] = *(const u32x4*)(Og + (long long)row * p.ldo + c * 8);
+      const unsigned q = tl + i * NTHREADS, row = min(q >> 3, (unsigned)Tn - 1u), c8 = (q & 7u) * 8u;
+      vq[i] = *(const u32x4*)(Qg + (row * ld + c8));
+      vd[i] = *(const u32x4*)(Dg + (row * ldo + c8));
+      vo[i] = *(const u32x4*)(Og + (row * ldo + c8));
     }
+    vl = (p.lse + (long long)it * Tn)[min(tl, (unsigned)Tn - 1u)];
   };
   request(blockIdx.x);
  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+#if ATTN_LAB == 9
+  const int lab_it = (item - (int)blockIdx.x) / (int)gridDim.x;
+  unsigned long long* lab = melgpt_attn_dbg + (size_t)(lab_it * 8 + (t >> 6)) * 8;
+  const bool lab_on = blockIdx.x == 17 && lab_it < 8 && lane == 0;
+  int lab_steps = 0;
+#define LAB_STAMP(k) do { if (lab_on) lab[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LAB_STAMP(k) do { } while (0)
+#endif
+  LAB_STAMP(0);
   const int b = item / p.H, h = item - b * p.H;
   const long long bh = item;
   const T* Kg = (const T*)p.K + (long long)b * Tn * p.ld + h * HS;
   // ---- Q and dO into LDS; delta = rowsum(dO * O) on the way
+  int ts = t;
+  asm volatile("" : "+v"(ts));  // (as in request(): LDS offsets recomputed per item)
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
-    const int q = t + i * NTHREADS, row = q >> 3, c = q & 7;
+    const int q = ts + i * NTHREADS, row = q >> 3, c = q & 7;
     float d = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -788,33 +809,48 @@ __global__ __launch_bounds__(NTHREADS, 2) void attn_bwd1_kernel(AttnParams p) {
       *(u32x4*)(Dt + offK<T>(row, c)) = row < Tn ? vd[i] : z;
       if (c == 0) {
         del_s[row] = row < Tn ? d / dsc : 0.f;
-        if (row < Tn) p.delta[bh * Tn + row] = d;
+        if (row < Tn) (p.delta + bh * Tn)[(unsigned)row] = d;
       }
     }
   }
-  for (int j = t; j < TP; j += NTHREADS) lse_s[j] = j < Tn ? p.lse[bh * Tn + j] * LOG2E : 0.f;
+  if (t < TP) lse_s[t] = t < Tn ? vl * LOG2E : 0.f;  // (TP <= 288 < the 512 threads)
   if (t < 2) ctr[t] = 0;
   __syncthreads();
-  request(min(item + (int)gridDim.x, nitems - 1));  // (past the end: a redundant reload instead of a branch around loads)
+  LAB_STAMP(1);
   const DropKeys dkeys = drop_keys(p.seed, p.stream_id, (unsigned)bh, p.drop_thresh);
 
   // ---- phase 1: this wave's next 16-key tile (key tile 0 is seen by every query: heaviest first); wave-uniform
-  for (;;) {
-    int job = 0;
-    if (lane == 0) job = atomicAdd(ctr, 1);
-    job = __builtin_amdgcn_readfirstlane(job);
-    if (job >= ntiles) break;
-    const int key0 = 16 * job, key = key0 + i16, kc = min(key, Tn - 1);
-    u32x4 kf[A::NKS], vf[A::NKS];
-    {
-      const T* kp = Kg + (long long)kc * p.ld;
-      const T* vp = (const T*)p.V + ((long long)b * Tn + kc) * p.ld + h * HS;
+  //      A wave claims its NEXT tile when it starts one and requests that tile's K / V fragments (global loads, ~2-4 k
+  //      cycles under load) under the current tile's steps.
+  auto claim = [&]() {
+    int j = 0;
+    if (lane == 0) j = atomicAdd(ctr, 1);
+    return __builtin_amdgcn_readfirstlane(j);
+  };
+  auto load_kv = [&](int jb, u32x4* kf_, u32x4* vf_) {
+    const unsigned kc = (unsigned)min(16 * min(jb, ntiles - 1) + i16, Tn - 1);
+    const T* kp = Kg + kc * (unsigned)p.ld;
+    const T* vp = (const T*)p.V + (long long)b * Tn * p.ld + h * HS + kc * (unsigned)p.ld;
 #pragma unroll
-      for (int ks = 0; ks < A::NKS; ++ks) {
-        kf[ks] = *(const u32x4*)(kp + (4 * ks + g) * A::VEC);
-        vf[ks] = *(const u32x4*)(vp + (4 * ks + g) * A::VEC);
-      }
+    for (int ks = 0; ks < A::NKS; ++ks) {
+      kf_[ks] = *(const u32x4*)(kp + (4 * ks + g) * A::VEC);
+      vf_[ks] = *(const u32x4*)(vp + (4 * ks + g) * A::VEC);
     }
+  };
+  u32x4 kf[A::NKS], vf[A::NKS];
+  int job = claim();
+  load_kv(job, kf, vf);
+  // Loads return in order, and the compiler places the wait for a load at its first use - for these fragments INSIDE
+  // the step loop, where it assumes the worst of all paths: with the next item's rows requested ahead of or behind them
+  // the first step waited for all 16 requests (the prefetch bought 4 us of a possible 40).  So: wait for the first
+  // tile's fragments here, by hand, and only then put the rows in flight.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+  request(min(item + (int)gridDim.x, nitems - 1));  // (past the end: a redundant reload instead of a branch)
+  while (job < ntiles) {
+    const int njob = claim();
+    u32x4 nkf[A::NKS], nvf[A::NKS];
+    load_kv(njob, nkf, nvf);  // (past the last tile: the last tile's again, unused)
+    const int key0 = 16 * job, key = key0 + i16;
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -897,9 +933,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void attn_bwd1_kernel(AttnParams p) {
     const int st1 = (ntiles + 1) / 2;
     const int stf0 = key0 + 16 <= Tn ? min(st1, (job + 2) / 2) : st1;  // first whole step ..
     const int stf1 = max(stf0, (Tn / 16) / 2);                          // .. and one past the last
-    for (int st = st0; st < stf0; ++st) step(st, true);
-    for (int st = stf0; st < stf1; ++st) step(st, false);  // (two steps in flight: measured the same)
-    for (int st = stf1; st < st1; ++st) step(st, true);
+    for (int st = st0; st < st1; ++st) {
+      step(st, st < stf0 || st >= stf1);
+#if ATTN_LAB == 9
+      ++lab_steps;
+#endif
+    }
 
     if (key < Tn) {
       T* kp = (T*)p.dK + ((long long)b * Tn + key) * p.ldg + h * HS;
@@ -911,25 +950,39 @@ __global__ __launch_bounds__(NTHREADS, 2) void attn_bwd1_kernel(AttnParams p) {
         store4<T>(vp + 16 * dt + 4 * g, dv[dt] * dsc);
       }
     }
-  }
-  __syncthreads();  // every dS tile is in LDS; nobody reads Q any more
-  // ---- phase 2: K over Q's tile, then dQ^T = K^T dS^T per 16-query tile
-  {
-    constexpr int NIT = (MAXT * 8 + NTHREADS - 1) / NTHREADS;
-    u32x4 vk[NIT];
+    job = njob;
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int q = t + i * NTHREADS, row = min(q >> 3, Tn - 1), c = q & 7;
-      vk[i] = *(const u32x4*)(Kg + (long long)row * p.ld + c * 8);
+    for (int ks = 0; ks < A::NKS; ++ks) {
+      kf[ks] = nkf[ks];
+      vf[ks] = nvf[ks];
     }
+  }
+  LAB_STAMP(2);
+#if ATTN_LAB == 9
+  if (lab_on) lab[7] = lab_steps;
+#endif
+  // ---- phase 2: K over Q's tile (requested before the barrier: a wave that is done early waits there anyway), then
+  //      dQ^T = K^T dS^T per 16-query tile
+  {
+    u32x4 vk[NIT];
+    unsigned tk = t;
+    asm volatile("" : "+v"(tk));
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int q = t + i * NTHREADS, row = q >> 3, c = q & 7;
+      const unsigned q = tk + i * NTHREADS, row = min(q >> 3, (unsigned)Tn - 1u), c8 = (q & 7u) * 8u;
+      vk[i] = *(const u32x4*)(Kg + (row * (unsigned)p.ld + c8));
+    }
+    __syncthreads();  // every dS tile is in LDS; nobody reads Q any more
+    LAB_STAMP(3);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int q = (int)tk + i * NTHREADS, row = q >> 3, c = q & 7;
       const u32x4 z = {0u, 0u, 0u, 0u};
       if (q < TP * 8) *(u32x4*)(Qt + offK<T>(row, c)) = row < Tn ? vk[i] : z;
     }
   }
   __syncthreads();
+  LAB_STAMP(4);
   const float oscale = p.scale * dsc;
   for (;;) {
     int job = 0;
@@ -962,7 +1015,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void attn_bwd1_kernel(AttnParams p) {
       for (int dt = 0; dt < 4; ++dt) store4<T>(op + 16 * dt + 4 * g, o[dt] * oscale);
     }
   }
+  LAB_STAMP(5);
   __syncthreads();  // the next item's rows replace K / dO / the statistics / the counters
+  LAB_STAMP(6);
  }  // item loop
 }
 
@@ -1041,7 +1096,7 @@ extern "C" int melgpt_attn_bwd(const void* q, const void* k, const void* v, long
     const char* e = getenv("MELGPT_ATTN_BWD_TWO_PASS");
     g_bwd_two_pass = e ? atoi(e) != 0 : 0;
   }
-  if (ATTN_LAB == 0 && !g_bwd_two_pass && dtype == MELGPT_BF16 && n_unmasked == 0 && bwd1_lds_bytes(T) <= 160 * 1024) {
+  if ((ATTN_LAB == 0 || ATTN_LAB == 9) && !g_bwd_two_pass && dtype == MELGPT_BF16 && n_unmasked == 0 && bwd1_lds_bytes(T) <= 160 * 1024) {
     switch (drop_mode(p)) {
       case DM_NONE: st = launch_bwd1<DM_NONE>(p, s); break;
       case DM_HALF: st = launch_bwd1<DM_HALF>(p, s); break;

@@ -473,11 +473,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
           }
           // piece k of NP goes out after MFMA row floor((k + 1) TM / NP) - 1
           const int np = ks == 0 ? PER : PER_A;
-          const int k_here = ((mt + 1) * np) / TM - (mt * np) / TM;  // 0 or 1 pieces after this row
+#ifndef G256_BFRONT
+#define G256_BFRONT 0
+#endif
+          const bool front = (G256_BFRONT == 1 && ks == 0) || G256_BFRONT == 2;
+          const int k_here = front ? (mt < np ? 1 : 0) : ((mt + 1) * np) / TM - (mt * np) / TM;  // 0 or 1 pieces after this row
+          const int k_idx = front ? mt : (mt * np) / TM;
           if (DMA_ON && k_here > 0) {
             __builtin_amdgcn_sched_barrier(0);
-            if (ks == 0) issue_b_piece(iu, dst_b, (mt * np) / TM);
-            else issue_a_piece(iu, dst_a, (mt * np) / TM);
+            if (ks == 0) issue_b_piece(iu, dst_b, k_idx);
+            else issue_a_piece(iu, dst_a, k_idx);
             __builtin_amdgcn_sched_barrier(0);
           }
         }

@@ -90,6 +90,21 @@ int main(int argc, char** argv) {
     printf("job %llu (%llu key tiles): start +%llu  pass1 %llu  pass2 %llu  tail %llu\n", hdbg[8 * i + 5], hdbg[8 * i + 4],
            hdbg[8 * i], hdbg[8 * i + 1], hdbg[8 * i + 2], hdbg[8 * i + 3]);
 #endif
+#if ATTN_LAB == 9
+  {
+    std::vector<unsigned long long> w(8 * 8 * 8);
+    hipMemcpyFromSymbol(w.data(), HIP_SYMBOL(melgpt_attn_dbg), w.size() * 8);
+    for (int it = 0; it < 8; ++it) {
+      const unsigned long long t0 = w[(it * 8) * 8];
+      printf("item %d (start %+lld after the previous item's end):\n", it, it ? (long long)(t0 - w[((it - 1) * 8) * 8 + 6]) : 0ll);
+      for (int wv = 0; wv < 8; ++wv) {
+        const unsigned long long* q = &w[(it * 8 + wv) * 8];
+        printf("  wave %d: staged %6llu | phase 1 done %6llu (%llu steps) | barrier %6llu | K restaged %6llu | phase 2 done %6llu | end %6llu\n",
+               wv, q[1] - t0, q[2] - t0, q[7], q[3] - t0, q[4] - t0, q[5] - t0, q[6] - t0);
+      }
+    }
+  }
+#endif
   std::vector<unsigned short> ho(16);
   hipMemcpy(ho.data(), o, 32, hipMemcpyDeviceToHost);
   printf("o[0..3] bits %04x %04x %04x %04x\n", ho[0], ho[1], ho[2], ho[3]);
