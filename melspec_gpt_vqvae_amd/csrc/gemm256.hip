@@ -541,6 +541,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
       if (sum[0] + sum[1] + sum[2] + sum[3] == 12345.f) *(float*)p.C = sum[0];
       continue;
     }
+#ifdef G256_EPI_SOLO  // lab: only workgroup 17 stores its tiles (is the epilogue bound by the chip-wide write burst?)
+    if (blockIdx.x != 17) {
+      GemmParams q = p;
+      q.N = p.alpha == 1.f ? 0 : p.N;
+      epilogue<bf16_t, TM, TN, MODE, ALAY != LAY_CONV>(q, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, bz, lane_e, smem + fill * HALF + w * 4096);
+      continue;
+    }
+#endif
     if (G256_LAB == 4) {  // full epilogue arithmetic + staging, stores predicated off at run time
       GemmParams q = p;
       q.N = p.alpha == 1.f ? 0 : p.N;

@@ -135,6 +135,34 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 template <int ROWB>
 __device__ __forceinline__ int stage_off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
 
+// Where a lane's 16-byte pieces of one staged 16-row slab sit - in the wave's staging block and in the output rows -
+// worked out ONCE per tile.  (Recomputed per piece - signed division of the lane index, the swizzle, a 64-bit row x ld
+// product and three predicates in front of every store, each store behind its own LDS read and lgkmcnt(0) - the plain
+// bf16 epilogue of a 256 x 256 tile was 1 120 instructions and 11 k cycles for 128 KiB; profiles/r03_gemm_lab.md.)
+template <int ROWB, int OS>  // staged row bytes, output element size
+struct OutPlan {
+  static constexpr int CPR = ROWB / 16, RPI = 64 / CPR, OSZ = OS;  // chunks per row, rows per 64-lane round
+  static constexpr bool WHOLE = (16 * CPR) % 64 == 0;              // (checked where a plan is used)
+  static constexpr int PER = WHOLE ? (16 * CPR) / 64 : 1;          // pieces per lane per slab
+  // Three registers per lane (the epilogues run at the register limit): piece j sits RPI j rows below piece 0 - in the
+  // staging block a constant apart (RPI = 8: the same swizzle) or a constant and one XOR apart (RPI = 4: row & 7
+  // alternates by 4, which flips bit 2 of the chunk index), in the output RPI j ld elements further on (wave-uniform).
+  int rd0;        // staging-block offset of piece 0
+  unsigned go0;   // byte offset of piece 0 from the slab's first output element (row mr, column n_base)
+  int lrow;       // row of piece 0 inside the slab; a lane whose columns are out of range: past any row count
+  static_assert(!WHOLE || RPI == 8 || RPI == 4 || RPI == 16, "row rounds of 4, 8 or 16");
+  __device__ __forceinline__ void init(int lane, long long ld, int n_base, int N) {
+    const unsigned ul = (unsigned)lane, ch = ul % CPR, row = ul / CPR;
+    rd0 = stage_off<ROWB>((int)row, (int)ch);
+    go0 = (row * (unsigned)ld + ch * (16 / OS)) * OS;
+    lrow = n_base + (int)(ch * (16 / OS)) < N ? (int)row : 0x3FFFFFFF;
+  }
+  __device__ __forceinline__ int rd(int j) const {  // (j is a compile-time constant at every call)
+    if constexpr (RPI == 4) return (rd0 ^ ((j & 1) << 6)) + j * RPI * ROWB;
+    else return rd0 + j * RPI * ROWB;
+  }
+};
+
 // MODE picks what is compiled in (the persistent 256-wide kernel instantiates one kernel per mode so that its
 // epilogue stays small enough for the instruction cache; the generic mode serves gemm.hip and conv_fused.hip):
 enum { EPI_GENERIC = 0, EPI_PLAIN16 = 1, EPI_PLAIN32 = 2, EPI_FULL16 = 3,
@@ -248,6 +276,29 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
         if (mr >= 0 && row < row_limit && m < p.M && n < p.N) dst[j] = *(const u32x4*)(Rb + (m * p.ldr + n) * ES);
       }
     };
+    OutPlan<TN * 32, 2> plan16;
+    if (CAN16 && MODE != EPI_FULL16 && !f32out) plan16.init(lane, p.ldc, n_base, p.N);
+    // all of a lane's pieces of the staged slab are read back first (ONE LDS round trip), then stored; `rmw` adds the old
+    // contents of C (accumulate)
+    auto flush = [&](auto& pl, char* Ob, const char* src, long long mr, auto rmw) {
+      using PL = typename std::remove_reference<decltype(pl)>::type;
+      constexpr int OS = PL::OSZ;
+      static_assert(PL::WHOLE, "a staged slab is a whole number of 64-lane rounds");
+      const int rows = mr < 0 ? 0 : (int)(p.M - mr < row_limit ? p.M - mr : row_limit);  // (wave-uniform)
+      char* sb = Ob + (mr * p.ldc + n_base) * OS;
+      const long long rstep = p.ldc * (PL::RPI * OS);  // (wave-uniform) bytes between a lane's pieces in the output
+      u32x4 o[PL::PER];
+#pragma clang loop unroll(full)
+      for (int j = 0; j < PL::PER; ++j) o[j] = *(const u32x4*)(src + pl.rd(j));
+#pragma clang loop unroll(full)
+      for (int j = 0; j < PL::PER; ++j)
+        if (pl.lrow + PL::RPI * j < rows) {
+          u32x4* dst = (u32x4*)(sb + j * rstep + pl.go0);
+          rmw(o[j], dst);
+          *dst = o[j];
+        }
+    };
+    auto no_rmw = [](u32x4&, const u32x4*) {};
     // one 16-row slab: accumulators av, first output row mr, R in register set SET
     auto slab = [&](const f32x4 (&av)[TN], long long mr, auto set_c) {
       constexpr int SET = decltype(set_c)::value;
@@ -273,7 +324,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
       const bool dact = MODE == EPI_DACT16 || (MODE == EPI_GENERIC && p.act == MELGPT_ACT_GELU_DACT);
       if constexpr ((MODE == EPI_GENERIC || MODE == EPI_DACT16) && CAN16) {
         if (dact && !f32out) {
-          constexpr int ROWB = TN * 32, CPR = ROWB / 16, PER = (16 * CPR) / 64;
+          constexpr int ROWB = TN * 32;
           static_assert(2 * 16 * ROWB <= 4096, "two bf16 slabs must fit the wave's staging block");
           char* st2 = stage + 16 * ROWB;
 #pragma clang loop unroll(full)
@@ -285,16 +336,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
             *(u32x2*)(stage + o) = u32x2{pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
             *(u32x2*)(st2 + o) = u32x2{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
           }
-#pragma clang loop unroll(full)
-          for (int j = 0; j < PER; ++j) {
-            const int q = lane + 64 * j, row = q / CPR, ch = q % CPR;
-            const long long mm = mr + row;
-            const int nn = n_base + ch * 8;
-            if (mr >= 0 && row < row_limit && mm < p.M && nn < p.N) {
-              *(u32x4*)(C2b + (mm * p.ldc + nn) * 2) = *(const u32x4*)(stage + stage_off<ROWB>(row, ch));
-              *(u32x4*)(Cb + (mm * p.ldc + nn) * 2) = *(const u32x4*)(st2 + stage_off<ROWB>(row, ch));
-            }
-          }
+          flush(plan16, C2b, stage, mr, no_rmw);
+          flush(plan16, Cb, st2, mr, no_rmw);
           return;
         }
       }
@@ -321,9 +364,12 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
         if (!Ob) continue;
         if (f32out) {
           if constexpr (CAN32) {
-            constexpr int ROWB = TN * 64, CPR = ROWB / 16, PER = (16 * CPR) / 64;
+            constexpr int ROWB = TN * 64;
 #pragma clang loop unroll(full)
             for (int nt = 0; nt < TN; ++nt) *(f32x4*)(stage + stage_off<ROWB>(i16, 4 * nt + g)) = value(pass, nt);
+            // (f32 rows keep the per-piece form: four pieces per lane read back together measured 1.5 % slower on the
+            // weight-gradient GEMMs - 1 453-1 467 -> 1 437 TFLOP/s in the lab - where the bf16 modes gained 3-5 %)
+            constexpr int CPR = ROWB / 16, PER = (16 * CPR) / 64;
 #pragma clang loop unroll(full)
             for (int j = 0; j < PER; ++j) {
               const int q = lane + 64 * j, row = q / CPR, ch = q % CPR;
@@ -339,29 +385,43 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
           }
         } else {
           if constexpr (CAN16) {
-            constexpr int ROWB = TN * 32, CPR = ROWB / 16, PER = (16 * CPR) / 64;
+            constexpr int ROWB = TN * 32;
 #pragma clang loop unroll(full)
             for (int nt = 0; nt < TN; ++nt) {
               const f32x4 v = value(pass, nt);
               *(u32x2*)(stage + stage_off<ROWB>(i16, 2 * nt + (g >> 1)) + (g & 1) * 8) =
                   u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             }
+            if constexpr (MODE == EPI_FULL16) {
+              // (the rolled full mode keeps the per-piece form: with the plan's three registers live across its loop the
+              // 256-row instantiation spills 10 VGPRs whose reloads land in the K loop)
+              constexpr int CPR = ROWB / 16, PER = (16 * CPR) / 64;
 #pragma clang loop unroll(full)
-            for (int j = 0; j < PER; ++j) {
-              const int q = lane + 64 * j, row = q / CPR, ch = q % CPR;
-              const long long mm = mr + row;
-              const int nn = n_base + ch * 8;
-              if (mr >= 0 && row < row_limit && mm < p.M && nn < p.N) {
-                u32x4 o = *(const u32x4*)(stage + stage_off<ROWB>(row, ch));
-                u32x4* dst = (u32x4*)(Ob + (mm * p.ldc + nn) * 2);
-                if (LOADS && pass == 1 && p.accumulate) {
-                  const u32x4 c = *dst;
+              for (int j = 0; j < PER; ++j) {
+                const int q = lane + 64 * j, row = q / CPR, ch = q % CPR;
+                const long long mm = mr + row;
+                const int nn = n_base + ch * 8;
+                if (mr >= 0 && row < row_limit && mm < p.M && nn < p.N) {
+                  u32x4 o = *(const u32x4*)(stage + stage_off<ROWB>(row, ch));
+                  u32x4* dst = (u32x4*)(Ob + (mm * p.ldc + nn) * 2);
+                  if (LOADS && pass == 1 && p.accumulate) {
+                    const u32x4 c = *dst;
 #pragma unroll
-                  for (int e = 0; e < 4; ++e)
-                    o[e] = pack_bf16x2(bf16lo(o[e]) + bf16lo(c[e]), bf16hi(o[e]) + bf16hi(c[e]));
+                    for (int e = 0; e < 4; ++e)
+                      o[e] = pack_bf16x2(bf16lo(o[e]) + bf16lo(c[e]), bf16hi(o[e]) + bf16hi(c[e]));
+                  }
+                  *dst = o;
                 }
-                *dst = o;
               }
+            } else if (LOADS && pass == 1 && p.accumulate) {
+              flush(plan16, Ob, stage, mr, [](u32x4& o, const u32x4* dst) {
+                const u32x4 c = *dst;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  o[e] = pack_bf16x2(bf16lo(o[e]) + bf16lo(c[e]), bf16hi(o[e]) + bf16hi(c[e]));
+              });
+            } else {
+              flush(plan16, Ob, stage, mr, no_rmw);
             }
           }
         }
