@@ -255,6 +255,18 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
     // ------------------------------------------------------------------ staged, row-contiguous path
     constexpr int IN_ROWB = TN * 16 * ES, IN_CPR = IN_ROWB / 16, IN_PER = (16 * IN_CPR) / 64;  // chunks / lane / slab
     constexpr int NR = IN_PER > 0 ? IN_PER : 1;
+    // (the rolled full mode at 256 rows keeps the per-piece forms: with the plan's registers live across its loop that
+    // instantiation spills 10 VGPRs whose reloads land in the K loop)
+    constexpr bool PLAN16 = CAN16 && (MODE != EPI_FULL16 || TM <= 6);
+    OutPlan<TN * 32, 2> plan16;
+    unsigned go_r0 = 0;  // the plan's go0 with R's leading dimension
+    int wr0 = 0;         // staging offset of this lane's accumulator-layout 8 bytes of column tile 0; tile nt: ^ (nt << 5)
+    if (PLAN16 && (!f32out || Rb)) {
+      plan16.init(lane, p.ldc, n_base, p.N);
+      if (LOADS && Rb) go_r0 = (unsigned)(((unsigned)lane / plan16.CPR) * (unsigned)p.ldr + ((unsigned)lane % plan16.CPR) * 8u) * 2u;
+      wr0 = stage_off<TN * 32>(i16, g >> 1) + (g & 1) * 8;
+    }
+    auto wr16 = [&](int nt) { return PLAN16 ? (wr0 ^ (nt << 5)) : stage_off<TN * 32>(i16, 2 * nt + (g >> 1)) + (g & 1) * 8; };
     // R is fetched for HALF the slabs at a time (NB register sets), consumed, then fetched for the other half.
     // Finer-grained prefetching does not survive the compiler: with LDS-DMA pieces possibly in flight (the persistent
     // kernel's ring) hipcc puts a full vmcnt(0) in front of every use of an ordinary load, so any fetch issued
@@ -267,6 +279,17 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
     constexpr int NB = (MODE == EPI_GENERIC || ROLLED) ? (TM < 2 ? 1 : 2) : (RALL && MODE == EPI_PLAIN16 ? TM : (TM + 1) / 2);
     u32x4 rin[NB][NR];
     auto fetch_r = [&](long long mr, u32x4 (&dst)[NR]) {
+      if constexpr (ES == 2 && PLAN16) {  // same geometry as the bf16 output slab: the plan's rows and pieces
+        const int rows = mr < 0 ? 0 : (int)(p.M - mr < row_limit ? p.M - mr : row_limit);  // (wave-uniform)
+        const char* sb = Rb + (mr * p.ldr + n_base) * 2;
+        const long long rstep = p.ldr * (plan16.RPI * 2);
+#pragma clang loop unroll(full)
+        for (int j = 0; j < IN_PER; ++j) {
+          dst[j] = u32x4{0u, 0u, 0u, 0u};
+          if (plan16.lrow + plan16.RPI * j < rows) dst[j] = *(const u32x4*)(sb + j * rstep + go_r0);
+        }
+        return;
+      }
 #pragma clang loop unroll(full)
       for (int j = 0; j < IN_PER; ++j) {
         const int q = lane + 64 * j, row = q / IN_CPR, ch = q % IN_CPR;
@@ -276,8 +299,6 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
         if (mr >= 0 && row < row_limit && m < p.M && n < p.N) dst[j] = *(const u32x4*)(Rb + (m * p.ldr + n) * ES);
       }
     };
-    OutPlan<TN * 32, 2> plan16;
-    if (CAN16 && MODE != EPI_FULL16 && !f32out) plan16.init(lane, p.ldc, n_base, p.N);
     // all of a lane's pieces of the staged slab are read back first (ONE LDS round trip), then stored; `rmw` adds the old
     // contents of C (accumulate)
     auto flush = [&](auto& pl, char* Ob, const char* src, long long mr, auto rmw) {
@@ -308,12 +329,13 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
 #pragma clang loop unroll(full)
         for (int j = 0; j < IN_PER; ++j) {
           const int q = lane + 64 * j;
-          *(u32x4*)(stage + stage_off<IN_ROWB>(q / IN_CPR, q % IN_CPR)) = rin[SET][j];
+          if constexpr (ES == 2 && PLAN16) *(u32x4*)(stage + plan16.rd(j)) = rin[SET][j];
+          else *(u32x4*)(stage + stage_off<IN_ROWB>(q / IN_CPR, q % IN_CPR)) = rin[SET][j];
         }
 #pragma clang loop unroll(full)
         for (int nt = 0; nt < TN; ++nt) {
           if constexpr (ES == 4) r4[nt] = *(const f32x4*)(stage + stage_off<IN_ROWB>(i16, 4 * nt + g));
-          else r4[nt] = unpack(*(const u32x2*)(stage + stage_off<IN_ROWB>(i16, 2 * nt + (g >> 1)) + (g & 1) * 8));
+          else r4[nt] = unpack(*(const u32x2*)(stage + wr16(nt)));
         }
       }
       // MELGPT_ACT_GELU_DACT (forward of Linear -> GELU): activation and derivative come from ONE evaluation of the
@@ -332,7 +354,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
             f32x4 a, d;
             gelu_both4(av[nt] * p.alpha + bv[nt], a, d);
             if constexpr (MODE != EPI_DACT16) a = math(a, Rb ? r4[nt] : a, m, n_base + nt * 16 + g * 4, Rb != nullptr);
-            const int o = stage_off<ROWB>(i16, 2 * nt + (g >> 1)) + (g & 1) * 8;
+            const int o = wr16(nt);
             *(u32x2*)(stage + o) = u32x2{pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
             *(u32x2*)(st2 + o) = u32x2{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
           }
@@ -389,12 +411,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
 #pragma clang loop unroll(full)
             for (int nt = 0; nt < TN; ++nt) {
               const f32x4 v = value(pass, nt);
-              *(u32x2*)(stage + stage_off<ROWB>(i16, 2 * nt + (g >> 1)) + (g & 1) * 8) =
-                  u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+              *(u32x2*)(stage + wr16(nt)) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             }
-            if constexpr (MODE == EPI_FULL16) {
-              // (the rolled full mode keeps the per-piece form: with the plan's three registers live across its loop the
-              // 256-row instantiation spills 10 VGPRs whose reloads land in the K loop)
+            if constexpr (!PLAN16) {
               constexpr int CPR = ROWB / 16, PER = (16 * CPR) / 64;
 #pragma clang loop unroll(full)
               for (int j = 0; j < PER; ++j) {
