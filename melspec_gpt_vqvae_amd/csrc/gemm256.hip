@@ -693,6 +693,10 @@ int launch_lay(const GemmParams& p, int batch, hipStream_t s) {
       return MELGPT_ERR_UNSUPPORTED;
     }
     if (p.act == MELGPT_ACT_MUL && !plain) return MELGPT_ERR_UNSUPPORTED;
+    if constexpr (ALAY == LAY_ROW && BLAY == LAY_ROW) {  // Linear -> dropout -> + residual: its own lean mode
+      if (p.act == MELGPT_ACT_NONE && p.drop_scale != 0.f && p.R && !p.C2 && !p.accumulate && (p.N & 3) == 0)
+        return launch_mode<ALAY, BLAY, EPI_DROPR16>(p, batch, s);
+    }
     if (!plain) return launch_mode<ALAY, BLAY, EPI_FULL16>(p, batch, s);
     return loads ? launch_mode<ALAY, BLAY, EPI_PLAIN16>(p, batch, s) : launch_mode<ALAY, BLAY, EPI_PLAIN16N>(p, batch, s);
   }

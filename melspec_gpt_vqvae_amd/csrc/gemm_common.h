@@ -174,7 +174,13 @@ enum { EPI_GENERIC = 0, EPI_PLAIN16 = 1, EPI_PLAIN32 = 2, EPI_FULL16 = 3,
        // forward of Linear -> GELU alone (MELGPT_ACT_GELU_DACT, bias, bf16 outputs C = gelu(v), C2 = gelu'(v); no R, no
        // dropout, no accumulation): the full mode's dropout / residual machinery costs 16 spilled VGPRs at 256 rows, whose
        // reloads sit in the K loop and drain the LDS-DMA ring on every unit (fc1: 9.7 -> 17 ms per step)
-       EPI_DACT16 = 6 };
+       EPI_DACT16 = 6,
+       // Linear -> dropout -> + residual alone (the attention projection and the MLP's second Linear in training: bias,
+       // dropout, R, bf16 output; no activation, no second output, no accumulation): unrolled slabs over the per-tile
+       // plan, the element counter of the dropout mask from a wave-uniform 64-bit row part + one 32-bit lane part.  In
+       // the rolled full mode - every activation compiled in, accumulators copied out through a switch, 100+ scalar
+       // registers spilled to lanes - this epilogue was 4.2 k instructions and 28 k cycles per 192 x 256 tile.
+       EPI_DROPR16 = 7 };
 //   EPI_GENERIC  everything, decided at run time; slabs unrolled
 //   EPI_PLAIN16  alpha, bias, +R, accumulate; bf16 output; slabs unrolled (a few hundred instructions in all)
 //   EPI_PLAIN32  the same with f32 output (split-K weight gradients)
@@ -266,6 +272,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
       if (LOADS && Rb) go_r0 = (unsigned)(((unsigned)lane / plan16.CPR) * (unsigned)p.ldr + ((unsigned)lane % plan16.CPR) * 8u) * 2u;
       wr0 = stage_off<TN * 32>(i16, g >> 1) + (g & 1) * 8;
     }
+    const unsigned lq = MODE == EPI_DROPR16 ? (unsigned)i16 * (unsigned)(p.N >> 2) + (unsigned)(n_base >> 2) + (unsigned)g : 0u;
     auto wr16 = [&](int nt) { return PLAN16 ? (wr0 ^ (nt << 5)) : stage_off<TN * 32>(i16, 2 * nt + (g >> 1)) + (g & 1) * 8; };
     // R is fetched for HALF the slabs at a time (NB register sets), consumed, then fetched for the other half.
     // Finer-grained prefetching does not survive the compiler: with LDS-DMA pieces possibly in flight (the persistent
@@ -364,8 +371,16 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
         }
       }
       f32x4 actv[MODE == EPI_GENERIC ? TN : 1];
+      // (EPI_DROPR16) mask counter of the slab's row mr, lane part added per column tile; N % 4 == 0 (as math() assumes)
+      const unsigned long long sq = MODE == EPI_DROPR16 ? ((unsigned long long)bz * p.M + mr) * (unsigned long long)(p.N >> 2) : 0ull;
       auto value = [&](int pass, int nt) -> f32x4 {
         f32x4 v = av[nt] * p.alpha + bv[nt];
+        if constexpr (MODE == EPI_DROPR16) {  // (the launcher picks this mode only with dropout on and R present)
+          const unsigned keep = dropout_keep4(p.seed, p.stream_id, sq + (lq + 4u * nt), p.drop_thresh);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (keep >> e & 1) ? v[e] * p.drop_scale : 0.f;
+          return v + r4[nt];
+        }
         if constexpr (MODE == EPI_GENERIC) {
           if (dact) {
             if (pass == 0) {
@@ -432,7 +447,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
                   *dst = o;
                 }
               }
-            } else if (LOADS && pass == 1 && p.accumulate) {
+            } else if (LOADS && MODE != EPI_DROPR16 && pass == 1 && p.accumulate) {
               flush(plan16, Ob, stage, mr, [](u32x4& o, const u32x4* dst) {
                 const u32x4 c = *dst;
 #pragma unroll

@@ -64,7 +64,8 @@ static void trace(int alay, int blay, int M, int N, int K, int full = 0) {
     if (full == 5) { p.drop_scale = 2.f; p.drop_thresh = 32768; p.seed = 7; }
   }
   for (int rep = 0; rep < 2; ++rep) {
-    if (full && full < 10) launch_mode<LAY_ROW, LAY_ROW, EPI_FULL16>(p, 1, 0);
+    if (full == 2 && getenv("DROPR")) launch_mode<LAY_ROW, LAY_ROW, EPI_DROPR16>(p, 1, 0);  // the lean mode of the same epilogue
+    else if (full && full < 10) launch_mode<LAY_ROW, LAY_ROW, EPI_FULL16>(p, 1, 0);
     else launch_mode<LAY_ROW, LAY_ROW, EPI_PLAIN16>(p, 1, 0);
   }
   hipDeviceSynchronize();
@@ -86,6 +87,9 @@ int main(int argc, char** argv) {
     printf("fc1 FULL16 +R\n"); trace(LAY_ROW, LAY_ROW, 33920, 4096, 1024, 4);
     printf("fc1 FULL16 drop\n"); trace(LAY_ROW, LAY_ROW, 33920, 4096, 1024, 5);
     printf("fc1 PLAIN16 +R\n"); trace(LAY_ROW, LAY_ROW, 33920, 4096, 1024, 14);
+    printf("proj (N = K = 1024) drop+R, as the step runs it\n"); trace(LAY_ROW, LAY_ROW, 33920, 1024, 1024, 2);
+    printf("fc2 (N = 1024, K = 4096) drop+R, as the step runs it\n"); trace(LAY_ROW, LAY_ROW, 33920, 1024, 4096, 2);
+    printf("proj plain (N = K = 1024)\n"); trace(LAY_ROW, LAY_ROW, 33920, 1024, 1024);
     printf("sq8k\n"); trace(LAY_ROW, LAY_ROW, 8192, 8192, 8192);
     return 0;
   }
