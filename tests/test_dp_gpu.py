@@ -53,10 +53,12 @@ def test_two_ranks_share_one_gpu_gradients_equal_single_process(which, tmp_path)
         got = r["grad"] / world                                                        # the optimizer's grad_scale
         err = float((got - want).abs().max() / want.abs().max())
         assert err < 1e-6, err
-        assert abs(r["metrics"][0] - sum(x["loss"] for x in res) / world) < 1e-5
+        mean_loss = sum(x["loss"] for x in res) / world
+        assert abs(r["metrics"][0] - mean_loss) <= 2e-7 * max(1.0, abs(mean_loss))         # (the VAE loss is ~1.3e3: one f32 ulp is 1.2e-4)
         assert r["metrics"][1] == 0.5 and r["metrics"][2] == 3.0                      # mean of the ranks' values
     assert torch.equal(res[0]["grad"], res[1]["grad"])                                 # both ranks hold the same sum
-    assert abs(sum(x["loss"] for x in res) / world - float(loss)) < 1e-5
+    mean_loss = sum(x["loss"] for x in res) / world
+    assert abs(mean_loss - float(loss)) <= 1e-6 * max(1.0, abs(float(loss)))           # (two half batches against one full batch)
     for rnk in range(world):
         assert torch.load(os.path.join(str(tmp_path), f"rank{rnk}_guard.pt"))["refused"]
 
