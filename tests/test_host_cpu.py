@@ -179,3 +179,23 @@ def test_spawn_ranks_starts_one_process_per_rank_and_relays_rank0():
 def test_spawn_ranks_propagates_a_failing_rank_instead_of_hanging():
     r = _run_launcher(["--fail-rank", "1"])
     assert r.returncode == 7, (r.returncode, r.stderr)
+
+
+def test_c_abi_host_paths_under_address_sanitizer(tmp_path):
+    """SURVEY 5 (sanitizer builds of the native layer): tools/asan_host.sh compiles every csrc/*.hip with
+    -fsanitize=address for the HOST code (GPU ASan is refused on this pool), links a scratch library outside the tree and
+    runs tools/asan_host_driver.c over the entry points' host paths - switches, workspace queries, argument refusals -
+    without a GPU.  ~1.5 min of hipcc; MELGPT_SKIP_ASAN=1 skips it."""
+    import shutil
+    import subprocess
+
+    if os.environ.get("MELGPT_SKIP_ASAN") == "1":
+        pytest.skip("MELGPT_SKIP_ASAN=1")
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not found")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MELGPT_ASAN_DIR=str(tmp_path))
+    r = subprocess.run(["bash", os.path.join(root, "tools", "asan_host.sh"), "6"], env=env, capture_output=True, text=True,
+                       timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "asan host driver: ok" in r.stdout
