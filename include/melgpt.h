@@ -414,16 +414,39 @@ int melgpt_permute_nchw_nhwc(const void* x, int x_dtype, void* y, int y_dtype, i
                              int to_nhwc, void* stream);
 
 /* ===================================================================== MelGAN generator glue (vocoder/modules.py:24-79)
- * Conv1d / ConvTranspose1d layers run as per-tap batched melgpt_gemm launches on shifted row windows of a
- * channels-last (B, L, C) activation; these two kernels are the rest:
+ * Conv1d / ConvTranspose1d layers run as implicit GEMMs (melgpt_conv1d_nlc below) on a channels-last (B, L, C)
+ * activation; the padded copy + single-channel convolution pair serves the last layer (Cout = 1):
  * y (B, L + 2 pad, C) = act(pad(x (B, L, C))): reflect != 0 is nn.ReflectionPad1d (pad < L), else zero rows;
  * act = LeakyReLU(slope), slope = 1 for none.  C % (16 / sizeof(T)) == 0. */
 int melgpt_pad1d_act(const void* x, void* y, int B, int L, int C, int pad, int reflect, float slope, int dtype,
                      void* stream);
+/* One Conv1d (stride 1) or one output phase of a ConvTranspose1d of the generator as ONE implicit GEMM on a channels-last
+ * activation x (B, L, Cin) - no padded copy, no per-tap launches (vocoder/modules.py:23-79: WNConv1d / WNConvTranspose1d
+ * with their ReflectionPad1d / LeakyReLU neighbours):
+ *   y[b, l, :] = bias + sum_{t < KW} W_t f(x[b, l - pad_l + t * dilation, :])  (+ residual[b, l, :]) (+ y when accumulate)
+ * f = LeakyReLU(in_slope) applied to the input operand (in_slope = 0: none); positions outside [0, L) are reflected
+ * (reflect != 0: nn.ReflectionPad1d, at most one reflection) or read as zeros.  wpack (Cout, KW * Cin): the taps' (Cout, Cin)
+ * slices side by side along K.  y / residual rows of Cout elements with row strides ldy / ldr (a transposed
+ * convolution's phase s writes rows s, s + r, ... of its output: ldy = r * Cout).  Cin, Cout multiples of 16 bytes. */
+int melgpt_conv1d_nlc(const void* x, int B, int L, int Cin, const void* wpack, int Cout, int KW, int dilation,
+                      int pad_l, int reflect, float in_slope, const float* bias, const void* residual, long long ldr,
+                      int accumulate, void* y, long long ldy, int dtype, void* stream);
 /* y (B, L) f32 = [tanh]( bias + sum_{t<K, c<C} xp[b, l + t, c] * w[t*C + c] ): the generator's last Conv1d(ngf, 1, 7)
  * + nn.Tanh on an already padded xp (B, L + K - 1, C); w (K*C) f32 = weight[0].T flattened tap-major. */
 int melgpt_conv1d_out1(const void* xp, const float* w, const float* bias, float* y, int B, int L, int C, int K,
                        int do_tanh, int dtype, void* stream);
+/* The same output layer WITHOUT the padded copy, 16-bit lane: y (B, L) f32 = [tanh]( bias + conv_K( reflect_pad(
+ * LeakyReLU_slope( h (B, L, C) ) ) ) ), C in {32, 64}, odd K; otherwise MELGPT_ERR_UNSUPPORTED (use the pair above). */
+int melgpt_conv1d_out1_fused(const void* h, const float* w, const float* bias, float* y, int B, int L, int C, int K,
+                             float slope, int do_tanh, int dtype, void* stream);
+/* One ResnetBlock of a NARROW generator stage (vocoder/modules.py:48-64, dim = 32 or 64) in one pass over the
+ * activation: y (B, L, C) = shortcut(x) + conv1( LeakyReLU( conv3_dilated( ReflectionPad1d( LeakyReLU(x) ) ) ) ).
+ * wfrag: the three weight matrices as MFMA operand fragments in lane order - 5 (C/32) (C/16) fragments of 64 lanes x 16
+ * bytes: [3 (C/32)][C/16] conv3 (tap-major), [C/32][C/16] shortcut, [C/32][C/16] conv1 with the accumulator's channel
+ * order as its k-slots (csrc/vocoder.hip; vocoder/modules.py packs them).  b3 = conv3's bias, b1s = conv1's + the
+ * shortcut's.  16-bit lane, L % 16 == 0; otherwise MELGPT_ERR_UNSUPPORTED (run the three convolutions separately). */
+int melgpt_resblock_narrow(const void* x, void* y, const void* wfrag, const float* b3, const float* b1s, int B, int L,
+                           int C, int dilation, float slope, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -147,14 +147,32 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         off = (k0 * ES + ch * 16 < p.K * ES) ? a_base[i] + k0 * ES : OOB;
       } else if constexpr (ALAY == LAY_KMAJ) {
         off = (a_base[i] == OOB) ? OOB : a_base[i] + (unsigned)((long long)k0 * p.lda * ES);
-      } else {
+      } else if (p.cC % KSTEP == 0) {  // (wave-uniform) a K step = KSTEP channels of ONE tap
         const int tap = k0 / p.cC, ci0 = k0 - tap * p.cC;
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        int iy = cy[i] + ky, ix = cx[i] + kx;
+        int iy = cy[i] + ky, ix = cx[i] + kx + kx * p.cdil_m1;
+        if (p.creflect) {  // nn.ReflectionPad1d: -j -> j, W - 1 + j -> W - 1 - j
+          ix = ix < 0 ? -ix : ix;
+          ix = ix >= p.cW ? 2 * (p.cW - 1) - ix : ix;
+        }
         const bool ok = iy >= 0 && ix >= 0 && iy < (p.cH << p.ups) && ix < (p.cW << p.ups);
         iy >>= p.ups;
         ix >>= p.ups;
         off = ok ? a_base[i] + (unsigned)((iy * p.cW + ix) * p.cC + ci0) * ES : OOB;
+      } else {  // Cin = 32 / 80 (MelGAN): a lane's 16-byte chunk has its own tap; Cin % (16 / ES) == 0
+        const int chl = (t + 256 * i) & 7;
+        const int k = k0 + chl * (16 / ES);
+        const int tap = k / p.cC, ci = k - tap * p.cC;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        int iy = cy[i] + ky, ix = cx[i] + kx + kx * p.cdil_m1;
+        if (p.creflect) {
+          ix = ix < 0 ? -ix : ix;
+          ix = ix >= p.cW ? 2 * (p.cW - 1) - ix : ix;
+        }
+        const bool ok = k < p.K && iy >= 0 && ix >= 0 && iy < (p.cH << p.ups) && ix < (p.cW << p.ups);
+        iy >>= p.ups;
+        ix >>= p.ups;
+        off = ok ? a_base[i] - chl * 16 + (unsigned)((iy * p.cW + ix) * p.cC + ci) * ES : OOB;
       }
       ar[S][i] = buf_load16(ra, off);
     }
@@ -174,8 +192,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     constexpr int S = decltype(setc)::value;
     char* sa = smem + buf * 2 * TILE_BYTES;
     char* sb = sa + TILE_BYTES;
+    if (p.a_leaky != 0.f) {  // (wave-uniform) LeakyReLU on the A operand: max(x, slope x), 0 < slope < 1; padding zeros stay zeros
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(u32x4*)(sa + a_lds[i]) = ar[S][i];
+      for (int i = 0; i < 4; ++i) {
+        u32x4 v = ar[S][i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (ES == 4) {
+            const float x = __uint_as_float(v[e]);
+            v[e] = __float_as_uint(fmaxf(x, x * p.a_leaky));
+          } else {
+            const float lo = bf16lo(v[e]), hi = bf16hi(v[e]);
+            v[e] = pack_bf16x2(fmaxf(lo, lo * p.a_leaky), fmaxf(hi, hi * p.a_leaky));
+          }
+        }
+        *(u32x4*)(sa + a_lds[i]) = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *(u32x4*)(sa + a_lds[i]) = ar[S][i];
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) *(u32x4*)(sb + b_lds[i]) = br[S][i];
   };
@@ -409,4 +445,37 @@ extern "C" int melgpt_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, c
     if (st != MELGPT_ERR_UNSUPPORTED) return st;
   }
   return dispatch<bf16_t>(p, LAY_CONV, LAY_ROW, 1, s);
+}
+
+// MelGAN's Conv1d / ConvTranspose1d layers (vocoder/modules.py:23-79) as ONE implicit GEMM each on a channels-last
+// (B, L, Cin) activation: y[b, l, :] (row stride ldy) = bias + sum_{t < KW} W_t . f(x[b, l - pad_l + t dilation, :]) (+ residual)
+// (+ y when accumulate), f = LeakyReLU(in_slope) (in_slope = 0: none), positions outside [0, L): reflected
+// (nn.ReflectionPad1d) or zero.  wpack (Cout, KW * Cin), tap-major along K.  Generic 128 x 128 kernel (the operand passes
+// through registers on its way into LDS, where the activation is applied); Cin % (16 / es) == 0.
+extern "C" int melgpt_conv1d_nlc(const void* x, int B, int L, int Cin, const void* wpack, int Cout, int KW, int dilation,
+                                 int pad_l, int reflect, float in_slope, const float* bias, const void* residual,
+                                 long long ldr, int accumulate, void* y, long long ldy, int dtype, void* stream) {
+  MELGPT_CHECK(x && wpack && y && B > 0 && L > 0 && Cin > 0 && Cout > 0 && KW > 0 && dilation > 0, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(dtype == MELGPT_F32 || dtype == MELGPT_BF16, MELGPT_ERR_UNSUPPORTED);
+  const int es = dtype == MELGPT_F32 ? 4 : 2;
+  MELGPT_CHECK(Cin % (16 / es) == 0 && Cout % (16 / es) == 0 && in_slope >= 0.f && in_slope < 1.f, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK(!reflect || (pad_l < L && (KW - 1) * dilation - pad_l < L), MELGPT_ERR_UNSUPPORTED);  // one reflection only
+  MELGPT_CHECK((((uintptr_t)x | (uintptr_t)wpack | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)bias) & 15) == 0,
+               MELGPT_ERR_ALIGN);
+  MELGPT_CHECK((ldy * es) % 16 == 0 && (!residual || (ldr * es) % 16 == 0), MELGPT_ERR_ALIGN);
+  const long long in_bytes = (long long)B * L * Cin * es, M = (long long)B * L;
+  MELGPT_CHECK(in_bytes < 0xFFFFFF00LL && M < 0x7FFFFF00LL, MELGPT_ERR_UNSUPPORTED);
+  GemmParams p{};
+  p.A = x; p.B = wpack; p.C = y; p.bias = bias; p.R = residual;
+  p.M = (int)M; p.N = Cout; p.K = KW * Cin;
+  p.lda = Cin; p.ldb = p.K; p.ldc = ldy; p.ldr = ldr;
+  p.a_bytes = (unsigned)in_bytes;
+  p.b_bytes = (unsigned)((long long)Cout * p.K * es);
+  p.alpha = 1.0f;
+  p.accumulate = accumulate;
+  p.vec_io = 1;
+  p.cH = 1; p.cW = L; p.cC = Cin; p.OH = 1; p.OW = L; p.cstride = 1; p.pad_t = 0; p.pad_l = pad_l; p.ups = 0; p.KW = KW;
+  p.cdil_m1 = dilation - 1; p.creflect = reflect; p.a_leaky = in_slope;
+  hipStream_t s = (hipStream_t)stream;
+  return dtype == MELGPT_F32 ? dispatch<float>(p, LAY_CONV, LAY_ROW, 1, s) : dispatch<bf16_t>(p, LAY_CONV, LAY_ROW, 1, s);
 }

@@ -40,6 +40,11 @@ struct GemmParams {
   unsigned stream_id;
   // implicit-GEMM convolution (A = NHWC input)
   int cH, cW, cC, OH, OW, cstride, pad_t, pad_l, ups, KW;
+  // 1-D extensions of the same addressing (MelGAN, generic 128 x 128 kernel only): taps cdil_m1 + 1 apart along x,
+  // nn.ReflectionPad1d as an address reflection, LeakyReLU(a_leaky) applied to the A operand on its way into LDS
+  // (0 = off).  All zero for the 2-D convolutions.
+  int cdil_m1, creflect;
+  float a_leaky;
   // optional (persistent kernel, both operands K-major, f32 output: the weight-gradient GEMM): partial sums over K of the
   // rows of A - the bias gradient when A = dY - as (batch * ceil(N / 256)) rows of M floats, row stride ld_rowsum
   float* a_rowsum;

@@ -731,6 +731,49 @@ def pad1d_act(x, pad, *, reflect=True, slope=1.0):
     return y
 
 
+def conv1d_nlc(x, wcat, bias, taps, *, dilation=1, pad_l=0, reflect=False, in_slope=0.0, residual=None, out=None,
+               accumulate=False):
+    """x (B, L, Cin) contiguous, wcat (Cout, taps * Cin) tap-major -> (B, L, Cout): one implicit-GEMM launch
+    (melgpt_conv1d_nlc): y[l] = bias + sum_t W_t f(x[l - pad_l + t dilation]) (+ residual) (+ out when accumulate),
+    f = LeakyReLU(in_slope) (0: none), out-of-range positions reflected or zero.  `out` may be a row-strided view
+    (B, L, Cout) of a larger tensor - a transposed convolution's output phase - as long as its rows are uniformly spaced."""
+    B, L, Cin = x.shape
+    Cout = wcat.shape[0]
+    assert x.is_contiguous() and wcat.is_contiguous() and wcat.shape[1] == taps * Cin and wcat.dtype == x.dtype
+    if out is None:
+        out = torch.empty(B, L, Cout, dtype=x.dtype, device=x.device)
+    assert out.shape == (B, L, Cout) and out.stride(2) == 1 and out.stride(0) == L * out.stride(1) and out.dtype == x.dtype
+    ldr = 0
+    if residual is not None:
+        assert residual.shape == (B, L, Cout) and residual.stride(2) == 1 and residual.stride(0) == L * residual.stride(1)
+        ldr = residual.stride(1)
+    call("melgpt_conv1d_nlc", ptr(x), B, L, Cin, ptr(wcat), Cout, int(taps), int(dilation), int(pad_l), int(bool(reflect)),
+         float(in_slope), ptr(bias), ptr(residual), ldr, int(bool(accumulate)), ptr(out), out.stride(1), dtype_code(x.dtype),
+         stream())
+    return out
+
+
+def resblock_narrow(x, wfrag, b3, b1s, dilation, slope):
+    """x (B, L, C) 16-bit, C in {32, 64}, L % 16 == 0 -> y (B, L, C): one MelGAN ResnetBlock in one pass
+    (melgpt_resblock_narrow; wfrag / b3 / b1s as vocoder.modules packs them)."""
+    B, L, C = x.shape
+    assert x.is_contiguous() and wfrag.is_contiguous() and b3.dtype == torch.float32 and b1s.dtype == torch.float32
+    y = torch.empty_like(x)
+    call("melgpt_resblock_narrow", ptr(x), ptr(y), ptr(wfrag), ptr(b3), ptr(b1s), B, L, C, int(dilation), float(slope),
+         dtype_code(x.dtype), stream())
+    return y
+
+
+def conv1d_out1_fused(h, w, bias, K, slope, tanh=True):
+    """h (B, L, C) 16-bit, w (K*C,) f32 tap-major -> (B, L) f32 = [tanh](conv to one channel of reflect_pad(leaky(h)))."""
+    B, L, C = h.shape
+    assert h.is_contiguous() and w.dtype == torch.float32 and w.numel() == K * C and w.is_contiguous()
+    y = torch.empty(B, L, dtype=torch.float32, device=h.device)
+    call("melgpt_conv1d_out1_fused", ptr(h), ptr(w), ptr(bias), ptr(y), B, L, C, K, float(slope), int(tanh),
+         dtype_code(h.dtype), stream())
+    return y
+
+
 def conv1d_out1(xp, w, bias, L, K, tanh=True):
     """xp (B, L + K - 1, C) padded activation, w (K*C,) f32 -> (B, L) f32 = [tanh](conv to one channel)."""
     B, Lp, C = xp.shape

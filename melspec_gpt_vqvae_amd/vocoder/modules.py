@@ -46,22 +46,27 @@ def _effective_weight(m):
 
 
 class _TapCache:
-    """per-module cache of the per-tap (Cout, Cin) weight slices in the compute dtype"""
+    """per-module cache of the packed weight in the compute dtype: Conv1d -> (Cout, k * Cin), the taps' (Cout, Cin) slices
+    side by side; ConvTranspose1d (stride r, kernel 2r) -> one (Cout, 2 * Cin) matrix per output phase"""
 
     def __init__(self):
-        self.key, self.taps = None, None
+        self.key, self.packed = None, None
 
     def get(self, m, dtype, transposed):
         key = (m.weight_g._version, m.weight_v._version, m.weight_g.data_ptr(), dtype)
         if key != self.key:
             w = _effective_weight(m)                           # Conv1d: (Cout, Cin, k); ConvTranspose1d: (Cin, Cout, k)
-            k = w.shape[2]
-            taps = []
-            for t in range(k):
-                wt = w[:, :, t].t() if transposed else w[:, :, t]
-                taps.append(ops.cast(wt.contiguous(), dtype))
-            self.key, self.taps = key, taps
-        return self.taps
+            if not transposed:
+                packed = ops.cast(w.permute(0, 2, 1).reshape(w.shape[0], -1).contiguous(), dtype)
+            else:
+                r, p = m.stride[0], m.padding[0]
+                packed = []
+                for s in range(r):                             # output row q r + s = W[phi + r] x[q + c - 1] + W[phi] x[q + c]
+                    _, phi = divmod(s + p, r)
+                    wt = torch.cat([w[:, :, phi + r].t(), w[:, :, phi].t()], dim=1)
+                    packed.append(ops.cast(wt.contiguous(), dtype))
+            self.key, self.packed = key, packed
+        return self.packed
 
 
 def _cache(m):
@@ -73,39 +78,31 @@ def _cache(m):
 
 
 def _conv1d(h, m, *, pad, reflect=True, leaky=False, out=None, accumulate=False):
-    """h (B, L, Cin) channels-last -> (B, L, Cout): Conv1d `m` (stride 1) on the [LeakyReLU ->] padded input."""
-    B, L, Cin = h.shape
+    """h (B, L, Cin) channels-last -> (B, L, Cout): [LeakyReLU ->] [ReflectionPad1d(pad) ->] Conv1d `m` (stride 1) as ONE
+    implicit-GEMM launch: the padding is an address reflection, the activation is applied to the operand on its way into
+    LDS (no padded copy, no per-tap launches)."""
     k, d = m.kernel_size[0], m.dilation[0]
     assert m.stride[0] == 1 and pad * 2 == d * (k - 1), "'same' convolutions only"
-    if pad > 0 or leaky:
-        h = ops.pad1d_act(h, pad, reflect=reflect, slope=LEAK if leaky else 1.0)
-    taps = _cache(m).get(m, h.dtype, False)
-    Cout = taps[0].shape[0]
-    if out is None:
-        out = torch.empty(B, L, Cout, dtype=h.dtype, device=h.device)
-    for t in range(k):
-        a = h[:, t * d:t * d + L, :]
-        ops.gemm(a, taps[t], out=out, accumulate=accumulate or t > 0, bias=m.bias if t == 0 else None)
-    return out
+    wcat = _cache(m).get(m, h.dtype, False)
+    return ops.conv1d_nlc(h, wcat, m.bias, k, dilation=d, pad_l=pad, reflect=reflect and pad > 0,
+                          in_slope=LEAK if leaky else 0.0, out=out, accumulate=accumulate)
 
 
 def _conv_transpose1d(h, m):
     """LeakyReLU -> ConvTranspose1d(stride r, kernel 2r, padding r//2 + r%2, output_padding r%2): (B, L, Cin) -> (B, rL, Cout).
-    Output row o = q r + s takes x[q + c] W[:, :, phi] + x[q + c - 1] W[:, :, phi + r] with (c, phi) = divmod(s + p, r)."""
+    Output row o = q r + s takes x[q + c] W[:, :, phi] + x[q + c - 1] W[:, :, phi + r] with (c, phi) = divmod(s + p, r): one
+    two-tap implicit GEMM per output phase s, writing rows s, s + r, ... of the output (zero rows outside the input)."""
     B, L, Cin = h.shape
     r, k, p = m.stride[0], m.kernel_size[0], m.padding[0]
     assert k == 2 * r and p == r // 2 + r % 2 and m.output_padding[0] == r % 2 and m.dilation[0] == 1
-    x0 = ops.pad1d_act(h, 1, reflect=False, slope=LEAK)       # one zero row on each side
-    taps = _cache(m).get(m, h.dtype, True)
-    Cout = taps[0].shape[0]
+    packed = _cache(m).get(m, h.dtype, True)
+    Cout = packed[0].shape[0]
     Lout = (L - 1) * r - 2 * p + k + m.output_padding[0]
     assert Lout == r * L
     y = torch.empty(B, Lout, Cout, dtype=h.dtype, device=h.device)
     for s in range(r):
-        c, phi = divmod(s + p, r)
-        dst = y[:, s::r, :]
-        ops.gemm(x0[:, c + 1:c + 1 + L, :], taps[phi], out=dst, bias=m.bias)
-        ops.gemm(x0[:, c:c + L, :], taps[phi + r], out=dst, accumulate=True)
+        c, _ = divmod(s + p, r)
+        ops.conv1d_nlc(h, packed[s], m.bias, 2, pad_l=1 - c, reflect=False, in_slope=LEAK, out=y[:, s::r, :])
     return y
 
 
@@ -121,8 +118,47 @@ class ResnetBlock(nn.Module):
         )
         self.shortcut = WNConv1d(dim, dim, kernel_size=1)
 
+    def _fragments(self, dtype):
+        """the three weight matrices as MFMA operand fragments in lane order (csrc/vocoder.hip, resblock_narrow_kernel):
+        lane = 16 g + i holds, of fragment (k-step, channel tile nt), output channel 16 nt + i and the 8 k-slots of group g"""
+        conv3, conv1, sc = self.block[2], self.block[4], self.shortcut
+        key = tuple((m.weight_g._version, m.weight_v._version, m.weight_g.data_ptr()) for m in (conv3, conv1, sc)) + (dtype,)
+        c = getattr(self, "_melgpt_frags", None)
+        if c is None or c[0] != key:
+            w3, w1, ws = _effective_weight(conv3), _effective_weight(conv1)[:, :, 0], _effective_weight(sc)[:, :, 0]
+            C = w3.shape[0]
+            NT, KS = C // 16, C // 32
+            dev = w3.device
+            i = torch.arange(16, device=dev).view(1, 16, 1)
+            g = torch.arange(4, device=dev).view(4, 1, 1)
+            j = torch.arange(8, device=dev).view(1, 1, 8)
+            frags = []
+            for tap in range(3):
+                for ks in range(KS):
+                    for nt in range(NT):
+                        frags.append(w3[16 * nt + i, 32 * ks + 8 * g + j, tap])               # (4, 16, 8) = [g][i][j]
+            for ks in range(KS):
+                for nt in range(NT):
+                    frags.append(ws[16 * nt + i, 32 * ks + 8 * g + j])
+            # conv1 contracts over leaky(t1) as the MFMA left it: k-slot j of group g = channel 4 g + j of the pair's first
+            # 16-channel tile (j < 4) or 4 g + j - 4 of its second
+            ch = torch.where(j < 4, 4 * g + j, 16 + 4 * g + j - 4)
+            for p in range(KS):
+                for nt in range(NT):
+                    frags.append(w1[16 * nt + i, 32 * p + ch])
+            wfrag = ops.cast(torch.stack(frags).reshape(-1, 8).contiguous(), dtype)               # (F * 64, 8)
+            b3 = conv3.bias.detach().float().contiguous()
+            b1s = (conv1.bias.detach().float() + sc.bias.detach().float()).contiguous()
+            c = (key, wfrag, b3, b1s)
+            object.__setattr__(self, "_melgpt_frags", c)
+        return c[1], c[2], c[3]
+
     def _run(self, h):
         d = self.block[1].padding[0]
+        B, L, C = h.shape
+        if h.dtype != torch.float32 and C in (32, 64) and L % 16 == 0 and d < L:
+            wfrag, b3, b1s = self._fragments(h.dtype)      # narrow stages: the whole block in one pass, weights in registers
+            return ops.resblock_narrow(h, wfrag, b3, b1s, d, LEAK)
         t1 = _conv1d(h, self.block[2], pad=d, leaky=True)
         y = _conv1d(h, self.shortcut, pad=0)
         return _conv1d(t1, self.block[4], pad=0, leaky=True, out=y, accumulate=True)   # shortcut(x) + block(x)
@@ -195,9 +231,17 @@ class Generator(nn.Module):
             elif isinstance(m, nn.LeakyReLU) and isinstance(layers[i + 1], nn.ReflectionPad1d):
                 last = layers[i + 2]
                 assert isinstance(last, nn.Conv1d) and last.out_channels == 1 and isinstance(layers[i + 3], nn.Tanh)
-                hp = ops.pad1d_act(h, layers[i + 1].padding[0], reflect=True, slope=LEAK)
-                w = _effective_weight(last)[0].t().contiguous().reshape(-1)     # (k, Cin) tap-major, f32
-                y = ops.conv1d_out1(hp, w.float(), last.bias, h.shape[1], last.kernel_size[0], tanh=True)
+                key = (last.weight_g._version, last.weight_v._version, last.weight_g.data_ptr())
+                c = getattr(last, "_melgpt_w1", None)
+                if c is None or c[0] != key:
+                    c = (key, _effective_weight(last)[0].t().contiguous().reshape(-1).float())   # (k, Cin) tap-major, f32
+                    object.__setattr__(last, "_melgpt_w1", c)
+                w, k, pad = c[1], last.kernel_size[0], layers[i + 1].padding[0]
+                if h.dtype != torch.float32 and h.shape[2] in (32, 64) and pad == k // 2 and k % 2 == 1 and pad < h.shape[1]:
+                    y = ops.conv1d_out1_fused(h, w, last.bias, k, LEAK, tanh=True)        # no padded copy
+                else:
+                    hp = ops.pad1d_act(h, pad, reflect=True, slope=LEAK)
+                    y = ops.conv1d_out1(hp, w, last.bias, h.shape[1], k, tanh=True)
                 return y.view(y.shape[0], 1, y.shape[1])
             else:
                 raise RuntimeError(f"unexpected layer {type(m).__name__} at model[{i}]")
