@@ -63,3 +63,92 @@ def test_resnet_block_and_reflect_padding_pieces():
     y = ops.conv1d_out1(xp.to(DEV), w[0].t().contiguous().reshape(-1).to(DEV), b.to(DEV), L, 7)
     ref = torch.tanh(F.conv1d(xp.permute(0, 2, 1), w, b))[:, 0]
     assert rel_err(y.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,k,dil,reflect,slope", [(80, 64, 7, 1, True, 0.0), (32, 32, 3, 9, True, 0.2),
+                                                           (64, 64, 3, 3, True, 0.2), (128, 128, 3, 1, True, 0.2),
+                                                           (32, 48, 1, 1, False, 0.2), (64, 32, 2, 1, False, 0.2)])
+def test_conv1d_as_one_implicit_gemm_matches_torch(cin, cout, k, dil, reflect, slope):
+    """melgpt_conv1d_nlc, f32 lane, against F.conv1d on the explicitly activated + padded input: taps as K steps,
+    reflection as an address predicate, LeakyReLU on the operand, Cin not a multiple of the K step (a lane's chunk carries
+    its own tap), accumulate and a row-strided output (vocoder/modules.py:23-79)."""
+    import torch.nn.functional as F
+
+    from melspec_gpt_vqvae_amd import ops
+
+    B, L = 2, 40
+    x = t(synth.normal(11, (B, L, cin), 1.0))
+    w = t(synth.normal(12, (cout, cin, k), 0.1))
+    b = t(synth.normal(13, (cout,), 0.1))
+    pad = dil * (k - 1) // 2 if k % 2 else 1
+    xa = F.leaky_relu(x, slope) if slope else x
+    xc = xa.permute(0, 2, 1)
+    right = dil * (k - 1) - pad
+    xp = F.pad(xc, (pad, right), mode="reflect") if reflect else F.pad(xc, (pad, right))
+    ref = F.conv1d(xp, w, b, dilation=dil).permute(0, 2, 1)                       # (B, L, cout)
+    wcat = w.permute(0, 2, 1).reshape(cout, -1).contiguous().to(DEV)
+    y = ops.conv1d_nlc(x.to(DEV), wcat, b.to(DEV), k, dilation=dil, pad_l=pad, reflect=reflect, in_slope=slope)
+    assert rel_err(y.cpu().numpy(), ref.numpy()) < 1e-5
+    # accumulate into every second row of a wider buffer (a transposed convolution's output phase)
+    big = t(synth.normal(14, (B, 2 * L, cout), 1.0)).to(DEV)
+    keep = big.clone()
+    ops.conv1d_nlc(x.to(DEV), wcat, b.to(DEV), k, dilation=dil, pad_l=pad, reflect=reflect, in_slope=slope, out=big[:, 1::2, :],
+                   accumulate=True)
+    assert torch.equal(big[:, 0::2, :], keep[:, 0::2, :])
+    assert rel_err((big[:, 1::2, :] - keep[:, 1::2, :]).cpu().numpy(), ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("r,cin,cout", [(8, 64, 32), (2, 32, 16)])
+def test_conv_transpose_phases_match_torch(r, cin, cout):
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    from melspec_gpt_vqvae_amd.vocoder import modules as vm
+
+    torch.manual_seed(3)
+    m = vm.WNConvTranspose1d(cin, cout, kernel_size=2 * r, stride=r, padding=r // 2 + r % 2, output_padding=r % 2).to(DEV)
+    x = torch.randn(2, 24, cin, device=DEV)
+    y = vm._conv_transpose1d(x, m)                                               # LeakyReLU -> ConvTranspose1d, channels-last
+    ref = m(F.leaky_relu(x, 0.2).permute(0, 2, 1)).permute(0, 2, 1)
+    assert y.shape == ref.shape and rel_err(y.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("C,dil,L", [(32, 1, 64), (32, 9, 48), (64, 3, 64), (64, 9, 32)])
+def test_narrow_resnet_block_in_one_pass_equals_the_three_convolutions(C, dil, L):
+    """resblock_narrow_kernel (weights as register fragments, t1 never stored) against the same block run as three
+    implicit GEMMs on the 16-bit lane: same operands, t1 rounded to the 16-bit format in both; and against torch in f32."""
+    import torch.nn.functional as F
+
+    from melspec_gpt_vqvae_amd import _ffi, ops
+    from melspec_gpt_vqvae_amd.vocoder import modules as vm
+
+    torch.manual_seed(C + dil)
+    blk = vm.ResnetBlock(C, dilation=dil).to(DEV).eval()
+    x = torch.randn(3, L, C, device=DEV)                                         # three clips: reflections at every clip end
+    xh = x.to(_ffi.HALF_DTYPE)
+    y1 = blk._run(xh)                                                           # one pass (C in {32, 64}, L % 16 == 0)
+    d = blk.block[1].padding[0]
+    t1 = vm._conv1d(xh, blk.block[2], pad=d, leaky=True)
+    y3 = vm._conv1d(xh, blk.shortcut, pad=0)
+    y3 = vm._conv1d(t1, blk.block[4], pad=0, leaky=True, out=y3, accumulate=True)
+    ref = (blk.shortcut(xh.float().permute(0, 2, 1)) + blk.block(xh.float().permute(0, 2, 1))).permute(0, 2, 1)
+    e13 = rel_err(y1.float().cpu().numpy(), y3.float().cpu().numpy())
+    e1r = rel_err(y1.float().cpu().numpy(), ref.detach().cpu().numpy())
+    report("melgan_resblock_one_pass", C=C, dilation=dil, vs_three_convs=e13, vs_torch_f32=e1r)
+    assert e13 < 1.5e-2 and e1r < 1.5e-2
+
+
+def test_output_layer_in_one_pass_matches_torch():
+    import torch.nn.functional as F
+
+    from melspec_gpt_vqvae_amd import _ffi, ops
+
+    for C in (32, 64):
+        B, L, K = 2, 300, 7
+        h = t(synth.normal(21, (B, L, C), 1.0)).to(DEV).to(_ffi.HALF_DTYPE)
+        w = t(synth.normal(22, (1, C, K), 0.1))
+        b = t(synth.normal(23, (1,), 0.1))
+        y = ops.conv1d_out1_fused(h, w[0].t().contiguous().reshape(-1).to(DEV), b.to(DEV), K, 0.2)
+        xa = F.leaky_relu(h.float().cpu(), 0.2).to(_ffi.HALF_DTYPE).float()      # the kernel rounds the activation to 16 bits
+        ref = torch.tanh(F.conv1d(F.pad(xa.permute(0, 2, 1), (3, 3), mode="reflect"), w, b))[:, 0]
+        assert rel_err(y.cpu().numpy(), ref.numpy()) < 1e-5
