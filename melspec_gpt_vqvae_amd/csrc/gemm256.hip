@@ -651,9 +651,15 @@ int launch_mode(const GemmParams& p, int batch, hipStream_t s) {
   if (ncu <= 0) return MELGPT_ERR_LAUNCH;
   if (ncu - melgpt_get_reserved_cus() >= 8) ncu -= melgpt_get_reserved_cus();  // CUs left to concurrent RCCL kernels
   if constexpr (ALAY != LAY_KMAJ) {
+    // cost of a launch = tile rounds x cycles of one tile.  A 192-row tile is NOT 3/4 of a 256-row one: its K unit takes
+    // 2.9 k cycles against 3.45 k (the B half-unit is staged for fewer rows) and its epilogue 6.3 k against 8 k, + ~2 k of
+    // drain and tile switch either way (s_memtime stamps, profiles/r03_gemm_lab.md).  Counting rounds x rows - the first
+    // model - put the qkv projection (N = 3072: 9 rounds of 192 rows against 7 of 256) on the wrong side: 5.10 -> 4.72 ms
+    // per step with 256 rows.
+    const long long nu = (p.K + KU - 1) / KU;
     auto cost = [&](int bm, int tm) {
       const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + 255) / 256) * batch;
-      return ((tiles + ncu - 1) / ncu) * tm;
+      return ((tiles + ncu - 1) / ncu) * (tm == 6 ? nu * 290 + 830 : nu * 345 + 1000);
     };
     static int forced = -1;  // MELGPT_GEMM_TM=6|8 pins the tile height (tests cover both)
     if (forced < 0) {
