@@ -194,6 +194,8 @@ def test_c_abi_host_paths_under_address_sanitizer(tmp_path):
     if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
         pytest.skip("hipcc not found")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "tools", "asan_host.sh")):
+        pytest.skip("tools/asan_host.sh is not shipped to the GPU box (.gpurunignore: sanitizer builds are refused there)")
     env = dict(os.environ, MELGPT_ASAN_DIR=str(tmp_path))
     r = subprocess.run(["bash", os.path.join(root, "tools", "asan_host.sh"), "6"], env=env, capture_output=True, text=True,
                        timeout=1500)
