@@ -147,32 +147,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         off = (k0 * ES + ch * 16 < p.K * ES) ? a_base[i] + k0 * ES : OOB;
       } else if constexpr (ALAY == LAY_KMAJ) {
         off = (a_base[i] == OOB) ? OOB : a_base[i] + (unsigned)((long long)k0 * p.lda * ES);
-      } else if (p.cC % KSTEP == 0) {  // (wave-uniform) a K step = KSTEP channels of ONE tap
+      } else if constexpr (ALAY == LAY_CONV) {
         const int tap = k0 / p.cC, ci0 = k0 - tap * p.cC;
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        int iy = cy[i] + ky, ix = cx[i] + kx + kx * p.cdil_m1;
-        if (p.creflect) {  // nn.ReflectionPad1d: -j -> j, W - 1 + j -> W - 1 - j
-          ix = ix < 0 ? -ix : ix;
-          ix = ix >= p.cW ? 2 * (p.cW - 1) - ix : ix;
-        }
+        int iy = cy[i] + ky, ix = cx[i] + kx;
         const bool ok = iy >= 0 && ix >= 0 && iy < (p.cH << p.ups) && ix < (p.cW << p.ups);
         iy >>= p.ups;
         ix >>= p.ups;
         off = ok ? a_base[i] + (unsigned)((iy * p.cW + ix) * p.cC + ci0) * ES : OOB;
-      } else {  // Cin = 32 / 80 (MelGAN): a lane's 16-byte chunk has its own tap; Cin % (16 / ES) == 0
+      } else {  // LAY_CONV1D (MelGAN): one row (H = 1), taps cdil_m1 + 1 apart, reflection or zeros outside [0, W);
+                // Cin need not be a multiple of the K step: a lane's 16-byte chunk carries its own tap (Cin % (16 / ES) == 0)
         const int chl = (t + 256 * i) & 7;
         const int k = k0 + chl * (16 / ES);
         const int tap = k / p.cC, ci = k - tap * p.cC;
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        int iy = cy[i] + ky, ix = cx[i] + kx + kx * p.cdil_m1;
-        if (p.creflect) {
+        int ix = cx[i] + tap + tap * p.cdil_m1;
+        if (p.creflect) {  // nn.ReflectionPad1d: -j -> j, W - 1 + j -> W - 1 - j
           ix = ix < 0 ? -ix : ix;
           ix = ix >= p.cW ? 2 * (p.cW - 1) - ix : ix;
         }
-        const bool ok = k < p.K && iy >= 0 && ix >= 0 && iy < (p.cH << p.ups) && ix < (p.cW << p.ups);
-        iy >>= p.ups;
-        ix >>= p.ups;
-        off = ok ? a_base[i] - chl * 16 + (unsigned)((iy * p.cW + ix) * p.cC + ci) * ES : OOB;
+        const bool ok = k < p.K && cy[i] == 0 && ix >= 0 && ix < p.cW;
+        off = ok ? a_base[i] - chl * 16 + (unsigned)(ix * p.cC + ci) * ES : OOB;
       }
       ar[S][i] = buf_load16(ra, off);
     }
@@ -192,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     constexpr int S = decltype(setc)::value;
     char* sa = smem + buf * 2 * TILE_BYTES;
     char* sb = sa + TILE_BYTES;
-    if (p.a_leaky != 0.f) {  // (wave-uniform) LeakyReLU on the A operand: max(x, slope x), 0 < slope < 1; padding zeros stay zeros
+    if (ALAY == LAY_CONV1D && p.a_leaky != 0.f) {  // (wave-uniform) LeakyReLU on the A operand: max(x, slope x), 0 < slope < 1; padding zeros stay zeros
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         u32x4 v = ar[S][i];
@@ -244,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   const int nk = (p.K + KSTEP - 1) / KSTEP;
   // depth-2 prefetch only where the extra 32 staging VGPRs do not spill (measured on MI355X, profiles/: K-contiguous
   // bf16 operands +8..14 %; the transposed-read variants need the registers for their fragment addressing)
-  constexpr bool DEEP = ES == 2 && ALAY != LAY_KMAJ && BLAY != LAY_KMAJ;
+  constexpr bool DEEP = ES == 2 && ALAY != LAY_KMAJ && ALAY != LAY_CONV1D && BLAY != LAY_KMAJ;  // (the 1-D convolution's per-lane taps + activation spill 60 VGPRs with it)
   if constexpr (DEEP) {
     issue(0, S0{});
     commit(0, S0{});
@@ -301,6 +295,7 @@ int dispatch(const GemmParams& p, int alay, int blay, int batch, hipStream_t s) 
   if (alay == LAY_KMAJ && blay == LAY_KMAJ) return launch<T, LAY_KMAJ, LAY_KMAJ>(p, batch, s);
   if (alay == LAY_KMAJ && blay == LAY_ROW) return launch<T, LAY_KMAJ, LAY_ROW>(p, batch, s);
   if (alay == LAY_CONV && blay == LAY_ROW) return launch<T, LAY_CONV, LAY_ROW>(p, batch, s);
+  if (alay == LAY_CONV1D && blay == LAY_ROW) return launch<T, LAY_CONV1D, LAY_ROW>(p, batch, s);
   return MELGPT_ERR_UNSUPPORTED;
 }
 
@@ -477,5 +472,5 @@ extern "C" int melgpt_conv1d_nlc(const void* x, int B, int L, int Cin, const voi
   p.cH = 1; p.cW = L; p.cC = Cin; p.OH = 1; p.OW = L; p.cstride = 1; p.pad_t = 0; p.pad_l = pad_l; p.ups = 0; p.KW = KW;
   p.cdil_m1 = dilation - 1; p.creflect = reflect; p.a_leaky = in_slope;
   hipStream_t s = (hipStream_t)stream;
-  return dtype == MELGPT_F32 ? dispatch<float>(p, LAY_CONV, LAY_ROW, 1, s) : dispatch<bf16_t>(p, LAY_CONV, LAY_ROW, 1, s);
+  return dtype == MELGPT_F32 ? dispatch<float>(p, LAY_CONV1D, LAY_ROW, 1, s) : dispatch<bf16_t>(p, LAY_CONV1D, LAY_ROW, 1, s);
 }

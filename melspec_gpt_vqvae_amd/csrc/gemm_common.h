@@ -8,7 +8,9 @@
 
 namespace gemmk {
 
-enum { LAY_ROW = 0, LAY_KMAJ = 1, LAY_CONV = 2 };
+enum { LAY_ROW = 0, LAY_KMAJ = 1, LAY_CONV = 2,
+       LAY_CONV1D = 3 };  // generic 128 x 128 kernel only: LAY_CONV + dilation / reflection / per-chunk taps / LeakyReLU on the operand
+                          // (an instantiation of its own: compiled into the 2-D kernels these options cost 15-20 spilled VGPRs)
 
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant expression
 template <int... I, class F>
