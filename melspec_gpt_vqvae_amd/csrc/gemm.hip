@@ -315,6 +315,11 @@ int pick_tile(const GemmParams& p, int batch) {
   const long long tiles256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch;
   const double fill = (double)p.M * p.N / ((double)((p.M + 191) / 192) * 192.0 * ((p.N + 255) / 256) * 256.0);
   if (tiles256 >= 192 && fill >= 0.8 && p.K >= 256) return 3;
+  // Fewer tiles than CUs but a LONG K loop (the VQ-VAE's 5 x 53 / 512-channel layers at 64 clips: M = 16 960, N = 512,
+  // K = 4 608 -> 178 tiles of 192 x 256): one partial round of the persistent kernel (72 K units x 2.9 k cycles = 92 us)
+  // still beats this kernel's 532 workgroups at 263 TFLOP/s (304 us per layer, 16 % of the decoder at batch 64).
+  const long long tiles192 = (long long)((p.M + 191) / 192) * ((p.N + 255) / 256) * batch;
+  if (tiles192 >= 96 && fill >= 0.8 && p.K >= 1024) return 3;
   return 1;
 }
 
