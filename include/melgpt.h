@@ -214,7 +214,8 @@ int melgpt_attn_fwd(const void* q, const void* k, const void* v, long long ld, v
 
 /* one KV-cached decoding step (replaces the full re-forward per sampled token of minGPT.py:293-360 /
  * decoders.py:89-123): qkv = the new token's packed projection rows (B, 3C) [key|query|value], row stride ld.
- * Appends its key / value at position `pos` of the (B, Tmax, C) caches and writes
+ * Appends its key / value at position `pos` of the caches (B * Tmax * C elements each, owned by this entry point: laid out
+ * head-major, (B, H, Tmax, 64), so that a (batch, head)'s rows are contiguous; callers only allocate them) and writes
  * out (B, C) = softmax(q . K[0..pos] / sqrt(hs)) @ V[0..pos], heads merged.  att_row: optional (B, H, Tmax) f32
  * probabilities of this row (entries > pos untouched).  head_size 64, Tmax <= 320, eval mode (no dropout).
  * pos_dev: optional device int; when given the position is read from it (one captured HIP graph then serves every

@@ -21,7 +21,7 @@ __device__ __forceinline__ void stf(T* p, float v) {
   else *p = v;
 }
 
-// qkv: (B, 3C) rows [key | query | value] of the new token (row stride ld); caches: (B, Tmax, C)
+// qkv: (B, 3C) rows [key | query | value] of the new token (row stride ld); caches: B * Tmax * C elements, head-major
 // One 256-thread workgroup per (batch, head).  A step is latency-bound (<= 2 x 320 cache rows of 128 / 256 bytes), so
 // every load of a phase is independent and in flight at once:
 //   scores: thread t owns key position t (and t + 256): its whole K row = ROWCH 16-byte loads, dotted with q from LDS;
@@ -46,8 +46,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
   __shared__ float s_new_sh;
   __shared__ float osum[4][HS];
   const T* row = qkv + (long long)b * ld;
-  T* kb = kc + ((long long)b * Tmax) * C + h * HS;
-  T* vb = vc + ((long long)b * Tmax) * C + h * HS;
+  // caches are HEAD-MAJOR, (B, H, Tmax, 64): the rows a workgroup reads are one contiguous run of 128-byte lines (as
+  // (B, Tmax, C) every row was 2 KB from the next and the step read its cache at 2.9 TB/s)
+  T* kb = kc + (((long long)b * gridDim.x + h) * Tmax) * HS;
+  T* vb = vc + (((long long)b * gridDim.x + h) * Tmax) * HS;
   const int len = pos + 1;
   // the cache rows this thread will need do not depend on the new token: request them first.  BOTH caches are read the
   // same way: thread = (position group g, 16-byte chunk c of the head dimension), rows g + G i - the ROWCH lanes of a
@@ -59,19 +61,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
     const int t = min(g + G * i, max(pos - 1, 0));  // clamped to rows that exist (their scores are masked below)
-    kr[i] = *(const u32x4*)(kb + (long long)t * C + cch * VEC);
+    kr[i] = *(const u32x4*)(kb + (long long)t * HS + cch * VEC);
   }
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
     const int t = min(g + G * i, max(pos - 1, 0));  // weight 0 beyond the end
-    vr[i] = *(const u32x4*)(vb + (long long)t * C + cch * VEC);
+    vr[i] = *(const u32x4*)(vb + (long long)t * HS + cch * VEC);
   }
   // append this token's key / value (wave 0: lane = head dimension); q and v stay in LDS, the newest key's score comes
   // from registers - nobody reads the freshly stored rows back
   if (wave == 0) {
     const float kn = ldf(row + h * HS + lane), qn = ldf(row + C + h * HS + lane), vn = ldf(row + 2 * C + h * HS + lane);
-    stf(kb + (long long)pos * C + lane, kn);
-    stf(vb + (long long)pos * C + lane, vn);
+    stf(kb + (long long)pos * HS + lane, kn);
+    stf(vb + (long long)pos * HS + lane, vn);
     qs[lane] = qn;
     // what the cache row holds is the ROUNDED value (bf16 lane): use the same for this step
     if constexpr (sizeof(T) == 2) {
