@@ -440,12 +440,13 @@ int melgpt_conv1d_out1(const void* xp, const float* w, const float* bias, float*
  * LeakyReLU_slope( h (B, L, C) ) ) ) ), C in {32, 64}, odd K; otherwise MELGPT_ERR_UNSUPPORTED (use the pair above). */
 int melgpt_conv1d_out1_fused(const void* h, const float* w, const float* bias, float* y, int B, int L, int C, int K,
                              float slope, int do_tanh, int dtype, void* stream);
-/* One ResnetBlock of a NARROW generator stage (vocoder/modules.py:48-64, dim = 32 or 64) in one pass over the
+/* One ResnetBlock of a generator stage of dim 32, 64 or 128 (vocoder/modules.py:48-64) in one pass over the
  * activation: y (B, L, C) = shortcut(x) + conv1( LeakyReLU( conv3_dilated( ReflectionPad1d( LeakyReLU(x) ) ) ) ).
  * wfrag: the three weight matrices as MFMA operand fragments in lane order - 5 (C/32) (C/16) fragments of 64 lanes x 16
  * bytes: [3 (C/32)][C/16] conv3 (tap-major), [C/32][C/16] shortcut, [C/32][C/16] conv1 with the accumulator's channel
  * order as its k-slots (csrc/vocoder.hip; vocoder/modules.py packs them).  b3 = conv3's bias, b1s = conv1's + the
- * shortcut's.  16-bit lane, L % 16 == 0; otherwise MELGPT_ERR_UNSUPPORTED (run the three convolutions separately). */
+ * shortcut's.  16-bit lane, L % 16 == 0.  C = 128 (L % 64 == 0) runs the same block with the 160 fragments filling the
+ * LDS instead of registers.  Otherwise MELGPT_ERR_UNSUPPORTED (run the three convolutions separately). */
 int melgpt_resblock_narrow(const void* x, void* y, const void* wfrag, const float* b3, const float* b1s, int B, int L,
                            int C, int dilation, float slope, int dtype, void* stream);
 

@@ -247,6 +247,130 @@ __global__ __launch_bounds__(256) void resblock_narrow_kernel(const bf16_t* __re
   }
 }
 
+// The same block at dim = 128 (the generator's second stage): its 160 weight fragments are 160 KiB - EXACTLY the LDS, and
+// the kernel needs no other byte of it (operands come straight from global memory, t1 stays in registers).  One
+// 256-thread workgroup per CU holds them for the whole launch; a wave owns 64 positions at a time (four 16-row tiles), so
+// that every weight fragment it reads from LDS feeds four MFMAs: 160 KiB of fragment reads per 64 rows per wave is
+// 20 LDS cycles per row per CU against 40 of MFMA issue and 26 of HBM time - matrix-pipe-bound where the three separate
+// implicit GEMMs were per-workgroup-latency-bound (380 us per block at 8 clips; 222 MB in and out).  t1 (128 registers) is
+// packed into operand fragments (64) before the output accumulators (128) take its place.
+__global__ __launch_bounds__(256) void resblock128_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                          const u32x4* __restrict__ wfrag, const float* __restrict__ b3,
+                                                          const float* __restrict__ b1s, int L, int dil, long long ntiles,
+                                                          float slope) {
+  typedef bf16_t T;
+  constexpr int C = 128, NT = 8, KS = 4, RT = 4, NF = 5 * KS * NT;  // 160 fragments of 1 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4;
+  for (int f = threadIdx.x; f < NF * 64; f += 256) *(u32x4*)(smem + (size_t)f * 16) = wfrag[f];
+  __syncthreads();
+  auto wld = [&](int f) { return *(const u32x4*)(smem + (size_t)f * 1024 + lane * 16); };
+  auto leaky_frag = [&](u32x4 v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = half_lo(v[e]), hi = half_hi(v[e]);
+      v[e] = pack_bf16x2(fmaxf(lo, lo * slope), fmaxf(hi, hi * slope));
+    }
+    return v;
+  };
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+  for (long long tile = wave; tile < ntiles; tile += nwaves) {  // 64 rows; L % 64 == 0: never across two clips
+    const long long row0 = tile * 64;
+    const long long clip0 = row0 / L * L;
+    const int l = (int)(row0 - clip0) + i16;
+    // ---- phase A: t1 = conv3(reflect_pad(leaky(x))) for the 64 rows (128 accumulator registers)
+    f32x4 t1[RT][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {  // (biases re-read per tile - L1 hits - instead of registers held for the launch)
+      const f32x4 c3 = *(const f32x4*)(b3 + 16 * nt + 4 * g);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) t1[rt][nt] = c3;
+    }
+#pragma unroll 1
+    for (int tap = 0; tap < 3; ++tap) {  // (rolled: unrolled, the scheduler hoists weight reads until 600 registers spill)
+      const T* src[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        int r = l + 16 * rt + (tap - 1) * dil;
+        r = r < 0 ? -r : r;
+        r = r >= L ? 2 * (L - 1) - r : r;
+        src[rt] = x + (clip0 + r) * C + 8 * g;
+      }
+#pragma unroll 1
+      for (int ks = 0; ks < KS; ++ks) {
+        u32x4 xl[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) xl[rt] = *(const u32x4*)(src[rt] + 32 * ks);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) xl[rt] = leaky_frag(xl[rt]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const u32x4 w = wld((tap * KS + ks) * NT + nt);
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) mma<T>(t1[rt][nt], w, xl[rt]);
+        }
+      }
+    }
+    // ---- phase B: leaky(t1) as operand fragments (channels 32 p .. 32 p + 31: see resblock_narrow_kernel); t1 is dead
+    // after this - the output accumulators take its registers (two 128-register sets at once spilled 100)
+    u32x4 pf[KS][RT];
+#pragma unroll
+    for (int p = 0; p < KS; ++p)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        f32x4 lo = t1[rt][2 * p], hi = t1[rt][2 * p + 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          lo[e] = fmaxf(lo[e], lo[e] * slope);
+          hi[e] = fmaxf(hi[e], hi[e] * slope);
+        }
+        pf[p][rt] = u32x4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase C: y = shortcut(x) (raw centre rows, re-read: L1 / L2 hits) + conv1(leaky(t1)) + biases
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const f32x4 c1 = *(const f32x4*)(b1s + 16 * nt + 4 * g);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt][nt] = c1;
+    }
+    {
+      const T* src0 = x + (row0 + i16) * C + 8 * g;
+#pragma unroll 1
+      for (int ks = 0; ks < KS; ++ks) {
+        u32x4 xr[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) xr[rt] = *(const u32x4*)(src0 + (long long)16 * rt * C + 32 * ks);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const u32x4 w = wld((3 * KS + ks) * NT + nt);
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) mma<T>(acc[rt][nt], w, xr[rt]);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < KS; ++p) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const u32x4 w = wld((4 * KS + p) * NT + nt);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) mma<T>(acc[rt][nt], w, pf[p][rt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // (one channel group at a time: hoisted weight reads end in scratch)
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      __builtin_amdgcn_sched_barrier(0);
+      T* dst = y + (row0 + 16 * rt + i16) * C + 4 * g;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        *(u32x2*)(dst + 16 * nt) = u32x2{pack_bf16x2(acc[rt][nt][0], acc[rt][nt][1]), pack_bf16x2(acc[rt][nt][2], acc[rt][nt][3])};
+    }
+  }
+}
+
 }  // namespace
 
 // One ResnetBlock of a narrow MelGAN stage: y (B, L, C) = shortcut(x) + conv1(leaky(conv3_dil(reflect_pad(leaky(x))))).
@@ -256,12 +380,26 @@ __global__ __launch_bounds__(256) void resblock_narrow_kernel(const bf16_t* __re
 extern "C" int melgpt_resblock_narrow(const void* x, void* y, const void* wfrag, const float* b3, const float* b1s, int B,
                                       int L, int C, int dilation, float slope, int dtype, void* stream) {
   MELGPT_CHECK(x && y && wfrag && b3 && b1s && B > 0 && L > 0 && dilation > 0, MELGPT_ERR_BAD_ARG);
-  MELGPT_CHECK(dtype == MELGPT_BF16 && (C == 32 || C == 64) && L % 16 == 0 && dilation < L && slope > 0.f && slope <= 1.f,
+  MELGPT_CHECK(dtype == MELGPT_BF16 && (C == 32 || C == 64 || C == 128) && L % (C == 128 ? 64 : 16) == 0 && dilation < L &&
+                   slope > 0.f && slope <= 1.f,
                MELGPT_ERR_UNSUPPORTED);
   MELGPT_CHECK((((uintptr_t)x | (uintptr_t)y | (uintptr_t)wfrag | (uintptr_t)b3 | (uintptr_t)b1s) & 15) == 0, MELGPT_ERR_ALIGN);
   const long long ntiles = (long long)B * L / 16;
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (C == 128) {  // weights in LDS (all of it), one workgroup per CU, 64-row wave tiles
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute((const void*)resblock128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return MELGPT_ERR_LAUNCH;
+      attr = true;
+    }
+    const long long nt64 = ntiles / 4, want128 = (nt64 + 3) / 4;
+    const unsigned grid128 = (unsigned)(want128 < ncu ? want128 : ncu);
+    hipLaunchKernelGGL(resblock128_kernel, dim3(grid128), dim3(256), 160 * 1024, (hipStream_t)stream, (const bf16_t*)x,
+                       (bf16_t*)y, (const u32x4*)wfrag, b3, b1s, L, dilation, nt64, slope);
+    return melgpt_launch_status();
+  }
   const long long want = (ntiles + 3) / 4;  // workgroups of four waves
   const long long cap = (long long)ncu * (C == 32 ? 4 : 2);
   const unsigned grid = (unsigned)(want < cap ? want : cap);

@@ -754,7 +754,7 @@ def conv1d_nlc(x, wcat, bias, taps, *, dilation=1, pad_l=0, reflect=False, in_sl
 
 
 def resblock_narrow(x, wfrag, b3, b1s, dilation, slope):
-    """x (B, L, C) 16-bit, C in {32, 64}, L % 16 == 0 -> y (B, L, C): one MelGAN ResnetBlock in one pass
+    """x (B, L, C) 16-bit, C in {32, 64} with L % 16 == 0 or C == 128 with L % 64 == 0 -> y (B, L, C): one MelGAN ResnetBlock in one pass
     (melgpt_resblock_narrow; wfrag / b3 / b1s as vocoder.modules packs them)."""
     B, L, C = x.shape
     assert x.is_contiguous() and wfrag.is_contiguous() and b3.dtype == torch.float32 and b1s.dtype == torch.float32

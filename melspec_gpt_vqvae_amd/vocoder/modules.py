@@ -156,8 +156,9 @@ class ResnetBlock(nn.Module):
     def _run(self, h):
         d = self.block[1].padding[0]
         B, L, C = h.shape
-        if h.dtype != torch.float32 and C in (32, 64) and L % 16 == 0 and d < L:
-            wfrag, b3, b1s = self._fragments(h.dtype)      # narrow stages: the whole block in one pass, weights in registers
+        if h.dtype != torch.float32 and d < L and ((C in (32, 64) and L % 16 == 0) or (C == 128 and L % 64 == 0)):
+            # the whole block in one pass: weights as MFMA fragments in registers (dim 32 / 64) or filling the LDS (dim 128)
+            wfrag, b3, b1s = self._fragments(h.dtype)
             return ops.resblock_narrow(h, wfrag, b3, b1s, d, LEAK)
         t1 = _conv1d(h, self.block[2], pad=d, leaky=True)
         y = _conv1d(h, self.shortcut, pad=0)

@@ -113,7 +113,7 @@ def test_conv_transpose_phases_match_torch(r, cin, cout):
     assert y.shape == ref.shape and rel_err(y.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("C,dil,L", [(32, 1, 64), (32, 9, 48), (64, 3, 64), (64, 9, 32)])
+@pytest.mark.parametrize("C,dil,L", [(32, 1, 64), (32, 9, 48), (64, 3, 64), (64, 9, 32), (128, 1, 64), (128, 9, 128), (128, 3, 192)])
 def test_narrow_resnet_block_in_one_pass_equals_the_three_convolutions(C, dil, L):
     """resblock_narrow_kernel (weights as register fragments, t1 never stored) against the same block run as three
     implicit GEMMs on the 16-bit lane: same operands, t1 rounded to the 16-bit format in both; and against torch in f32."""
