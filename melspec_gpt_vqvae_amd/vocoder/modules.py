@@ -47,7 +47,7 @@ def _effective_weight(m):
 
 class _TapCache:
     """per-module cache of the packed weight in the compute dtype: Conv1d -> (Cout, k * Cin), the taps' (Cout, Cin) slices
-    side by side; ConvTranspose1d (stride r, kernel 2r) -> one (Cout, 2 * Cin) matrix per output phase"""
+    side by side; ConvTranspose1d (stride r, kernel 2r) -> ((r * Cout, 3 * Cin) phase-major matrix, bias repeated r times)"""
 
     def __init__(self):
         self.key, self.packed = None, None
@@ -59,12 +59,20 @@ class _TapCache:
             if not transposed:
                 packed = ops.cast(w.permute(0, 2, 1).reshape(w.shape[0], -1).contiguous(), dtype)
             else:
+                # All r output phases as ONE three-tap convolution with r * Cout output channels: output row q r + s =
+                # W[phi + r] x[q + c - 1] + W[phi] x[q + c], (c, phi) = divmod(s + p, r), c in {0, 1} - so phase s uses taps
+                # c and c + 1 of the window (x[q - 1], x[q], x[q + 1]) and a zero block for the third; the (B, L, r * Cout)
+                # result IS the (B, r L, Cout) output.  One launch that reads x once instead of r launches of two taps
+                # (1.5 x the MACs, which these memory- / latency-bound layers do not notice).
                 r, p = m.stride[0], m.padding[0]
-                packed = []
-                for s in range(r):                             # output row q r + s = W[phi + r] x[q + c - 1] + W[phi] x[q + c]
-                    _, phi = divmod(s + p, r)
-                    wt = torch.cat([w[:, :, phi + r].t(), w[:, :, phi].t()], dim=1)
-                    packed.append(ops.cast(wt.contiguous(), dtype))
+                cin, cout = w.shape[0], w.shape[1]
+                wall = torch.zeros(r, cout, 3, cin, dtype=w.dtype, device=w.device)
+                for s in range(r):
+                    c, phi = divmod(s + p, r)
+                    wall[s, :, c, :] = w[:, :, phi + r].t()
+                    wall[s, :, c + 1, :] = w[:, :, phi].t()
+                packed = (ops.cast(wall.reshape(r * cout, 3 * cin).contiguous(), dtype),
+                          m.bias.detach().float().repeat(r).contiguous() if m.bias is not None else None)
             self.key, self.packed = key, packed
         return self.packed
 
@@ -90,20 +98,17 @@ def _conv1d(h, m, *, pad, reflect=True, leaky=False, out=None, accumulate=False)
 
 def _conv_transpose1d(h, m):
     """LeakyReLU -> ConvTranspose1d(stride r, kernel 2r, padding r//2 + r%2, output_padding r%2): (B, L, Cin) -> (B, rL, Cout).
-    Output row o = q r + s takes x[q + c] W[:, :, phi] + x[q + c - 1] W[:, :, phi + r] with (c, phi) = divmod(s + p, r): one
-    two-tap implicit GEMM per output phase s, writing rows s, s + r, ... of the output (zero rows outside the input)."""
+    Output row o = q r + s takes x[q + c] W[:, :, phi] + x[q + c - 1] W[:, :, phi + r] with (c, phi) = divmod(s + p, r): all
+    phases together are one three-tap implicit GEMM with r * Cout output channels (zero rows outside the input)."""
     B, L, Cin = h.shape
     r, k, p = m.stride[0], m.kernel_size[0], m.padding[0]
     assert k == 2 * r and p == r // 2 + r % 2 and m.output_padding[0] == r % 2 and m.dilation[0] == 1
-    packed = _cache(m).get(m, h.dtype, True)
-    Cout = packed[0].shape[0]
+    wall, bias_r = _cache(m).get(m, h.dtype, True)
+    Cout = wall.shape[0] // r
     Lout = (L - 1) * r - 2 * p + k + m.output_padding[0]
     assert Lout == r * L
-    y = torch.empty(B, Lout, Cout, dtype=h.dtype, device=h.device)
-    for s in range(r):
-        c, _ = divmod(s + p, r)
-        ops.conv1d_nlc(h, packed[s], m.bias, 2, pad_l=1 - c, reflect=False, in_slope=LEAK, out=y[:, s::r, :])
-    return y
+    y = ops.conv1d_nlc(h, wall, bias_r, 3, pad_l=1, reflect=False, in_slope=LEAK)      # (B, L, r * Cout)
+    return y.view(B, Lout, Cout)
 
 
 class ResnetBlock(nn.Module):
