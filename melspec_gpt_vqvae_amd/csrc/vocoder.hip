@@ -160,7 +160,9 @@ __global__ __launch_bounds__(256) void conv1d_out1_fused_kernel(const bf16_t* __
 //     convolution's weights are packed with that same slot order, so no lane exchange is needed (the attention kernels'
 //     accumulator-as-operand trick);
 //   * the shortcut's 1 x 1 convolution of the raw centre tap accumulates into the same output registers.
-template <int C>
+template <int C, int RT>  // RT 16-row tiles per wave iteration: their loads are in flight together (a wave that walks the
+                          // tensor one tile at a time pays one HBM latency per 2 KB: 1.0 ms per block at 64 clips / dim 64,
+                          // 2.8 x its HBM time)
 __global__ __launch_bounds__(256) void resblock_narrow_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                               const u32x4* __restrict__ wfrag, const float* __restrict__ b3,
                                                               const float* __restrict__ b1s, int L, int dil,
@@ -196,54 +198,77 @@ __global__ __launch_bounds__(256) void resblock_narrow_kernel(const bf16_t* __re
     return v;
   };
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
-  for (long long tile = wave; tile < ntiles; tile += nwaves) {
-    const long long row0 = tile * 16;          // L % 16 == 0: a tile never straddles two clips
-    const long long clip0 = row0 / L * L;      // first row of the tile's clip
-    const int l = (int)(row0 - clip0) + i16;
-    u32x4 xa[3][KS];
+  const long long ngroups = (ntiles + RT - 1) / RT;
+  // the NEXT group's fragments are requested before the current group is computed (a lone wave per SIMD - dim 64 - has
+  // nobody else to cover its loads): two register sets, rotated by copies
+  auto request = [&](long long grp, u32x4 (&xr)[RT][3][KS], long long (&r0)[RT]) {
 #pragma unroll
-    for (int tap = 0; tap < 3; ++tap) {
-      int r = l + (tap - 1) * dil;
-      r = r < 0 ? -r : r;
-      r = r >= L ? 2 * (L - 1) - r : r;
-      const T* src = x + (clip0 + r) * C + 8 * g;
+    for (int rt = 0; rt < RT; ++rt) {
+      const long long tile = grp * RT + rt < ntiles ? grp * RT + rt : ntiles - 1;  // (a group's tail repeats the last tile)
+      r0[rt] = tile * 16;                      // L % 16 == 0: a tile never straddles two clips
+      const long long clip0 = r0[rt] / L * L;  // first row of the tile's clip
+      const int l = (int)(r0[rt] - clip0) + i16;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) xa[tap][ks] = *(const u32x4*)(src + 32 * ks);
+      for (int tap = 0; tap < 3; ++tap) {
+        int r = l + (tap - 1) * dil;
+        r = r < 0 ? -r : r;
+        r = r >= L ? 2 * (L - 1) - r : r;
+        const T* src = x + (clip0 + r) * C + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xr[rt][tap][ks] = *(const u32x4*)(src + 32 * ks);
+      }
     }
-    f32x4 t1[NT], acc[NT];
+  };
+  u32x4 xa[RT][3][KS], xn[RT][3][KS];
+  long long row0[RT], rown[RT];
+  if (wave < ngroups) request(wave, xa, row0);
+  for (long long grp = wave; grp < ngroups; grp += nwaves) {
+    request(grp + nwaves < ngroups ? grp + nwaves : ngroups - 1, xn, rown);  // (past the end: a redundant reload)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      t1[nt] = bias3[nt];
-      acc[nt] = bias1s[nt];
-    }
+    for (int rt = 0; rt < RT; ++rt) {
+      f32x4 t1[NT], acc[NT];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)  // shortcut on the raw centre tap
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) mma<T>(acc[nt], wsc[ks][nt], xa[1][ks]);
-#pragma unroll
-    for (int tap = 0; tap < 3; ++tap)
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const u32x4 xl = leaky_frag(xa[tap][ks]);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) mma<T>(t1[nt], w3[tap * KS + ks][nt], xl);
+      for (int nt = 0; nt < NT; ++nt) {
+        t1[nt] = bias3[nt];
+        acc[nt] = bias1s[nt];
       }
 #pragma unroll
-    for (int p = 0; p < KS; ++p) {  // channels 32 p .. 32 p + 31 of leaky(t1) as one operand fragment
-      f32x4 lo = t1[2 * p], hi = t1[2 * p + 1];
+      for (int ks = 0; ks < KS; ++ks)  // shortcut on the raw centre tap
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        lo[e] = fmaxf(lo[e], lo[e] * slope);
-        hi[e] = fmaxf(hi[e], hi[e] * slope);
+        for (int nt = 0; nt < NT; ++nt) mma<T>(acc[nt], wsc[ks][nt], xa[rt][1][ks]);
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const u32x4 xl = leaky_frag(xa[rt][tap][ks]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) mma<T>(t1[nt], w3[tap * KS + ks][nt], xl);
+        }
+#pragma unroll
+      for (int p = 0; p < KS; ++p) {  // channels 32 p .. 32 p + 31 of leaky(t1) as one operand fragment
+        f32x4 lo = t1[2 * p], hi = t1[2 * p + 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          lo[e] = fmaxf(lo[e], lo[e] * slope);
+          hi[e] = fmaxf(hi[e], hi[e] * slope);
+        }
+        const u32x4 pf = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) mma<T>(acc[nt], w1[p][nt], pf);
       }
-      const u32x4 pf = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+      T* dst = y + (row0[rt] + i16) * C + 4 * g;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) mma<T>(acc[nt], w1[p][nt], pf);
+      for (int nt = 0; nt < NT; ++nt)
+        *(u32x2*)(dst + 16 * nt) = u32x2{pack_bf16x2(acc[nt][0], acc[nt][1]), pack_bf16x2(acc[nt][2], acc[nt][3])};
     }
-    T* dst = y + (row0 + i16) * C + 4 * g;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-      *(u32x2*)(dst + 16 * nt) = u32x2{pack_bf16x2(acc[nt][0], acc[nt][1]), pack_bf16x2(acc[nt][2], acc[nt][3])};
+    for (int rt = 0; rt < RT; ++rt) {
+      row0[rt] = rown[rt];
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xa[rt][tap][ks] = xn[rt][tap][ks];
+    }
   }
 }
 
@@ -278,7 +303,22 @@ __global__ __launch_bounds__(256) void resblock128_kernel(const bf16_t* __restri
     const long long row0 = tile * 64;
     const long long clip0 = row0 / L * L;
     const int l = (int)(row0 - clip0) + i16;
-    // ---- phase A: t1 = conv3(reflect_pad(leaky(x))) for the 64 rows (128 accumulator registers)
+    // ---- phase A: t1 = conv3(reflect_pad(leaky(x))) for the 64 rows (128 accumulator registers).  ALL 48 operand
+    // fragments of the tile (3 taps x 4 k-steps x 4 row tiles, 192 registers) are requested before the first is used:
+    // requested step by step, the lone wave of a SIMD paid one HBM latency per k-step - 12 per tile, 1.0 ms per block
+    // at 64 clips against 0.23 ms of MFMA issue.
+    u32x4 xa[3][KS][RT];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        int r = l + 16 * rt + (tap - 1) * dil;
+        r = r < 0 ? -r : r;
+        r = r >= L ? 2 * (L - 1) - r : r;
+        const T* src = x + (clip0 + r) * C + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xa[tap][ks][rt] = *(const u32x4*)(src + 32 * ks);
+      }
     f32x4 t1[RT][NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {  // (biases re-read per tile - L1 hits - instead of registers held for the launch)
@@ -286,29 +326,21 @@ __global__ __launch_bounds__(256) void resblock128_kernel(const bf16_t* __restri
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) t1[rt][nt] = c3;
     }
-#pragma unroll 1
-    for (int tap = 0; tap < 3; ++tap) {  // (rolled: unrolled, the scheduler hoists weight reads until 600 registers spill)
-      const T* src[RT];
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        int r = l + 16 * rt + (tap - 1) * dil;
-        r = r < 0 ? -r : r;
-        r = r >= L ? 2 * (L - 1) - r : r;
-        src[rt] = x + (clip0 + r) * C + 8 * g;
-      }
-#pragma unroll 1
+    for (int tap = 0; tap < 3; ++tap) {
+#pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         u32x4 xl[RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) xl[rt] = *(const u32x4*)(src[rt] + 32 * ks);
+        for (int rt = 0; rt < RT; ++rt) xl[rt] = leaky_frag(xa[tap][ks][rt]);
+        u32x4 wv[NT];  // all eight fragment reads of the k-step, then its 32 MFMAs
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) xl[rt] = leaky_frag(xl[rt]);
+        for (int nt = 0; nt < NT; ++nt) wv[nt] = wld((tap * KS + ks) * NT + nt);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const u32x4 w = wld((tap * KS + ks) * NT + nt);
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt) mma<T>(t1[rt][nt], w, xl[rt]);
-        }
+          for (int rt = 0; rt < RT; ++rt) mma<T>(t1[rt][nt], wv[nt], xl[rt]);
+        __builtin_amdgcn_sched_barrier(0);  // (one k-step at a time: weight reads hoisted across steps end in scratch)
       }
     }
     // ---- phase B: leaky(t1) as operand fragments (channels 32 p .. 32 p + 31: see resblock_narrow_kernel); t1 is dead
@@ -327,7 +359,7 @@ __global__ __launch_bounds__(256) void resblock128_kernel(const bf16_t* __restri
         pf[p][rt] = u32x4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
       }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- phase C: y = shortcut(x) (raw centre rows, re-read: L1 / L2 hits) + conv1(leaky(t1)) + biases
+    // ---- phase C: y = shortcut(x) + conv1(leaky(t1)) + biases
     f32x4 acc[RT][NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -335,29 +367,26 @@ __global__ __launch_bounds__(256) void resblock128_kernel(const bf16_t* __restri
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[rt][nt] = c1;
     }
-    {
-      const T* src0 = x + (row0 + i16) * C + 8 * g;
-#pragma unroll 1
-      for (int ks = 0; ks < KS; ++ks) {
-        u32x4 xr[RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) xr[rt] = *(const u32x4*)(src0 + (long long)16 * rt * C + 32 * ks);
+    for (int ks = 0; ks < KS; ++ks) {  // (the raw centre-tap fragments are still in registers)
+      u32x4 wv[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const u32x4 w = wld((3 * KS + ks) * NT + nt);
+      for (int nt = 0; nt < NT; ++nt) wv[nt] = wld((3 * KS + ks) * NT + nt);
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt) mma<T>(acc[rt][nt], w, xr[rt]);
-        }
-      }
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) mma<T>(acc[rt][nt], wv[nt], xa[1][ks][rt]);
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int p = 0; p < KS; ++p) {
+      u32x4 wv[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const u32x4 w = wld((4 * KS + p) * NT + nt);
+      for (int nt = 0; nt < NT; ++nt) wv[nt] = wld((4 * KS + p) * NT + nt);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) mma<T>(acc[rt][nt], w, pf[p][rt]);
-      }
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) mma<T>(acc[rt][nt], wv[nt], pf[p][rt]);
       __builtin_amdgcn_sched_barrier(0);  // (one channel group at a time: hoisted weight reads end in scratch)
     }
 #pragma unroll
@@ -405,10 +434,10 @@ extern "C" int melgpt_resblock_narrow(const void* x, void* y, const void* wfrag,
   const unsigned grid = (unsigned)(want < cap ? want : cap);
   hipStream_t s = (hipStream_t)stream;
   if (C == 32)
-    hipLaunchKernelGGL(resblock_narrow_kernel<32>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y,
+    hipLaunchKernelGGL((resblock_narrow_kernel<32, 4>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y,
                        (const u32x4*)wfrag, b3, b1s, L, dilation, ntiles, slope);
   else
-    hipLaunchKernelGGL(resblock_narrow_kernel<64>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y,
+    hipLaunchKernelGGL((resblock_narrow_kernel<64, 2>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y,
                        (const u32x4*)wfrag, b3, b1s, L, dilation, ntiles, slope);
   return melgpt_launch_status();
 }
