@@ -440,8 +440,10 @@ def attn_decode(qkv, kcache, vcache, n_head, pos, att_row=None, pos_dev=None, ou
 
 
 SKINNY_LN_MAX_ROWS = int(os.environ.get("MELGPT_SKINNY_LN_MAX_ROWS", "64"))  # lab switch (0: never fuse)
-LDS_LINEAR_MIN_ROWS = int(os.environ.get("MELGPT_LDS_LINEAR_MIN_ROWS", "17"))  # lab switch (999: never; default from
-# profiles/r03_decode_lab.md: at <= 16 rows the register-pipelined kernel is as fast and needs no second launch for K = 4096)
+LDS_LINEAR_MIN_ROWS = int(os.environ.get("MELGPT_LDS_LINEAR_MIN_ROWS", "5"))  # lab switch (999: never).  Default from the
+# end-to-end chain (profiles/r03_decode_lab.md): sampling 265 tokens at 16 sequences 238.8 -> 210.5 ms, at 8 sequences
+# 216.0 -> 202.4 ms with the LDS-resident linear instead of the register-pipelined one (whose per-kernel timing at <= 16
+# rows had looked equal in isolation)
 
 
 _LN_FOLD = {}   # (weight, bias, gamma, beta versions) -> (W' bf16, c1, c2): melgpt_ln_fold_prepare, rebuilt when any changes

@@ -118,7 +118,9 @@ def test_linear_rows_weight_streaming_kernel(dt, M, N, K):
     if dt == "bf16":
         h = F.layer_norm(xs.float(), (K,), gm, bt, 1e-5).to(torch.bfloat16).float()
     y = ops.linear_rows(xs.to(DEV), w.to(DEV), bias=b.to(DEV), ln=(gm.to(DEV), bt.to(DEV), 1e-5), out_dtype=torch.float32)
-    assert rel_err(y.cpu().numpy(), (h @ w.float().T + b).numpy()) < (2e-5 if dt == "f32" else 2e-3)
+    # (bf16, 5+ rows, K = 1024: the LN is folded into the weight algebraically - W'x - mu c1 cancels the row mean in f32
+    # after the product instead of before it; same bound as test_skinny_linear_with_layernorm_folded_in)
+    assert rel_err(y.cpu().numpy(), (h @ w.float().T + b).numpy()) < (2e-5 if dt == "f32" else 8e-3)
 
 
 @pytest.mark.parametrize("M", [5, 16, 17, 33, 64, 100, 128])
