@@ -478,7 +478,8 @@ def linear_rows(x, w, *, bias=None, act=ACT_NONE, residual=None, out_dtype=None,
     odt = out_dtype or x.dtype
     assert odt in (x.dtype, torch.float32)
     skinny = x.dtype == _ffi.HALF_DTYPE and 4 < M <= 128 and N % 16 == 0 and K % 128 == 0
-    if skinny and M >= LDS_LINEAR_MIN_ROWS and K % 1024 == 0 and K <= 8192 and (ln is None or K == 1024):
+    lds_ok = x.dtype == _ffi.HALF_DTYPE and LDS_LINEAR_MIN_ROWS <= M <= 128 and N % 16 == 0
+    if lds_ok and K % 1024 == 0 and K <= 8192 and (ln is None or K == 1024):
         # 17 .. 128 rows: x through LDS by LDS-DMA, weights to registers, everything requested up front (melgpt_linear_lds)
         y = torch.empty(M, N, dtype=odt, device=x.device)
         if residual is not None:
