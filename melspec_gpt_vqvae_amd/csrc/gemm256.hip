@@ -463,7 +463,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
           for (int mt = 0; mt < TM; ++mt) fa[mt] = load_frag<ALAY, BM>(sa, wm * TM + mt, ks, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+#ifndef G256_PRIO
+#define G256_PRIO 1  // lab: priority of the MFMA phase (0: none, 1: as shipped, 3: highest)
+#endif
+        __builtin_amdgcn_s_setprio(G256_PRIO);
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
 #pragma unroll
