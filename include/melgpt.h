@@ -425,13 +425,14 @@ int melgpt_pad1d_act(const void* x, void* y, int B, int L, int C, int pad, int r
  * activation x (B, L, Cin) - no padded copy, no per-tap launches (vocoder/modules.py:23-79: WNConv1d / WNConvTranspose1d
  * with their ReflectionPad1d / LeakyReLU neighbours):
  *   y[b, l, :] = bias + sum_{t < KW} W_t f(x[b, l - pad_l + t * dilation, :])  (+ residual[b, l, :]) (+ y when accumulate)
- * f = LeakyReLU(in_slope) applied to the input operand (in_slope = 0: none); positions outside [0, L) are reflected
+ * f = LeakyReLU(in_slope) applied to the input operand (in_slope = 0: none); out_slope != 0 applies LeakyReLU(out_slope) to
+ * bias + sum before the residual; positions outside [0, L) are reflected
  * (reflect != 0: nn.ReflectionPad1d, at most one reflection) or read as zeros.  wpack (Cout, KW * Cin): the taps' (Cout, Cin)
  * slices side by side along K.  y / residual rows of Cout elements with row strides ldy / ldr (a transposed
  * convolution's phase s writes rows s, s + r, ... of its output: ldy = r * Cout).  Cin, Cout multiples of 16 bytes. */
 int melgpt_conv1d_nlc(const void* x, int B, int L, int Cin, const void* wpack, int Cout, int KW, int dilation,
                       int pad_l, int reflect, float in_slope, const float* bias, const void* residual, long long ldr,
-                      int accumulate, void* y, long long ldy, int dtype, void* stream);
+                      int accumulate, float out_slope, void* y, long long ldy, int dtype, void* stream);
 /* y (B, L) f32 = [tanh]( bias + sum_{t<K, c<C} xp[b, l + t, c] * w[t*C + c] ): the generator's last Conv1d(ngf, 1, 7)
  * + nn.Tanh on an already padded xp (B, L + K - 1, C); w (K*C) f32 = weight[0].T flattened tap-major. */
 int melgpt_conv1d_out1(const void* xp, const float* w, const float* bias, float* y, int B, int L, int C, int K,

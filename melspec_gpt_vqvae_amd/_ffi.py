@@ -59,7 +59,7 @@ _PROTOS = {
     "melgpt_embed_decode": [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p],
     "melgpt_incr_i32": [_p, _p],
     "melgpt_pad1d_act": [_p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
-    "melgpt_conv1d_nlc": [_p, _i, _i, _i, _p, _i, _i, _i, _i, _i, _f, _p, _p, _l, _i, _p, _l, _i, _p],
+    "melgpt_conv1d_nlc": [_p, _i, _i, _i, _p, _i, _i, _i, _i, _i, _f, _p, _p, _l, _i, _f, _p, _l, _i, _p],
     "melgpt_conv1d_out1": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "melgpt_conv1d_out1_fused": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p],
     "melgpt_resblock_narrow": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p],

@@ -449,16 +449,20 @@ extern "C" int melgpt_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, c
 
 // MelGAN's Conv1d / ConvTranspose1d layers (vocoder/modules.py:23-79) as ONE implicit GEMM each on a channels-last
 // (B, L, Cin) activation: y[b, l, :] (row stride ldy) = bias + sum_{t < KW} W_t . f(x[b, l - pad_l + t dilation, :]) (+ residual)
-// (+ y when accumulate), f = LeakyReLU(in_slope) (in_slope = 0: none), positions outside [0, L): reflected
+// (+ y when accumulate), f = LeakyReLU(in_slope) (in_slope = 0: none); out_slope != 0: LeakyReLU(out_slope) on bias + sum
+// before the residual (the block's conv3 hands conv1 an activated t1); positions outside [0, L): reflected
 // (nn.ReflectionPad1d) or zero.  wpack (Cout, KW * Cin), tap-major along K.  Generic 128 x 128 kernel (the operand passes
 // through registers on its way into LDS, where the activation is applied); Cin % (16 / es) == 0.
 extern "C" int melgpt_conv1d_nlc(const void* x, int B, int L, int Cin, const void* wpack, int Cout, int KW, int dilation,
                                  int pad_l, int reflect, float in_slope, const float* bias, const void* residual,
-                                 long long ldr, int accumulate, void* y, long long ldy, int dtype, void* stream) {
+                                 long long ldr, int accumulate, float out_slope, void* y, long long ldy, int dtype,
+                                 void* stream) {
   MELGPT_CHECK(x && wpack && y && B > 0 && L > 0 && Cin > 0 && Cout > 0 && KW > 0 && dilation > 0, MELGPT_ERR_BAD_ARG);
   MELGPT_CHECK(dtype == MELGPT_F32 || dtype == MELGPT_BF16, MELGPT_ERR_UNSUPPORTED);
   const int es = dtype == MELGPT_F32 ? 4 : 2;
-  MELGPT_CHECK(Cin % (16 / es) == 0 && Cout % (16 / es) == 0 && in_slope >= 0.f && in_slope < 1.f, MELGPT_ERR_UNSUPPORTED);
+  MELGPT_CHECK(Cin % (16 / es) == 0 && Cout % (16 / es) == 0 && in_slope >= 0.f && in_slope < 1.f && out_slope >= 0.f &&
+                   out_slope < 1.f,
+               MELGPT_ERR_UNSUPPORTED);
   MELGPT_CHECK(!reflect || (pad_l < L && (KW - 1) * dilation - pad_l < L), MELGPT_ERR_UNSUPPORTED);  // one reflection only
   MELGPT_CHECK((((uintptr_t)x | (uintptr_t)wpack | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)bias) & 15) == 0,
                MELGPT_ERR_ALIGN);
@@ -475,7 +479,7 @@ extern "C" int melgpt_conv1d_nlc(const void* x, int B, int L, int Cin, const voi
   p.accumulate = accumulate;
   p.vec_io = 1;
   p.cH = 1; p.cW = L; p.cC = Cin; p.OH = 1; p.OW = L; p.cstride = 1; p.pad_t = 0; p.pad_l = pad_l; p.ups = 0; p.KW = KW;
-  p.cdil_m1 = dilation - 1; p.creflect = reflect; p.a_leaky = in_slope;
+  p.cdil_m1 = dilation - 1; p.creflect = reflect; p.a_leaky = in_slope; p.out_leaky = out_slope;
   hipStream_t s = (hipStream_t)stream;
   return dtype == MELGPT_F32 ? dispatch<float>(p, LAY_CONV1D, LAY_ROW, 1, s) : dispatch<bf16_t>(p, LAY_CONV1D, LAY_ROW, 1, s);
 }

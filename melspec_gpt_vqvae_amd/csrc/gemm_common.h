@@ -47,6 +47,7 @@ struct GemmParams {
   // (0 = off).  All zero for the 2-D convolutions.
   int cdil_m1, creflect;
   float a_leaky;
+  float out_leaky;  // generic epilogue only: LeakyReLU(out_leaky) on alpha * acc + bias, before the residual (0 = off)
   // optional (persistent kernel, both operands K-major, f32 output: the weight-gradient GEMM): partial sums over K of the
   // rows of A - the bias gradient when A = dY - as (batch * ceil(N / 256)) rows of M floats, row stride ld_rowsum
   float* a_rowsum;
@@ -253,6 +254,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
         v *= gelu_grad4(r4);
       } else if (MODE == EPI_GENERIC && p.act == MELGPT_ACT_MUL) {  // the 256-wide kernel serves MUL in its plain modes
         v *= r4;
+      }
+      if (MODE == EPI_GENERIC && p.out_leaky != 0.f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * p.out_leaky);
       }
       if (p.drop_scale != 0.f) {
         const unsigned long long e0 = ((unsigned long long)bz * p.M + m) * (unsigned long long)p.N + n;

@@ -735,10 +735,10 @@ def pad1d_act(x, pad, *, reflect=True, slope=1.0):
 
 
 def conv1d_nlc(x, wcat, bias, taps, *, dilation=1, pad_l=0, reflect=False, in_slope=0.0, residual=None, out=None,
-               accumulate=False):
+               accumulate=False, out_slope=0.0):
     """x (B, L, Cin) contiguous, wcat (Cout, taps * Cin) tap-major -> (B, L, Cout): one implicit-GEMM launch
     (melgpt_conv1d_nlc): y[l] = bias + sum_t W_t f(x[l - pad_l + t dilation]) (+ residual) (+ out when accumulate),
-    f = LeakyReLU(in_slope) (0: none), out-of-range positions reflected or zero.  `out` may be a row-strided view
+    f = LeakyReLU(in_slope) (0: none), out-of-range positions reflected or zero; out_slope != 0: LeakyReLU on bias + sum.  `out` may be a row-strided view
     (B, L, Cout) of a larger tensor - a transposed convolution's output phase - as long as its rows are uniformly spaced."""
     B, L, Cin = x.shape
     Cout = wcat.shape[0]
@@ -751,8 +751,8 @@ def conv1d_nlc(x, wcat, bias, taps, *, dilation=1, pad_l=0, reflect=False, in_sl
         assert residual.shape == (B, L, Cout) and residual.stride(2) == 1 and residual.stride(0) == L * residual.stride(1)
         ldr = residual.stride(1)
     call("melgpt_conv1d_nlc", ptr(x), B, L, Cin, ptr(wcat), Cout, int(taps), int(dilation), int(pad_l), int(bool(reflect)),
-         float(in_slope), ptr(bias), ptr(residual), ldr, int(bool(accumulate)), ptr(out), out.stride(1), dtype_code(x.dtype),
-         stream())
+         float(in_slope), ptr(bias), ptr(residual), ldr, int(bool(accumulate)), float(out_slope), ptr(out), out.stride(1),
+         dtype_code(x.dtype), stream())
     return out
 
 

@@ -85,7 +85,7 @@ def _cache(m):
     return c
 
 
-def _conv1d(h, m, *, pad, reflect=True, leaky=False, out=None, accumulate=False):
+def _conv1d(h, m, *, pad, reflect=True, leaky=False, out=None, accumulate=False, out_leaky=False):
     """h (B, L, Cin) channels-last -> (B, L, Cout): [LeakyReLU ->] [ReflectionPad1d(pad) ->] Conv1d `m` (stride 1) as ONE
     implicit-GEMM launch: the padding is an address reflection, the activation is applied to the operand on its way into
     LDS (no padded copy, no per-tap launches)."""
@@ -98,7 +98,8 @@ def _conv1d(h, m, *, pad, reflect=True, leaky=False, out=None, accumulate=False)
         B, L, Cin = h.shape
         return ops.gemm(h.view(B * L, Cin), wcat, bias=m.bias).view(B, L, wcat.shape[0])
     return ops.conv1d_nlc(h, wcat, m.bias, k, dilation=d, pad_l=pad, reflect=reflect and pad > 0,
-                          in_slope=LEAK if leaky else 0.0, out=out, accumulate=accumulate)
+                          in_slope=LEAK if leaky else 0.0, out=out, accumulate=accumulate,
+                          out_slope=LEAK if out_leaky else 0.0)
 
 
 def _conv_transpose1d(h, m):
@@ -170,9 +171,11 @@ class ResnetBlock(nn.Module):
             # the whole block in one pass: weights as MFMA fragments in registers (dim 32 / 64) or filling the LDS (dim 128)
             wfrag, b3, b1s = self._fragments(h.dtype)
             return ops.resblock_narrow(h, wfrag, b3, b1s, d, LEAK)
-        t1 = _conv1d(h, self.block[2], pad=d, leaky=True)
+        t1 = _conv1d(h, self.block[2], pad=d, leaky=True, out_leaky=True)                # leaky(conv3(pad(leaky(x))))
         y = _conv1d(h, self.shortcut, pad=0)
-        return _conv1d(t1, self.block[4], pad=0, leaky=True, out=y, accumulate=True)   # shortcut(x) + block(x)
+        # shortcut(x) + conv1(leaky t1): a plain GEMM with the shortcut as its residual operand (persistent kernel at dim 256)
+        w1 = _cache(self.block[4]).get(self.block[4], h.dtype, False)
+        return ops.gemm(t1.view(B * L, C), w1, bias=self.block[4].bias, residual=y.view(B * L, C)).view(B, L, C)
 
     def forward(self, x):  # (B, C, L) like the reference
         return _from_cl(self._run(_to_cl(x, _dtype_of(self))), x.dtype)

@@ -89,6 +89,8 @@ def test_conv1d_as_one_implicit_gemm_matches_torch(cin, cout, k, dil, reflect, s
     wcat = w.permute(0, 2, 1).reshape(cout, -1).contiguous().to(DEV)
     y = ops.conv1d_nlc(x.to(DEV), wcat, b.to(DEV), k, dilation=dil, pad_l=pad, reflect=reflect, in_slope=slope)
     assert rel_err(y.cpu().numpy(), ref.numpy()) < 1e-5
+    yl = ops.conv1d_nlc(x.to(DEV), wcat, b.to(DEV), k, dilation=dil, pad_l=pad, reflect=reflect, in_slope=slope, out_slope=0.2)
+    assert rel_err(yl.cpu().numpy(), F.leaky_relu(ref, 0.2).numpy()) < 1e-5       # LeakyReLU on the output (conv3 -> conv1)
     # accumulate into every second row of a wider buffer (a transposed convolution's output phase)
     big = t(synth.normal(14, (B, 2 * L, cout), 1.0)).to(DEV)
     keep = big.clone()
