@@ -136,10 +136,10 @@ def gpt_vae_xl_rank(a, device, dtype, steps=3):
 def e2e_fp16_child(timeout=420):
     """BASELINE configs[4] beside the metric: the end-to-end chain in the library's fp16 flavour - a CHILD process
     (MELGPT_HALF is a property of the process; started after this one's GPU work is done, never replacing it): batch 1
-    latency percentiles and batch 64 clips/s with per-stage milliseconds (tools/bench_e2e.py)."""
+    latency percentiles, batch 64 and batch 128 clips/s with per-stage milliseconds (tools/bench_e2e.py)."""
     import subprocess
 
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_e2e.py"), "--dtype", "fp16", "--batches", "1,64"]
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_e2e.py"), "--dtype", "fp16", "--batches", "1,64,128"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MELGPT_HALF")}
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
@@ -155,10 +155,15 @@ def e2e_fp16_child(timeout=420):
     if r.returncode != 0 or len(rows) < 2:
         return {"error": f"rc {r.returncode}", "stderr_tail": r.stderr[-400:]}
     b1, b64 = rows[0], rows[1]
-    return {"workload": "wav -> HIP STFT/mel -> VQ encode -> GPT sample 265 (KV-cached) -> VQ decode -> MelGAN, fp16 flavour, one GPU",
+    b128 = rows[2] if len(rows) > 2 else None
+    out = {"workload": "wav -> HIP STFT/mel -> VQ encode -> GPT sample 265 (KV-cached) -> VQ decode -> MelGAN, fp16 flavour, one GPU",
             "batch1_latency_ms": b1["latency_ms"], "batch1_stage_ms": b1["stage_ms_median"],
             "batch64_clips_per_s": b64["clips_per_s"], "batch64_latency_ms": b64["latency_ms"],
             "batch64_stage_ms": b64["stage_ms_median"], "x_realtime_batch64": b64["x_realtime"]}
+    if b128:
+        out.update({"batch128_clips_per_s": b128["clips_per_s"], "batch128_latency_ms": b128["latency_ms"],
+                    "batch128_stage_ms": b128["stage_ms_median"]})
+    return out
 
 
 def pmc_summary(workload="class_gpt"):

@@ -10,7 +10,7 @@ The reference runs these stages as separate scripts (feature_extraction/extract_
 callbacks/GPT_callbacks.py:83-105).  One JSON line per batch size: per-stage milliseconds, latency percentiles per
 batch and clips per second.
 
-  python tools/bench_e2e.py [--dtype fp16] [--batches 1,16,64] [--gpus N]
+  python tools/bench_e2e.py [--dtype fp16] [--batches 1,16,64,128] [--gpus N]
 
 `--gpus N`: the chain shards per clip with no exchange step, so N ranks (one process per GPU, started here
 before anything touches a GPU) each take clips r::N of the global list of N x batch clips, run the same loop with NO
@@ -37,7 +37,7 @@ REPS = {1: 12, 16: 4, 64: 3}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
-    ap.add_argument("--batches", default="1,16,64", help="clips per GPU per pass, comma separated")
+    ap.add_argument("--batches", default="1,16,64,128", help="clips per GPU per pass, comma separated")
     ap.add_argument("--gpus", type=int, default=1)
     return ap.parse_args()
 
