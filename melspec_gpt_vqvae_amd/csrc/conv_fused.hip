@@ -64,9 +64,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(FusedConvParams q) {
   if (norm) {
     const int cg = Cin / 32;
     for (int c = t; c < Cin; c += 256) {
-      const float a = q.rstd[b * 32 + c / cg] * q.gamma[c];
+      // all four loads before the first LDS store (which may alias them, as far as the compiler knows: written as
+      // a = ...; ab[2c] = a; ab[2c+1] = beta - mean * a it compiled to two dependent round trips)
+      const float rs = q.rstd[b * 32 + c / cg], ga = q.gamma[c], be = q.beta[c], me = q.mean[b * 32 + c / cg];
+      const float a = rs * ga;
       ab[2 * c] = a;
-      ab[2 * c + 1] = q.beta[c] - q.mean[b * 32 + c / cg] * a;
+      ab[2 * c + 1] = be - me * a;
     }
   }
   // ---- weight tile staging: the (128 x 128 B) tile of a K step goes L2 -> LDS by LDS-DMA in sixteen 1 KiB pieces
@@ -187,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(FusedConvParams q) {
 #endif
 #if CONVW_LAB
 __device__ unsigned long long melgpt_convw_dbg[64];
+__device__ unsigned long long melgpt_convw_dbg2[16];
 #endif
 
 constexpr int WTH = 16, WTW = 16, WPH = WTH + 2, WPW = WTW + 2, WNPIX = WPH * WPW, WNST = 4;
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
   float* ab = (float*)(wring + WNST * 16384);                // [Cin][2]
   float* stp = ab + 2 * Cin;                                 // [4 wm][32 groups][2]: output statistics of a tile
   char* rturn = (char*)(stp + 256) + (threadIdx.x >> 6) * 1024;  // per wave: 8 residual rows on their way into accumulator layout
+  float* gb = (float*)((char*)(stp + 256) + 8 * 1024);           // [Cin][2]: gamma, beta
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w >> 1, wn = w & 1;
   const int i16 = lane & 15, g = lane >> 4;
@@ -268,7 +273,35 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
       raw[i] = buf_load16(rx, off);
     }
   };
+  // GroupNorm constants (a, b) of a tile's image: thread c < Cin owns channel c (Cin <= 512: the launcher checks).  The
+  // image's rstd / mean are REQUESTED with the tile's patch (one tile ahead) and folded into (a, b) before the previous
+  // tile's epilogue stores go out; gamma / beta wait in LDS.  Computed at the top of the tile from four global loads, the
+  // constants cost 2-5 k of a tile's 47 k cycles: two dependent round trips (the LDS store between them may alias, as
+  // far as the compiler knows), each behind a vmcnt(0) that also waits for the epilogue's stores to retire.
+  const bool abt = norm && t < Cin;
+  const int cgs = Cin / 32, tiles_img = q.tiles_x * q.tiles_y;
+  float nr = 0.f, nm = 0.f, na = 0.f, nbb = 0.f;
+  auto fetch_stats = [&](int tile) {
+    if (abt && tile < total_tiles) {
+      const int b = tile / tiles_img;
+      nr = q.rstd[b * 32 + t / cgs];
+      nm = q.mean[b * 32 + t / cgs];
+    }
+  };
+  auto fold_stats = [&]() {
+    if (abt) {
+      na = nr * gb[2 * t];
+      nbb = gb[2 * t + 1] - nm * na;
+    }
+    asm volatile("" : "+v"(na), "+v"(nbb));  // here, not at their use behind the epilogue's stores
+  };
+  if (abt) {
+    gb[2 * t] = q.gamma[t];
+    gb[2 * t + 1] = q.beta[t];
+  }
+  fetch_stats(blockIdx.x);
   fetch_patch(blockIdx.x);
+  fold_stats();  // (a thread reads back its own two LDS words: no barrier)
 
   for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     const int tx = tile % q.tiles_x, ty = (tile / q.tiles_x) % q.tiles_y, b = tile / (q.tiles_x * q.tiles_y);
@@ -276,13 +309,9 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
 #if CONVW_LAB
     unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st2 = 0;
 #endif
-    if (norm) {
-      const int cg = Cin / 32;
-      for (int c = t; c < Cin; c += 512) {
-        const float a = q.rstd[b * 32 + c / cg] * q.gamma[c];
-        ab[2 * c] = a;
-        ab[2 * c + 1] = q.beta[c] - q.mean[b * 32 + c / cg] * a;
-      }
+    if (abt) {
+      ab[2 * t] = na;
+      ab[2 * t + 1] = nbb;
     }
     // The accumulators START from bias + residual instead of zero, and the epilogue is left with rounding and stores.
     // (Fetched by the epilogue - two batches of row slabs through the LDS staging block - the residual cost a tile 7 500
@@ -291,8 +320,6 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
     // accumulator layout (8 bytes per lane, neighbouring lanes 256 bytes apart) every lane is a memory request of its
     // own and the 128 loads of a tile take as long to issue as they save - lands under the staging pass below and is
     // turned into accumulator layout through a 1 KiB block of LDS per wave when the accumulators are initialised.
-    // Requested AFTER the normalisation constants above: those loads are waited for with vmcnt(0), which would wait for
-    // these as well.
     u32x4 rrow[4][2];
     f32x4 bv[4];
 #pragma unroll
@@ -311,6 +338,9 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
         rrow[mt][hp] = buf_load16(rres, off);
       }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ab visible; previous tile's epilogue is out of the patch
+#if CONVW_LAB
+    const unsigned long long stA = __builtin_amdgcn_s_memtime();
+#endif
     // ---- stage the input patch (normalise + swish on the fly; out-of-image pixels are zeros AFTER the normalisation)
     f32x4 sc[4];  // (a, b) of channels 8 ch .. 8 ch + 7, interleaved
     if (norm) {
@@ -342,6 +372,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
 #if CONVW_LAB
     st1 = __builtin_amdgcn_s_memtime();
 #endif
+    fetch_stats(tile + gridDim.x);
     fetch_patch(tile + gridDim.x);  // lands under this tile's K loop
     // (the first K-step's barrier below publishes the patch)
 
@@ -409,6 +440,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
 #if CONVW_LAB
     st2 = __builtin_amdgcn_s_memtime();
 #endif
+    fold_stats();  // the next tile's (a, b)
     asm volatile("s_barrier" ::: "memory");  // everybody is done reading the patch: it becomes the epilogue's staging
     if constexpr (STATS) {
       // GroupNorm(32) statistics of THIS conv's output (Cout = 128: a lane's four consecutive channels are one group),
@@ -468,6 +500,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
     if (blockIdx.x == 7 && t == 0) {
       const int k = (tile - 7) / gridDim.x;
       if (k < 15) {
+        melgpt_convw_dbg2[k] = stA;
         melgpt_convw_dbg[4 * k] = st0; melgpt_convw_dbg[4 * k + 1] = st1; melgpt_convw_dbg[4 * k + 2] = st2;
         melgpt_convw_dbg[4 * k + 3] = __builtin_amdgcn_s_memtime();
       }
@@ -481,7 +514,8 @@ int launch_fused_wide(const FusedConvParams& q0, int B, hipStream_t s) {
   FusedConvParams q = q0;
   q.tiles_x = (q.W + WTW - 1) / WTW;
   q.tiles_y = (q.H + WTH - 1) / WTH;
-  const size_t lds = (size_t)WNPIX * q.Cin * 2 + WNST * 16384 + (size_t)q.Cin * 8 + 1024 + 8 * 1024;
+  const size_t lds = (size_t)WNPIX * q.Cin * 2 + WNST * 16384 + (size_t)q.Cin * 8 + 1024 + 8 * 1024 + (size_t)q.Cin * 8;
+  if (q.Cin > 512 || lds > 160 * 1024) return MELGPT_ERR_UNSUPPORTED;
   static int ncu = 0;
   if (!ncu) {
     int dev = 0, n = 0;

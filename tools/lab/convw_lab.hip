@@ -23,8 +23,10 @@ int main() {
   }
   unsigned long long h[64];
   hipMemcpyFromSymbol(h, HIP_SYMBOL(melgpt_convw_dbg), sizeof(h));
+  unsigned long long h2[16];
+  hipMemcpyFromSymbol(h2, HIP_SYMBOL(melgpt_convw_dbg2), sizeof(h2));
   for (int i = 1; i < 6 && h[4 * i]; ++i)
-    printf("tile %d: ab+stage %6llu  K loop %6llu  epilogue %6llu  (gap %6lld)\n", i, h[4 * i + 1] - h[4 * i],
+    printf("tile %d: ab %6llu  ab+stage %6llu  K loop %6llu  epilogue %6llu  (gap %6lld)\n", i, h2[i] - h[4 * i], h[4 * i + 1] - h[4 * i],
            h[4 * i + 2] - h[4 * i + 1], h[4 * i + 3] - h[4 * i + 2], h[4 * i + 4] ? (long long)(h[4 * i + 4] - h[4 * i + 3]) : -1LL);
   return 0;
 }
