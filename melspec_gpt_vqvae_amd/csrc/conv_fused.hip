@@ -454,22 +454,31 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           if (xin && y0 + wm * 4 + mt < q.H) {
+            // rounded as the epilogue will round them, two values per v_cvt_pk (bias and residual are in the accumulators)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float v = bf16_to_f32(f32_to_bf16(acc[mt][nt][e]));  // (bias and residual are in the accumulators)
-              s1[nt] += v;
-              s2[nt] = fmaf(v, v, s2[nt]);
+            for (int e = 0; e < 4; e += 2) {
+              const unsigned pk = pack_bf16x2(acc[mt][nt][e], acc[mt][nt][e + 1]);
+              const float v0 = bf16lo(pk), v1 = bf16hi(pk);
+              s1[nt] += v0;
+              s2[nt] = fmaf(v0, v0, s2[nt]);
+              s1[nt] += v1;
+              s2[nt] = fmaf(v1, v1, s2[nt]);
             }
           }
         }
       }
+      // the 16 pixels of a row of lanes: four DPP steps (a ds_bpermute shuffle per step was 32 LDS round trips per tile)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          s1[nt] += __shfl_xor(s1[nt], o, 64);
-          s2[nt] += __shfl_xor(s2[nt], o, 64);
-        }
+      for (int nt = 0; nt < 4; ++nt) {
+        s1[nt] += dpp_move<0xB1>(s1[nt]);
+        s2[nt] += dpp_move<0xB1>(s2[nt]);
+        s1[nt] += dpp_move<0x4E>(s1[nt]);
+        s2[nt] += dpp_move<0x4E>(s2[nt]);
+        s1[nt] += dpp_move<0x141>(s1[nt]);
+        s2[nt] += dpp_move<0x141>(s2[nt]);
+        s1[nt] += dpp_move<0x140>(s1[nt]);
+        s2[nt] += dpp_move<0x140>(s2[nt]);
+      }
       if (i16 == 0) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {

@@ -13,10 +13,32 @@ int main() {
   hipMalloc(&mean, B * 32 * 4); hipMalloc(&rstd, B * 32 * 4); hipMalloc(&gamma, C * 4); hipMalloc(&beta, C * 4); hipMalloc(&bias, C * 4);
   hipMemset(x, 0x3c, n * 2); hipMemset(res, 0, n * 2); hipMemset(wp, 0x3c, (size_t)C * 9 * C * 2);
   hipMemset(mean, 0, B * 32 * 4); hipMemset(rstd, 0, B * 32 * 4); hipMemset(gamma, 0, C * 4); hipMemset(beta, 0, C * 4); hipMemset(bias, 0, C * 4);
+  if (getenv("RANDOM")) {  // random bf16 operands (|v| < 2) and unit statistics: the chip clocks lower on them than on constants
+    std::vector<unsigned short> hx(n);
+    unsigned sd = 12345u;
+    auto rnd = [&]() { sd = sd * 1664525u + 1013904223u; return (unsigned short)(0x3c00u + ((sd >> 9) & 0x3ffu) + ((sd >> 20 & 1u) << 15)); };
+    for (auto& v : hx) v = rnd();
+    hipMemcpy(x, hx.data(), n * 2, hipMemcpyHostToDevice);
+    for (auto& v : hx) v = rnd();
+    hipMemcpy(res, hx.data(), n * 2, hipMemcpyHostToDevice);
+    std::vector<unsigned short> hw((size_t)C * 9 * C);
+    for (auto& v : hw) v = (unsigned short)(rnd() - 0x0400u);
+    hipMemcpy(wp, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+    std::vector<float> ones(B * 32, 1.0f), g1(C, 1.0f);
+    hipMemcpy(rstd, ones.data(), B * 32 * 4, hipMemcpyHostToDevice);
+    hipMemcpy(gamma, g1.data(), C * 4, hipMemcpyHostToDevice);
+  }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(e0, 0);
-    int st = melgpt_conv3x3_gn_nhwc(x, B, H, W, C, mean, rstd, gamma, beta, 1, wp, C, bias, getenv("NORES") ? nullptr : res, y, MELGPT_BF16, 0);
+    int st;
+    if (getenv("STATS")) {  // the instance that also emits the output's GroupNorm partial sums
+      static float *om = nullptr, *orr = nullptr, *ws = nullptr;
+      if (!om) { hipMalloc(&om, B * 32 * 4); hipMalloc(&orr, B * 32 * 4); hipMalloc(&ws, (size_t)melgpt_conv3x3_gn_stats_workspace(B, H, W) * 4); }
+      st = melgpt_conv3x3_gn_nhwc_stats(x, B, H, W, C, mean, rstd, gamma, beta, 1, wp, C, bias, getenv("NORES") ? nullptr : res, y, MELGPT_BF16, 1e-6f, om, orr, ws, 0);
+    } else {
+      st = melgpt_conv3x3_gn_nhwc(x, B, H, W, C, mean, rstd, gamma, beta, 1, wp, C, bias, getenv("NORES") ? nullptr : res, y, MELGPT_BF16, 0);
+    }
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("status %d  %.3f ms  %.1f TFLOP/s\n", st, ms, 2.0 * B * H * W * C * 9.0 * C / ms / 1e9);
