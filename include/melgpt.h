@@ -284,6 +284,13 @@ int melgpt_layernorm_bwd_nwaves(long long M);
 int melgpt_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                          const float* rstd, const void* add_in, void* dx, float* dgamma, float* dbeta,
                          int accumulate, float* workspace, long long M, int C, int dtype, void* stream);
+/* The same pass with a second output: dx_masked = dropout_apply(dx, drop_p, seed, stream_id) - the mask replay of the
+ * branch that consumes dx next (the Block's backward, minGPT.py:107-119: x + drop(branch(LN(x)))), bit for bit what
+ * melgpt_dropout_apply makes of the stored dx.  dx_masked NULL = melgpt_layernorm_bwd. */
+int melgpt_layernorm_bwd_masked(const void* dy, const void* x, const float* gamma, const float* mean,
+                                const float* rstd, const void* add_in, void* dx, float* dgamma, float* dbeta,
+                                int accumulate, float* workspace, long long M, int C, void* dx_masked, float drop_p,
+                                unsigned long long seed, unsigned stream_id, int dtype, void* stream);
 /* out[n] (+)= sum_m a[m,n] (bias gradients).  workspace: f32 [melgpt_colsum_rows() * N]. */
 int melgpt_colsum_rows(void);
 int melgpt_colsum(const void* a, long long M, int N, long long lda, float* out, int accumulate,

@@ -74,6 +74,7 @@ _PROTOS = {
     "melgpt_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _l, _i, _f, _i, _p],
     "melgpt_layernorm_bwd_nwaves": [_l],
     "melgpt_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _l, _i, _i, _p],
+    "melgpt_layernorm_bwd_masked": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _l, _i, _p, _f, _u64, C.c_uint, _i, _p],
     "melgpt_colsum_rows": [],
     "melgpt_colsum": [_p, _l, _i, _l, _p, _i, _p, _i, _p],
     "melgpt_embed_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _l, _i, _i, _p, _i, _f, _u64, C.c_uint, _p],

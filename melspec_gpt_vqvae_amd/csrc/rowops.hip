@@ -119,7 +119,9 @@ __global__ __launch_bounds__(64 * WPB) void layernorm_bwd_kernel(const T* __rest
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
                                                             const T* __restrict__ add_in, T* __restrict__ dx,
-                                                            float* __restrict__ partials, long long M, int C) {
+                                                            float* __restrict__ partials, long long M, int C,
+                                                            T* __restrict__ dxm, float mscale, unsigned mthresh,
+                                                            unsigned long long mseed, unsigned msid) {
   constexpr int N = V16<T>::N;
   typedef typename std::conditional<sizeof(T) == 2, u32x4, f32x4>::type Raw;  // one 16-byte chunk as loaded
   const int lane = threadIdx.x & 63;
@@ -215,6 +217,20 @@ __global__ __launch_bounds__(64 * WPB) void layernorm_bwd_kernel(const T* __rest
 #pragma unroll
       for (int e = 0; e < N; ++e) o[e] += r.rs * (g[i][e] - c1 - xh[i][e] * c2);
       if (live[i]) V16<T>::st(dx + row * C + chc[i] * N, o);
+      if (dxm) {
+        // second output: dx under the dropout mask of the branch that consumes it next (melgpt_dropout_apply's
+        // result on the STORED dx, bit for bit: rounded to T first, then keep * scale) - saves that pass's read
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+          for (int e = 0; e < N; e += 2) {
+            const unsigned pk = pack_bf16x2(o[e], o[e + 1]);
+            o[e] = half_lo(pk);
+            o[e + 1] = half_hi(pk);
+          }
+        }
+        keep_mask(mseed, msid, (unsigned long long)(row * C + chc[i] * N), N, mthresh, mscale, o);
+        if (live[i]) V16<T>::st(dxm + row * C + chc[i] * N, o);
+      }
     }
   };
   RowIn ra, rb;
@@ -1042,10 +1058,15 @@ extern "C" int melgpt_layernorm_bwd_nwaves(long long M) {
   return (int)((w + 3) / 4 * 4);
 }
 
-extern "C" int melgpt_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                                    const float* rstd, const void* add_in, void* dx, float* dgamma, float* dbeta,
-                                    int accumulate, float* workspace, long long M, int C, int dtype, void* stream) {
+extern "C" int melgpt_layernorm_bwd_masked(const void* dy, const void* x, const float* gamma, const float* mean,
+                                           const float* rstd, const void* add_in, void* dx, float* dgamma,
+                                           float* dbeta, int accumulate, float* workspace, long long M, int C,
+                                           void* dx_masked, float drop_p, unsigned long long seed, unsigned stream_id,
+                                           int dtype, void* stream) {
   MELGPT_CHECK(dy && x && gamma && mean && rstd && dx && M > 0 && C > 0, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(!dx_masked || (drop_p > 0.f && drop_p < 1.f && dx_masked != dx), MELGPT_ERR_BAD_ARG);
+  const float mscale = dx_masked ? 1.f / (1.f - drop_p) : 0.f;
+  const unsigned mthresh = dx_masked ? thresh_of(drop_p) : 0u;
   MELGPT_CHECK((dgamma == nullptr) == (dbeta == nullptr), MELGPT_ERR_BAD_ARG);
   MELGPT_CHECK(!dgamma || workspace, MELGPT_ERR_BAD_ARG);
   const int vec = dtype == MELGPT_F32 ? 4 : 8;
@@ -1059,7 +1080,8 @@ extern "C" int melgpt_layernorm_bwd(const void* dy, const void* x, const float* 
 #define LN_BWD_LAUNCH(ADD_, WPB_)                                                                                         \
   DISPATCH_LN(dtype, C, hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH, ADD_, WPB_>), dim3(nwaves / WPB_), dim3(64 * WPB_), \
                                            lds, s, (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)add_in, (T*)dx, \
-                                           dgamma ? workspace : nullptr, M, C))
+                                           dgamma ? workspace : nullptr, M, C, (T*)dx_masked, mscale, mthresh, seed,      \
+                                           stream_id))
   if (add_in) {
     if (wide) { LN_BWD_LAUNCH(true, 8); } else { LN_BWD_LAUNCH(true, 4); }
   } else {
@@ -1071,6 +1093,13 @@ extern "C" int melgpt_layernorm_bwd(const void* dy, const void* x, const float* 
     launch_reduce_rows(workspace, nblocks, 2LL * C, 2LL * C, dgamma, dbeta, (long long)C, accumulate, 1.0f, s);
   }
   return melgpt_launch_status();
+}
+
+extern "C" int melgpt_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                    const float* rstd, const void* add_in, void* dx, float* dgamma, float* dbeta,
+                                    int accumulate, float* workspace, long long M, int C, int dtype, void* stream) {
+  return melgpt_layernorm_bwd_masked(dy, x, gamma, mean, rstd, add_in, dx, dgamma, dbeta, accumulate, workspace, M, C,
+                                     nullptr, 0.f, 0ull, 0u, dtype, stream);
 }
 
 extern "C" int melgpt_colsum_rows(void) { return 256; }

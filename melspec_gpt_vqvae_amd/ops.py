@@ -160,8 +160,10 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, want_stats=True):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, *, add_in=None, dgamma=None, dbeta=None, accumulate=False):
-    """returns dx (= add_in + LN'(dy)); writes dgamma/dbeta (f32, (+)= if accumulate) when given."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, *, add_in=None, dgamma=None, dbeta=None, accumulate=False, mask=None):
+    """returns dx (= add_in + LN'(dy)); writes dgamma/dbeta (f32, (+)= if accumulate) when given.
+    mask = (drop_p, seed, stream_id): returns (dx, dropout_apply(dx, drop_p, seed, stream_id)) from the same pass - the
+    mask replay of the branch that consumes dx next."""
     M, C = x.shape
     assert dy.is_contiguous() and x.is_contiguous() and dy.dtype == x.dtype
     dx = torch.empty_like(x)
@@ -169,9 +171,16 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, add_in=None, dgamma=None, dbeta=N
     if dgamma is not None:
         nw = _ffi.lib().melgpt_layernorm_bwd_nwaves(M)
         ws = workspace(nw * 2 * C, x.device)
-    call("melgpt_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(add_in), ptr(dx),
-         ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), M, C, dtype_code(x.dtype), stream())
-    return dx
+    if mask is None:
+        call("melgpt_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(add_in), ptr(dx),
+             ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), M, C, dtype_code(x.dtype), stream())
+        return dx
+    drop_p, seed, stream_id = mask
+    dxm = torch.empty_like(x)
+    call("melgpt_layernorm_bwd_masked", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(add_in), ptr(dx),
+         ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), M, C, ptr(dxm), float(drop_p), int(seed), int(stream_id),
+         dtype_code(x.dtype), stream())
+    return dx, dxm
 
 
 def colsum(a, out, accumulate=False):

@@ -95,6 +95,34 @@ class _BlockWeights:
 
 
 # ========================================================================================== functional core
+_FUSE_MASK = os.environ.get("MELGPT_LN_MASK_FUSE", "1") != "0"   # lab switch (A/B of the masked second output)
+
+
+def _ln_bwd_for_below(owner, dh, x, ln, mu, rs, **kw):
+    """LayerNorm backward whose dx is the incoming gradient of the block BELOW `owner` (owner._below): when that block
+    replays an MLP dropout mask on it, the masked copy comes out of the same pass and waits on the block
+    (`_masked_grad`, keyed by dx's address) - its backward then skips a read + write pass over (B*T, C)."""
+    below = getattr(owner, "_below", None)
+    m = getattr(below, "_mlp_mask", None) if below is not None else None
+    if m is None or not _FUSE_MASK:
+        return ops.layernorm_bwd(dh, x, ln.weight, mu, rs, **kw)
+    dx, dxm = ops.layernorm_bwd(dh, x, ln.weight, mu, rs, mask=m, **kw)
+    object.__setattr__(below, "_masked_grad", (dx.data_ptr(), tuple(dx.shape), dx.dtype, m, dxm))
+    return dx
+
+
+def _take_masked_grad(blk, dy2, mask):
+    """the masked copy of dy2 left by the producer of dy2, if it is of exactly this tensor and this mask"""
+    hit = getattr(blk, "_masked_grad", None)
+    if hit is None:
+        return None
+    object.__setattr__(blk, "_masked_grad", None)
+    ptr_, shape, dtype, m, dxm = hit
+    if ptr_ == dy2.data_ptr() and shape == tuple(dy2.shape) and dtype == dy2.dtype and m == mask:
+        return dxm
+    return None
+
+
 def _attention_core(x2d, w_qkv, b_qkv, w_proj, b_proj, *, B, T, n_head, n_unmasked, attn_p, resid_p, seed, site,
                     residual, want_att):
     """qkv projection -> fused attention -> output projection (+bias, dropout, residual).  x2d (B*T, C)."""
@@ -108,12 +136,16 @@ def _attention_core(x2d, w_qkv, b_qkv, w_proj, b_proj, *, B, T, n_head, n_unmask
 
 
 def _attention_core_bwd(dy, x2d, saved, w_qkv, w_proj, fp, blkw_params, *, B, T, n_head, n_unmasked, attn_p, resid_p,
-                        seed, site, need_dx=True):
-    """backward of _attention_core w.r.t. its input (without the residual path) and its parameters."""
+                        seed, site, need_dx=True, d_masked=None):
+    """backward of _attention_core w.r.t. its input (without the residual path) and its parameters.
+    d_masked: dy under the residual dropout's mask, when the producer of dy already wrote it."""
     qkv, a, lse = saved
     C = x2d.shape[1]
     (qkv_p, qkvb_p, proj_w, proj_b) = blkw_params
-    d = ops.dropout_apply(dy, resid_p, seed, site + 1) if resid_p > 0 else dy   # mask replay
+    if d_masked is not None:
+        d = d_masked
+    else:
+        d = ops.dropout_apply(dy, resid_p, seed, site + 1) if resid_p > 0 else dy   # mask replay
     gb, accb = fp.grad_target(proj_b)
     gw, acc = fp.grad_target(proj_w)
     # dW_proj = d^T a; the bias gradient (column sums of d) rides in the same GEMM's K loop
@@ -158,6 +190,7 @@ class _BlockFn(torch.autograd.Function):
         act = ops.gemm(h2, W.w_fc1, bias=m[0].bias, act=ops.ACT_GELU_DACT, pre_out=dact)
         y = ops.gemm(act, W.w_fc2, bias=m[2].bias, drop_p=mlp_p, seed=seed, stream_id=site + 2, residual=x1)
         ctx.blk, ctx.seed, ctx.site = blk, seed, site
+        object.__setattr__(blk, "_mlp_mask", (float(mlp_p), int(seed), site + 2) if mlp_p > 0 else None)
         ctx.cfg = (B, T, C, attn_p, resid_p, mlp_p, dt)
         ctx.save_for_backward(x2, mu1, rs1, h1, sav[0], sav[1], sav[2], x1, mu2, rs2, h2, dact, act)
         if att is None:
@@ -178,7 +211,9 @@ class _BlockFn(torch.autograd.Function):
         if dy2.dtype != dt or not dy2.is_contiguous():
             dy2 = ops.cast(dy2.contiguous(), dt)
         # ---- MLP branch: y = x1 + drop(fc2(gelu(fc1(ln2(x1)))))
-        d = ops.dropout_apply(dy2, mlp_p, seed, site + 2) if mlp_p > 0 else dy2
+        d = _take_masked_grad(blk, dy2, (float(mlp_p), int(seed), site + 2)) if mlp_p > 0 else dy2
+        if d is None:
+            d = ops.dropout_apply(dy2, mlp_p, seed, site + 2)
         gb, accb = fp.grad_target(m[2].bias)
         gw, acc = fp.grad_target(m[2].weight)
         ops.wgrad(d, act, gw, acc, bias_out=gb, bias_accumulate=accb)
@@ -190,14 +225,21 @@ class _BlockFn(torch.autograd.Function):
         g2, accg = fp.grad_target(blk.ln2.weight)
         b2, accb = fp.grad_target(blk.ln2.bias)
         assert accg == accb
-        dx1 = ops.layernorm_bwd(dh2, x1, blk.ln2.weight, mu2, rs2, add_in=dy2, dgamma=g2, dbeta=b2, accumulate=accg)
+        # (dx1 also under the residual dropout's mask, from the same pass, when that dropout is on)
+        d1m = None
+        if resid_p > 0 and _FUSE_MASK:
+            dx1, d1m = ops.layernorm_bwd(dh2, x1, blk.ln2.weight, mu2, rs2, add_in=dy2, dgamma=g2, dbeta=b2,
+                                         accumulate=accg, mask=(resid_p, seed, site + 1))
+        else:
+            dx1 = ops.layernorm_bwd(dh2, x1, blk.ln2.weight, mu2, rs2, add_in=dy2, dgamma=g2, dbeta=b2, accumulate=accg)
         # ---- attention branch: x1 = x + drop(proj(attn(ln1(x))))
         dh1 = _attention_core_bwd(dx1, h1, (qkv, a_out, lse), W.w_qkv, W.w_proj, fp,
                                   (W.qkv_p, W.qkvb_p, a.proj.weight, a.proj.bias), B=B, T=T, n_head=a.n_head,
-                                  n_unmasked=a.n_unmasked, attn_p=attn_p, resid_p=resid_p, seed=seed, site=site)
+                                  n_unmasked=a.n_unmasked, attn_p=attn_p, resid_p=resid_p, seed=seed, site=site,
+                                  d_masked=d1m)
         g1, accg = fp.grad_target(blk.ln1.weight)
         b1, accb = fp.grad_target(blk.ln1.bias)
-        dx = ops.layernorm_bwd(dh1, x2, blk.ln1.weight, mu1, rs1, add_in=dx1, dgamma=g1, dbeta=b1, accumulate=accg)
+        dx = _ln_bwd_for_below(blk, dh1, x2, blk.ln1, mu1, rs1, add_in=dx1, dgamma=g1, dbeta=b1, accumulate=accg)
         hook = getattr(blk, "_grad_ready_hook", None)
         if hook is not None:
             hook(blk)
@@ -391,7 +433,7 @@ class _HeadFn(torch.autograd.Function):
         dh = ops.gemm(d, w, b_kmajor=True)
         g, accg = fp.grad_target(gpt.ln_f.weight)
         b, accb = fp.grad_target(gpt.ln_f.bias)
-        dx = ops.layernorm_bwd(dh, x2, gpt.ln_f.weight, mu, rs, dgamma=g, dbeta=b, accumulate=accg)
+        dx = _ln_bwd_for_below(gpt, dh, x2, gpt.ln_f, mu, rs, dgamma=g, dbeta=b, accumulate=accg)
         return (dx.view(B, T, C), None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
@@ -450,6 +492,11 @@ class GPT(nn.Module):
         self.config = config
         for i, blk in enumerate(self.blocks):
             object.__setattr__(blk, "_layer_index", i)
+            # the module whose backward PRODUCES this block's incoming gradient (next block, or the head) finds the block
+            # through `_below` and writes that gradient under the block's MLP dropout mask in the same pass (_masked_grad)
+            if i + 1 < len(self.blocks):
+                object.__setattr__(self.blocks[i + 1], "_below", blk)
+        object.__setattr__(self, "_below", self.blocks[-1] if len(self.blocks) else None)
         self.compute_dtype = torch.float32
 
     def get_block_size(self):
