@@ -499,6 +499,16 @@ class LitVQVAE(_LitBase):
         self.min_adapt_weight = min_adapt_weight
         self.max_adapt_weight = max_adapt_weight
 
+    # The kernels address an activation through 32-bit buffer offsets: a full-resolution 128-channel 16-bit tensor may
+    # hold 4 GiB, i.e. 247 tiles of 80 x 848.  Inference entry points split bigger batches into chunks of this many
+    # full-resolution pixels (128 tiles of 80 x 848) - the training path is never that large (BASELINE batch 128 per GPU).
+    _CHUNK_PIXELS = 128 * 80 * 848
+
+    @classmethod
+    def _chunks(cls, B, pixels_per_item):
+        n = max(1, cls._CHUNK_PIXELS // max(1, pixels_per_item))
+        return [(i, min(B, i + n)) for i in range(0, B, n)] if B > n else None
+
     def encode(self, x):
         """reference :604-608 -> z logical (B, D, 5, 53) (channels-last strides: the flat (N, D) matrix the
         codebook kernel wants)."""
@@ -509,6 +519,9 @@ class LitVQVAE(_LitBase):
     def decode(self, quant):
         """reference :610-614."""
         _require_cuda(quant)
+        ck = None if torch.is_grad_enabled() else self._chunks(quant.shape[0], 256 * quant.shape[2] * quant.shape[3])
+        if ck is not None:
+            return torch.cat([self.decode(quant[a:b]) for a, b in ck], 0)
         dt = _cdtype(self._decoder)
         q = _conv(self.post_quant_conv, ops.to_nhwc(quant, dt))
         return _as_nchw(self._decoder._nhwc(_as_nchw(q)))
@@ -521,6 +534,9 @@ class LitVQVAE(_LitBase):
         codebook image - z is never formed; f32 parity lane (or fused=False): quant_conv, then the reference's
         (|x|^2 + |e|^2) - 2 x.e on the real z."""
         _require_cuda(x)
+        ck = self._chunks(x.shape[0], x.shape[2] * x.shape[3])
+        if ck is not None:
+            return torch.cat([self.encode_to_codes(x[a:b], fused) for a, b in ck], 0)
         h = self._encoder._nhwc(x)
         if fused is None:
             fused = h.dtype == _ffi.HALF_DTYPE

@@ -145,6 +145,30 @@ def test_full_vqvae_tile_to_codes_vs_reference_golden():
     assert rel_err(rec.float().cpu().numpy(), g["rec"]) < 1e-4
 
 
+def test_oversized_inference_batches_are_split_and_give_the_same_results(monkeypatch):
+    """encode_to_codes / decode split a batch whose full-resolution activation would pass the kernels' 4 GiB buffer range
+    (LitVQVAE._chunks): with the budget lowered to one tile per chunk, three tiles give the codes and the reconstruction
+    of the unsplit call bit for bit (GroupNorm statistics are per image, nothing couples the tiles)."""
+    from melspec_gpt_vqvae_amd.vqvae.big_model_attn_gan import LitVQVAE
+
+    assert LitVQVAE._chunks(128, 80 * 848) is None and LitVQVAE._chunks(256, 80 * 848) == [(0, 128), (128, 256)]
+    assert LitVQVAE._chunks(300, 256 * 5 * 53) == [(0, 128), (128, 256), (256, 300)]
+    g = golden("vqvae_full")
+    m = LitVQVAE(num_embeddings=128, embedding_dim=256)
+    _load(m, synth.vqvae_state_dict(int(g["seed"])), allow_missing_prefix="discriminator.")
+    m.to(DEV).eval()
+    x = t(g["x"], DEV)
+    x3 = torch.cat([x, x[:1].flip(-1)], 0)
+    with torch.no_grad():
+        codes = m.encode_to_codes(x3)
+        q = m._vq_vae.get_codebook_entry(codes.reshape(-1), shape=(3, 5, 53, 256))
+        rec = m.decode(q)
+        monkeypatch.setattr(LitVQVAE, "_CHUNK_PIXELS", 80 * 848)
+        assert LitVQVAE._chunks(3, 80 * 848) == [(0, 1), (1, 2), (2, 3)]
+        assert torch.equal(m.encode_to_codes(x3), codes)
+        assert torch.equal(m.decode(q), rec)
+
+
 def test_full_vqvae_bf16_lane_reports_code_agreement():
     """bf16 throughput lane of the encoder: reported (not gated at 1e-4) - latent error and code agreement."""
     from melspec_gpt_vqvae_amd.vqvae.big_model_attn_gan import LitVQVAE, set_compute_dtype
