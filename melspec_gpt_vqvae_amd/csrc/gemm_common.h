@@ -298,7 +298,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
     // (RALL: the plain bf16 mode requests ALL its slabs up front: the loads are ordinary, counted loads - the persistent
     // kernel's LDS-DMA is invisible to the compiler since round 2 - so only the first slab's latency is exposed; the
     // implicit-GEMM convolution's 256-row instantiation has no registers for it)
-    constexpr int NB = (MODE == EPI_GENERIC || ROLLED) ? (TM < 2 ? 1 : 2) : (RALL && MODE == EPI_PLAIN16 ? TM : (TM + 1) / 2);
+    // (the lean dropout + residual mode at 192 rows sits at 191 VGPRs: all six slabs' R up front as well - one exposed
+    // latency per tile instead of two)
+    constexpr int NB = (MODE == EPI_GENERIC || ROLLED) ? (TM < 2 ? 1 : 2)
+                       : ((RALL && MODE == EPI_PLAIN16) || (MODE == EPI_DROPR16 && TM <= 6) ? TM : (TM + 1) / 2);
     u32x4 rin[NB][NR];
     auto fetch_r = [&](long long mr, u32x4 (&dst)[NR]) {
       if constexpr (ES == 2 && PLAN16) {  // same geometry as the bf16 output slab: the plan's rows and pieces
