@@ -20,6 +20,11 @@ static float run(int alay, int blay, int M, int N, int K, int cfg, int iters, in
   p.a_bytes = (unsigned)(an * 2); p.b_bytes = (unsigned)(bn * 2);
   p.alpha = 1.f; p.vec_io = 1;
   void *C2 = nullptr, *R = nullptr; float* bias = nullptr;
+  if (!full && getenv("BIAS")) {  // the plain modes with a bias vector (what the step's Linear layers pass)
+    hipMalloc(&bias, (size_t)N * 4);
+    hipMemset(bias, 0, (size_t)N * 4);
+    p.bias = bias;
+  }
   if (full) {
     hipMalloc(&C2, (size_t)M * N * 2); hipMalloc(&R, (size_t)M * N * 2); hipMalloc(&bias, (size_t)N * 4);
     hipMemset(R, 0, (size_t)M * N * 2); hipMemset(bias, 0, (size_t)N * 4);
