@@ -193,13 +193,35 @@ __device__ unsigned long long melgpt_convw_dbg[64];
 __device__ unsigned long long melgpt_convw_dbg2[16];
 #endif
 
-constexpr int WTH = 16, WTW = 16, WPH = WTH + 2, WPW = WTW + 2, WNPIX = WPH * WPW, WNST = 4;
+constexpr int WNST = 4;
+// Output tile of the persistent kernel: 16 x 16 pixels, or 8 x 32 (W8) where the height pads badly to 16 rows (40 x 424:
+// 3 x 27 tiles of 16 x 16 compute 20 % more pixels than the image has, 5 x 14 of 8 x 32 compute 6 %).  Either way 16
+// row-blocks of 16 consecutive pixels; row-block rb sits at tile row rb (16 x 16) or row rb / 2, columns 16 (rb % 2) ...
+template <bool W8>
+struct WideTile {
+  static constexpr int TH = W8 ? 8 : 16, TW = W8 ? 32 : 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW;
+  static __device__ __forceinline__ int row(int rb) { return W8 ? rb >> 1 : rb; }
+  static __device__ __forceinline__ int xh(int rb) { return W8 ? (rb & 1) * 16 : 0; }
+};
+// (host) the shape a layer runs with: 8 x 32 when it computes fewer pixels and the last column tile's second half is
+// either whole or empty (the epilogue takes ONE valid-pixel count per tile)
+static bool wide_w8(int H, int W) {
+  static int off = -1;  // lab switch: MELGPT_CONV_W8=0 keeps every layer on 16 x 16 tiles
+  if (off < 0) off = getenv("MELGPT_CONV_W8") && atoi(getenv("MELGPT_CONV_W8")) == 0;
+  if (off) return false;
+  const long long p16 = (long long)((H + 15) / 16) * ((W + 15) / 16), p8 = (long long)((H + 7) / 8) * ((W + 31) / 32);
+  return p8 < p16 && (W % 32 == 0 || W % 32 <= 16);
+}
+static int wide_tiles_x(int H, int W) { return wide_w8(H, W) ? (W + 31) / 32 : (W + 15) / 16; }
+static int wide_tiles_y(int H, int W) { return wide_w8(H, W) ? (H + 7) / 8 : (H + 15) / 16; }
 
 // STATS: also emit the GroupNorm partial sums of the output tile (a separate instance: its extra live values would cost
 // the plain one 8 spilled VGPRs)
-template <bool STATS>
+template <bool STATS, bool W8>
 __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q, int total_tiles) {
   typedef bf16_t T;
+  typedef WideTile<W8> WT;
+  constexpr int WTH = WT::TH, WTW = WT::TW, WPW = WT::PW, WNPIX = WT::NPIX;
   constexpr int ES = 2, KSTEP = 64, VEC = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const GemmParams& p = q.g;
@@ -332,7 +354,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int hp = 0; hp < 2; ++hp) {
-        const int y = y0 + wm * 4 + mt, x = x0 + hp * 8 + (lane >> 3), n = n0 + wn * 64 + (lane & 7) * 8;
+        const int y = y0 + WT::row(wm * 4 + mt), x = x0 + WT::xh(wm * 4 + mt) + hp * 8 + (lane >> 3), n = n0 + wn * 64 + (lane & 7) * 8;
         const bool ok = p.R && y < q.H && x < q.W && n < p.N;
         const unsigned off = ok ? (unsigned)(((((long long)b * q.H + y) * q.W + x) * p.ldr + n) * ES) : OOB;
         rrow[mt][hp] = buf_load16(rres, off);
@@ -420,7 +442,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
           u32x4 fa[4], fb[4];
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) {
-            const int pix = (wm * 4 + mt + ky) * WPW + i16 + kx;  // output row (wm*4+mt), shifted by the tap
+            const int pix = (WT::row(wm * 4 + mt) + ky) * WPW + WT::xh(wm * 4 + mt) + i16 + kx;  // row-block wm*4+mt, shifted by the tap
             fa[mt] = *(const u32x4*)(patch + patch_off<T>(pix, kc * 8 + 4 * ks + g, pix_bytes));
           }
 #pragma unroll
@@ -448,12 +470,11 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
       // pass over the 2.2 GB tensor.  Per tile a (32, 2) partial, summed across the four pixel-row waves in wave
       // order; melgpt_groupnorm_finalize adds the tiles of an image in tile order.
       float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-      const bool xin = x0 + i16 < q.W;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-          if (xin && y0 + wm * 4 + mt < q.H) {
+          if (x0 + WT::xh(wm * 4 + mt) + i16 < q.W && y0 + WT::row(wm * 4 + mt) < q.H) {
             // rounded as the epilogue will round them, two values per v_cvt_pk (bias and residual are in the accumulators)
 #pragma unroll
             for (int e = 0; e < 4; e += 2) {
@@ -496,15 +517,16 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
     long long mrow[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      const int y = y0 + wm * 4 + mt;
-      mrow[mt] = (y < q.H) ? ((long long)b * q.H + y) * q.W + x0 : -1;
+      const int y = y0 + WT::row(wm * 4 + mt), xs = x0 + WT::xh(wm * 4 + mt);
+      mrow[mt] = (y < q.H && xs < q.W) ? ((long long)b * q.H + y) * q.W + xs : -1;
     }
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));  // keep the epilogue's per-lane offsets out of the tile loop's live range
     GemmParams pe = p;  // (bias and residual are in the accumulators: the loadless plain mode)
     pe.bias = nullptr;
     pe.R = nullptr;
-    epilogue_rows<T, 4, 4, EPI_PLAIN16N>(pe, acc, mrow, min(WTW, q.W - x0), n0 + wn * 64, 0, lane_e, smem + w * 4096);
+    // (valid pixels of a row-block: the launcher picks 8 x 32 only where the second half of the last column tile is whole or empty)
+    epilogue_rows<T, 4, 4, EPI_PLAIN16N>(pe, acc, mrow, min(16, q.W - x0), n0 + wn * 64, 0, lane_e, smem + w * 4096);
 #if CONVW_LAB
     if (blockIdx.x == 7 && t == 0) {
       const int k = (tile - 7) / gridDim.x;
@@ -519,11 +541,12 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-int launch_fused_wide(const FusedConvParams& q0, int B, hipStream_t s) {
+template <bool W8>
+int launch_fused_wide_t(const FusedConvParams& q0, int B, hipStream_t s) {
   FusedConvParams q = q0;
-  q.tiles_x = (q.W + WTW - 1) / WTW;
-  q.tiles_y = (q.H + WTH - 1) / WTH;
-  const size_t lds = (size_t)WNPIX * q.Cin * 2 + WNST * 16384 + (size_t)q.Cin * 8 + 1024 + 8 * 1024 + (size_t)q.Cin * 8;
+  q.tiles_x = (q.W + WideTile<W8>::TW - 1) / WideTile<W8>::TW;
+  q.tiles_y = (q.H + WideTile<W8>::TH - 1) / WideTile<W8>::TH;
+  const size_t lds = (size_t)WideTile<W8>::NPIX * q.Cin * 2 + WNST * 16384 + (size_t)q.Cin * 8 + 1024 + 8 * 1024 + (size_t)q.Cin * 8;
   if (q.Cin > 512 || lds > 160 * 1024) return MELGPT_ERR_UNSUPPORTED;
   static int ncu = 0;
   if (!ncu) {
@@ -531,9 +554,9 @@ int launch_fused_wide(const FusedConvParams& q0, int B, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
       return MELGPT_ERR_LAUNCH;
-    if (hipFuncSetAttribute((const void*)conv3x3_gn_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)conv3x3_gn_wide_kernel<false, W8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv3x3_gn_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void*)conv3x3_gn_wide_kernel<true, W8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return MELGPT_ERR_LAUNCH;
     ncu = n;
@@ -547,11 +570,14 @@ int launch_fused_wide(const FusedConvParams& q0, int B, hipStream_t s) {
   if (gx > total) gx = (int)total;
   if (q.stat_part) {
     if (gy != 1) return MELGPT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(conv3x3_gn_wide_kernel<true>, dim3(gx, gy), dim3(512), lds, s, q, (int)total);
+    hipLaunchKernelGGL((conv3x3_gn_wide_kernel<true, W8>), dim3(gx, gy), dim3(512), lds, s, q, (int)total);
   } else {
-    hipLaunchKernelGGL(conv3x3_gn_wide_kernel<false>, dim3(gx, gy), dim3(512), lds, s, q, (int)total);
+    hipLaunchKernelGGL((conv3x3_gn_wide_kernel<false, W8>), dim3(gx, gy), dim3(512), lds, s, q, (int)total);
   }
   return melgpt_launch_status();
+}
+int launch_fused_wide(const FusedConvParams& q, int B, hipStream_t s) {
+  return wide_w8(q.H, q.W) ? launch_fused_wide_t<true>(q, B, s) : launch_fused_wide_t<false>(q, B, s);
 }
 
 template <typename T>
@@ -606,12 +632,13 @@ static int conv3x3_gn_impl(const void* x, int B, int H, int W, int Cin, const fl
   if (stat_part && (dtype != MELGPT_BF16 || Cout != 128)) return MELGPT_ERR_UNSUPPORTED;
   if (dtype == MELGPT_F32) return launch_fused<float>(q, B, s);
   // narrow bf16 layers with plenty of 16 x 16 tiles: the persistent kernel with the weight ring
-  const size_t wide_lds = (size_t)WNPIX * Cin * 2 + WNST * 16384 + (size_t)Cin * 8 + 1024 + 8 * 1024;
-  const long long wide_tiles = (long long)((W + WTW - 1) / WTW) * ((H + WTH - 1) / WTH) * B;
+  const bool w8 = wide_w8(H, W);
+  const size_t wide_lds = (size_t)(w8 ? WideTile<true>::NPIX : WideTile<false>::NPIX) * Cin * 2 + WNST * 16384 + (size_t)Cin * 16 + 1024 + 8 * 1024;
+  const long long wide_tiles = (long long)wide_tiles_x(H, W) * wide_tiles_y(H, W) * B;
   static int wide_off = -1;
   if (wide_off < 0) wide_off = getenv("MELGPT_CONV_WIDE") && atoi(getenv("MELGPT_CONV_WIDE")) == 0;
   // 16-row tiles pay for the rows they pad: take them only while they compute at most 1/4 more pixels than 8-row tiles
-  const long long wide_px = wide_tiles * WTH * WTW, narrow_px = (long long)q.tiles_x * q.tiles_y * B * TH * TW;
+  const long long wide_px = wide_tiles * 256, narrow_px = (long long)q.tiles_x * q.tiles_y * B * TH * TW;
   if (!wide_off && wide_lds <= 160 * 1024 && wide_tiles >= 512 && wide_px * 4 <= narrow_px * 5 && q.g.vec_io &&
       Cin == 128 &&
       M * Cin * 2 < 0xFFFFFF00LL && (!residual || M * Cout * 2 < 0xFFFFFF00LL)) {
@@ -631,7 +658,7 @@ extern "C" int melgpt_conv3x3_gn_nhwc(const void* x, int B, int H, int W, int Ci
 }
 
 extern "C" int melgpt_conv3x3_gn_stats_workspace(int B, int H, int W) {
-  return B * ((W + WTW - 1) / WTW) * ((H + WTH - 1) / WTH) * 64;
+  return B * wide_tiles_x(H, W) * wide_tiles_y(H, W) * 64;
 }
 
 extern "C" int melgpt_conv3x3_gn_nhwc_stats(const void* x, int B, int H, int W, int Cin, const float* mean,
@@ -643,6 +670,6 @@ extern "C" int melgpt_conv3x3_gn_nhwc_stats(const void* x, int B, int H, int W, 
   int st = conv3x3_gn_impl(x, B, H, W, Cin, mean, rstd, gamma, beta, swish, wpack, Cout, bias, residual, y, dtype,
                            workspace, stream);
   if (st != MELGPT_OK) return st;
-  const int nchunks = ((W + WTW - 1) / WTW) * ((H + WTH - 1) / WTH);
+  const int nchunks = wide_tiles_x(H, W) * wide_tiles_y(H, W);
   return melgpt_groupnorm_finalize(workspace, nchunks, B, (double)H * W * (Cout / 32), out_eps, out_mean, out_rstd, stream);
 }

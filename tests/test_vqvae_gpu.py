@@ -250,6 +250,14 @@ def test_fused_conv_also_yields_groupnorm_stats_of_its_output(H, W, B, with_res)
         pytest.skip("this shape does not run on the persistent fused kernel")
     y, (mean, rstd) = r
     assert torch.equal(y, y0)
+    # the persistent kernel against torch's own GroupNorm -> swish -> conv2d in f32 (16 x 16-pixel tiles at 80 x 848 and
+    # 37 x 250, 8 x 32 at 40 x 424; edge tiles in both)
+    h = F.group_norm(x.float().permute(0, 3, 1, 2), 32, gm, bt, eps=1e-6)
+    h = (h * torch.sigmoid(h)).to(torch.bfloat16).float()
+    ref = F.conv2d(h, w.float().to(DEV), bias, padding=1).permute(0, 2, 3, 1)
+    if with_res:
+        ref = ref + res.float()
+    assert rel_err(y.float().cpu().numpy(), ref.cpu().numpy()) < 8e-3
     m2, r2 = ops.groupnorm_stats(y, 1e-6)
     assert float((mean - m2).abs().max()) < 2e-5 * max(1.0, float(m2.abs().max()))
     assert float(((rstd - r2) / r2).abs().max()) < 1e-4
