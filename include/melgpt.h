@@ -341,6 +341,18 @@ int melgpt_vae_reparam_fwd(const float* stats, float* eps, int gen_eps, unsigned
                            int nz, float* z, float* kl, void* stream);
 int melgpt_vae_reparam_bwd(const float* stats, const float* eps, const float* dz, const float* dkl, int B, int ns,
                            int nz, float* dstats, void* stream);
+/* GPTEncoder.eval_inference_dist (encoders.py:106-134) and the density table inside calc_mi (:154-163):
+ * log N(z; mu, exp(logvar)), statistics rows mu / logvar (X, nz) f32 at row pitch ld_stats.  pairwise == 0: z (X, S, nz),
+ * out[x][s] = density of z[x][s] under row x's own statistics (out (X, S)); pairwise != 0: z (S, nz),
+ * out[i][x] = density of z[i] under row x's statistics (out (S, X)). */
+int melgpt_gauss_log_density(const float* z, const float* mu, const float* logvar, long long ld_stats, int X, int S,
+                             int nz, int pairwise, float* out, void* stream);
+/* GPTEncoder.calc_mi (encoders.py:136-170; utils.log_sum_exp :6-19): the mutual-information estimate
+ * E log q(z|x) - E log q(z) with one reparameterised draw per row and the batch mixture as aggregate posterior.
+ * eps (B, nz): the draw's noise - an input (gen_eps == 0) or drawn in-kernel and written (as melgpt_vae_reparam_fwd).
+ * workspace: B * nz + B floats.  mi: one f32. */
+int melgpt_vae_calc_mi(const float* mu, const float* logvar, long long ld_stats, float* eps, int gen_eps,
+                       unsigned long long seed, int B, int nz, float* workspace, float* mi, void* stream);
 int melgpt_sum_f32(const float* in, long long n, float scale, float* out, int accumulate, void* stream);
 /* y = keep(x)/(1-p) with the same Philox mask an epilogue used for element i of a contiguous tensor */
 int melgpt_dropout_apply(const void* x, void* y, long long n, float drop_p, unsigned long long seed,

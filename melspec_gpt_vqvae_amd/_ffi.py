@@ -86,6 +86,8 @@ _PROTOS = {
     "melgpt_sample_logits_dev": [_p, _l, _i, _i, _f, _i, _i, _u64, _p, _i, _p, _p, _l, _p],
     "melgpt_vae_reparam_fwd": [_p, _p, _i, _u64, _i, _i, _i, _p, _p, _p],
     "melgpt_vae_reparam_bwd": [_p, _p, _p, _p, _i, _i, _i, _p, _p],
+    "melgpt_gauss_log_density": [_p, _p, _p, _l, _i, _i, _i, _i, _p, _p],
+    "melgpt_vae_calc_mi": [_p, _p, _l, _p, _i, _u64, _i, _i, _p, _p, _p],
     "melgpt_sum_f32": [_p, _l, _f, _p, _i, _p],
     "melgpt_dropout_apply": [_p, _p, _l, _f, _u64, C.c_uint, _i, _p],
     "melgpt_dropout_apply_colsum": [_p, _p, _l, _i, _f, _u64, C.c_uint, _p, _i, _p, _i, _p],

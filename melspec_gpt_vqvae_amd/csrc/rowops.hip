@@ -991,6 +991,90 @@ __global__ void vae_reparam_bwd_kernel(const float* __restrict__ stats, const fl
   dstats[(long long)b * 2 * nz + nz + c] = dl;
 }
 
+// GPTEncoder.eval_inference_dist and the density table of calc_mi (encoders.py:106-134, 154-163):
+// log N(z; mu, exp(logvar)) = -0.5 sum_c (z - mu)^2 / exp(logvar) - 0.5 (nz log 2pi + sum_c logvar).  One WAVE per
+// (z row, statistics row) pair.  pairwise == 0: z (X, S, nz), pair p = (x, s) uses row x's statistics -> out (X, S);
+// pairwise != 0: z (S, nz), pair p = (i, x): z row i under row x's statistics -> out (S, X).
+__device__ __forceinline__ float gauss_logq_wave(const float* __restrict__ zr, const float* __restrict__ mu,
+                                                 const float* __restrict__ lv, int nz, int lane) {
+  float q = 0.f, sl = 0.f;
+  for (int c = lane; c < nz; c += 64) {
+    const float l = lv[c], d = zr[c] - mu[c];
+    q += d * d / expf(l);
+    sl += l;
+  }
+  q = wave_sum(q);
+  sl = wave_sum(sl);
+  return -0.5f * q - 0.5f * ((float)nz * 1.8378770664093453f + sl);  // log(2 pi)
+}
+
+__global__ __launch_bounds__(256) void gauss_log_density_kernel(const float* __restrict__ z, const float* __restrict__ mu,
+                                                                const float* __restrict__ logvar, long long ld_stats, int X,
+                                                                int S, int nz, int pairwise, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long pair = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), npairs = (long long)X * S;
+  if (pair >= npairs) return;
+  const long long zrow = pairwise ? pair / X : pair;
+  const int x = pairwise ? (int)(pair - zrow * X) : (int)(pair / S);
+  const float v = gauss_logq_wave(z + zrow * nz, mu + x * ld_stats, logvar + x * ld_stats, nz, lane);
+  if (lane == 0) out[pair] = v;
+}
+
+// GPTEncoder.calc_mi (encoders.py:136-170), one workgroup per row i of the batch: z_i = mu_i + eps_i exp(logvar_i / 2)
+// (ONE draw per row, given or drawn as in vae_reparam_fwd_kernel), log q(z_i | x_j) for every j (a wave per j), the
+// aggregate posterior log q(z_i) = logsumexp_j - log B (utils.log_sum_exp: max first), and the row's entropy term;
+// term[i] = (-0.5 nz log 2pi - 0.5 sum_c (1 + logvar_i)) - log q(z_i).  MI = mean_i term[i] (melgpt_sum_f32).
+__global__ __launch_bounds__(256) void vae_calc_mi_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                                                          long long ld_stats, float* __restrict__ eps, int gen_eps,
+                                                          unsigned long long seed, int B, int nz,
+                                                          float* __restrict__ zbuf, float* __restrict__ term) {
+  __shared__ float sm[4], ss[4];
+  const int i = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const float* mi = mu + i * ld_stats;
+  const float* li = logvar + i * ld_stats;
+  float* zi = zbuf + (long long)i * nz;
+  for (int c = t; c < nz; c += 256) {
+    const long long o = (long long)i * nz + c;
+    float e;
+    if (gen_eps) {
+      Philox4 r = philox4x32_10(seed, (unsigned long long)o, 0x7AE5u);
+      const float u1 = ((r.x >> 8) + 1.0f) * (1.0f / 16777217.0f), u2 = (r.y >> 8) * (1.0f / 16777216.0f);
+      e = sqrtf(-2.0f * __logf(u1)) * cospif(2.0f * u2);
+      eps[o] = e;
+    } else {
+      e = eps[o];
+    }
+    zi[c] = mi[c] + e * expf(0.5f * li[c]);
+  }
+  __syncthreads();  // (zi is read back by this workgroup only)
+  float m = -INFINITY, sum = 0.f;  // running max / sum of exp over this wave's j (wave-uniform)
+  for (int j = w; j < B; j += 4) {
+    const float v = gauss_logq_wave(zi, mu + j * ld_stats, logvar + j * ld_stats, nz, lane);
+    const float mn = fmaxf(m, v);
+    sum = sum * expf(m - mn) + expf(v - mn);
+    m = mn;
+  }
+  if (lane == 0) {
+    sm[w] = m;
+    ss[w] = sum;
+  }
+  float sl = 0.f;
+  for (int c = t; c < nz; c += 256) sl += 1.0f + li[c];
+  __shared__ float sh[256];
+  sh[t] = sl;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) sh[t] += sh[t + o];
+    __syncthreads();
+  }
+  if (t == 0) {
+    float mm = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])), tot = 0.f;
+    for (int k = 0; k < 4; ++k) tot += sm[k] == -INFINITY ? 0.f : ss[k] * expf(sm[k] - mm);
+    const float log_qz = mm + logf(tot) - logf((float)B);
+    term[i] = (-0.5f * (float)nz * 1.8378770664093453f - 0.5f * sh[0]) - log_qz;
+  }
+}
+
 inline int grid_for(long long work_items, int per_block, int cap = 8192) {
   long long g = (work_items + per_block - 1) / per_block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -1314,6 +1398,28 @@ extern "C" int melgpt_vae_reparam_fwd(const float* stats, float* eps, int gen_ep
   hipLaunchKernelGGL(vae_reparam_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, stats, eps, gen_eps, seed, B, ns,
                      nz, z, kl);
   return melgpt_launch_status();
+}
+
+extern "C" int melgpt_gauss_log_density(const float* z, const float* mu, const float* logvar, long long ld_stats, int X,
+                                        int S, int nz, int pairwise, float* out, void* stream) {
+  MELGPT_CHECK(z && mu && logvar && out && X > 0 && S > 0 && nz > 0 && ld_stats >= nz, MELGPT_ERR_BAD_ARG);
+  const long long pairs = (long long)X * S;
+  MELGPT_CHECK(pairs <= 0x7FFFFFFFLL * 4, MELGPT_ERR_UNSUPPORTED);
+  hipLaunchKernelGGL(gauss_log_density_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z, mu,
+                     logvar, ld_stats, X, S, nz, pairwise, out);
+  return melgpt_launch_status();
+}
+
+extern "C" int melgpt_vae_calc_mi(const float* mu, const float* logvar, long long ld_stats, float* eps, int gen_eps,
+                                  unsigned long long seed, int B, int nz, float* workspace, float* mi, void* stream) {
+  MELGPT_CHECK(mu && logvar && eps && workspace && mi && B > 0 && nz > 0 && ld_stats >= nz, MELGPT_ERR_BAD_ARG);
+  float* zbuf = workspace;                         // (B, nz)
+  float* term = workspace + (long long)B * nz;     // (B,)
+  hipLaunchKernelGGL(vae_calc_mi_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mu, logvar, ld_stats, eps, gen_eps,
+                     seed, B, nz, zbuf, term);
+  int st = melgpt_launch_status();
+  if (st != MELGPT_OK) return st;
+  return melgpt_sum_f32(term, B, 1.0f / (float)B, mi, 0, stream);
 }
 
 extern "C" int melgpt_vae_reparam_bwd(const float* stats, const float* eps, const float* dz, const float* dkl, int B,

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void conv_in_c1_stats_kernel(const TI* __restr
   int p = p0 + pl;
   int yh = p / W, xw = p - yh * W;
   for (; p < p1; p += 16, xw += 16) {
-    if (xw >= W) {
+    while (xw >= W) {  // (a loop: images narrower than the 16-pixel stride wrap more than once per trip)
       xw -= W;
       ++yh;
     }

@@ -139,6 +139,13 @@ class DataParallel:
         if self._on_gpu:
             _ffi.call("melgpt_set_reserved_cus", 0)
         self.hook_calls = 0           # Block hooks fired since construction (tests count them)
+        # which parameters got a gradient this step must be the SAME on every rank: FusedAdamW skips a parameter whose
+        # .grad is None (torch.optim.AdamW's rule) and decides that per rank, so a parameter missing on one rank only
+        # would be restored there and stepped elsewhere - silently diverging replicas (the reference's DDP raises).  The
+        # has-gradient bitmask is all-reduced with the gradients; the first step is checked synchronously, later steps
+        # through a pinned host flag read at the next finish() (no extra host synchronisation per step).
+        self._mask_steps = 0
+        self._mask_flag = None        # (pinned host tensor, event) of the previous step's check
         self._segs = {}
         self.blocks = [m for m in module.modules() if hasattr(m, "_layer_index") and hasattr(m, "attn")]
         if active and self.overlap:
@@ -168,10 +175,47 @@ class DataParallel:
         step - zeroed first so that no stale slice is summed), then wait for every launched piece."""
         if self.ex.active:
             self.fp.zero_missing_grads()
+        self._check_grad_sets()
         self.ex.finish()
         self._reserve(False)  # everything launched after this is stream-ordered behind the last all-reduce
 
+    def _raise_if_flagged(self, wait):
+        if self._mask_flag is None:
+            return
+        host, ev = self._mask_flag
+        if ev is not None:
+            if not wait and not ev.query():
+                return
+            ev.synchronize()
+        self._mask_flag = None
+        if int(host.item()) != 0:
+            raise RuntimeError("data-parallel ranks disagree on which parameters received a gradient this step "
+                               "(a parameter with .grad None on some ranks only): the replicas would diverge - "
+                               "make the unused branch the same on every rank")
+
+    def _check_grad_sets(self):
+        """all-reduce the has-gradient bitmask of the flat store's parameters; see __init__."""
+        if self.world <= 1:
+            return
+        self._raise_if_flagged(wait=False)
+        has = torch.tensor([0.0 if p.grad is None else 1.0 for p in self.fp.params], dtype=torch.float32)
+        has = has.to(self.fp.device, non_blocking=True)
+        dist.all_reduce(has, op=dist.ReduceOp.SUM, group=self.ex.group)
+        bad = ((has != 0) & (has != float(self.world))).any().to(torch.int32).reshape(1)
+        if self._on_gpu:
+            host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            host.copy_(bad, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._mask_flag = (host, ev)
+        else:
+            self._mask_flag = (bad.clone(), None)
+        self._mask_steps += 1
+        if self._mask_steps == 1 or not self._on_gpu:
+            self._raise_if_flagged(wait=True)
+
     def detach(self):
+        self._raise_if_flagged(wait=True)
         for blk in self.blocks:
             if getattr(blk, "_grad_ready_hook", None) is not None:
                 object.__setattr__(blk, "_grad_ready_hook", None)

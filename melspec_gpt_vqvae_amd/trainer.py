@@ -80,6 +80,7 @@ class Fit:
                 self.dp.finish()
             if self._step_ok():
                 self.opt.step()
+            self._grow_loss_scale()
             self.global_step += 1
             losses.append(loss.detach())
             freq = int(getattr(self.args, "logging_frequency", 200) or 200)
@@ -101,7 +102,10 @@ class Fit:
 
     def _step_ok(self):
         """fp16 lane only: is the (scaled, reduced) gradient finite?  One fused sum over the flat buffer and one host
-        read per step; an overflow skips the step and halves the scale, 200 clean steps double it (up to 65 536)."""
+        read per step; an overflow skips the step and halves the scale at once (the step is not taken, so nothing sees the
+        new factor with the old gradient); 200 clean steps double it (up to 65 536) - but only AFTER `opt.step()` has
+        consumed this backward's gradient with the grad_scale that matches the scale it was produced at
+        (`_grow_loss_scale`)."""
         if not self.fp16:
             return True
         from . import ops
@@ -112,15 +116,19 @@ class Fit:
         ok = bool(torch.isfinite(ops.sum_f32(fp.grad)).item())
         if ok:
             self._good_steps += 1
-            if self._good_steps >= 200 and self.loss_scale < 65536.0:
-                self.loss_scale *= 2.0
-                self._good_steps = 0
         else:
             self.skipped_steps += 1
             self._good_steps = 0
             self.loss_scale = max(1.0, self.loss_scale / 2.0)
-        self.opt.grad_scale = 1.0 / (self.world * self.loss_scale)
+            self.opt.grad_scale = 1.0 / (self.world * self.loss_scale)
         return ok
+
+    def _grow_loss_scale(self):
+        """fp16 lane, after the optimizer step: 200 clean steps in a row double the loss scale for the NEXT backward."""
+        if self.fp16 and self._good_steps >= 200 and self.loss_scale < 65536.0:
+            self.loss_scale *= 2.0
+            self._good_steps = 0
+            self.opt.grad_scale = 1.0 / (self.world * self.loss_scale)
 
     @torch.no_grad()
     def validate(self):

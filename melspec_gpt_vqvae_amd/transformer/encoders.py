@@ -1,6 +1,7 @@
 """GPT encoder of the GPT-VAE on the HIP kernels - mirror of the reference's transformer/encoders.py
-(GPTEncoder :11-104): an unmasked GPT whose last position yields (mu, logvar); reparameterisation and the KL term
-run in one kernel (melgpt_vae_reparam_fwd / _bwd)."""
+(GPTEncoder :11-170): an unmasked GPT whose last position yields (mu, logvar); reparameterisation and the KL term
+run in one kernel (melgpt_vae_reparam_fwd / _bwd); the eval-time analytics log q(z|x) and the mutual-information
+estimate are one launch each (melgpt_gauss_log_density, melgpt_vae_calc_mi)."""
 from __future__ import annotations
 
 import math
@@ -81,3 +82,38 @@ class GPTEncoder(nn.Module):
             mu, _ = last_state.chunk(2, -1)
             last_state = torch.cat((mu, mu.new_full(mu.shape, math.log(self.args.fix_var))), -1)
         return _ReparamFn.apply(last_state, eps, nsamples, _Seeds.next())
+
+    @staticmethod
+    def _f32(v):
+        return v.detach().float().contiguous()
+
+    @torch.no_grad()
+    def eval_inference_dist(self, x, z, param=None):
+        """log q(z|x) of z (batch, nsamples, nz) under the row's own posterior -> (batch, nsamples); `param` =
+        (mu, logvar) skips the encoder pass - reference :106-134."""
+        if not param:
+            mu, logvar, _ = self.forward(x)
+        else:
+            mu, logvar = param
+        mu, logvar, z = self._f32(mu), self._f32(logvar), self._f32(z)
+        B, S, nz = z.shape
+        assert mu.shape == (B, nz) and logvar.shape == (B, nz)
+        out = torch.empty(B, S, dtype=torch.float32, device=z.device)
+        _ffi.call("melgpt_gauss_log_density", _ffi.ptr(z), _ffi.ptr(mu), _ffi.ptr(logvar), nz, B, S, nz, 0, _ffi.ptr(out),
+                  _ffi.stream())
+        return out
+
+    @torch.no_grad()
+    def calc_mi(self, x, eps=None):
+        """I(x, z) ~ E_x E_q(z|x) log q(z|x) - E_x E_q(z|x) log q(z) -> Python float - reference :136-170.  The one
+        reparameterised draw per row uses `eps` (batch, 1, nz) when given, else noise drawn in-kernel."""
+        mu, logvar, _ = self.forward(x)
+        mu, logvar = self._f32(mu), self._f32(logvar)
+        B, nz = mu.shape
+        gen = eps is None
+        e = torch.empty(B, nz, dtype=torch.float32, device=mu.device) if gen else self._f32(eps).reshape(B, nz)
+        ws = torch.empty(B * nz + B, dtype=torch.float32, device=mu.device)
+        mi = torch.empty(1, dtype=torch.float32, device=mu.device)
+        _ffi.call("melgpt_vae_calc_mi", _ffi.ptr(mu), _ffi.ptr(logvar), nz, _ffi.ptr(e), int(gen), int(_Seeds.next()), B,
+                  nz, _ffi.ptr(ws), _ffi.ptr(mi), _ffi.stream())
+        return mi.item()

@@ -107,7 +107,10 @@ def _ln_bwd_for_below(owner, dh, x, ln, mu, rs, **kw):
     if m is None or not _FUSE_MASK:
         return ops.layernorm_bwd(dh, x, ln.weight, mu, rs, **kw)
     dx, dxm = ops.layernorm_bwd(dh, x, ln.weight, mu, rs, mask=m, **kw)
-    object.__setattr__(below, "_masked_grad", (dx.data_ptr(), tuple(dx.shape), dx.dtype, m, dxm))
+    # dx itself is kept (so its storage cannot be freed and handed out again at the same address before the consumer
+    # looks) together with its version counter (an in-place accumulation into it - a second consumer's gradient added
+    # by autograd, a tensor hook - bumps it, and views share their base's counter): a stale masked copy is never taken
+    object.__setattr__(below, "_masked_grad", (dx, dx._version, m, dxm))
     return dx
 
 
@@ -117,8 +120,9 @@ def _take_masked_grad(blk, dy2, mask):
     if hit is None:
         return None
     object.__setattr__(blk, "_masked_grad", None)
-    ptr_, shape, dtype, m, dxm = hit
-    if ptr_ == dy2.data_ptr() and shape == tuple(dy2.shape) and dtype == dy2.dtype and m == mask:
+    dx, version, m, dxm = hit
+    if (dx.data_ptr() == dy2.data_ptr() and tuple(dx.shape) == tuple(dy2.shape) and dx.dtype == dy2.dtype
+            and dy2._version == version and dx._version == version and m == mask):
         return dxm
     return None
 

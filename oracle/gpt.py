@@ -203,6 +203,34 @@ def vae_validation_step(enc_sd, dec_sd, x, eps, n_layer, n_head, block_size):
             "report_num_words": (x.size(1) - 1) * x.size(0), "report_num_sents": x.size(0)}
 
 
+def log_sum_exp(value, dim):
+    """utils.log_sum_exp (transformer/utils.py:6-19), the `dim is not None, keepdim=False` branch the encoder uses."""
+    m, _ = torch.max(value, dim=dim, keepdim=True)
+    return m.squeeze(dim) + torch.log(torch.sum(torch.exp(value - m), dim=dim))
+
+
+def vae_eval_inference_dist(mu, logvar, z):
+    """GPTEncoder.eval_inference_dist (encoders.py:106-134): log q(z|x) of z (B, S, nz) under N(mu, exp(logvar)) of
+    its own row -> (B, S)."""
+    nz = z.size(2)
+    mu, logvar = mu.unsqueeze(1), logvar.unsqueeze(1)
+    dev = z - mu
+    return -0.5 * ((dev ** 2) / logvar.exp()).sum(dim=-1) - 0.5 * (nz * math.log(2 * math.pi) + logvar.sum(-1))
+
+
+def vae_calc_mi(mu, logvar, eps):
+    """GPTEncoder.calc_mi (encoders.py:136-170): I(x, z) ~ E log q(z|x) - E log q(z), one reparameterised draw per x
+    (eps (B, 1, nz) = that draw's noise), the aggregate posterior as the batch mixture -> Python float."""
+    x_batch, nz = mu.size()
+    neg_entropy = (-0.5 * nz * math.log(2 * math.pi) - 0.5 * (1 + logvar).sum(-1)).mean()
+    z_samples = mu.unsqueeze(1) + eps * (0.5 * logvar).exp().unsqueeze(1)
+    mu, logvar = mu.unsqueeze(0), logvar.unsqueeze(0)
+    dev = z_samples - mu
+    log_density = -0.5 * ((dev ** 2) / logvar.exp()).sum(dim=-1) - 0.5 * (nz * math.log(2 * math.pi) + logvar.sum(-1))
+    log_qz = log_sum_exp(log_density, dim=1) - math.log(x_batch)
+    return (neg_entropy - log_qz.mean(-1)).item()
+
+
 def optimizer_groups(param_names):
     """configure_optimizers' partition (minGPT.py:618-665) expressed on parameter NAMES:
     decay = weights of Linear layers; no_decay = biases, LayerNorm/Embedding weights, pos_emb."""

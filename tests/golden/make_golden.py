@@ -14,6 +14,7 @@ none of them touches the arithmetic being recorded.
 from __future__ import annotations
 
 import importlib.machinery
+import math
 import os
 import sys
 import types
@@ -347,6 +348,40 @@ def gen_vae(ref_gpt, ref_enc, ref_dec):
     save("gpt_vae_small", **out)
 
 
+def gen_vae_mi(ref_enc):
+    """GPTEncoder.eval_inference_dist and calc_mi (encoders.py:106-170; utils.log_sum_exp :6-19) of the real encoder on
+    a batch of 5: log q(z|x) at recorded z points (own statistics, and `param=` given), and the mutual-information
+    estimate with the reparameterisation noise of its one draw recorded (the encoder runs without dropout, so the
+    only consumer of the generator between the seed and `normal_()` is that draw)."""
+    print("GPT-VAE eval_inference_dist / calc_mi")
+    args = synth.gpt_args(n_layer=2, n_head=4, n_embd=256, block_size=265, fix_var=0)
+    enc = ref_enc.GPTEncoder(args, n_unmasked=265, last_linear=512)
+    load_sd(enc.transformer, synth.gpt_state_dict(args, 5, block_size=265, with_embedder=False, out_features=512))
+    enc.eval()
+    B, S, nz = 5, 3, 256
+    x = synth.randint(410, 0, 128, (B, 265))
+    with torch.no_grad():
+        mu, logvar, _ = enc(t(x))
+        z = mu.unsqueeze(1) + t(synth.normal(411, (B, S, nz))) * (0.5 * logvar).exp().unsqueeze(1) * 1.5
+        logq = enc.eval_inference_dist(t(x), z)
+        mu_p, logvar_p = t(synth.normal(412, (B, nz), 0.5)), t(synth.normal(413, (B, nz), 0.3))
+        logq_p = enc.eval_inference_dist(t(x), z, param=(mu_p, logvar_p))
+        torch.manual_seed(4141)
+        mi = enc.calc_mi(t(x))
+        torch.manual_seed(4141)
+        eps = torch.zeros(B, 1, nz).normal_()
+        # the recorded noise really is the draw calc_mi made: its lines restated on (mu, logvar, eps) give the same number
+        zs = mu.unsqueeze(1) + eps * (0.5 * logvar).exp().unsqueeze(1)
+        dev = zs - mu.unsqueeze(0)
+        ld = -0.5 * ((dev ** 2) / logvar.exp().unsqueeze(0)).sum(-1) - 0.5 * (nz * math.log(2 * math.pi) + logvar.unsqueeze(0).sum(-1))
+        m = ld.max(1, keepdim=True)[0]
+        lqz = (m.squeeze(1) + torch.log(torch.exp(ld - m).sum(1))) - math.log(B)
+        ne = (-0.5 * nz * math.log(2 * math.pi) - 0.5 * (1 + logvar).sum(-1)).mean()
+        assert abs((ne - lqz.mean(-1)).item() - mi) <= 1e-6 * max(1.0, abs(mi)), ((ne - lqz.mean(-1)).item(), mi)
+    save("gpt_vae_mi", x=x, z=z.numpy(), mu=mu.numpy(), logvar=logvar.numpy(), logq=logq.numpy(), mu_p=mu_p.numpy(),
+         logvar_p=logvar_p.numpy(), logq_p=logq_p.numpy(), mi=np.float64(mi), mi_eps=eps.numpy(), enc_seed=5)
+
+
 # ------------------------------------------------------------------ GPT_VAE.training_step / validation_step
 def _import_ref_gpt_vae():
     """the reference's real LightningModule (transformer/Lit_GPT_VAE.py:23-89); its data loading
@@ -640,7 +675,7 @@ def main():
     torch.manual_seed(synth.SEED)
     torch.set_num_threads(8)
     ref_gpt, ref_enc, ref_dec, ref_vq = import_reference()
-    which = set(sys.argv[1:]) or {"vq", "attn", "gpt", "lit", "vae", "vae_steps", "vae_xl", "vqvae", "melgan", "mel"}
+    which = set(sys.argv[1:]) or {"vq", "attn", "gpt", "lit", "vae", "vae_mi", "vae_steps", "vae_xl", "vqvae", "melgan", "mel"}
     if which <= {"melgan", "mel"}:
         if "melgan" in which:
             gen_melgan()
@@ -658,6 +693,8 @@ def main():
         gen_lit(ref_gpt)
     if "vae" in which:
         gen_vae(ref_gpt, ref_enc, ref_dec)
+    if "vae_mi" in which:
+        gen_vae_mi(ref_enc)
     if "vae_steps" in which:
         gen_vae_steps()
     if "vae_xl" in which:

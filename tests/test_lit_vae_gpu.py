@@ -238,3 +238,31 @@ def test_gpt_vae_xl_width_vs_reference(lane):
                     worst = max(worst, abs(got - float(g[k])) / float(g[k]))
     report("gpt_vae_xl2_vs_reference", lane=lane, worst_grad_norm_rel_dev=worst,
            loss_rel_err=abs(loss.item() - float(g["loss"])) / abs(float(g["loss"])))
+
+
+def test_gpt_encoder_eval_inference_dist_and_calc_mi_vs_reference():
+    """GPTEncoder.eval_inference_dist / calc_mi (reference encoders.py:106-170) against outputs of the real encoder
+    (tests/golden/gpt_vae_mi.npz): log q(z|x) with the encoder's own statistics and with `param=` given, the
+    mutual-information estimate on the recorded draw; f32 lane, 1e-4."""
+    from melspec_gpt_vqvae_amd.transformer.encoders import GPTEncoder
+
+    g = golden("gpt_vae_mi")
+    args = synth.gpt_args(n_layer=2, n_head=4, n_embd=256, block_size=265, fix_var=0)
+    enc = GPTEncoder(args, n_unmasked=265, last_linear=512)
+    _load(enc.transformer, synth.gpt_state_dict(args, int(g["enc_seed"]), block_size=265, with_embedder=False,
+                                                 out_features=512))
+    enc.to(DEV).eval()
+    x, z = t(g["x"], DEV), t(g["z"], DEV)
+    lq = enc.eval_inference_dist(x, z)
+    assert lq.shape == (5, 3) and rel_err(lq.cpu().numpy(), g["logq"]) < 1e-4
+    lqp = enc.eval_inference_dist(x, z, param=(t(g["mu_p"], DEV), t(g["logvar_p"], DEV)))
+    assert rel_err(lqp.cpu().numpy(), g["logq_p"]) < 1e-5
+    # the kernel alone on the reference's statistics: f32 rounding only
+    lq0 = enc.eval_inference_dist(x, z, param=(t(g["mu"], DEV), t(g["logvar"], DEV)))
+    assert rel_err(lq0.cpu().numpy(), g["logq"]) < 1e-5
+    mi = enc.calc_mi(x, eps=t(g["mi_eps"], DEV))
+    assert isinstance(mi, float) and abs(mi - float(g["mi"])) <= 1e-4 * max(1.0, abs(float(g["mi"])))
+    # in-kernel noise: for 5 well separated posteriors the estimate is log 5 + (sum eps^2 - nz) / 2 averaged over the
+    # rows - standard deviation sqrt(nz / 10) = 5 per call, 0.9 over 32 calls with fresh draws
+    mis = [enc.calc_mi(x) for _ in range(32)]
+    assert np.isfinite(mis).all() and len(set(mis)) > 16 and abs(np.mean(mis) - np.log(5.0)) < 4.5

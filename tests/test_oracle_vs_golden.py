@@ -327,3 +327,22 @@ def test_get_spectrogram_host_rule_and_numpy_lines(tag):
     assert str(mel.dtype) == str(g[f"{tag}.mel_dtype"]) and mel.shape == (80, 860)
     assert np.array_equal(mel, g[f"{tag}.mel"])
     assert list(g["saved_names"]) == ["short_clip_mel.npy"] and list(g["saved_shape"]) == [80, 860]
+
+
+def test_gpt_vae_eval_inference_dist_and_calc_mi():
+    """encoders.py:106-170 restated (oracle.gpt.vae_eval_inference_dist / vae_calc_mi) against the real GPTEncoder's
+    outputs: own statistics, `param=` given, and the MI estimate on the recorded draw."""
+    g = golden("gpt_vae_mi")
+    args = synth.gpt_args(n_layer=2, n_head=4, n_embd=256, block_size=265)
+    enc = ogpt.as_torch_sd(synth.gpt_state_dict(args, int(g["enc_seed"]), block_size=265, with_embedder=False,
+                                                out_features=512))
+    with torch.no_grad():
+        mu, logvar, _ = ogpt.vae_encode_stats(enc, t(g["x"]), 2, 4, 265)
+    assert rel_err(mu.numpy(), g["mu"]) < 5e-6 and rel_err(logvar.numpy(), g["logvar"]) < 5e-6
+    lq = ogpt.vae_eval_inference_dist(t(g["mu"]), t(g["logvar"]), t(g["z"]))
+    assert lq.shape == (5, 3) and np.array_equal(lq.numpy(), g["logq"])
+    lqp = ogpt.vae_eval_inference_dist(t(g["mu_p"]), t(g["logvar_p"]), t(g["z"]))
+    assert np.array_equal(lqp.numpy(), g["logq_p"])
+    mi = ogpt.vae_calc_mi(t(g["mu"]), t(g["logvar"]), t(g["mi_eps"]))
+    assert abs(mi - float(g["mi"])) <= 1e-6 * max(1.0, abs(float(g["mi"])))
+    assert abs(ogpt.vae_calc_mi(mu, logvar, t(g["mi_eps"])) - float(g["mi"])) <= 1e-4 * max(1.0, abs(float(g["mi"])))

@@ -36,3 +36,40 @@ def test_gpt_vae_train_flags():
     assert (a.embd_pdrop, a.resid_pdrop, a.attn_pdrop, a.learning_rate) == (0.0, 0.0, 0.0, 1e-6)
     v = GPT_VAE_train.init_config(["--dataset", "vas", "--experiment", "e", "--fb", "2", "--target_kl", "8"])
     assert (v.n_layer, v.n_embd, v.batch_size, v.embd_pdrop, v.fb, v.target_kl) == (24, 1024, 24, 0.3, 2, 8.0)
+
+
+def test_fp16_loss_scale_grows_only_after_the_step_that_used_the_old_scale(monkeypatch):
+    """Dynamic loss scaling (trainer.Fit): the optimizer step that follows the 200th clean backward must still see the
+    grad_scale of the scale that backward ran at; the doubled scale applies from the next backward on.  An overflow
+    halves the scale at once (that step is skipped)."""
+    import types
+
+    import torch
+
+    from melspec_gpt_vqvae_amd import flat, ops, trainer
+
+    class _FP:
+        grad = torch.zeros(4)
+
+        def zero_missing_grads(self):
+            pass
+
+    finite = {"v": True}
+    monkeypatch.setattr(flat, "ensure_flat", lambda m: _FP())
+    monkeypatch.setattr(ops, "sum_f32", lambda g: torch.tensor(0.0 if finite["v"] else float("inf")))
+    f = trainer.Fit.__new__(trainer.Fit)
+    f.fp16, f.world, f.loss_scale, f._good_steps, f.skipped_steps, f.target = True, 2, 4096.0, 198, 0, None
+    f.opt = types.SimpleNamespace(grad_scale=1.0 / (2 * 4096.0))
+    seen = []
+    for _ in range(3):                       # clean steps 199, 200, 201
+        scale_at_backward = f.loss_scale
+        assert f._step_ok()
+        seen.append((scale_at_backward, f.opt.grad_scale))   # what opt.step() would use
+        f._grow_loss_scale()
+    assert seen == [(4096.0, 1 / 8192.0), (4096.0, 1 / 8192.0), (8192.0, 1 / 16384.0)]
+    assert f.loss_scale == 8192.0 and f._good_steps == 1
+    finite["v"] = False
+    assert not f._step_ok()
+    assert f.loss_scale == 4096.0 and f.opt.grad_scale == 1 / 8192.0 and f.skipped_steps == 1 and f._good_steps == 0
+    f._grow_loss_scale()
+    assert f.loss_scale == 4096.0

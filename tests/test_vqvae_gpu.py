@@ -62,6 +62,15 @@ def test_conv_in_out_single_channel_and_permute(dt):
     g = y.float().cpu().reshape(B, H * W, 32, 4).permute(0, 2, 1, 3).reshape(B * 32, -1).double()
     assert rel_err(mean.cpu().numpy(), g.mean(1).numpy()) < 1e-5
     assert rel_err(rstd.cpu().numpy(), (1.0 / torch.sqrt(g.var(1, unbiased=False) + 1e-6)).numpy()) < 1e-5
+    # images narrower than the statistics kernel's 16-pixel stride (the pixel walk wraps more than once per trip)
+    for (hn, wn) in ((9, 5), (3, 16), (40, 7)):
+        xn = t(synth.normal(12, (B, hn, wn)))
+        yn, (mn, rn) = ops.conv_in_c1(xn.to(DEV), w.to(DEV), b.to(DEV), DT[dt], stats_eps=1e-6)
+        refn = F.conv2d(xn.to(DT[dt]).float()[:, None], w, b, padding=1).permute(0, 2, 3, 1)
+        assert rel_err(yn.float().cpu().numpy(), refn.numpy()) < (1e-6 if dt == "f32" else 8e-3), (hn, wn)
+        gn = yn.float().cpu().reshape(B, hn * wn, 32, 4).permute(0, 2, 1, 3).reshape(B * 32, -1).double()
+        assert rel_err(mn.cpu().numpy(), gn.mean(1).numpy()) < 1e-5, (hn, wn)
+        assert rel_err(rn.cpu().numpy(), (1.0 / torch.sqrt(gn.var(1, unbiased=False) + 1e-6)).numpy()) < 1e-5, (hn, wn)
     # 128 -> 1
     h = t(synth.normal(8, (B, 20, 53, C))).to(DT[dt])
     wo = t(synth.uniform(9, (1, C, 3, 3), -0.05, 0.05))
