@@ -312,7 +312,7 @@ class ClassGPTStep:
         self.x_mel, self.c = synthetic_batch(a.batch, rank, device)
         self.opt = FusedAdamW(self.gpt, lr=gargs.learning_rate, betas=(0.9, 0.95), weight_decay=0.01)
         self.opt.grad_scale = 1.0 / world
-        self.dp = DataParallel(self.gpt) if world > 1 or FORCE_DP else None
+        self.dp = DataParallel(self.gpt, grad_dtype=a.grad_dtype) if world > 1 or FORCE_DP else None
         self.full = a.layers == 24
         self.workload = ("VQ-encode (LitVQVAE encoder + 128-code L2 argmin on 80x848 mel tiles) + class-GPT VAS "
                          f"({a.layers} L, 1024, 16 H, T=265, V=128, dropout 0.5) fwd/bwd + AdamW")
@@ -364,7 +364,7 @@ class GPTVAEXLStep:
         self.x = torch.randint(0, 1024, (a.batch, 265), generator=g).to(device)
         self.opt = FusedAdamW(self.vae, lr=args.learning_rate, betas=(0.9, 0.95), weight_decay=0.01)
         self.opt.grad_scale = 1.0 / world
-        self.dp = DataParallel(self.vae) if world > 1 or FORCE_DP else None
+        self.dp = DataParallel(self.vae, grad_dtype=a.grad_dtype) if world > 1 or FORCE_DP else None
         self.full = layers == 40
         self.n_params = sum(p.numel() for p in self.vae.parameters())
         self.workload = (f"GPT-VAE XL (encoder + decoder GPT, {layers}+{layers} L, 1472, 23 H, T=265, V=1024, "
@@ -397,6 +397,9 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="sequences per GPU per step (BASELINE configs 3 and 4: 128)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "f32"],
                     help="bf16 (default, the metric's lane) | fp16 (the library's IEEE-half flavour) | f32 (parity lane)")
+    ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"],
+                    help="wire format of the data-parallel gradient exchange (N > 1): f32 (default) | bf16 = cast slice -> "
+                         "all-reduce -> back into the f32 buffer (half the bytes: 8.37 -> 4.18 GB per step for GPT-VAE XL)")
     ap.add_argument("--layers", type=int, default=24, help="debug only; anything but the configuration's depth is flagged")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -469,6 +472,8 @@ def main():
         step()
     for k in phases:
         phases[k] = 0.0
+    if job.dp is not None:
+        job.dp.ex.time_events = True   # two event records per step around finish()'s waits -> exposed_comm_ms
     ops.TIMER = ops.KernelTimer()
     fence()
     t0 = time.perf_counter()
@@ -480,10 +485,14 @@ def main():
     timer, ops.TIMER = ops.TIMER, None
     loss_val = float(loss.detach())
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    # the part of the gradient exchange the backward pass did not hide (dp.GradientExchange.exposed_ms), per step
+    exposed = job.dp.ex.exposed_ms() if job.dp is not None else []
+    exposed_ms = sum(exposed) / len(exposed) if exposed else 0.0
+    dp_info = job.dp.describe() if job.dp is not None else None
+    tmax = torch.tensor([elapsed, exposed_ms], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    elapsed, exposed_ms = float(tmax[0].item()), float(tmax[1].item())
     ms_per_step = 1e3 * elapsed / a.steps
     value = world * a.batch * a.steps / elapsed
 
@@ -522,6 +531,11 @@ def main():
                 "worst_shape": worst, "per_shape": major,
             },
         }
+        if dp_info is not None:
+            # a scaling record explains itself: what was exchanged, in which format, under which persistent-kernel
+            # switches, and how much of it the backward pass did not hide (max over ranks)
+            out["config"].update(dp_info)
+            out["exposed_comm_ms"] = round(exposed_ms, 3)
         if not job.full:
             out["config"]["INVALID_debug_layers"] = a.layers
         if share:

@@ -21,10 +21,26 @@ import torch
 import torch.distributed as dist
 
 
-class GradientExchange:
-    """All-reduce (sum) of `grad` in segments; segments may be launched early (overlap) and in any order."""
+def _convert(src, dst):
+    """dtype-converting copy dst <- src: the library's cast kernel on the GPU, a torch copy on the CPU rig of the tests."""
+    if src.is_cuda:
+        from . import ops
 
-    def __init__(self, grad: torch.Tensor, group=None, max_bucket_elems: int = 64 << 20):
+        ops.cast(src, dst.dtype, out=dst)
+    else:
+        dst.copy_(src)
+
+
+class GradientExchange:
+    """All-reduce (sum) of `grad` in segments; segments may be launched early (overlap) and in any order.
+
+    wire_dtype (default None = the gradient's own f32): a 16-bit format to exchange in - SURVEY 2b C2, for the GPT-VAE XL
+    job whose f32 gradient is 8.37 GB per step: a launched slice is cast into a staging buffer of that format, the
+    staging slice is all-reduced, and finish() converts the sums back into the f32 buffer (moments and master weights
+    stay f32).  The reduction itself then runs in 16 bits: ~2^-9 relative per addition for bf16; tested at 1e-3 of
+    the gradient's maximum on two ranks, off by default."""
+
+    def __init__(self, grad: torch.Tensor, group=None, max_bucket_elems: int = 64 << 20, wire_dtype=None):
         assert grad.dim() == 1
         self.grad = grad
         self.group = group
@@ -33,8 +49,32 @@ class GradientExchange:
         # all-reduces anyway, so that a single rank drives RCCL exactly as a rank of an N-GPU run does
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("MELGPT_DP_FORCE_EXCHANGE") == "1")
         self.max_bucket = int(max_bucket_elems)
+        self.wire_dtype = None if wire_dtype in (None, torch.float32) else wire_dtype
+        self._wire = None             # staging buffer in wire_dtype (allocated on first use)
         self._works = []
         self._done = []  # (lo, hi) already launched this step
+        self._wired = []              # (lo, hi) whose sums sit in the staging buffer until finish()
+        self.last_wait_ms = 0.0       # host time finish() spent in the waits (GPU backends: the time to ENQUEUE them)
+        self.time_events = False      # GPU: bracket finish()'s waits with stream events -> exposed_ms()
+        self._events = []
+
+    @property
+    def bytes_per_step(self):
+        return self.grad.numel() * (4 if self.wire_dtype is None else 2)
+
+    def _reduce(self, lo, hi):
+        buf = self.grad
+        if self.wire_dtype is not None:
+            if self._wire is None:
+                self._wire = torch.empty(self.grad.numel(), dtype=self.wire_dtype, device=self.grad.device)
+            _convert(self.grad[lo:hi], self._wire[lo:hi])
+            self._wired.append((lo, hi))
+            buf = self._wire
+        pos = lo
+        while pos < hi:
+            end = min(hi, pos + self.max_bucket)
+            self._works.append(dist.all_reduce(buf[pos:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            pos = end
 
     def launch(self, lo: int, hi: int):
         """start reducing grad[lo:hi] (asynchronously on GPU backends); safe to call from a backward hook."""
@@ -47,16 +87,13 @@ class GradientExchange:
                                "backward pass, or disable early launches (DataParallel(..., overlap=False)) when "
                                "accumulating gradients")
         self._done.append((lo, hi))
-        pos = lo
-        while pos < hi:
-            end = min(hi, pos + self.max_bucket)
-            self._works.append(dist.all_reduce(self.grad[pos:end], op=dist.ReduceOp.SUM, group=self.group,
-                                               async_op=True))
-            pos = end
+        self._reduce(lo, hi)
 
     def finish(self):
         """reduce everything not launched yet, then make the current stream wait for all of it."""
         if self.active:
+            import time
+
             covered = sorted(self._done)
             pos = 0
             for lo, hi in covered:
@@ -64,18 +101,35 @@ class GradientExchange:
                 self.launch_uncounted(pos, lo)
                 pos = hi
             self.launch_uncounted(pos, self.grad.numel())
+            ev = None
+            if self.time_events and self.grad.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()                  # behind the last kernel of the backward pass
+            t0 = time.perf_counter()
             for w in self._works:
                 w.wait()
-        self._works, self._done = [], []
+            self.last_wait_ms = 1e3 * (time.perf_counter() - t0)
+            for lo, hi in self._wired:          # the 16-bit sums back into the f32 gradient
+                _convert(self._wire[lo:hi], self.grad[lo:hi])
+            if ev is not None:
+                ev[1].record()                  # behind the last collective (and the conversion back)
+                self._events.append(ev)
+        self._works, self._done, self._wired = [], [], []
 
     def launch_uncounted(self, lo, hi):
         if hi > lo:
-            pos = lo
-            while pos < hi:
-                end = min(hi, pos + self.max_bucket)
-                self._works.append(dist.all_reduce(self.grad[pos:end], op=dist.ReduceOp.SUM, group=self.group,
-                                                   async_op=True))
-                pos = end
+            self._reduce(lo, hi)
+
+    def exposed_ms(self, reset=True):
+        """with time_events: per finish() call, the GPU time between the end of the backward pass' last kernel and the
+        end of the last all-reduce - the part of the exchange that was NOT hidden under the backward GEMMs.  Synchronises."""
+        if not self._events:
+            return []
+        torch.cuda.synchronize()
+        out = [a.elapsed_time(b) for a, b in self._events]
+        if reset:
+            self._events = []
+        return out
 
 
 def block_segments(fp, block):
@@ -109,13 +163,15 @@ class DataParallel:
     (whose grad_scale = 1/world folds the averaging in)."""
 
     def __init__(self, module, group=None, overlap=True, max_bucket_elems: int = 64 << 20, reserve_cus=None,
-                 dynamic_tiles=None):
+                 dynamic_tiles=None, grad_dtype=None):
         from . import _ffi
         from .flat import ensure_flat
 
         self.module = module
         self.fp = ensure_flat(module)
-        self.ex = GradientExchange(self.fp.grad, group, max_bucket_elems=max_bucket_elems)
+        if isinstance(grad_dtype, str):      # "f32" | "bf16" | "fp16" (the library flavour's 16-bit format), as the CLIs spell it
+            grad_dtype = {"f32": None, "bf16": _ffi.HALF_DTYPE, "fp16": _ffi.HALF_DTYPE, "half": _ffi.HALF_DTYPE}[grad_dtype]
+        self.ex = GradientExchange(self.fp.grad, group, max_bucket_elems=max_bucket_elems, wire_dtype=grad_dtype)
         self.world = self.ex.world
         self.overlap = bool(overlap)
         # The persistent GEMM / conv kernels own one CU per workgroup for a whole launch; an RCCL kernel that holds a CU
@@ -213,6 +269,12 @@ class DataParallel:
         self._mask_steps += 1
         if self._mask_steps == 1 or not self._on_gpu:
             self._raise_if_flagged(wait=True)
+
+    def describe(self):
+        """what a bench line needs to explain a scaling record: the exchange's size and the two persistent-kernel switches"""
+        return {"exchange_bytes": int(self.ex.bytes_per_step), "exchange_dtype": str(self.ex.wire_dtype or torch.float32)[6:],
+                "dp_tiles": "claimed" if self.dynamic_tiles else "static", "reserved_cus": int(self.reserve_cus),
+                "overlap": bool(self.overlap), "backend": dist.get_backend(self.ex.group) if dist.is_initialized() else None}
 
     def detach(self):
         self._raise_if_flagged(wait=True)

@@ -43,6 +43,24 @@ def main():
     assert dp.world == world and len(dp.blocks) == (4 if which == "vae" else 2)
     n = next(iter(batch.values())).shape[0] // world
     local = {k: v[rank * n:(rank + 1) * n] for k, v in batch.items()}
+    if os.environ.get("DP_MISMATCH") == "1":
+        # rank 1 ends its backward with one parameter (outside the Blocks) WITHOUT a gradient, rank 0 with all of them:
+        # finish() must refuse on both ranks (the sets are compared through an all-reduced bitmask)
+        loss = loss_fn(model, local)
+        loss.backward()
+        if rank == 1:
+            victim = [p for nm, p in model.named_parameters() if nm.endswith("pos_emb") or nm.endswith("head.weight")][0]
+            victim.grad = None
+        refused = False
+        try:
+            dp.finish()
+        except RuntimeError as e:
+            refused = "disagree on which parameters received a gradient" in str(e)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.save({"refused": refused}, os.path.join(outdir, f"rank{rank}_mismatch.pt"))
+        dist.destroy_process_group()
+        return
     loss = loss_fn(model, local)
     loss.backward()
     launched_early = len(dp.ex._done)

@@ -9,6 +9,7 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -93,3 +94,70 @@ def test_one_rank_over_a_real_rccl_group_bit_identical_to_no_dp(tmp_path):
     assert float(loss) == r["loss"]
     assert torch.equal(r["grad"], want), float((r["grad"] - want).abs().max())
     assert torch.load(os.path.join(str(tmp_path), "rank0_guard.pt"))["refused"]
+
+
+def _run_child(argv, extra_env, timeout):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MELGPT_BENCH_SHARE_GPU="1", **extra_env)
+    r = subprocess.run([sys.executable] + argv, env=env, capture_output=True, text=True, timeout=timeout,
+                       cwd=os.path.dirname(HERE))
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, lines
+
+
+def test_bench_self_launches_two_ranks_and_prints_one_self_describing_line():
+    """The multi-rank rehearsal a 1-GPU box allows, in the driver-run suite: `python bench.py --gpus 2` (no launcher
+    around it) starts its two ranks itself (launch.spawn_ranks) before touching the GPU; under MELGPT_BENCH_SHARE_GPU=1
+    they share cuda:0 and rendezvous over gloo.  Checked: exit status 0, exactly ONE JSON line (rank 0's), the whole-job
+    fields (n_gpus, global_batch = 2 x per-GPU batch, parallelism dp2), the run flagged INVALID_debug_shared_gpu, and the
+    fields a SCALE record needs to explain itself (exchange bytes / format, claimed-tile and reserved-CU switches,
+    exposed_comm_ms); then the same with the 16-bit wire format."""
+    import json
+
+    base = [os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--layers", "2", "--steps", "2", "--warmup",
+            "1", "--batch", "32", "--no-cpu-baseline", "--no-extras"]
+    for wire, nbytes_per_param in (("f32", 4), ("bf16", 2)):
+        r, lines = _run_child(base + ["--grad-dtype", wire], {}, 900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        assert len(lines) == 1, r.stdout
+        o = json.loads(lines[0])
+        c = o["config"]
+        assert o["n_gpus"] == 2 and o["scaling"] == "weak" and o["steps"] == 2 and o["value"] > 0
+        assert c["batch_per_gpu"] == 32 and c["global_batch"] == 64 and c["parallelism"] == "dp2"
+        assert c["INVALID_debug_shared_gpu"] is True and c["INVALID_debug_layers"] == 2
+        assert abs(o["value"] - 64 / (o["ms_per_step"] * 1e-3)) <= 1e-3 * o["value"]
+        assert c["exchange_dtype"] == ("float32" if wire == "f32" else "bfloat16") and c["backend"] == "gloo"
+        assert c["exchange_bytes"] % nbytes_per_param == 0 and c["exchange_bytes"] // nbytes_per_param > 25_000_000
+        assert c["dp_tiles"] in ("claimed", "static") and c["reserved_cus"] == 0 and c["overlap"] is True
+        assert o["exposed_comm_ms"] >= 0.0 and np.isfinite(c["final_loss"])
+
+
+def test_bench_e2e_self_launches_two_ranks_clips_sharded_no_collective():
+    """tools/bench_e2e.py --gpus 2 under MELGPT_BENCH_SHARE_GPU=1: two ranks, clips r::2, no collective on the data path;
+    the parent prints one line per batch size with the ranks' clips/s summed."""
+    import json
+
+    r, lines = _run_child([os.path.join(os.path.dirname(HERE), "tools", "bench_e2e.py"), "--gpus", "2", "--batches", "1"],
+                          {}, 900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert len(lines) == 1, r.stdout
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 2 and o["batch_per_gpu"] == 1 and o["INVALID_debug_shared_gpu"] is True
+    assert len(o["clips_per_s_by_rank"]) == 2 and abs(sum(o["clips_per_s_by_rank"]) - o["clips_per_s"]) < 0.02
+    assert o["clip_ids_by_rank"] == [[0, 0], [1, 1]]
+
+
+def test_ranks_that_disagree_on_which_parameters_got_a_gradient_are_refused(tmp_path):
+    """One rank feeds the class token, the other does not (its class embedder gets no gradient): torch's DDP - the
+    reference - raises; here finish() raises on both ranks instead of letting the replicas diverge."""
+    world, port = 2, _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", DP_MISMATCH="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), "gptclass", str(tmp_path)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    for rnk in range(world):
+        assert torch.load(os.path.join(str(tmp_path), f"rank{rnk}_mismatch.pt"))["refused"]

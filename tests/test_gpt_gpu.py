@@ -191,3 +191,63 @@ def test_training_with_dropout_decreases_loss_and_is_seed_reproducible():
     l1, l2 = run(), run()
     assert l1[-1] < l1[0] - 0.05, l1
     assert l1 == l2, "same torch seed -> same dropout masks -> bit-identical losses"
+
+
+def test_loss_trajectory_20_adamw_steps_f32_and_bf16_lanes_vs_f32_oracle():
+    """Multi-step behaviour pinned (not only one forward/backward): 20 AdamW steps of the 2-layer VAS-width class-GPT
+    on ONE repeated batch at dropout 0, the learning rate raised to 3e-4 so that the loss really moves (5.07 -> 0.012:
+    the batch is memorised), against the CPU oracle's trajectory (oracle.gpt.class_gpt_loss + torch.optim.AdamW with the reference's
+    groups, minGPT.py:618-665).  f32 lane: every step's loss within 1e-4 relative; bf16 throughput lane (bf16 operands,
+    f32 master weights / gradients / moments): within BF16_TOL at every step and no drift - the bound does not grow
+    along the trajectory."""
+    from melspec_gpt_vqvae_amd.optim import FusedAdamW
+    from melspec_gpt_vqvae_amd.transformer.minGPT import GPTClass, cross_entropy, set_compute_dtype
+    from oracle import gpt as ogpt
+
+    steps, lr, B = 20, 3e-4, 4
+    args = synth.gpt_args(n_layer=2, n_head=16, n_embd=1024)
+    sd_np = synth.gpt_state_dict(args, 31)
+    x = t(synth.randint(32, 0, 128, (B, 265)))
+    c = t(synth.randint(33, 0, 8, (B, 1)))
+
+    # ---- oracle: f32 on the host cores
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    sd = ogpt.as_torch_sd(sd_np, requires_grad=True)
+    decay, no_decay = ogpt.optimizer_groups(list(sd.keys()))
+    opt = torch.optim.AdamW([{"params": [sd[k] for k in decay], "weight_decay": 0.01},
+                             {"params": [sd[k] for k in no_decay], "weight_decay": 0.0}], lr=lr, betas=(0.9, 0.95))
+    want = []
+    for _ in range(steps):
+        loss, _, _ = ogpt.class_gpt_loss(sd, x, c, 2, 16)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        want.append(float(loss.detach()))
+    assert want[0] - want[-1] > 1.0, want          # the trajectory is not flat: the steps matter
+
+    def run(dtype):
+        m = GPTClass(args)
+        _load(m, sd_np)
+        m.to(DEV).train()
+        set_compute_dtype(m, dtype)
+        o = FusedAdamW(m, lr=lr, betas=(0.9, 0.95), weight_decay=0.01)
+        got = []
+        xd, cd = x.to(DEV), c.to(DEV)
+        for _ in range(steps):
+            logits, _, _ = m(xd[:, :-1], cd)
+            loss = cross_entropy(logits.reshape(-1, 128), xd.reshape(-1))   # shared_step, minGPT.py:413-417
+            o.zero_grad()
+            loss.backward()
+            o.step()
+            got.append(float(loss.detach()))
+        return got
+
+    got32 = run(torch.float32)
+    got16 = run(torch.bfloat16)
+    d32 = [abs(a - b) / abs(b) for a, b in zip(got32, want)]
+    d16 = [abs(a - b) for a, b in zip(got16, want)]
+    report("loss_trajectory_20_steps_vs_f32_oracle", oracle_first=want[0], oracle_last=want[-1], f32_max_rel=max(d32),
+           bf16_max_abs=max(d16), bf16_abs_first5=max(d16[:5]), bf16_abs_last5=max(d16[-5:]))
+    assert max(d32) < 1e-4, (d32, got32, want)
+    BF16_TOL = 3e-2
+    assert max(d16) < BF16_TOL, (d16, got16, want)

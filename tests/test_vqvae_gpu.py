@@ -178,8 +178,37 @@ def test_oversized_inference_batches_are_split_and_give_the_same_results(monkeyp
         assert torch.equal(m.decode(q), rec)
 
 
+def _flip_margins(g):
+    """Per fixture vector, from the f32 reference's latent (f64 arithmetic): the distances to all 128 codes and, for
+    any code c, the FLIP MARGIN rho(c) = (d_c - d_min) / (2 |e_c - e_min|) - how far the latent has to move along the
+    unit direction e_c - e_min before c becomes the nearest code (|z| <= 1.0 in this fixture).  A lane whose latent
+    error has projection sigma on a fixed direction re-decides vectors with rho of a few sigma and no others."""
+    sd = synth.vqvae_state_dict(int(g["seed"]))
+    E = sd["_vq_vae._embedding.weight"].astype(np.float64)
+    z = g["z"].astype(np.float64).transpose(0, 2, 3, 1).reshape(-1, E.shape[1])
+    d = (z ** 2).sum(1)[:, None] + (E ** 2).sum(1)[None] - 2.0 * z @ E.T
+    best = d.argmin(1)
+    assert np.array_equal(best, g["indices"].astype(np.int64))
+    n = np.arange(len(z))
+    en = np.linalg.norm(E[:, None, :] - E[None, :, :], axis=-1)          # (128, 128) code-to-code distances
+    rho = (d - d[n, best][:, None]) / (2.0 * np.maximum(en[best], 1e-30))  # (530, 128); rho[n, best[n]] = 0
+    return z, E, best, rho
+
+
+# Resolution of the 16-bit lanes on this fixture, fixed here from profiles/r04_parity_report.jsonl: the bf16 encoder's
+# latent error projected on a vector's (nearest, second-nearest) code direction has an rms of BF16_PROJ_RMS; the
+# disagreements of all three lookup paths sit at flip margins below BF16_FLIP_RES (= a few rms).  A change that only
+# re-decides near-ties moves WHICH of the ~40 vectors inside the resolution flip; a real regression either raises the
+# projected error or flips a vector outside it - both fail below, neither depends on the count of coin flips.
+BF16_FLIP_RES = 0.012
+BF16_PROJ_RMS = 4.0e-3
+
+
 def test_full_vqvae_bf16_lane_reports_code_agreement():
-    """bf16 throughput lane of the encoder: reported (not gated at 1e-4) - latent error and code agreement."""
+    """bf16 throughput lane of the encoder against the f32 reference (north_star's "indices bit-exact" is the f32 lane's
+    property; the 16-bit lane is held to its own resolution): every code that differs from the reference's is on a vector
+    whose reference flip margin is inside the lane's resolution, none outside; latent error bounded elementwise and in
+    projection on the deciding directions."""
     from melspec_gpt_vqvae_amd.vqvae.big_model_attn_gan import LitVQVAE, set_compute_dtype
 
     g = golden("vqvae_full")
@@ -194,17 +223,35 @@ def test_full_vqvae_bf16_lane_reports_code_agreement():
         codes_lo = m._vq_vae.encode_indices_fused(m._encoder._nhwc(t(g["x"], DEV)).permute(0, 3, 1, 2), m.quant_conv,
                                                   with_lo=True)
     err = rel_err(z.float().cpu().numpy(), g["z"])
-    want = g["indices"].astype(np.int64)
-    agree = float((codes.cpu().numpy().ravel() == want).mean())
-    agree_unfused = float((codes_unfused.cpu().numpy().ravel() == want).mean())
-    agree_lo = float((codes_lo.cpu().numpy().ravel() == want).mean())
-    report("vqvae_full_bf16_lane_vs_f32_reference", latent_rel_to_max_err=err, code_agreement_fused_hi_only=agree,
-           code_agreement_unfused=agree_unfused, code_agreement_fused_hi_lo=agree_lo, vectors=530)
-    # gate = the measured agreement (0.987 / 0.983 / 0.987 of 530 codes, profiles/r02_h_parity_report.jsonl) minus a
-    # margin of two or three flips, not a loose bound: north_star's "indices bit-exact" is the f32 lane's property, the
-    # 16-bit lane's is reported and held at >= 0.98
-    assert err < 5e-2 and agree >= 0.98 and agree_unfused >= 0.975 and agree_lo >= 0.98
-    assert agree >= agree_unfused - 0.02       # folding the conv must not cost agreement with the f32 reference
+    zref, E, best, rho = _flip_margins(g)
+    nvec = len(best)
+    n = np.arange(nvec)
+    # the lane's latent error along each vector's deciding direction (nearest -> second-nearest code)
+    second = np.where(np.arange(128)[None] == best[:, None], np.inf, rho).argmin(1)
+    dz = z.float().cpu().numpy().astype(np.float64).transpose(0, 2, 3, 1).reshape(nvec, -1) - zref
+    u = E[second] - E[best]
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    proj = (dz * u).sum(1)
+    proj_rms, proj_max = float(np.sqrt((proj ** 2).mean())), float(np.abs(proj).max())
+    at_risk = int((rho[n, second] <= BF16_FLIP_RES).sum())
+    rec = dict(latent_rel_to_max_err=err, latent_proj_rms=proj_rms, latent_proj_max=proj_max, vectors=nvec,
+               flip_resolution=BF16_FLIP_RES, vectors_inside_resolution=at_risk)
+    worst = 0.0
+    for name, c in (("fused_hi_only", codes), ("unfused", codes_unfused), ("fused_hi_lo", codes_lo)):
+        got = c.cpu().numpy().ravel().astype(np.int64)
+        diff = np.nonzero(got != best)[0]
+        margins = rho[diff, got[diff]]
+        rec["code_agreement_" + name] = float((got == best).mean())
+        rec["flips_" + name] = int(diff.size)
+        rec["max_flip_margin_" + name] = float(margins.max()) if diff.size else 0.0
+        rec["flips_outside_resolution_" + name] = int((margins > BF16_FLIP_RES).sum())
+        worst = max(worst, rec["max_flip_margin_" + name])
+    report("vqvae_full_bf16_lane_vs_f32_reference", **rec)
+    assert err < 5e-2 and proj_rms <= 1.5 * BF16_PROJ_RMS and proj_max <= 6 * 1.5 * BF16_PROJ_RMS, rec
+    for name in ("fused_hi_only", "unfused", "fused_hi_lo"):
+        assert rec["flips_outside_resolution_" + name] == 0, (name, rec)
+        assert rec["flips_" + name] <= at_risk, (name, rec)        # (cannot exceed the population it is drawn from)
+        assert rec["code_agreement_" + name] >= 0.95, (name, rec)  # sanity floor only; the gates are the two above
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
