@@ -249,5 +249,5 @@ def test_loss_trajectory_20_adamw_steps_f32_and_bf16_lanes_vs_f32_oracle():
     report("loss_trajectory_20_steps_vs_f32_oracle", oracle_first=want[0], oracle_last=want[-1], f32_max_rel=max(d32),
            bf16_max_abs=max(d16), bf16_abs_first5=max(d16[:5]), bf16_abs_last5=max(d16[-5:]))
     assert max(d32) < 1e-4, (d32, got32, want)
-    BF16_TOL = 3e-2
+    BF16_TOL = 8e-3        # measured 2.0e-3 (profiles/r04_parity_report.jsonl), largest in the steep part of the descent
     assert max(d16) < BF16_TOL, (d16, got16, want)

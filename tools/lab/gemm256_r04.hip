@@ -1,0 +1,813 @@
+// Wide-tile bf16 MFMA GEMM for gfx950: persistent 512-thread workgroups, 256x256 output tiles, operands streamed
+// L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`: no VGPR round trip, out-of-range lanes deposit zeros) into
+// a ring of five 32 KiB half-unit slots, v_mfma_f32_16x16x32_bf16.
+//
+// Why a second kernel: a 128x128 tile moves 64 FLOP per byte staged from L2 - at the 2.5 PFLOP/s MFMA peak that is
+// ~39 TB/s of L2->LDS traffic, and the measured ceiling of that path is ~30 TB/s with everything hitting in L2
+// (tools/lab/dma_lab.hip).  256x256 halves the traffic (128 FLOP/B); LDS-DMA frees the staging VGPRs so a wave
+// can hold its 128x64 accumulator block (128 VGPRs).
+//
+// Synchronisation: per K-unit ONE counted `s_waitcnt vmcnt(n)` (this wave's pieces of the unit have landed, the
+// younger half-unit keeps flying) and ONE raw `s_barrier` (everybody's pieces landed + everybody is done reading
+// the slots that are refilled next).  __syncthreads() is not used in the loop: its fence makes the compiler
+// drain vmcnt(0), which would serialise the ring.
+// Same operand layouts, fragment maps and fused epilogue as gemm.hip (gemm_common.h); the f32 parity lane stays
+// on gemm.hip.
+//   LDS-DMA writes are lane-linear (wave-uniform base + 16*lane), so the XOR swizzle is applied to the SOURCE
+//   address (which chunk a lane fetches) and again on the fragment read - both sides or neither.
+#include <cstdlib>
+
+#include "gemm_common.h"
+
+using namespace gemmk;
+
+#ifndef G256_LAB
+#define G256_LAB 0  // tools/lab/gemm_lab.hip builds ablated variants; the library always builds 0
+#endif
+
+namespace {
+
+#if G256_LAB & 8
+__device__ unsigned long long* g256_dbg;  // lab build only: phase stamps of workgroup 17
+#endif
+
+constexpr int KU = 64;  // bf16 elements of K per unit = 128 bytes per ROW-layout row (full L2 lines per request)
+
+template <int MN>
+__device__ __forceinline__ int kmaj_off(int krow, int lc) {
+  // K-major half-unit: 64 k-rows of MN bf16 (MN*2 bytes); 32-byte column blocks XOR-ed so that the 8 rows a
+  // half-wave touches in one ds_read_b64_tr_b16 land on 8 different 32-byte slots of the 256-byte bank row
+  const int s = (krow & 3) | (((krow >> 3) & 1) << 2);
+  return krow * (MN * 2) + ((lc ^ (s << 1)) << 4);
+}
+
+template <int LAY, int MN>
+__device__ __forceinline__ u32x4 load_frag(const char* tile, int st, int ks, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  if constexpr (LAY != LAY_KMAJ) {
+    return *(const u32x4*)(tile + row_off(st * 16 + i, 4 * ks + g));
+  } else {
+    const int q = i >> 2, pp = i & 3;
+    const int k0 = 32 * ks + 8 * g + q;
+    const int lc = 2 * st + (pp >> 1);
+    const char* a0 = tile + kmaj_off<MN>(k0, lc) + (pp & 1) * 8;
+    const char* a1 = tile + kmaj_off<MN>(k0 + 4, lc) + (pp & 1) * 8;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
+    s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(u32x4, f);
+  }
+}
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from the buffer `rs` (per-lane byte offset voff, out of range -> zeros) to the
+// 1 KiB of LDS at lds_wave_base.  Written as inline asm ON PURPOSE: hipcc models the builtin as an LDS store that is
+// complete only at vmcnt(0) and put a full `s_waitcnt vmcnt(0)` into every K unit (in front of the first LDS read, and in
+// front of the first write to the registers next to the piece's address register), draining the half-unit the ring is
+// built to keep in flight.  Instructions the compiler cannot see get no such waits; ordering is ours: the counted wait +
+// barrier of wait_vm_barrier, and the drain in front of the epilogue.  (Invisible operations can only make the
+// compiler's own vmcnt waits for the epilogue's loads longer, never shorter: the counter is in order.)
+// Hazards are ours as well: the block opens with `s_nop 2` because the resource SGPRs may just have been restored from a
+// spill lane by v_readlane (VALU write of an SGPR -> VMEM read: 5 wait states, which the hazard recogniser only inserts
+// for instructions it can see), and keeps one wait state between the m0 write and the load.
+typedef u32x4 rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc4(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  return rsrc_t{(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};  // stride 0, raw buffer (as make_rsrc)
+}
+__device__ __forceinline__ void dma16(rsrc_t rs, char* lds_wave_base, unsigned voff) {
+  const unsigned m0v = (unsigned)(size_t)LDS_PTR(char, lds_wave_base);
+  // Cache policy of the requests (lab switch): " sc1" (served by L2 without allocating in the CU's vector L1) measured
+  // +0.5 .. 2.5 % per shape on constant operands and NEUTRAL in the training step (GEMM family 88.8-89.4 ms per step
+  // either way, three alternating runs) while FETCH_SIZE read 15 % more bytes per step; " nt" -3 .. -15 % (the panels are
+  // re-read out of L2 by the other tiles of the XCD's block).  Default policy kept.  profiles/r03_gemm_lab.md
+#ifndef G256_DMA_POLICY
+#define G256_DMA_POLICY ""
+#endif
+  asm volatile("s_nop 2\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" G256_DMA_POLICY " lds"
+               :
+               : "s"(m0v), "v"(voff), "s"(rs)
+               : "memory", "m0");
+}
+
+// wait until at most N of this wave's vector-memory operations are outstanding, then workgroup barrier
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// 256 x 256 output tile, 8 waves as 2 (M) x 4 (N), each wave 128 x 64 = 8 x 4 accumulator tiles of 16 x 16.
+//
+// LDS = five 32 KiB slots holding HALF-units: H(2u) = the A operand of K-unit u (256 rows x 128 B), H(2u+1) = its
+// B operand; H(j) lives in slot j mod 5.  While unit u is multiplied (two slots), H(2u+2..2u+4) - 96 KiB - are in
+// flight or landed; when unit u is done its two slots are refilled with H(2u+5), H(2u+6).  (Measured with
+// tools/lab/dma_lab.hip: the L2 -> LDS path needs ~96 KiB in flight per CU and full 128-byte lines per request to
+// reach ~30 TB/s; 64 KiB in flight gives ~20, 64-byte row slices ~17.)
+//
+// PERSISTENT: gridDim.x workgroups (one per CU) walk their tile lists; the ring does not stop at tile boundaries,
+// so the next tile's first three half-units land while this tile's accumulators go through the epilogue, and the
+// epilogue's stores drain under the next tile's MFMAs.  The epilogue stages through the slot that is refilled next.
+//
+// Tile order: the 32 workgroups of one XCD (blockIdx & 7, round-robin dispatch) take an RM x RN block of tiles, so
+// one L2 serves RM row panels of A and RN column panels of B instead of 1 + 32.
+//
+// KUB = 32 (round 4, both operands K-major only): a K-major k-row is 512 contiguous bytes whatever the unit's depth, so a
+// unit can be 32 k-rows deep at full line width.  The ring then has TEN 16 KiB slots; only 32 KiB are being multiplied at
+// any time and 128 KiB (four units ahead, instead of one and a half) are in flight or landed: a request has 3-4 unit
+// times to arrive instead of 0.5-1.5.  Price: one barrier per 32-wide step instead of one per 64.
+// profiles/r04_gemm_lab.md has the A/B.
+//
+// NWV = 4 (round 4, row-major operands, 256 x 256 only): FOUR waves, one per SIMD, each holding a 128 x 128 accumulator
+// block (256 registers: the accumulator half of the unified file; 512 registers per wave at one wave per SIMD).  A wave
+// has no partner to run in lockstep with, reads 16 fragments per 64 MFMAs (the 8-wave form: 12 per 32) and issues 16
+// LDS-DMA pieces per unit.  profiles/r04_gemm_lab.md has the A/B.
+template <int ALAY, int BLAY, int MODE, int TM, bool DYN = false, int KUB = 64, int NWV = 8>
+__global__ __launch_bounds__(NWV * 64) void gemm256_kernel(GemmParams p, int tiles_m, int tiles_n, int batch, int RN, int* sched) {
+  constexpr int NW = NWV, WN = NW / 2, TN = 16 / WN, BM = 32 * TM, BN = 256;  // TM = 8: 256 x 256; TM = 6: 192 x 256 (A row-major only)
+  static_assert(NW == 8 || (NW == 4 && TM == 8 && ALAY == LAY_ROW && BLAY == LAY_ROW && !DYN && KUB == 64),
+                "four-wave form: 256 x 256 tiles of row-major operands, static lists");
+  constexpr int KU = KUB;                  // (shadows the file-level 64)
+  constexpr bool K32 = KUB == 32;
+  constexpr int HALF = 256 * KU * 2, NSLOT = K32 ? 10 : 5;
+  constexpr int KSTEPS = KU / 32;          // 32-wide MFMA k-steps per unit
+  constexpr int AHEAD = 4;                 // K32: units requested ahead of the one being multiplied
+  constexpr int PER = HALF / 1024 / NW;   // LDS-DMA pieces per wave per B half-unit (4; K32: 2)
+  constexpr int PER_A = BM * KU * 2 / 1024 / NW;  // ... per A half-unit (4 or 3; K32: 2)
+  static_assert(KUB == 64 || KUB == 32, "K units are 64 or 32 deep");
+  static_assert(!K32 || (ALAY == LAY_KMAJ && BLAY == LAY_KMAJ && TM == 8 && !DYN),
+                "32-deep units: both operands K-major (512-byte k-rows), static tile lists");
+  static_assert(TM == 8 || (TM == 6 && ALAY != LAY_KMAJ), "the K-major A image assumes 512-byte k-rows");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [5][32 KiB]
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w / WN, wn = w % WN;
+  const int G = gridDim.x;
+  const int nu = (p.K + KU - 1) / KU;
+  const int rows_m = tiles_m * batch;  // tile rows over all batches
+  const int total = rows_m * tiles_n;
+
+  // ---- this workgroup's tile list: item r -> (batch, m0, n0) or "not a tile"
+  const int RM = RN > 0 ? (G >> 3) / RN : 0;
+  const int blocks_n = RN > 0 ? (tiles_n + RN - 1) / RN : 0;
+  const int nblocks = RN > 0 ? ((rows_m + RM - 1) / RM) * blocks_n : 0;
+  const int xcd = blockIdx.x & 7, jslot = blockIdx.x >> 3;
+  // CLAIMED TILES (the DYN variant, sched != nullptr): instead of a static list every tile is drawn from a counter, so a
+  // workgroup that starts late - its CU was held by an RCCL kernel overlapped with the backward pass - or runs slowly
+  // does not leave a whole list undone: the others take the work.  With XCD blocks (RN > 0) each XCD has its OWN counter
+  // over its own blocks (ticket t of XCD x = slot t % per of its block number t / per, per = G / 8 workgroups), so the
+  // tickets a chip's 32 workgroups draw one after the other are the tiles of one RM x RN block and its L2 serves the
+  // same few panels as with the static lists; without blocks there is one counter over the linear tile order.
+  // Tickets are drawn by wave 0 with a scalar-memory atomic (executed at L2, does not touch vmcnt), one or two items ahead
+  // (see "WHEN a ticket is drawn" below), and handed to the other seven waves through a two-slot mailbox in global memory
+  // (the ring leaves no LDS byte free): written with a posted s_atomic_swap, read with s_atomic_or 0 - both at L2, no cache
+  // to go stale - and always at least one workgroup barrier apart (wave 0 waits for its write in front of that barrier).  Cell layout: counter of queue q at sched[32 q] (a 128-byte line each), mailbox of
+  // workgroup b at sched[256 + 2 b + (item & 1)].  A ticket >= qtotal ends the list.  Every workgroup draws exactly one
+  // dead ticket (it stops drawing then), so a queue sees qtotal + qgroups draws: the one that returns
+  // qtotal + qgroups - 1 is the last and puts the counter back to 0 for the cell's next launch.
+  constexpr bool dyn = DYN;  // a kernel variant of its own: the static-list kernels keep their register budget
+  const int per = G >> 3;    // workgroups per XCD (RN > 0 implies G % 8 == 0)
+  const int qgroups = RN > 0 ? per : G;
+  const int qtotal = RN > 0 ? per * (nblocks > xcd ? (nblocks - xcd + 7) >> 3 : 0) : total;
+  int tk0 = 0x3FFFFFFF, tk1 = 0x3FFFFFFF;  // tickets of this workgroup's even / odd items (wave-uniform)
+  int own0 = 0x3FFFFFFF, own1 = 0x3FFFFFFF;  // wave 0: the tickets it drew (it does not read its own mail)
+  bool drawing = true;                      // wave 0: no dead ticket drawn yet
+  auto satomic = [](int* addr, int v, auto op_c) -> int {
+    constexpr int OP = decltype(op_c)::value;  // 0 add, 1 swap, 2 or (returned value waited for); 3 swap, posted
+    // (operands pinned to SGPRs: everything here is wave-uniform, but the compiler cannot always prove it)
+    const unsigned long long a64 = (unsigned long long)addr;
+    // (the builtin returns int: without the casts a low word with bit 31 set sign-extends over the high word)
+    addr = (int*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a64 >> 32)) << 32) |
+                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a64));
+    v = __builtin_amdgcn_readfirstlane(v);
+    if constexpr (OP == 0) asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(addr) : "memory");
+    else if constexpr (OP == 1) asm volatile("s_atomic_swap %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(addr) : "memory");
+    else if constexpr (OP == 2) asm volatile("s_atomic_or %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(addr) : "memory");
+    else asm volatile("s_atomic_swap %0, %1, 0x0" : : "s"(v), "s"(addr) : "memory");  // performed at L2 by the next lgkmcnt(0)
+    return v;
+  };
+  using op_add = std::integral_constant<int, 0>;
+  using op_swap = std::integral_constant<int, 1>;
+  using op_or = std::integral_constant<int, 2>;
+  using op_post = std::integral_constant<int, 3>;
+  int* counter = sched + (RN > 0 ? 32 * xcd : 0);
+  int* mail = sched + 256 + 2 * (int)blockIdx.x;
+  // ticket -> tile row / column over all batches; false: a slot of a block that hangs over the edge of the tile grid
+  auto ticket_tile = [&](int tl, int& tm, int& tn) -> bool {
+    if (RN > 0) {
+      const int lb = tl / per, j = tl - lb * per, blk = lb * 8 + xcd;
+      const int bm = blk / blocks_n, jm = j / RN;
+      tm = bm * RM + jm;
+      tn = (blk - bm * blocks_n) * RN + (j - jm * RN);
+      return tm < rows_m && tn < tiles_n;
+    }
+    tm = tl / tiles_n;
+    tn = tl - tm * tiles_n;
+    return true;
+  };
+  auto draw = [&](int item) {  // wave 0: ticket for `item` into its mailbox slot
+    int tkt = 0x3FFFFFFF;
+    if (drawing) {
+      int tm, tn;
+      do {  // (tickets of overhanging slots are drawn and dropped)
+        tkt = satomic(counter, 1, op_add{});
+        if (tkt == qtotal + qgroups - 1) satomic(counter, 0, op_swap{});  // the queue's last draw: counter back to 0
+      } while (tkt < qtotal && !ticket_tile(tkt, tm, tn));
+      drawing = tkt < qtotal;
+    }
+    if (item & 1) own1 = tkt;
+    else own0 = tkt;
+    // posted: wave 0 waits for it (lgkmcnt(0)) in front of the next workgroup barrier, and the others read the slot
+    // at least one barrier later
+    satomic(mail + (item & 1), tkt, op_post{});
+  };
+  auto take = [&](int item) {  // every wave: ticket of `item` out of the mailbox (written at least one barrier ago)
+    const int o0 = own0, o1 = own1, odd = -(item & 1);  // (chosen by mask, as in ticket() below)
+    const int tkt = w == 0 ? ((o1 & odd) | (o0 & ~odd)) : satomic(mail + (item & 1), 0, op_or{});
+    if (item & 1) tk1 = tkt;
+    else tk0 = tkt;
+  };
+  // (both tickets read, then chosen by mask: written as `r & 1 ? tk1 : tk0` the compiler selects between the two
+  // ADDRESSES inside the closure, which keeps closure and tickets in scratch memory)
+  auto ticket = [&](int r) {
+    const int a = tk0, b = tk1, odd = -(r & 1);
+    return __builtin_amdgcn_readfirstlane((b & odd) | (a & ~odd));  // wave-uniform by construction: say so
+  };
+  auto live = [&](int r) {
+    if constexpr (dyn) return ticket(r) < qtotal;
+    else return RN > 0 ? r * 8 + xcd < nblocks : r * G + (int)blockIdx.x < total;
+  };
+  auto decode = [&](int r, int& bz, int& m0, int& n0) -> bool {
+    int tm, tn;
+    if constexpr (dyn) {
+      const int tl = ticket(r);
+      if (tl >= qtotal) return false;
+      ticket_tile(tl, tm, tn);  // (draw() only hands out tickets of real tiles)
+    } else if (RN > 0) {
+      const int blk = r * 8 + xcd;
+      tm = (blk / blocks_n) * RM + jslot / RN;
+      tn = (blk % blocks_n) * RN + jslot % RN;
+      if (tm >= rows_m || tn >= tiles_n) return false;
+    } else {
+      const int gsz = min(G, total - r * G);
+      const int tl = r * G + xcd_remap(blockIdx.x, gsz);
+      tm = tl / tiles_n;
+      tn = tl - tm * tiles_n;
+    }
+    bz = tm / tiles_m;
+    m0 = (tm - bz * tiles_m) * BM;
+    n0 = tn * BN;
+    return true;
+  };
+  auto next_item = [&](int r) {  // first item after r that is a tile, or the first dead one
+    if constexpr (dyn) {
+      return r + 1;  // (its ticket was taken out of the mailbox at the top of the K unit that gets here)
+    } else {
+      int bz, m0, n0;
+      do ++r;
+      while (live(r) && !decode(r, bz, m0, n0));
+      return r;
+    }
+  };
+  // WHEN a ticket is drawn.  Needed: when the load cursor enters item ir + 1, during the last K unit but one of item
+  // ir; the others take it at the top of that unit (iu + 1 == nu), so wave 0 must have drawn it by the top of the unit
+  // before (iu + 2 == nu) - the LATE draw, a claim held for under three K units.  Drawing late costs every tile a second
+  // L2 round trip in front of a barrier (measured: + 3 % on the step's GEMMs), so while MORE THAN ONE ROUND of tickets
+  // is left in the queue (qtotal - last ticket > qgroups: nobody can be left without work by it) wave 0 draws item
+  // ir + 2 EARLY, in the same unit top in which item ir + 1 is taken.  Drawn early without that test, the first
+  // workgroups to start took two tiles each of a 240-tile launch and left the rest of the chip idle (8.1 ms against 4.3).
+  // Launches with fewer than three K units per tile have no room for the late draw: always two items ahead.
+  const bool early = nu < 3;
+  int drawn = -1, t_last = 0;  // wave 0: last item drawn for, and its ticket
+  auto plenty = [&]() { return early || qtotal - t_last > qgroups; };
+  auto draw_next = [&]() {
+    ++drawn;
+    draw(drawn);
+    const int o0 = own0, o1 = own1, odd = -(drawn & 1);
+    t_last = (o1 & odd) | (o0 & ~odd);
+  };
+  if constexpr (dyn) {  // first draws; a barrier between the mailbox writes and the first read
+    if (w == 0) {
+      draw_next();
+      if (plenty()) draw_next();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    take(0);
+  }
+
+  // ---- issue cursor: source plan of the tile whose half-units are being requested.  Piece j of a wave is piece
+  // w + 8 j of the half-unit; its rows are 64 j rows (ROW) / 16 j k-rows (K-major) below piece 0's, and the swizzled
+  // chunk a lane fetches is the same for every j, so one base offset per operand describes all four pieces.
+  rsrc_t ra, rb;
+  unsigned a_base0, b_base0;  // byte offset of this lane's chunk in piece 0 at k = 0, or OOB when its column is out
+  int pm0 = 0, pn0 = 0;       // tile origin of the plan
+  int cv_y[ALAY == LAY_CONV ? 4 : 1], cv_x[ALAY == LAY_CONV ? 4 : 1];  // LAY_CONV: per piece, top-left tap position
+  unsigned cv_img[ALAY == LAY_CONV ? 4 : 1];                           // ... and byte offset of the pixel's image
+  bool pok = false;
+  // ROW: rows 8 w + 8 NW j + (lane >> 3), logical chunk = physical chunk ^ ((row >> 1) & 7)  (row_off's swizzle)
+  const int r_row0 = 8 * w + (lane >> 3), r_c = (lane & 7) ^ ((4 * w + (lane >> 4)) & 7);
+  // K-major: k-rows 2 w + 16 j + (lane >> 5), 32 column chunks, logical = physical ^ (s << 1)  (kmaj_off's swizzle)
+  const int k_row0 = 2 * w + (lane >> 5);
+  const int k_lc = (lane & 31) ^ (((k_row0 & 3) | (((k_row0 >> 3) & 1) << 2)) << 1);
+  auto plan = [&](int r) {
+    int bz = 0;
+    pm0 = pn0 = 0;
+    pok = live(r) && decode(r, bz, pm0, pn0);  // dead: every request is out of bounds (zero fills nobody reads)
+    ra = make_rsrc4((const char*)p.A + (long long)bz * p.sA * 2, p.a_bytes);
+    rb = make_rsrc4((const char*)p.B + (long long)bz * p.sB * 2, p.b_bytes);
+    if constexpr (DYN) {  // wave-uniform by construction (the ticket is): pinned to SGPRs for the LDS-DMA asm blocks
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ra[e] = __builtin_amdgcn_readfirstlane(ra[e]);
+        rb[e] = __builtin_amdgcn_readfirstlane(rb[e]);
+      }
+    }
+    if constexpr (ALAY == LAY_KMAJ) {
+      a_base0 = (pok && pm0 + k_lc * 8 < p.M) ? (unsigned)(((long long)k_row0 * p.lda + pm0) * 2) + k_lc * 16 : OOB;
+    } else if constexpr (ALAY == LAY_CONV) {
+      // implicit im2col: row m of A is output pixel m; per piece keep the pixel's image offset and its top-left tap
+      // position (a far-out y marks rows past M, so that every tap of such a row is out of the image)
+      a_base0 = pok ? (unsigned)(r_c * 16) : OOB;
+      const int ohw = p.OH * p.OW;
+#pragma unroll
+      for (int j = 0; j < PER_A; ++j) {
+        const int m = pm0 + r_row0 + 64 * j;
+        const int bb = m / ohw, rem = m - bb * ohw;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        cv_y[j] = (pok && m < p.M) ? oy * p.cstride - p.pad_t : -100000;
+        cv_x[j] = ox * p.cstride - p.pad_l;
+        cv_img[j] = (unsigned)((long long)bb * p.cH * p.cW * p.cC * 2);
+      }
+    } else {
+      a_base0 = pok ? (unsigned)(((long long)(pm0 + r_row0) * p.lda) * 2) + r_c * 16 : OOB;
+    }
+    if constexpr (BLAY == LAY_KMAJ)
+      b_base0 = (pok && pn0 + k_lc * 8 < p.N) ? (unsigned)(((long long)k_row0 * p.ldb + pn0) * 2) + k_lc * 16 : OOB;
+    else
+      b_base0 = pok ? (unsigned)(((long long)(pn0 + r_row0) * p.ldb) * 2) + r_c * 16 : OOB;
+  };
+  // piece j (of PER) of one operand's half-unit u: `lay`-layout source with leading dimension ld, tile origin o0 of
+  // extent lim
+  auto issue_piece = [&](auto lay, rsrc_t rs, unsigned base0, long long ld, int o0, int lim, int u,
+                         char* dst, int j) {
+    const int k0 = u * KU;
+    unsigned off;
+    if constexpr (decltype(lay)::value == LAY_KMAJ)
+      off = (base0 != OOB && k0 + k_row0 + 16 * j < p.K) ? base0 + (unsigned)((long long)(k0 + 16 * j) * ld * 2) : OOB;
+    else
+      off = (base0 != OOB && o0 + r_row0 + NW * 8 * j < lim && k0 * 2 + r_c * 16 < p.K * 2)
+                ? base0 + (unsigned)((long long)(NW * 8 * j) * ld * 2) + k0 * 2
+                : OOB;
+    dma16(rs, dst + (w + NW * j) * 1024, off);
+  };
+  auto issue_a_piece = [&](int u, char* dst, int j) {
+    if constexpr (ALAY == LAY_CONV) {
+      // one K unit = 64 channels of one filter tap (Cin % 64 == 0): the row's source is the tap-shifted input pixel;
+      // padding, the stride-2 asymmetric pad and nearest-x2 upsampling are address predicates (zero fill)
+      const int k0 = u * KU;
+      const int tap = k0 / p.cC, ci0 = k0 - tap * p.cC;
+      const int ky = tap / p.KW, kx = tap - ky * p.KW;
+      int iy = cv_y[j] + ky, ix = cv_x[j] + kx;
+      const bool ok = a_base0 != OOB && k0 < p.K && iy >= 0 && ix >= 0 && iy < (p.cH << p.ups) && ix < (p.cW << p.ups);
+      iy >>= p.ups;
+      ix >>= p.ups;
+      const unsigned off = ok ? cv_img[j] + (unsigned)(((iy * p.cW + ix) * p.cC + ci0) * 2) + a_base0 : OOB;
+      dma16(ra, dst + (w + NW * j) * 1024, off);
+    } else {
+      issue_piece(std::integral_constant<int, ALAY>{}, ra, a_base0, p.lda, pm0, p.M, u, dst, j);
+    }
+  };
+  auto issue_b_piece = [&](int u, char* dst, int j) {
+    issue_piece(std::integral_constant<int, BLAY>{}, rb, b_base0, p.ldb, pn0, p.N, u, dst, j);
+  };
+
+  int first_item = -1;
+  first_item = next_item(first_item);  // (claimed tiles: item 0, ticket taken above)
+  // Issue cursor.  The stream of half-units is A(0) B(0) A(1) | B(1) A(2) | B(2) A(3) | ... : three up front, then
+  // every K-unit iteration requests the B half of unit `iu` and the A half of the unit after it.
+  int ir = first_item, iu = 0;  // item and K-unit of the next B half to request
+  int fill = 0;                 // slot of the next half-unit to request
+  plan(ir);
+  auto next_slot = [&]() { fill = fill + 1 == NSLOT ? 0 : fill + 1; };
+  // claimed tiles: called (by every wave) at the top of a K unit, no LDS read in flight, the cursor in item `ir`
+  auto claim = [&]() {
+    if (iu + 2 == nu) {
+      if (w == 0 && drawn < ir + 1) draw_next();  // late (into the slot of item ir - 1)
+    } else if (iu + 1 == nu) {
+      take(ir + 1);
+      if (w == 0 && drawn < ir + 2 && plenty()) draw_next();  // early (into the slot of item ir)
+    }
+  };
+  auto next_unit = [&]() {      // the B half of unit iu is out: move on (possibly to the next tile)
+    if (++iu == nu) {
+      iu = 0;
+      ir = next_item(ir);
+      plan(ir);
+    }
+  };
+  if constexpr (dyn) if (nu == 1) {  // the prologue's next_unit() below already moves to item 1
+    asm volatile("s_barrier" ::: "memory");  // every wave has taken item 0 out of the slot item 2 is drawn into
+    claim();
+  }
+  if constexpr (K32) {
+    // the cursor (ir, iu) is the next UNIT to request (both halves); units 0 .. AHEAD-1 up front: A(q) -> slot 2q,
+    // B(q) -> slot 2q + 1
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q) {
+#pragma unroll
+      for (int j = 0; j < PER_A; ++j) issue_a_piece(iu, smem + (2 * q) * HALF, j);
+#pragma unroll
+      for (int j = 0; j < PER; ++j) issue_b_piece(iu, smem + (2 * q + 1) * HALF, j);
+      next_unit();
+    }
+    fill = 2 * AHEAD;
+  } else {
+#pragma unroll
+  for (int j = 0; j < PER_A; ++j) issue_a_piece(0, smem, j);           // A(0) -> slot 0
+#pragma unroll
+  for (int j = 0; j < PER; ++j) issue_b_piece(0, smem + HALF, j);      // B(0) -> slot 1
+  next_unit();
+#pragma unroll
+  for (int j = 0; j < PER_A; ++j) issue_a_piece(iu, smem + 2 * HALF, j);  // A(1) -> slot 2
+  fill = 3;
+  }
+  int slot = 0;  // slot of the A half of the unit being multiplied
+  bool first = true;
+  for (int r = first_item; live(r); r = next_item(r)) {
+    int bz, m0, n0;
+    decode(r, bz, m0, n0);
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if ((G256_LAB & 8)) ts0 = __builtin_amdgcn_s_memtime();
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ROW SUMS OF A (p.a_rowsum, weight-gradient instantiation only): the bias gradient is the sum over the reduction
+    // rows of the same dY the K loop streams through LDS anyway - one more MFMA per A fragment against a fragment of
+    // ones (every output row then holds sum_k A[m][k]) instead of a pass of its own over the tensor.  The tiles of one
+    // tile row share the work: tile column tn takes K units tn, tn + tiles_n, ... (each of the four waves of a row group
+    // two of its eight 16-row fragments: 8 registers - with all eight in one wave the kernel spilled 31), and writes its
+    // partial sums as row (batch, tn) of p.a_rowsum; the host adds the rows in fixed order.
+    constexpr bool CS = ALAY == LAY_KMAJ && BLAY == LAY_KMAJ && MODE == EPI_PLAIN32N && TM == 8;
+    constexpr int CSN = TM / WN;
+    f32x4 cs[CS ? CSN : 1];
+    int cs_next = 0x7FFFFFFF;
+    if constexpr (CS) {
+#pragma unroll
+      for (int a = 0; a < CSN; ++a) cs[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.a_rowsum) cs_next = n0 >> 8;
+    }
+
+    auto unit = [&](int u) {
+      // H(2u), H(2u+1) must have landed for every wave and every wave must be past its reads of unit u-1, whose two
+      // slots are refilled now.  One younger half-unit (an A half: PER_A operations) may still be in flight.  The half-units
+      // requested before the previous tile's epilogue were drained there (vmcnt(0)): barrier only.
+      if constexpr (dyn) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave 0's posted mailbox write (no LDS read is pending here)
+      // (K32: the three younger units - 3 x (PER_A + PER) operations of this wave - may still be in flight)
+      if (first || u > 0) wait_vm_barrier<K32 ? (AHEAD - 1) * (PER_A + PER) : PER_A>();
+      else asm volatile("s_barrier" ::: "memory");
+      if constexpr (dyn) claim();  // (iu + 1 == nu: this unit's next_unit() moves the cursor to the next item)
+      // The eight LDS-DMA pieces of this iteration (B of unit iu, then A of the unit after) are issued ONE AT A TIME
+      // between groups of MFMAs: a piece occupies the issuing wave for 60-180 cycles, and all 64 of a workgroup's
+      // pieces issued together right after the barrier stall every wave for as long as the whole K-unit's MFMAs
+      // take (measured: K-unit time = MFMA time + DMA time).  Spread out, the SIMD's other wave keeps the matrix
+      // pipe busy meanwhile.
+      constexpr bool DMA_ON = G256_LAB != 1 && G256_LAB != 9;
+      // 64-deep units: this iteration requests the B half of unit iu, then the A half of the unit after it;
+      // 32-deep units: both halves of unit iu, A into the even slot
+      char* dst_b = smem + (K32 ? fill + 1 : fill) * HALF;
+      char* dst_a = smem + (K32 ? fill : (fill + 1 == NSLOT ? 0 : fill + 1)) * HALF;
+      next_slot();
+      next_slot();
+      const char* sa = smem + slot * HALF;
+      const char* sb = smem + (slot + 1 == NSLOT ? 0 : slot + 1) * HALF;
+      // (four-wave form: a wave has 256 registers besides its accumulators - the second k-step's fragments are requested
+      // together with the first's and arrive under the first's MFMAs; the eight-wave form has no registers for that)
+      constexpr bool PRE = NW == 4;
+      u32x4 fa_[PRE ? 2 : 1][TM], fb_[PRE ? 2 : 1][TN];
+#pragma unroll
+      for (int ks = 0; ks < (G256_LAB == 10 ? 0 : KSTEPS); ++ks) {
+        // all 12 fragment reads of this k-step go out back to back, then the MFMAs run at raised priority: the LDS
+        // sees a short read burst and is otherwise free for the LDS-DMA writes that are landing.  (Left to itself
+        // the compiler reads one A fragment at a time, each behind an lgkmcnt(0), to save registers.)
+        u32x4 (&fa)[TM] = fa_[PRE ? ks : 0];
+        u32x4 (&fb)[TN] = fb_[PRE ? ks : 0];
+        if (G256_LAB == 12) {  // MFMAs on whatever is in the registers: no LDS reads
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt) { fb[nt] = u32x4{(unsigned)lane, 1u, 2u, 3u}; asm volatile("" : "+v"(fb[nt])); }
+#pragma unroll
+          for (int mt = 0; mt < TM; ++mt) { fa[mt] = u32x4{(unsigned)lane, 1u, 2u, 3u}; asm volatile("" : "+v"(fa[mt])); }
+        } else if (!PRE || ks == 0) {
+#pragma unroll
+          for (int k2 = ks; k2 < (PRE ? KSTEPS : ks + 1); ++k2) {
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) fb_[PRE ? k2 : 0][nt] = load_frag<BLAY, BN>(sb, wn * TN + nt, k2, lane);
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) fa_[PRE ? k2 : 0][mt] = load_frag<ALAY, BM>(sa, wm * TM + mt, k2, lane);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef G256_PRIO
+#define G256_PRIO 1  // lab: priority of the MFMA phase (0: none, 1: as shipped, 3: highest)
+#endif
+        __builtin_amdgcn_s_setprio(G256_PRIO);
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt) {
+            if (G256_LAB == 13) asm volatile("" ::"v"(fb[nt]), "v"(fa[mt]));      // lab: LDS-DMA + fragment reads, no MFMA
+            else mma<bf16_t>(acc[mt][nt], fb[nt], fa[mt]);  // rows = n, cols = m
+          }
+          // piece k of NP goes out after MFMA row floor((k + 1) TM / NP) - 1
+          // (K32: the unit's one k-step carries all four pieces - A, A, B, B after rows 1, 3, 5, 7)
+          const int np = K32 ? PER_A + PER : (ks == 0 ? PER : PER_A);
+#ifndef G256_BFRONT
+#define G256_BFRONT 0
+#endif
+          const bool front = (G256_BFRONT == 1 && ks == 0) || G256_BFRONT == 2;
+          const int k_here = front ? (mt < np ? 1 : 0) : ((mt + 1) * np) / TM - (mt * np) / TM;  // 0 or 1 pieces after this row
+          const int k_idx = front ? mt : (mt * np) / TM;
+          if (DMA_ON && k_here > 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (K32) {
+              if (k_idx < PER_A) issue_a_piece(iu, dst_a, k_idx);
+              else issue_b_piece(iu, dst_b, k_idx - PER_A);
+            } else {
+              if (ks == 0) issue_b_piece(iu, dst_b, k_idx);
+              else issue_a_piece(iu, dst_a, k_idx);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if constexpr (CS) {
+          if (u == cs_next) {  // (wave-uniform)
+            const unsigned one2 = pack_bf16x2(1.0f, 1.0f);
+            const u32x4 ones = {one2, one2, one2, one2};
+            static_for<WN>([&](auto wn_c) {  // (wave-uniform: one copy of the two MFMAs per wave column)
+              constexpr int W0 = decltype(wn_c)::value;
+              if (wn == W0) {
+#pragma unroll
+                for (int a = 0; a < CSN; ++a) mma<bf16_t>(cs[a], ones, fa[W0 * CSN + a]);
+              }
+            });
+            if (ks == KSTEPS - 1) cs_next += tiles_n;
+          }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (DMA_ON && ks == 0) next_unit();  // (K32: after both halves of unit iu; else between B(iu) and A(iu + 1))
+      }
+      if (DMA_ON && G256_LAB == 10) {  // lab: DMA only
+        if constexpr (K32) {
+#pragma unroll
+          for (int j = 0; j < PER_A; ++j) issue_a_piece(iu, dst_a, j);
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) issue_b_piece(iu, dst_b, j);
+        next_unit();
+        if constexpr (!K32) {
+#pragma unroll
+          for (int j = 0; j < PER_A; ++j) issue_a_piece(iu, dst_a, j);
+        }
+      }
+      slot = slot + 2 >= NSLOT ? slot + 2 - NSLOT : slot + 2;
+    };
+    // The first unit of a tile is peeled off the loop: the registers that held the previous tile's epilogue loads are
+    // re-used by the loop body, the compiler guards their first re-use with a vector-memory wait, and inside the loop
+    // that wait would run - and drain the ring - on every unit.
+    unit(0);
+    for (int u = 1; u < nu; ++u) unit(u);
+    first = false;
+    if ((G256_LAB & 8)) ts1 = __builtin_amdgcn_s_memtime();
+    // this wave's pieces of the next three half-units have landed; every wave is past its reads of the last unit,
+    // whose A slot ( = `fill`, refilled at the next barrier) is the epilogue's staging block
+    // (the drain is written with the builtin, not inline asm, so that the compiler's own wait-count bookkeeping
+    // knows that no vector-memory operation is outstanding here: with LDS-DMA pieces "possibly in flight" it would
+    // put a full vmcnt(0) in front of every use of an ordinary load in the epilogue - the residual slabs)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+    asm volatile("s_barrier" ::: "memory");
+    // the epilogue's per-lane offsets are tile-invariant; hoisted out of the tile loop they would sit in scratch
+    // (the K loop owns the whole register file) and every reload is a memory round trip - recompute them per tile
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    if ((G256_LAB & 8)) ts2 = __builtin_amdgcn_s_memtime();
+    if (G256_LAB == 6) {  // no epilogue, accumulators kept alive
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) sum += acc[a][b];
+      if (sum[0] + sum[1] + sum[2] + sum[3] == 12345.f) *(float*)p.C = sum[0];
+      continue;
+    }
+#ifdef G256_EPI_SOLO  // lab: only workgroup 17 stores its tiles (is the epilogue bound by the chip-wide write burst?)
+    if (blockIdx.x != 17) {
+      GemmParams q = p;
+      q.N = p.alpha == 1.f ? 0 : p.N;
+      epilogue<bf16_t, TM, TN, MODE, ALAY != LAY_CONV>(q, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, bz, lane_e, smem + fill * HALF + w * (32768 / NW));
+      continue;
+    }
+#endif
+    if (G256_LAB == 4) {  // full epilogue arithmetic + staging, stores predicated off at run time
+      GemmParams q = p;
+      q.N = p.alpha == 1.f ? 0 : p.N;
+      epilogue<bf16_t, TM, TN, MODE, ALAY != LAY_CONV>(q, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, bz, lane_e, smem + fill * HALF + w * (32768 / NW));
+      continue;
+    }
+    epilogue<bf16_t, TM, TN, MODE, ALAY != LAY_CONV>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, bz, lane_e, smem + fill * HALF + w * (32768 / NW));
+    if constexpr (CS) {
+      if (p.a_rowsum && (lane_e >> 4) == 0) {  // every tile writes its slice, zeros when it took no K unit
+        float* dst = p.a_rowsum + ((long long)bz * tiles_n + (n0 >> 8)) * p.ld_rowsum;
+#pragma unroll
+        for (int a = 0; a < CSN; ++a) {
+          const int m = m0 + wm * TM * 16 + (wn * CSN + a) * 16 + (lane_e & 15);
+          if (m < p.M) dst[m] = cs[a][0];
+        }
+      }
+    }
+#if G256_LAB & 8
+    if (blockIdx.x == 17 && t == 0) {
+      unsigned long long* dbg = g256_dbg + 4 * (r - first_item);
+      dbg[0] = ts0; dbg[1] = ts1; dbg[2] = ts2; dbg[3] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+static int device_cus();
+
+template <int ALAY, int BLAY, int MODE, int TM>
+int launch_tm(const GemmParams& p, int batch, int ncu, hipStream_t s) {
+  constexpr int LDS = 5 * 256 * 128;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)gemm256_kernel<ALAY, BLAY, MODE, TM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS) != hipSuccess)
+      return MELGPT_ERR_LAUNCH;
+    attr = true;
+  }
+  constexpr int BM = 32 * TM;
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + 255) / 256;
+  const long long total = (long long)tiles_m * tiles_n * batch;
+  if (total > 0x3FFFFFFF) return MELGPT_ERR_UNSUPPORTED;
+  int grid = (int)(total < ncu ? total : ncu);  // LDS footprint: exactly one workgroup per CU
+  // XCD blocks need every XCD to own the same number of workgroups; otherwise the linear order is used
+  int RN = 0;
+  if (grid == ncu && ncu % 8 == 0) {
+    // block shape RM x RN with RM * RN = workgroups per XCD: the one that pads the tile grid least (a 3-wide block on a
+    // 4-column grid leaves a third of the workgroups of every second block without a tile - 240 workgroups, 30 per XCD,
+    // N = 1024: + 18 % on the step), the most square among equals
+    const int per = ncu / 8;
+    const long long rows_m = (long long)tiles_m * batch;
+    long long best = 0;
+    for (int c = 1; c * c <= per; ++c) {
+      if (per % c != 0 || c > tiles_n) continue;
+      const int rm = per / c;
+      const long long slots = ((tiles_n + c - 1) / c) * (long long)c * (((rows_m + rm - 1) / rm) * rm);
+      if (RN == 0 || slots <= best) {
+        best = slots;
+        RN = c;
+      }
+    }
+  }
+  int* sched = nullptr;
+  if (melgpt_get_dynamic_tiles() && 256 + 2 * grid <= MELGPT_TILE_CELL_INTS)
+    sched = melgpt_tile_cell();  // claimed tiles: this launch's counters + mailboxes (abi.hip); nullptr -> static lists
+  if (sched) {
+    static bool attr_dyn = false;
+    if (!attr_dyn) {
+      if (hipFuncSetAttribute((const void*)gemm256_kernel<ALAY, BLAY, MODE, TM, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        return MELGPT_ERR_LAUNCH;
+      attr_dyn = true;
+    }
+    hipLaunchKernelGGL((gemm256_kernel<ALAY, BLAY, MODE, TM, true>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n,
+                       batch, RN, sched);
+  } else {
+    // Lab variants of round 4, both measured slower and OFF unless asked for (profiles/r04_gemm_lab.md):
+    // MELGPT_GEMM_KU32=1: 32-deep K units on a ten-slot ring (both operands K-major, f32 output: the weight gradients);
+    // MELGPT_GEMM_W4=1: four waves with 128 x 128 accumulator blocks (row-major operands, plain bf16 epilogues).
+    if constexpr (ALAY == LAY_ROW && BLAY == LAY_ROW && TM == 8 && (MODE == EPI_PLAIN16 || MODE == EPI_PLAIN16N)) {
+      const char* e = getenv("MELGPT_GEMM_W4");
+      if (e && e[0] == '1') {
+        static bool attr4 = false;
+        if (!attr4) {
+          if (hipFuncSetAttribute((const void*)gemm256_kernel<ALAY, BLAY, MODE, TM, false, 64, 4>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return MELGPT_ERR_LAUNCH;
+          attr4 = true;
+        }
+        hipLaunchKernelGGL((gemm256_kernel<ALAY, BLAY, MODE, TM, false, 64, 4>), dim3(grid), dim3(256), LDS, s, p, tiles_m,
+                           tiles_n, batch, RN, sched);
+        return melgpt_launch_status();
+      }
+    }
+    if constexpr (ALAY == LAY_KMAJ && BLAY == LAY_KMAJ && TM == 8 && (MODE == EPI_PLAIN32 || MODE == EPI_PLAIN32N)) {
+      const char* e = getenv("MELGPT_GEMM_KU32");
+      if (e && e[0] == '1') {
+        static bool attr32 = false;
+        if (!attr32) {
+          if (hipFuncSetAttribute((const void*)gemm256_kernel<ALAY, BLAY, MODE, TM, false, 32>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return MELGPT_ERR_LAUNCH;
+          attr32 = true;
+        }
+        hipLaunchKernelGGL((gemm256_kernel<ALAY, BLAY, MODE, TM, false, 32>), dim3(grid), dim3(512), LDS, s, p, tiles_m,
+                           tiles_n, batch, RN, sched);
+        return melgpt_launch_status();
+      }
+    }
+    hipLaunchKernelGGL((gemm256_kernel<ALAY, BLAY, MODE, TM, false>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n,
+                       batch, RN, sched);
+  }
+  return melgpt_launch_status();
+}
+
+static int device_cus() {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+      ncu = n;
+  }
+  return ncu;
+}
+
+// Tile height: 256 rows, or 192 when that leaves fewer padded tile-rounds (rounds x tile rows) on this many CUs -
+// e.g. M = 33920, N = 1024: 532 tiles of 256 x 256 are 3 rounds on 256 CUs (cost 3 x 8), 708 of 192 x 256 are 3 shorter
+// rounds (3 x 6).
+template <int ALAY, int BLAY, int MODE>
+int launch_mode(const GemmParams& p, int batch, hipStream_t s) {
+  int ncu = device_cus();
+  if (ncu <= 0) return MELGPT_ERR_LAUNCH;
+  if (ncu - melgpt_get_reserved_cus() >= 8) ncu -= melgpt_get_reserved_cus();  // CUs left to concurrent RCCL kernels
+  if constexpr (ALAY != LAY_KMAJ) {
+    // cost of a launch = tile rounds x cycles of one tile.  A 192-row tile is NOT 3/4 of a 256-row one: its K unit takes
+    // 2.9 k cycles against 3.45 k (the B half-unit is staged for fewer rows) and its epilogue 6.3 k against 8 k, + ~2 k of
+    // drain and tile switch either way (s_memtime stamps, profiles/r03_gemm_lab.md).  Counting rounds x rows - the first
+    // model - put the qkv projection (N = 3072: 9 rounds of 192 rows against 7 of 256) on the wrong side: 5.10 -> 4.72 ms
+    // per step with 256 rows.
+    const long long nu = (p.K + KU - 1) / KU;
+    auto cost = [&](int bm, int tm) {
+      const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + 255) / 256) * batch;
+      return ((tiles + ncu - 1) / ncu) * (tm == 6 ? nu * 290 + 830 : nu * 345 + 1000);
+    };
+    static int forced = -1;  // MELGPT_GEMM_TM=6|8 pins the tile height (tests cover both)
+    if (forced < 0) {
+      const char* e = getenv("MELGPT_GEMM_TM");
+      forced = e ? atoi(e) : 0;
+    }
+    // the full-epilogue kernel with a K-major B operand spills 8 VGPRs at 256 rows, and its reloads sit in the K loop
+    // where their vmcnt(0) drains the ring on every unit (GELU' dgrad: 11.1 -> 15.3 ms per step): ties go to 192 rows
+    const bool tie6 = MODE == EPI_FULL16 && BLAY == LAY_KMAJ;
+    const long long c6 = cost(192, 6), c8 = cost(256, 8);
+    if (forced == 6 || (forced != 8 && (c6 < c8 || (tie6 && c6 == c8)))) return launch_tm<ALAY, BLAY, MODE, 6>(p, batch, ncu, s);
+  }
+  return launch_tm<ALAY, BLAY, MODE, 8>(p, batch, ncu, s);
+}
+
+template <int ALAY, int BLAY>
+int launch_lay(const GemmParams& p, int batch, hipStream_t s) {
+  if (!p.vec_io) return MELGPT_ERR_UNSUPPORTED;
+  // MELGPT_ACT_MUL (v *= R: the saved GELU derivative) is a plain mode: same loads and stores as a residual add
+  const bool plain = (p.act == MELGPT_ACT_NONE || p.act == MELGPT_ACT_MUL) && p.drop_scale == 0.f && !p.C2;
+  if (p.a_rowsum) {  // row sums of A ride on the weight-gradient instantiation only (K-major x K-major, f32 out, no loads)
+    if constexpr (!(ALAY == LAY_KMAJ && BLAY == LAY_KMAJ)) return MELGPT_ERR_UNSUPPORTED;
+    if (!p.out_f32 || !plain || p.R || p.accumulate || p.act != MELGPT_ACT_NONE) return MELGPT_ERR_UNSUPPORTED;
+  }
+  if constexpr (ALAY == LAY_CONV) {  // convolutions: bias + residual, bf16 out - the only form the VQ-VAE uses
+    return (plain && !p.out_f32) ? launch_mode<ALAY, BLAY, EPI_PLAIN16>(p, batch, s) : MELGPT_ERR_UNSUPPORTED;
+  } else {
+    const bool loads = p.R || p.accumulate;
+    if (p.out_f32) {
+      if (!plain) return MELGPT_ERR_UNSUPPORTED;
+      return loads ? launch_mode<ALAY, BLAY, EPI_PLAIN32>(p, batch, s) : launch_mode<ALAY, BLAY, EPI_PLAIN32N>(p, batch, s);
+    }
+    if (p.act == MELGPT_ACT_GELU_DACT) {  // forward of Linear -> GELU: its own lean mode, or the generic 128-tile kernel
+      if constexpr (ALAY == LAY_ROW && BLAY == LAY_ROW) {
+        if (p.drop_scale == 0.f && !loads && p.C2) return launch_mode<ALAY, BLAY, EPI_DACT16>(p, batch, s);
+      }
+      return MELGPT_ERR_UNSUPPORTED;
+    }
+    if (p.act == MELGPT_ACT_MUL && !plain) return MELGPT_ERR_UNSUPPORTED;
+    if constexpr (ALAY == LAY_ROW && BLAY == LAY_ROW) {  // Linear -> dropout -> + residual: its own lean mode
+      if (p.act == MELGPT_ACT_NONE && p.drop_scale != 0.f && p.R && !p.C2 && !p.accumulate && (p.N & 3) == 0)
+        return launch_mode<ALAY, BLAY, EPI_DROPR16>(p, batch, s);
+    }
+    if (!plain) return launch_mode<ALAY, BLAY, EPI_FULL16>(p, batch, s);
+    return loads ? launch_mode<ALAY, BLAY, EPI_PLAIN16>(p, batch, s) : launch_mode<ALAY, BLAY, EPI_PLAIN16N>(p, batch, s);
+  }
+}
+
+}  // namespace
+
+int gemmk::launch_gemm256(const GemmParams& p, int alay, int blay, int batch, int tile_cfg, hipStream_t s) {
+  if (tile_cfg != 3) return MELGPT_ERR_UNSUPPORTED;
+  if (alay == LAY_ROW && blay == LAY_ROW) return launch_lay<LAY_ROW, LAY_ROW>(p, batch, s);
+  if (alay == LAY_ROW && blay == LAY_KMAJ) return launch_lay<LAY_ROW, LAY_KMAJ>(p, batch, s);
+  if (alay == LAY_KMAJ && blay == LAY_KMAJ) return launch_lay<LAY_KMAJ, LAY_KMAJ>(p, batch, s);
+  if (alay == LAY_CONV && blay == LAY_ROW) return launch_lay<LAY_CONV, LAY_ROW>(p, batch, s);
+  return MELGPT_ERR_UNSUPPORTED;
+}
