@@ -38,6 +38,8 @@ typedef _Float16 melgpt_half_native;
 typedef __attribute__((ext_vector_type(8))) _Float16 melgpt_half8;
 #define MELGPT_MFMA_16x16x32(a, b, c) \
   __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(melgpt_half8, a), __builtin_bit_cast(melgpt_half8, b), c, 0, 0, 0)
+#define MELGPT_MFMA_32x32x16(a, b, c) \
+  __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(melgpt_half8, a), __builtin_bit_cast(melgpt_half8, b), c, 0, 0, 0)
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }
 __device__ __forceinline__ float half_lo(unsigned v) { return bf16_to_f32((bf16_t)(v & 0xFFFFu)); }
@@ -45,6 +47,8 @@ __device__ __forceinline__ float half_hi(unsigned v) { return bf16_to_f32((bf16_
 #else
 #define MELGPT_MFMA_16x16x32(a, b, c) \
   __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0)
+#define MELGPT_MFMA_32x32x16(a, b, c) \
+  __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0)
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   // plain cast semantic (round-to-nearest-even); hipcc lowers __bf16 casts to v_cvt_pk_bf16_f32 on gfx950

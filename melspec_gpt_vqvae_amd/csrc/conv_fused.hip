@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(FusedConvParams q) {
 #if CONVW_LAB
 __device__ unsigned long long melgpt_convw_dbg[64];
 __device__ unsigned long long melgpt_convw_dbg2[16];
+__device__ unsigned long long melgpt_convws_dbg[2][16][8];  // [role][tile ordinal][stamp]: workgroup 7, waves 0 and 4
 #endif
 
 constexpr int WNST = 4;
@@ -205,10 +206,16 @@ struct WideTile {
 };
 // (host) the shape a layer runs with: 8 x 32 when it computes fewer pixels and the last column tile's second half is
 // either whole or empty (the epilogue takes ONE valid-pixel count per tile)
+// the wave-specialised kernel (conv3x3_gn_ws_kernel below; 16 x 16 tiles only): MELGPT_CONV_WS=0 keeps the round-3 kernel
+static bool conv_ws_on() {
+  static int on = -1;
+  if (on < 0) on = !(getenv("MELGPT_CONV_WS") && atoi(getenv("MELGPT_CONV_WS")) == 0);
+  return on != 0;
+}
 static bool wide_w8(int H, int W) {
   static int off = -1;  // lab switch: MELGPT_CONV_W8=0 keeps every layer on 16 x 16 tiles
   if (off < 0) off = getenv("MELGPT_CONV_W8") && atoi(getenv("MELGPT_CONV_W8")) == 0;
-  if (off) return false;
+  if (off || conv_ws_on()) return false;
   const long long p16 = (long long)((H + 15) / 16) * ((W + 15) / 16), p8 = (long long)((H + 7) / 8) * ((W + 31) / 32);
   return p8 < p16 && (W % 32 == 0 || W % 32 <= 16);
 }
@@ -541,6 +548,456 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// WAVE-SPECIALISED form of the persistent kernel (round 4; bf16, Cin = Cout = 128, 16 x 16-pixel tiles).
+// In the kernel above all 8 waves do everything in turn: stage the patch (VALU: affine + swish, 10.5 k cycles), multiply
+// (33 k), store (3.8 k) - 49 k cycles per tile for 18.4 k cycles of MFMA issue, and the two waves of a SIMD run the same
+// stream in lockstep, so VALU work placed "under" the MFMAs stalls the matrix pipe for both (profiles/r03_gemm_lab.md).
+// Here the two waves of a SIMD have different JOBS:
+//   waves 0-3 (one per SIMD) MULTIPLY with v_mfma_f32_32x32x16 (an MFMA holds the SIMD's vector issue for 8 of its 32
+//     cycles - the 16x16x32 form for 8 of 16 - which is what leaves the partner wave its VALU slots): wave tile 64 pixels
+//     x 128 channels = 2 x 4 tiles of 32 x 32, per 16-wide step 2 patch + 4 weight fragments for 8 MFMAs, the next step's
+//     fragments requested under the current step's MFMAs, every fragment address = one per-lane base + a compile-time
+//     offset (the patch is LINEAR with a 272-byte pixel pitch: 16 consecutive pixels cover all 64 banks without an XOR,
+//     so tap shifts and channel steps are immediates - no address VALU in the loop);
+//   waves 4-7 STAGE: raw patch loads one phase ahead, GroupNorm affine + swish, ds_write, and all LDS-DMA requests of the
+//     weight ring - on the VALU / memory pipes while their SIMD partner owns the matrix pipe (tools/lab/ws_lab.hip).
+// One patch buffer serves both: the K loop runs CHANNEL-HALF-major (half 0: 9 taps, half 1: 9 taps), so while half 1 of tile
+// t is multiplied, half 0 of tile t + 1 is staged over the bytes half 0 of tile t no longer needs, and vice versa:
+//   phase A(t): multiply half 0 (t)   | stage half 1 (t)      -> barrier
+//   phase B(t): multiply half 1 (t)   | stage half 0 (t + 1)  -> epilogue (multiplying waves) -> barrier
+// Two workgroup barriers per tile.  The weight ring (4 stages x 16 KiB, a stage = 64 channels of one tap) is handed over
+// through two sets of LDS counters instead: full[s] (K-steps whose pieces staging wave s has seen land: its counted
+// s_waitcnt vmcnt, then a ds_write) and free[w] (K-steps multiplying wave w has read: LDS executes a wave's operations in
+// order, so the ds_write behind the last fragment read is the release).  K-step k is requested when k - 4 is free - three
+// K-steps before it is needed.  Every vector-memory operation of a staging wave is inline asm with a hand-counted wait
+// (the compiler cannot count LDS-DMA, and would drain the ring in front of any load it can see).
+// MFMA rows are weight rows in a PERMUTED order - fragment row rho of tile nt is channel 32 nt + 16 ((rho >> 2) & 1) +
+// 4 (rho >> 3) + (rho & 3) - so that the 16 accumulator registers of a lane are 16 CONSECUTIVE channels of its pixel:
+// stores and residual loads are 16 bytes per lane (two per tile), 64 contiguous bytes per pixel.  The residual of the next
+// tile is fetched during this tile's epilogue and the accumulators start from bias + residual.  Every spin is bounded.
+constexpr int WS_PP = 272, WS_NPIX = 18 * 18, WS_PATCH = WS_NPIX * WS_PP, WS_RING = 4 * 16384;
+constexpr int WS_LDS = WS_PATCH + WS_RING + 1024 /* gamma, beta */ + 512 /* bias */ + 1024 /* output statistics */ + 64 /* counters */;
+constexpr int WS_SPIN = 1 << 22;
+#ifndef WS_LAB
+#define WS_LAB 0   // lab: 1 no affine / swish arithmetic in the staging pass, 2 no LDS-DMA requests (stale weights), 4 no polls in the multiplying waves
+#endif
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <bool STATS>
+__global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, int total_tiles) {
+  constexpr int PP = WS_PP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const GemmParams& p = q.g;
+  char* patch = smem;
+  char* ring = smem + WS_PATCH;
+  float* gb = (float*)(ring + WS_RING);           // [128][2]: gamma, beta
+  float* bias_l = gb + 256;                       // [128]
+  float* stp = bias_l + 128;                      // [4 waves][32 groups][2]
+  // (LDS-address-space pointers on purpose: through a generic volatile pointer the counters became FLAT loads / stores,
+  // which count on vmcnt AND lgkmcnt, out of order - every poll drained the staging waves' LDS-DMA ring)
+  volatile __attribute__((address_space(3))) u32x4* cnt4 = LDS_PTR(volatile u32x4, stp + 256);   // [0] full[0..3], [1] free[0..3]
+  volatile __attribute__((address_space(3))) unsigned* cnt = LDS_PTR(volatile unsigned, stp + 256);
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool norm = q.mean != nullptr;
+  const int tiles_img = q.tiles_x * q.tiles_y, G = gridDim.x;
+  if (t < 128) {
+    gb[2 * t] = norm ? q.gamma[t] : 1.f;
+    gb[2 * t + 1] = norm ? q.beta[t] : 0.f;
+    bias_l[t] = p.bias ? p.bias[t] : 0.f;
+  }
+  if (t < 8) cnt[t] = 0u;
+  __syncthreads();
+  auto min4 = [](u32x4 v) -> unsigned {
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)min(min(v[0], v[1]), min(v[2], v[3])));
+  };
+
+  if (w < 4) {
+    // ================================================================== multiplying waves
+    const int wm = w, r32 = lane & 31, h = lane >> 5;
+    // patch fragment f (32 pixels = row-blocks 4 wm + 2 f, + 1): lane = pixel r32 of it, 16-byte k-chunk h of the step
+    const char* abase = patch + ((wm * 4 + (r32 >> 4)) * 18 + (r32 & 15)) * PP + h * 16;
+    // weight fragment nt: lane = fragment row r32 = channel 32 nt + perm(r32), chunk 2 ks + h of the 128-byte row
+    const int perm = 16 * ((r32 >> 2) & 1) + 4 * (r32 >> 3) + (r32 & 3);
+    const char* bb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bb[ks] = ring + row_off(perm, 2 * ks + h);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.R, p.R ? q.r_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.C, q.r_bytes);
+    auto out_off = [&](int tile, int f) -> unsigned {  // byte offset of (this lane's pixel of fragment f, channel 16 h) in y / R
+      const int b = tile / tiles_img, r = tile - b * tiles_img, ty = r / q.tiles_x, tx = r - ty * q.tiles_x;
+      const int y = ty * 16 + wm * 4 + 2 * f + (r32 >> 4), x = tx * 16 + (r32 & 15);
+      const bool ok = tile < total_tiles && y < q.H && x < q.W;
+      return ok ? (unsigned)(((((long long)b * q.H + y) * q.W + x) * 128 + 16 * h) * 2) : OOB;
+    };
+    u32x4 rr[2][4][2];  // residual of the tile about to be multiplied, in accumulator layout (channels 32 nt + 16 h + 0..15)
+    auto fetch_res = [&](int tile) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const unsigned o = out_off(tile, f);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+            rr[f][nt][e] = (p.R && o != OOB) ? buf_load16(rres, o + nt * 64 + e * 16) : u32x4{0u, 0u, 0u, 0u};
+      }
+    };
+#if CONVW_LAB
+    unsigned long long spins = 0;
+#endif
+    auto wait_full = [&](unsigned k) {   // K-step k has landed for every staging wave
+      if (!(WS_LAB & 4)) {
+        for (int it = 0; min4(cnt4[0]) <= k && it < WS_SPIN; ++it) {
+          __builtin_amdgcn_s_sleep(1);
+#if CONVW_LAB
+          ++spins;
+#endif
+        }
+      }
+      // (volatile orders the poll against other volatile accesses only: without this the compiler is free to hoist the
+      // plain fragment loads of the stage ABOVE the poll that guards it)
+      asm volatile("" ::: "memory");
+    };
+    u32x4 fa0[2], fa1[2], fb[4];
+    auto loadA = [&](const char* ab, int kx, int ks, u32x4 (&fa)[2]) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) fa[f] = *(const u32x4*)(ab + (f * 36 + kx) * PP + ks * 32);
+    };
+    f32x16 acc[2][4];
+    // one 16-wide step: the next step's patch fragments first, then tile column by tile column - a weight fragment is
+    // re-requested (for the next step: `sbn`) as soon as its two MFMAs are out
+    auto step = [&](u32x4 (&fc)[2], const char* sbn, bool reload) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) acc[f][nt] = MELGPT_MFMA_32x32x16(fb[nt], fc[f], acc[f][nt]);
+        if (reload) fb[nt] = *(const u32x4*)(sbn + nt * 4096);
+      }
+    };
+    unsigned kg = 0;  // K-steps multiplied so far (over all tiles)
+    fetch_res(blockIdx.x);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // half 0 of the first tile is staged
+    for (int tile = blockIdx.x; tile < total_tiles; tile += G) {
+#if CONVW_LAB
+      unsigned long long ws_t[8];
+      ws_t[0] = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        f32x4 bv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = *(const f32x4*)(bias_l + nt * 32 + h * 16 + 4 * e);
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int e = 0; e < 16; e += 2) {
+            const unsigned pk = rr[f][nt][e >> 3][(e >> 1) & 3];
+            acc[f][nt][e] = bf16lo(pk) + bv[e >> 2][e & 3];
+            acc[f][nt][e + 1] = bf16hi(pk) + bv[e >> 2][(e & 3) + 1];
+          }
+      }
+#pragma unroll 1
+      for (int hk = 0; hk < 6; ++hk) {  // (channel half, filter row): three K-steps (kx = 0, 1, 2) each
+        const int half = hk >= 3 ? 1 : 0, ky = hk - 3 * half;
+        const char* ab = abase + ky * 18 * PP + half * 128;
+        if (hk == 0 || hk == 3) {
+          // a phase starts: (hk == 3) everybody is done with half 0 and half 1 is staged
+#if CONVW_LAB
+          if (hk == 3) ws_t[1] = __builtin_amdgcn_s_memtime();
+#endif
+          if (hk == 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if CONVW_LAB
+          if (hk == 3) ws_t[2] = __builtin_amdgcn_s_memtime();
+#endif
+          wait_full(kg);
+          loadA(ab, 0, 0, fa0);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) fb[nt] = *(const u32x4*)(bb[0] + ((kg & 3u) << 14) + nt * 4096);
+        }
+        const bool last_hk = hk == 2 || hk == 5;
+        const char* abn = ab + 18 * PP;  // (not used behind the phase's last filter row)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx, ++kg) {
+          const unsigned so = (kg & 3u) << 14, son = ((kg + 1u) & 3u) << 14;
+          const bool last = last_hk && kx == 2;  // the phase's last K-step: nothing of the next one may be touched yet
+          loadA(ab, kx, 1, fa1);
+          step(fa0, bb[1] + so, true);
+          loadA(ab, kx, 2, fa0);
+          step(fa1, bb[2] + so, true);
+          loadA(ab, kx, 3, fa1);
+          step(fa0, bb[3] + so, true);
+          asm volatile("" ::: "memory");          // (no fragment load of this stage may sink below its release)
+          if (lane == 0) cnt[4 + wm] = kg + 1u;   // behind this wave's last read of the stage (LDS runs a wave's ops in order)
+          if (!last) {
+            wait_full(kg + 1u);
+            if (kx < 2) loadA(ab, kx + 1, 0, fa0);
+            else loadA(abn, 0, 0, fa0);
+          }
+          step(fa1, bb[0] + son, !last);
+        }
+      }
+#if CONVW_LAB
+      ws_t[3] = __builtin_amdgcn_s_memtime();
+#endif
+      // ---- epilogue: the next tile's residual first (into registers the K loop does not hold)
+      fetch_res(tile + G);
+      const int b = tile / tiles_img, rt = tile - b * tiles_img, ty = rt / q.tiles_x, tx = rt - ty * q.tiles_x;
+      const int y0 = ty * 16, x0 = tx * 16;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          u32x4 pk[2];
+#pragma unroll
+          for (int e = 0; e < 16; e += 2) pk[e >> 3][(e >> 1) & 3] = pack_bf16x2(acc[f][nt][e], acc[f][nt][e + 1]);
+          const unsigned o = out_off(tile, f);
+          if (o != OOB) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, pk[0]), ry, o + nt * 64, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, pk[1]), ry, o + nt * 64 + 16, 0, 0);
+          }
+          if constexpr (STATS) {
+            // GroupNorm(32) statistics of THIS conv's output on the values as stored: a lane's registers 4 j .. 4 j + 3 are
+            // group 8 nt + 4 h + j of its pixel
+            if (o != OOB) {
+#pragma unroll
+              for (int e = 0; e < 16; e += 2) {
+                const unsigned v = pk[e >> 3][(e >> 1) & 3];
+                const float v0 = bf16lo(v), v1 = bf16hi(v);
+                s1[e >> 2] += v0 + v1;
+                s2[e >> 2] = fmaf(v1, v1, fmaf(v0, v0, s2[e >> 2]));
+              }
+            }
+          }
+        }
+        if constexpr (STATS) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {   // over the 32 pixels of the lane's half-wave: four DPP steps + the row pair
+            float a = s1[j], c = s2[j];
+            a += dpp_move<0xB1>(a);
+            c += dpp_move<0xB1>(c);
+            a += dpp_move<0x4E>(a);
+            c += dpp_move<0x4E>(c);
+            a += dpp_move<0x141>(a);
+            c += dpp_move<0x141>(c);
+            a += dpp_move<0x140>(a);
+            c += dpp_move<0x140>(c);
+            a += __shfl_xor(a, 16, 64);
+            c += __shfl_xor(c, 16, 64);
+            if (r32 == 0) {
+              stp[(wm * 32 + 8 * nt + 4 * h + j) * 2] = a;
+              stp[(wm * 32 + 8 * nt + 4 * h + j) * 2 + 1] = c;
+            }
+          }
+        }
+      }
+#if CONVW_LAB
+      ws_t[4] = __builtin_amdgcn_s_memtime();
+#endif
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // half 1 is free; half 0 of the next tile is staged
+#if CONVW_LAB
+      ws_t[5] = __builtin_amdgcn_s_memtime();
+      if (blockIdx.x == 7 && t == 0) {
+        const int k = (tile - 7) / G;
+        if (k < 16) {
+          for (int e = 0; e < 6; ++e) melgpt_convws_dbg[0][k][e] = ws_t[e];
+          melgpt_convws_dbg[0][k][6] = spins;
+        }
+      }
+#endif
+      if constexpr (STATS) {
+        if (wm == 0) {
+          const float v = ((stp[lane] + stp[64 + lane]) + stp[128 + lane]) + stp[192 + lane];
+          q.stat_part[(long long)tile * 64 + lane] = v;  // tile = (b * tiles_y + ty) * tiles_x + tx
+        }
+      }
+    }
+  } else {
+    // ================================================================== staging waves
+    const int s = w - 4, sthr = t - 256, ch = sthr & 7, prow = sthr >> 3;   // 8 chunks (64 channels) x 32 pixels per trip
+    const unsigned long long wb_addr = (unsigned long long)p.B, x_addr = (unsigned long long)q.x;
+    const u32x4 rb = {(unsigned)wb_addr, (unsigned)(wb_addr >> 32) & 0xFFFFu, p.b_bytes, 0x00020000u};
+    const u32x4 rx = {(unsigned)x_addr, (unsigned)(x_addr >> 32) & 0xFFFFu, q.x_bytes, 0x00020000u};
+    const unsigned long long rs_addr = (unsigned long long)q.rstd, mn_addr = (unsigned long long)q.mean;
+    const unsigned st_bytes = norm ? (unsigned)((total_tiles / tiles_img) * 32 * 4) : 0u;
+    const u32x4 rrs = {(unsigned)rs_addr, (unsigned)(rs_addr >> 32) & 0xFFFFu, st_bytes, 0x00020000u};
+    const u32x4 rmn = {(unsigned)mn_addr, (unsigned)(mn_addr >> 32) & 0xFFFFu, st_bytes, 0x00020000u};
+    // weight pieces of this wave: four 1 KiB pieces (8 weight rows x 128 bytes) per K-step; per-lane source offsets fixed,
+    // the K-step's (tap, half) goes into the instruction's scalar offset
+    unsigned b_base[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = s + 4 * i, row = piece * 8 + (lane >> 3), chs = (lane & 7) ^ ((row >> 1) & 7);
+      b_base[i] = (row < p.N && !(WS_LAB & 2)) ? (unsigned)(((long long)row * p.ldb) * 2) + chs * 16 : OOB;
+    }
+    auto issue_w = [&](int kt, unsigned stage) {  // K-step kt of a tile (channel-half-major)
+      const int half = kt >= 9 ? 1 : 0, tap = kt - 9 * half;
+      const unsigned koff = (unsigned)(tap * 128 + half * 64) * 2u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned m0v = (unsigned)(size_t)LDS_PTR(char, ring + stage * 16384 + (s + 4 * i) * 1024);
+        // (an out-of-range lane offset stays out of range: 0xFFFFFFF0 + koff < 2^32)
+        asm volatile("s_nop 2\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :
+                     : "s"(m0v), "v"(b_base[i]), "s"(rb), "s"(koff)
+                     : "memory", "m0");
+      }
+    };
+    // raw chunks of one channel half of a tile: 11 trips of 32 pixels x 8 chunks (+ the image's rstd / mean pairs of this
+    // thread's two groups): 13 vector-memory operations per call, whatever the tile (the waits below count on it).
+    // Tile-invariant per trip: the pixel's patch coordinates and its byte offset relative to the tile's origin pixel.
+    int pyx[11], poff[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+      const int pix = prow + 32 * i, py = pix / 18, px = pix - py * 18;
+      pyx[i] = pix < WS_NPIX ? (py << 8 | px) : 0x7F7F;
+      poff[i] = ((py - 1) * q.W + (px - 1)) * 256 + ch * 16;
+    }
+    struct Raw {
+      u32x4 v[11];
+      u32x2 rs, mn;
+      unsigned ok;  // bit i: pixel of trip i lies inside the image
+    };
+    auto load_raw = [&](int tile, int half, Raw& r) {
+      const int b = tile / tiles_img, rt = tile - b * tiles_img, ty = rt / q.tiles_x, tx = rt - ty * q.tiles_x;
+      const int y0 = ty * 16, x0 = tx * 16;
+      // patch rows [ylo, yhi) and columns [xlo, xhi) lie inside the image (all wave-uniform)
+      const int live = tile < total_tiles;
+      const int ylo = (live && y0 == 0) ? 1 : 0, yhi = live ? min(18, q.H - y0 + 1) : 0, xlo = x0 == 0 ? 1 : 0, xhi = min(18, q.W - x0 + 1);
+      const unsigned base = (unsigned)((((long long)b * q.H + y0) * q.W + x0) * 256) + half * 128;
+      r.ok = 0u;
+#pragma unroll
+      for (int i = 0; i < 11; ++i) {
+        const int py = pyx[i] >> 8, px = pyx[i] & 255;
+        const bool ok = (unsigned)(py - ylo) < (unsigned)(yhi - ylo) && (unsigned)(px - xlo) < (unsigned)(xhi - xlo);
+        r.ok |= ok ? (1u << i) : 0u;
+        const unsigned off = ok ? base + (unsigned)poff[i] : OOB;
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r.v[i]) : "v"(off), "s"(rx) : "memory");
+      }
+      const unsigned so = (norm && live) ? (unsigned)((b * 32 + half * 16 + 2 * ch) * 4) : OOB;
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(r.rs) : "v"(so), "s"(rrs) : "memory");
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(r.mn) : "v"(so), "s"(rmn) : "memory");
+      if (WS_LAB & 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    // wait until at most N of this wave's vector-memory operations are outstanding; names every register of r so that no
+    // use of them is scheduled above it
+    auto wait_raw = [&](auto n_c, Raw& r) {
+      constexpr int N = decltype(n_c)::value;
+      asm volatile("s_waitcnt vmcnt(%[n])"
+                   : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4]), "+v"(r.v[5]), "+v"(r.v[6]),
+                     "+v"(r.v[7]), "+v"(r.v[8]), "+v"(r.v[9]), "+v"(r.v[10]), "+v"(r.rs), "+v"(r.mn)
+                   : [n] "n"(N)
+                   : "memory");
+    };
+    float ca[8], cb[8];  // affine of this thread's 8 channels for the half being staged
+    auto affine = [&](int half, const Raw& r) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = half * 64 + ch * 8 + e;
+        const float rs = __uint_as_float(r.rs[e >> 2]), mn = __uint_as_float(r.mn[e >> 2]);
+        const float a = norm ? rs * gb[2 * c] : 1.f;
+        ca[e] = a;
+        cb[e] = norm ? gb[2 * c + 1] - mn * a : 0.f;
+      }
+    };
+    auto convert = [&](int half, int i, const Raw& r) {
+      if ((pyx[i] & 255) < 18) {   // (the eleventh trip covers 4 pixels only)
+        u32x4 v = r.v[i];
+        if (!(WS_LAB & 1) && norm) {   // branch-free: computed for every pixel, zeroed outside the image
+          const unsigned keep = (r.ok >> i & 1u) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float o0 = fmaf(bf16lo(v[e]), ca[2 * e], cb[2 * e]);
+            float o1 = fmaf(bf16hi(v[e]), ca[2 * e + 1], cb[2 * e + 1]);
+            if (q.swish) {
+              o0 = o0 * __builtin_amdgcn_rcpf(1.0f + __expf(-o0));
+              o1 = o1 * __builtin_amdgcn_rcpf(1.0f + __expf(-o1));
+            }
+            v[e] = pack_bf16x2(o0, o1) & keep;
+          }
+        }
+        const int pix = prow + 32 * i;
+        *(u32x4*)(patch + pix * PP + half * 128 + ch * 16) = v;   // (outside the image: the load returned zeros)
+      }
+    };
+#if CONVW_LAB
+    unsigned long long ws_pre = 0, ws_pre2 = 0, ws_spin = 0;  // time of reaching the barrier of phase A / B; free-poll spins
+#endif
+    // One phase: `use` is staged into channel half `half` while `next` (the half after it) is requested; the nine slots
+    // follow the multiplying waves' K-steps sigma0 .. sigma0 + 8: slot j requests K-step sigma0 + j + 3 (tile-local index
+    // kt0 + j, mod 18) once K-step sigma0 + j - 1 is free, then publishes K-step sigma0 + j + 1.
+    auto phase = [&](int half, Raw& use, int next_tile, int next_half, Raw& next, unsigned sigma0, int kt0) {
+      load_raw(next_tile, next_half, next);
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        const unsigned sigma = sigma0 + j;
+        for (int it = 0; min4(cnt4[1]) < sigma && it < WS_SPIN; ++it) {
+          __builtin_amdgcn_s_sleep(1);
+#if CONVW_LAB
+          ++ws_spin;
+#endif
+        }
+        asm volatile("" ::: "memory");
+        int kt = kt0 + j;
+        kt = kt >= 18 ? kt - 18 : kt;
+        issue_w(kt, (sigma + 3u) & 3u);
+        // this wave's pieces of K-step sigma + 1 have landed: younger are K-step sigma + 2, sigma + 3 (4 + 4) and, in slots
+        // 0 and 1, the 13 loads of `next`
+        if (j == 0) wait_raw(std::integral_constant<int, 21>{}, use);   // ... which also covers `use` (requested a phase ago)
+        else if (j == 1) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (lane == 0) cnt[s] = sigma + 2u;
+        if (j == 0) affine(half, use);
+        convert(half, j, use);
+        if (j == 2) convert(half, 9, use);
+        if (j == 5) convert(half, 10, use);
+      }
+#if CONVW_LAB
+      if (half == 1) ws_pre = __builtin_amdgcn_s_memtime();
+      else ws_pre2 = __builtin_amdgcn_s_memtime();
+#endif
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    Raw r0, r1;
+    // prologue: both halves of the first tile requested, K-steps 0, 1, 2 requested, half 0 staged, K-step 0 published
+    load_raw(blockIdx.x, 0, r0);
+    load_raw(blockIdx.x, 1, r1);
+    issue_w(0, 0u);
+    issue_w(1, 1u);
+    issue_w(2, 2u);
+    wait_raw(std::integral_constant<int, 25>{}, r0);   // younger than r0's 13: r1's 13 + 12 pieces
+    affine(0, r0);
+#pragma unroll
+    for (int i = 0; i < 11; ++i) convert(0, i, r0);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // K-step 0 (and r1) landed
+    if (lane == 0) cnt[s] = 1u;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    unsigned sigma0 = 0;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += G) {
+#if CONVW_LAB
+      const unsigned long long sa = __builtin_amdgcn_s_memtime();
+#endif
+      phase(1, r1, tile + G, 0, r0, sigma0, 3);        // A(t): stage half 1 of t, request half 0 of the next tile
+#if CONVW_LAB
+      const unsigned long long sb = __builtin_amdgcn_s_memtime();
+#endif
+      phase(0, r0, tile + G, 1, r1, sigma0 + 9u, 12);  // B(t): stage half 0 of the next tile, request its half 1
+#if CONVW_LAB
+      if (blockIdx.x == 7 && t == 256) {
+        const int k = (tile - 7) / G;
+        if (k < 16) {
+          melgpt_convws_dbg[1][k][0] = sa; melgpt_convws_dbg[1][k][1] = ws_pre; melgpt_convws_dbg[1][k][2] = sb;
+          melgpt_convws_dbg[1][k][3] = ws_pre2; melgpt_convws_dbg[1][k][4] = __builtin_amdgcn_s_memtime(); melgpt_convws_dbg[1][k][5] = ws_spin;
+        }
+      }
+#endif
+      sigma0 += 18u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+  }
+}
+
 template <bool W8>
 int launch_fused_wide_t(const FusedConvParams& q0, int B, hipStream_t s) {
   FusedConvParams q = q0;
@@ -576,7 +1033,32 @@ int launch_fused_wide_t(const FusedConvParams& q0, int B, hipStream_t s) {
   }
   return melgpt_launch_status();
 }
+int launch_fused_ws(const FusedConvParams& q0, int B, hipStream_t s) {
+  FusedConvParams q = q0;
+  q.tiles_x = (q.W + 15) / 16;
+  q.tiles_y = (q.H + 15) / 16;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      return MELGPT_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void*)conv3x3_gn_ws_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv3x3_gn_ws_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS) != hipSuccess)
+      return MELGPT_ERR_LAUNCH;
+    ncu = n;
+  }
+  const long long total = (long long)q.tiles_x * q.tiles_y * B;
+  if (total > 0x3FFFFFFF) return MELGPT_ERR_UNSUPPORTED;
+  const int avail = ncu - melgpt_get_reserved_cus() >= 8 ? ncu - melgpt_get_reserved_cus() : ncu;
+  const int gx = (int)(total < avail ? total : avail);
+  if (q.stat_part) hipLaunchKernelGGL((conv3x3_gn_ws_kernel<true>), dim3(gx), dim3(512), WS_LDS, s, q, (int)total);
+  else hipLaunchKernelGGL((conv3x3_gn_ws_kernel<false>), dim3(gx), dim3(512), WS_LDS, s, q, (int)total);
+  return melgpt_launch_status();
+}
 int launch_fused_wide(const FusedConvParams& q, int B, hipStream_t s) {
+  // (Cin = 128 is checked by the caller; the wave-specialised kernel also wants exactly 128 output channels)
+  if (conv_ws_on() && q.g.N == 128) return launch_fused_ws(q, B, s);
   return wide_w8(q.H, q.W) ? launch_fused_wide_t<true>(q, B, s) : launch_fused_wide_t<false>(q, B, s);
 }
 
@@ -643,7 +1125,8 @@ static int conv3x3_gn_impl(const void* x, int B, int H, int W, int Cin, const fl
       Cin == 128 &&
       M * Cin * 2 < 0xFFFFFF00LL && (!residual || M * Cout * 2 < 0xFFFFFF00LL)) {
     q.x_bytes = (unsigned)(M * Cin * 2);
-    q.r_bytes = residual ? (unsigned)(M * Cout * 2) : 0u;
+    if (M * Cout * 2 >= 0xFFFFFF00LL) return MELGPT_ERR_UNSUPPORTED;
+    q.r_bytes = (unsigned)(M * Cout * 2);   // bytes of y (and of the residual, when there is one: same shape)
     return launch_fused_wide(q, B, s);
   }
   if (stat_part) return MELGPT_ERR_UNSUPPORTED;

@@ -50,6 +50,16 @@ int main() {
   for (int i = 1; i < 6 && h[4 * i]; ++i)
     printf("tile %d: ab %6llu  ab+stage %6llu  K loop %6llu  epilogue %6llu  (gap %6lld)\n", i, h2[i] - h[4 * i], h[4 * i + 1] - h[4 * i],
            h[4 * i + 2] - h[4 * i + 1], h[4 * i + 3] - h[4 * i + 2], h[4 * i + 4] ? (long long)(h[4 * i + 4] - h[4 * i + 3]) : -1LL);
+  unsigned long long ws[2][16][8];
+  hipMemcpyFromSymbol(ws, HIP_SYMBOL(melgpt_convws_dbg), sizeof(ws));
+  for (int k = 1; k < 7 && ws[0][k][0]; ++k) {
+    const unsigned long long* m = ws[0][k];
+    const unsigned long long* sg = ws[1][k];
+    printf("ws tile %d MULT: init+A %6llu | wait bar1 %5llu | B %6llu | epilogue %6llu | wait bar2 %5llu | total %6llu  spins(cum) %llu\n", k,
+           m[1] - m[0], m[2] - m[1], m[3] - m[2], m[4] - m[3], m[5] - m[4], m[5] - m[0], m[6]);
+    printf("          STAGE: A work %6llu | wait bar1 %5llu | B work %6llu | wait bar2 %5llu | total %6llu  free-spins(cum) %llu   (A start vs MULT start %lld)\n",
+           sg[1] - sg[0], sg[2] - sg[1], sg[3] - sg[2], sg[4] - sg[3], sg[4] - sg[0], sg[5], (long long)(sg[0] - m[0]));
+  }
   return 0;
 }
 // stand-ins for the two library entry points conv_fused.hip references (not exercised by this harness)

@@ -1,0 +1,228 @@
+// Feasibility harness for a WAVE-SPECIALISED fused GroupNorm+swish+conv3x3 tile loop (round 4): can ONE wave per SIMD keep
+// the matrix pipe busy from LDS-resident operands while its SIMD partner does the staging pass' VALU work?
+//   waves 0-3 ("matrix" role): the K loop of a 256-pixel x 128-channel tile, wave tile 64 pixels x 128 channels
+//     (4 patch fragments + 8 weight fragments per 32 MFMAs of v_mfma_f32_16x16x32_bf16), fragments of the next 32-wide
+//     step requested under the current step's MFMAs; 18 K-steps of 64 channels per tile, weight stages cycling.
+//   waves 4-7 ("staging" role): per tile 20 chunks of 16 bytes per lane: global load, bf16 -> f32, affine, swish (exp + rcp),
+//     pack, ds_write_b128 - the arithmetic of conv3x3_gn_wide_kernel's staging pass for a 18 x 18 x 128 patch on 256 lanes.
+// No hand-offs between the roles here: this measures issue / pipe contention only.  MODE: 1 matrix waves only, 2 staging
+// waves only, 3 both.  Prints shader cycles per tile for each role (s_memtime of workgroup 17), random operands.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I melspec_gpt_vqvae_amd/csrc tools/lab/ws_lab.hip -o ws_lab
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "gemm_common.h"
+
+using namespace gemmk;
+
+__device__ __forceinline__ int patch_off(int pix, int chunk) { return pix * 256 + ((chunk ^ (pix & 15)) << 4); }
+
+template <int SHAPE32>
+__global__ __launch_bounds__(512) void ws_kernel(const unsigned short* __restrict__ src, float* __restrict__ sink,
+                                                 unsigned long long* __restrict__ stamps, int tiles, int mode, int prio) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* patch = smem;                      // [324][256 B]
+  char* ring = smem + 324 * 272;           // [4][16 KiB]
+  char* scratch = ring + 4 * 16384;        // 4 staging waves x 1 KiB
+  const int t = threadIdx.x, lane = t & 63, i16 = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  // fill LDS with the (random) source once
+  for (int i = t; i < (324 * 272 + 4 * 16384) / 16; i += 512) *(u32x4*)(smem + 16 * i) = *(const u32x4*)(src + 8 * (i & 4095));
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (w < 4 && SHAPE32) {
+    // timing form of the 32x32x16 variant: wave tile 64 pixels x 128 channels = 2 x 4 tiles of 32 x 32 (16 accumulator
+    // registers each), per 16-wide k-step 2 patch + 4 weight fragments (ds_read_b128) and 8 MFMAs of 32 cycles
+    if (!(mode & 1)) return;
+    if (prio) __builtin_amdgcn_s_setprio(1);
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    const int wm = w, r32 = lane & 31, h2 = lane >> 5;
+    constexpr int PP = 272;
+    // rows 0-15 of a fragment = row-block 2 mt, rows 16-31 = row-block 2 mt + 1 (one patch row further down)
+    const char* abase = patch + (wm * 4 * 18 + (r32 >> 4) * 18 + (r32 & 15)) * PP + h2 * 16;
+    const char* bbase = ring + row_off(r32, h2);   // (the XOR term moves with the k-step: close enough for timing)
+    u32x4 fa0[2], fa1[2], fb[4];
+    auto loadA = [&](const char* ab, int kx, int ks, u32x4 (&fa)[2]) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) fa[mt] = *(const u32x4*)(ab + (mt * 36 + kx) * PP + ks * 32);
+    };
+    auto loadB = [&](const char* sb, int ks) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) fb[nt] = *(const u32x4*)(sb + nt * 4096 + ks * 32);
+    };
+    auto mm = [&](u32x4 (&fc)[2]) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, fb[nt]), __builtin_bit_cast(s16x8, fc[mt]), acc[mt][nt], 0, 0, 0);
+    };
+    int kg = 0;
+    loadA(abase, 0, 0, fa0);
+    loadB(bbase, 0);
+    for (int tile = 0; tile < tiles; ++tile) {
+      for (int hk = 0; hk < 6; ++hk) {
+        const int half = hk / 3, ky = hk - 3 * half;
+        const char* ab = abase + ky * 18 * PP + half * 128;
+        const int hkn = hk + 1 == 6 ? 0 : hk + 1, hn = hkn / 3, kyn = hkn - 3 * hn;
+        const char* abn = abase + kyn * 18 * PP + hn * 128;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx, ++kg) {
+          const char* sb = bbase + (kg & 3) * 16384, *sbn = bbase + ((kg + 1) & 3) * 16384;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {   // four 16-wide k-steps per 64-channel K-step
+            u32x4 (&fc)[2] = (ks & 1) ? fa1 : fa0;
+            u32x4 (&fn)[2] = (ks & 1) ? fa0 : fa1;
+            if (ks < 3) loadA(ab, kx, ks + 1, fn);
+            else if (kx < 2) loadA(ab, kx + 1, 0, fn);
+            else loadA(abn, 0, 0, fn);
+            mm(fc);
+            if (ks < 3) loadB(sb, ks + 1);
+            else loadB(sbn, 0);
+          }
+        }
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[a][b][e];
+    if (s == 12345.678f) sink[t] = s;
+    if (blockIdx.x == 17 && t == 0) { stamps[0] = t0; stamps[1] = __builtin_amdgcn_s_memtime(); }
+  } else if (w < 4) {
+    if (!(mode & 1)) return;
+    if (prio) __builtin_amdgcn_s_setprio(1);
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int wm = w;
+    // LINEAR padded patch (pixel pitch 272 bytes: 16 consecutive pixels of a row cover all 64 banks, no XOR), so a
+    // fragment's address is ONE per-lane base + a compile-time offset (tap, row-block, channel step): no address VALU.
+    constexpr int PP = 272;
+    const char* abase = patch + (wm * 4 * 18 + i16) * PP + g * 16;               // row-block 0, tap (0,0), chunk g
+    const char* bbase0 = ring + row_off(i16, g), *bbase1 = ring + row_off(i16, 4 + g);  // ks = 0 / 1 (the XOR moves with ks)
+    u32x4 fa0[4], fa1[4], fb[8];
+    auto loadA = [&](const char* ab, int kx, int ks, u32x4 (&fa)[4]) {          // ab: base of (half, ky)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) fa[mt] = *(const u32x4*)(ab + (mt * 18 + kx) * PP + ks * 64);
+    };
+    auto loadBh = [&](const char* sb, int h, u32x4 (&fbb)[8]) {
+#pragma unroll
+      for (int nt = 4 * h; nt < 4 * h + 4; ++nt) fbb[nt] = *(const u32x4*)(sb + nt * 2048);
+    };
+    auto mm = [&](u32x4 (&fc)[4], int h) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 4 * h; nt < 4 * h + 4; ++nt) mma<bf16_t>(acc[mt][nt], fb[nt], fc[mt]);
+    };
+    int kg = 0;
+    loadA(abase, 0, 0, fa0);
+    loadBh(bbase0, 0, fb);
+    loadBh(bbase0, 1, fb);
+    for (int tile = 0; tile < tiles; ++tile) {
+      for (int hk = 0; hk < 6; ++hk) {                 // (half, ky): 3 K-steps (kx = 0, 1, 2) each
+        const int half = hk / 3, ky = hk - 3 * half;
+        const char* ab = abase + ky * 18 * PP + half * 128;
+        const int hkn = hk + 1 == 6 ? 0 : hk + 1, hn = hkn / 3, kyn = hkn - 3 * hn;
+        const char* abn = abase + kyn * 18 * PP + hn * 128;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx, ++kg) {
+          const int so = (kg & 3) * 16384, son = ((kg + 1) & 3) * 16384;
+          // step 0: request step 1's patch fragments; weights reloaded in place behind their last use
+          loadA(ab, kx, 1, fa1);
+          mm(fa0, 0);
+          loadBh(bbase1 + so, 0, fb);
+          mm(fa0, 1);
+          loadBh(bbase1 + so, 1, fb);
+          // step 1: request the next K-step's step-0 fragments
+          if (kx < 2) loadA(ab, kx + 1, 0, fa0);
+          else loadA(abn, 0, 0, fa0);
+          mm(fa1, 0);
+          loadBh(bbase0 + son, 0, fb);
+          mm(fa1, 1);
+          loadBh(bbase0 + son, 1, fb);
+        }
+      }
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) s += acc[a][b];
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678f) sink[t] = s[0];
+    if (blockIdx.x == 17 && t == 0) { stamps[0] = t0; stamps[1] = __builtin_amdgcn_s_memtime(); }
+  } else {
+    if (!(mode & 2)) return;
+    const int sw = w - 4, st = t - 256;
+    char* my = scratch + sw * 1024;
+    float a = 1.0f + 1e-3f * lane, bb = 0.01f * lane;
+    unsigned chk = 0;
+    for (int tile = 0; tile < tiles; ++tile) {
+      u32x4 raw[20];
+#pragma unroll
+      for (int i = 0; i < 20; ++i) raw[i] = *(const u32x4*)(src + 8 * ((st + 256 * i + 37 * tile) & 4095));
+#pragma unroll
+      for (int i = 0; i < 20; ++i) {
+        u32x4 v = raw[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float o0 = fmaf(bf16lo(v[e]), a, bb);
+          float o1 = fmaf(bf16hi(v[e]), a, -bb);
+          o0 = o0 * __builtin_amdgcn_rcpf(1.0f + __expf(-o0));
+          o1 = o1 * __builtin_amdgcn_rcpf(1.0f + __expf(-o1));
+          v[e] = pack_bf16x2(o0, o1);
+        }
+        *(u32x4*)(my + ((lane ^ (i & 63)) << 4)) = v;
+        chk ^= v[0];
+      }
+    }
+    if (chk == 0x12345678u) sink[t] = 1.f;
+    if (blockIdx.x == 17 && t == 256) { stamps[2] = t0; stamps[3] = __builtin_amdgcn_s_memtime(); }
+  }
+}
+
+int main(int argc, char** argv) {
+  const int tiles = 40;
+  unsigned short* src; float* sink; unsigned long long* stamps;
+  hipMalloc(&src, 4096 * 16); hipMalloc(&sink, 4096); hipMalloc(&stamps, 64);
+  std::vector<unsigned short> h(4096 * 8);
+  unsigned sd = 12345u;
+  for (auto& v : h) { sd = sd * 1664525u + 1013904223u; v = (unsigned short)(0x3c00u + ((sd >> 9) & 0x3ffu) + ((sd >> 20 & 1u) << 15) - 0x0200u); }
+  hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+  const size_t lds = 324 * 272 + 4 * 16384 + 4 * 1024;
+  hipFuncSetAttribute((const void*)ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute((const void*)ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  for (int shape = 0; shape <= 1; ++shape)
+  for (int prio = 0; prio <= 0; ++prio)
+    for (int mode = 1; mode <= 3; ++mode) {
+      for (int rep = 0; rep < 2; ++rep) {
+        hipMemset(stamps, 0, 64);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, 0);
+        if (shape) hipLaunchKernelGGL(ws_kernel<1>, dim3(256), dim3(512), lds, 0, src, sink, stamps, tiles, mode, prio);
+        else hipLaunchKernelGGL(ws_kernel<0>, dim3(256), dim3(512), lds, 0, src, sink, stamps, tiles, mode, prio);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long s[8];
+        hipMemcpy(s, stamps, 64, hipMemcpyDeviceToHost);
+        if (rep == 1)
+          printf("%s prio %d mode %d: %.3f ms | matrix waves %7.0f cycles/tile (ideal 18432: %.2f) | staging waves %7.0f cycles/tile\n", shape ? "32x32x16" : "16x16x32", prio, mode, ms,
+                 (double)(s[1] - s[0]) / tiles, s[1] > s[0] ? 18432.0 * tiles / (double)(s[1] - s[0]) : 0.0, (double)(s[3] - s[2]) / tiles);
+      }
+    }
+  return 0;
+}
