@@ -22,6 +22,12 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
          "-ffp-contract=fast", "-fno-gpu-rdc"]
 
 
+# per-source extra flags.  conv_fused.hip: no SLP vectorisation - hipcc packs the staging pass' scalar f32 arithmetic into
+# v_pk_fma_f32 / v_pk_mul_f32, which run slower beside a SIMD partner's MFMAs (guide, cycle constants: "an anti-lever
+# beside MFMAs"; the wave-specialised conv's conversion pass: 106 k -> 90 k cycles per 5 tiles, profiles/r04_conv_lab.md)
+EXTRA_FLAGS = {"conv_fused.hip": ["-fno-slp-vectorize"]}
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -30,7 +36,7 @@ def _hipcc():
 
 
 def _digest(paths):
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
     for p in paths:
         with open(p, "rb") as f:
             h.update(f.read())
@@ -60,7 +66,7 @@ def _compile(src, stamp, verbose, flavour="bf16"):
     tag = obj + ".sha"
     if os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == stamp:
         return obj, False
-    cmd = [_hipcc(), *FLAGS, *extra, "-c", src, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), *extra, "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

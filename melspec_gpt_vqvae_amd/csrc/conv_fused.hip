@@ -579,6 +579,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
 constexpr int WS_PP = 272, WS_NPIX = 18 * 18, WS_PATCH = WS_NPIX * WS_PP, WS_RING = 4 * 16384;
 constexpr int WS_LDS = WS_PATCH + WS_RING + 1024 /* gamma, beta */ + 512 /* bias */ + 1024 /* output statistics */ + 64 /* counters */;
 constexpr int WS_SPIN = 1 << 22;
+constexpr float LOG2E_F = 1.4426950408889634f;
 #ifndef WS_LAB
 #define WS_LAB 0   // lab: 1 no affine / swish arithmetic in the staging pass, 2 no LDS-DMA requests (stale weights), 4 no polls in the multiplying waves
 #endif
@@ -667,12 +668,16 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
     f32x16 acc[2][4];
     // one 16-wide step: the next step's patch fragments first, then tile column by tile column - a weight fragment is
     // re-requested (for the next step: `sbn`) as soon as its two MFMAs are out
+    // (the scheduling fences pin what is written: left alone the compiler sinks every fragment load to just in front of
+    // its first use - fewer live registers, and the LDS latency exposed four times per step)
     auto step = [&](u32x4 (&fc)[2], const char* sbn, bool reload) {
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) acc[f][nt] = MELGPT_MFMA_32x32x16(fb[nt], fc[f], acc[f][nt]);
         if (reload) fb[nt] = *(const u32x4*)(sbn + nt * 4096);
+        __builtin_amdgcn_sched_barrier(0);
       }
     };
     unsigned kg = 0;  // K-steps multiplied so far (over all tiles)
@@ -721,6 +726,9 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
         for (int kx = 0; kx < 3; ++kx, ++kg) {
           const unsigned so = (kg & 3u) << 14, son = ((kg + 1u) & 3u) << 14;
           const bool last = last_hk && kx == 2;  // the phase's last K-step: nothing of the next one may be touched yet
+          // the counters of the NEXT K-step are read now and looked at three steps later (they only grow: a value that
+          // already says "landed" stays true; the round trip of a poll in front of the last step cost ~250 cycles per K-step)
+          const u32x4 pf = cnt4[0];
           loadA(ab, kx, 1, fa1);
           step(fa0, bb[1] + so, true);
           loadA(ab, kx, 2, fa0);
@@ -730,7 +738,8 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
           asm volatile("" ::: "memory");          // (no fragment load of this stage may sink below its release)
           if (lane == 0) cnt[4 + wm] = kg + 1u;   // behind this wave's last read of the stage (LDS runs a wave's ops in order)
           if (!last) {
-            wait_full(kg + 1u);
+            if ((WS_LAB & 4) || min4(pf) > kg + 1u) asm volatile("" ::: "memory");
+            else wait_full(kg + 1u);
             if (kx < 2) loadA(ab, kx + 1, 0, fa0);
             else loadA(abn, 0, 0, fa0);
           }
@@ -815,6 +824,10 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
     }
   } else {
     // ================================================================== staging waves
+#ifndef WS_PRIO
+#define WS_PRIO 0   // lab: s_setprio of the staging waves
+#endif
+    if (WS_PRIO) __builtin_amdgcn_s_setprio(WS_PRIO);
     const int s = w - 4, sthr = t - 256, ch = sthr & 7, prow = sthr >> 3;   // 8 chunks (64 channels) x 32 pixels per trip
     const unsigned long long wb_addr = (unsigned long long)p.B, x_addr = (unsigned long long)q.x;
     const u32x4 rb = {(unsigned)wb_addr, (unsigned)(wb_addr >> 32) & 0xFFFFu, p.b_bytes, 0x00020000u};
@@ -906,16 +919,23 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
         u32x4 v = r.v[i];
         if (!(WS_LAB & 1) && norm) {   // branch-free: computed for every pixel, zeroed outside the image
           const unsigned keep = (r.ok >> i & 1u) ? 0xFFFFFFFFu : 0u;
+          float o[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float o0 = fmaf(bf16lo(v[e]), ca[2 * e], cb[2 * e]);
-            float o1 = fmaf(bf16hi(v[e]), ca[2 * e + 1], cb[2 * e + 1]);
-            if (q.swish) {
-              o0 = o0 * __builtin_amdgcn_rcpf(1.0f + __expf(-o0));
-              o1 = o1 * __builtin_amdgcn_rcpf(1.0f + __expf(-o1));
-            }
-            v[e] = pack_bf16x2(o0, o1) & keep;
+            o[2 * e] = fmaf(bf16lo(v[e]), ca[2 * e], cb[2 * e]);
+            o[2 * e + 1] = fmaf(bf16hi(v[e]), ca[2 * e + 1], cb[2 * e + 1]);
           }
+          if (q.swish) {   // ONE uniform branch around all eight chains (a test per pair kept the compiler from interleaving them)
+            float d[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = __builtin_amdgcn_exp2f(o[e] * -LOG2E_F);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = __builtin_amdgcn_rcpf(1.0f + d[e]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] *= d[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = pack_bf16x2(o[2 * e], o[2 * e + 1]) & keep;
         }
         const int pix = prow + 32 * i;
         *(u32x4*)(patch + pix * PP + half * 128 + ch * 16) = v;   // (outside the image: the load returned zeros)
@@ -927,31 +947,54 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
     // One phase: `use` is staged into channel half `half` while `next` (the half after it) is requested; the nine slots
     // follow the multiplying waves' K-steps sigma0 .. sigma0 + 8: slot j requests K-step sigma0 + j + 3 (tile-local index
     // kt0 + j, mod 18) once K-step sigma0 + j - 1 is free, then publishes K-step sigma0 + j + 1.
+    unsigned free_seen = 0;   // K-steps every multiplying wave was seen to have read
+    u32x4 pf_free = {0u, 0u, 0u, 0u};
+#if CONVW_LAB
+    unsigned long long pc[5] = {0, 0, 0, 0, 0};  // cycles in: raw loads, free poll, piece issue, landing wait + publish, convert
+#define WS_T(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pc[k] += n_ - tl; tl = n_; }
+#else
+#define WS_T(k)
+#endif
     auto phase = [&](int half, Raw& use, int next_tile, int next_half, Raw& next, unsigned sigma0, int kt0) {
+#if CONVW_LAB
+      unsigned long long tl = __builtin_amdgcn_s_memtime();
+#endif
       load_raw(next_tile, next_half, next);
+      WS_T(0)
 #pragma unroll
       for (int j = 0; j < 9; ++j) {
         const unsigned sigma = sigma0 + j;
-        for (int it = 0; min4(cnt4[1]) < sigma && it < WS_SPIN; ++it) {
-          __builtin_amdgcn_s_sleep(1);
+        // FIRST the publication the multiplying waves may be waiting for: this wave's pieces of K-step sigma + 1 (requested
+        // two slots ago) have landed - younger are K-step sigma + 2 (4 pieces) and, in slots 0 and 1, the 13 loads of `next`
+        if (j == 0) wait_raw(std::integral_constant<int, 17>{}, use);   // ... which also covers `use` (requested a phase ago)
+        else if (j == 1) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (lane == 0) cnt[s] = sigma + 2u;
+        WS_T(3)
+        // then the request of K-step sigma + 3, once K-step sigma - 1 is free (the counters only grow: a poll that saw the
+        // multiplying waves ahead serves the following slots too, and the value read before the previous slot's
+        // conversion work is looked at first)
+        free_seen = max(free_seen, min4(pf_free));
+        if (free_seen < sigma) {
+          for (int it = 0; (free_seen = min4(cnt4[1])) < sigma && it < WS_SPIN; ++it) {
+            __builtin_amdgcn_s_sleep(1);
 #if CONVW_LAB
-          ++ws_spin;
+            ++ws_spin;
 #endif
+          }
         }
         asm volatile("" ::: "memory");
+        WS_T(1)
         int kt = kt0 + j;
         kt = kt >= 18 ? kt - 18 : kt;
         issue_w(kt, (sigma + 3u) & 3u);
-        // this wave's pieces of K-step sigma + 1 have landed: younger are K-step sigma + 2, sigma + 3 (4 + 4) and, in slots
-        // 0 and 1, the 13 loads of `next`
-        if (j == 0) wait_raw(std::integral_constant<int, 21>{}, use);   // ... which also covers `use` (requested a phase ago)
-        else if (j == 1) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        if (lane == 0) cnt[s] = sigma + 2u;
+        WS_T(2)
+        pf_free = cnt4[1];
         if (j == 0) affine(half, use);
         convert(half, j, use);
         if (j == 2) convert(half, 9, use);
         if (j == 5) convert(half, 10, use);
+        WS_T(4)
       }
 #if CONVW_LAB
       if (half == 1) ws_pre = __builtin_amdgcn_s_memtime();
@@ -986,9 +1029,10 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
 #if CONVW_LAB
       if (blockIdx.x == 7 && t == 256) {
         const int k = (tile - 7) / G;
-        if (k < 16) {
+        if (k < 15) {
           melgpt_convws_dbg[1][k][0] = sa; melgpt_convws_dbg[1][k][1] = ws_pre; melgpt_convws_dbg[1][k][2] = sb;
           melgpt_convws_dbg[1][k][3] = ws_pre2; melgpt_convws_dbg[1][k][4] = __builtin_amdgcn_s_memtime(); melgpt_convws_dbg[1][k][5] = ws_spin;
+          if (k == 4) for (int e = 0; e < 5; ++e) melgpt_convws_dbg[1][15][e] = pc[e];
         }
       }
 #endif

@@ -60,6 +60,8 @@ int main() {
     printf("          STAGE: A work %6llu | wait bar1 %5llu | B work %6llu | wait bar2 %5llu | total %6llu  free-spins(cum) %llu   (A start vs MULT start %lld)\n",
            sg[1] - sg[0], sg[2] - sg[1], sg[3] - sg[2], sg[4] - sg[3], sg[4] - sg[0], sg[5], (long long)(sg[0] - m[0]));
   }
+  printf("staging wave, cumulative over 5 tiles (cycles): raw loads %llu | free poll %llu | piece issue %llu | landing wait + publish %llu | convert %llu\n",
+         ws[1][15][0], ws[1][15][1], ws[1][15][2], ws[1][15][3], ws[1][15][4]);
   return 0;
 }
 // stand-ins for the two library entry points conv_fused.hip references (not exercised by this harness)
