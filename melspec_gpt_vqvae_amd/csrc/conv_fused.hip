@@ -215,7 +215,7 @@ static bool conv_ws_on() {
 static bool wide_w8(int H, int W) {
   static int off = -1;  // lab switch: MELGPT_CONV_W8=0 keeps every layer on 16 x 16 tiles
   if (off < 0) off = getenv("MELGPT_CONV_W8") && atoi(getenv("MELGPT_CONV_W8")) == 0;
-  if (off || conv_ws_on()) return false;
+  if (off) return false;
   const long long p16 = (long long)((H + 15) / 16) * ((W + 15) / 16), p8 = (long long)((H + 7) / 8) * ((W + 31) / 32);
   return p8 < p16 && (W % 32 == 0 || W % 32 <= 16);
 }
@@ -576,8 +576,14 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
 // 4 (rho >> 3) + (rho & 3) - so that the 16 accumulator registers of a lane are 16 CONSECUTIVE channels of its pixel:
 // stores and residual loads are 16 bytes per lane (two per tile), 64 contiguous bytes per pixel.  The residual of the next
 // tile is fetched during this tile's epilogue and the accumulators start from bias + residual.  Every spin is bounded.
-constexpr int WS_PP = 272, WS_NPIX = 18 * 18, WS_PATCH = WS_NPIX * WS_PP, WS_RING = 4 * 16384;
-constexpr int WS_LDS = WS_PATCH + WS_RING + 1024 /* gamma, beta */ + 512 /* bias */ + 1024 /* output statistics */ + 64 /* counters */;
+// Output tile 16 x 16 pixels, or 8 x 32 (W8) where 16 rows pad badly (40 x 424: 70 tiles per image instead of 81), as in the
+// kernel above; a 32-pixel fragment is two 16-pixel rows of the patch (16 x 16) or 32 consecutive pixels of one row (8 x 32).
+constexpr int WS_PP = 272, WS_RING = 4 * 16384;
+template <bool W8>
+struct WsTile {
+  static constexpr int TH = W8 ? 8 : 16, TW = W8 ? 32 : 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, PATCH = NPIX * WS_PP;
+  static constexpr int LDS = PATCH + WS_RING + 1024 /* gamma, beta */ + 512 /* bias */ + 1024 /* output statistics */ + 64 /* counters */;
+};
 constexpr int WS_SPIN = 1 << 22;
 constexpr float LOG2E_F = 1.4426950408889634f;
 #ifndef WS_LAB
@@ -585,9 +591,11 @@ constexpr float LOG2E_F = 1.4426950408889634f;
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <bool STATS>
+template <bool STATS, bool W8>
 __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, int total_tiles) {
-  constexpr int PP = WS_PP;
+  typedef WsTile<W8> WT;
+  constexpr int PP = WS_PP, PW = WT::PW, PH = WT::PH, TH = WT::TH, TW = WT::TW, WS_NPIX = WT::NPIX, WS_PATCH = WT::PATCH;
+  constexpr int FSTEP = W8 ? PW : 2 * PW;   // patch pixels between the two 32-pixel fragments of a wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const GemmParams& p = q.g;
   char* patch = smem;
@@ -618,7 +626,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
     // ================================================================== multiplying waves
     const int wm = w, r32 = lane & 31, h = lane >> 5;
     // patch fragment f (32 pixels = row-blocks 4 wm + 2 f, + 1): lane = pixel r32 of it, 16-byte k-chunk h of the step
-    const char* abase = patch + ((wm * 4 + (r32 >> 4)) * 18 + (r32 & 15)) * PP + h * 16;
+    const char* abase = patch + (W8 ? (wm * 2 * PW + r32) : ((wm * 4 + (r32 >> 4)) * PW + (r32 & 15))) * PP + h * 16;
     // weight fragment nt: lane = fragment row r32 = channel 32 nt + perm(r32), chunk 2 ks + h of the 128-byte row
     const int perm = 16 * ((r32 >> 2) & 1) + 4 * (r32 >> 3) + (r32 & 3);
     const char* bb[4];
@@ -628,7 +636,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
     const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.C, q.r_bytes);
     auto out_off = [&](int tile, int f) -> unsigned {  // byte offset of (this lane's pixel of fragment f, channel 16 h) in y / R
       const int b = tile / tiles_img, r = tile - b * tiles_img, ty = r / q.tiles_x, tx = r - ty * q.tiles_x;
-      const int y = ty * 16 + wm * 4 + 2 * f + (r32 >> 4), x = tx * 16 + (r32 & 15);
+      const int y = W8 ? ty * 8 + wm * 2 + f : ty * 16 + wm * 4 + 2 * f + (r32 >> 4), x = W8 ? tx * 32 + r32 : tx * 16 + (r32 & 15);
       const bool ok = tile < total_tiles && y < q.H && x < q.W;
       return ok ? (unsigned)(((((long long)b * q.H + y) * q.W + x) * 128 + 16 * h) * 2) : OOB;
     };
@@ -663,7 +671,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
     u32x4 fa0[2], fa1[2], fb[4];
     auto loadA = [&](const char* ab, int kx, int ks, u32x4 (&fa)[2]) {
 #pragma unroll
-      for (int f = 0; f < 2; ++f) fa[f] = *(const u32x4*)(ab + (f * 36 + kx) * PP + ks * 32);
+      for (int f = 0; f < 2; ++f) fa[f] = *(const u32x4*)(ab + (f * FSTEP + kx) * PP + ks * 32);
     };
     f32x16 acc[2][4];
     // one 16-wide step: the next step's patch fragments first, then tile column by tile column - a weight fragment is
@@ -705,7 +713,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
 #pragma unroll 1
       for (int hk = 0; hk < 6; ++hk) {  // (channel half, filter row): three K-steps (kx = 0, 1, 2) each
         const int half = hk >= 3 ? 1 : 0, ky = hk - 3 * half;
-        const char* ab = abase + ky * 18 * PP + half * 128;
+        const char* ab = abase + ky * PW * PP + half * 128;
         if (hk == 0 || hk == 3) {
           // a phase starts: (hk == 3) everybody is done with half 0 and half 1 is staged
 #if CONVW_LAB
@@ -721,7 +729,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
           for (int nt = 0; nt < 4; ++nt) fb[nt] = *(const u32x4*)(bb[0] + ((kg & 3u) << 14) + nt * 4096);
         }
         const bool last_hk = hk == 2 || hk == 5;
-        const char* abn = ab + 18 * PP;  // (not used behind the phase's last filter row)
+        const char* abn = ab + PW * PP;  // (not used behind the phase's last filter row)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx, ++kg) {
           const unsigned so = (kg & 3u) << 14, son = ((kg + 1u) & 3u) << 14;
@@ -751,8 +759,6 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
 #endif
       // ---- epilogue: the next tile's residual first (into registers the K loop does not hold)
       fetch_res(tile + G);
-      const int b = tile / tiles_img, rt = tile - b * tiles_img, ty = rt / q.tiles_x, tx = rt - ty * q.tiles_x;
-      const int y0 = ty * 16, x0 = tx * 16;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -863,7 +869,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
     int pyx[11], poff[11];
 #pragma unroll
     for (int i = 0; i < 11; ++i) {
-      const int pix = prow + 32 * i, py = pix / 18, px = pix - py * 18;
+      const int pix = prow + 32 * i, py = pix / PW, px = pix - py * PW;
       pyx[i] = pix < WS_NPIX ? (py << 8 | px) : 0x7F7F;
       poff[i] = ((py - 1) * q.W + (px - 1)) * 256 + ch * 16;
     }
@@ -874,10 +880,10 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
     };
     auto load_raw = [&](int tile, int half, Raw& r) {
       const int b = tile / tiles_img, rt = tile - b * tiles_img, ty = rt / q.tiles_x, tx = rt - ty * q.tiles_x;
-      const int y0 = ty * 16, x0 = tx * 16;
+      const int y0 = ty * TH, x0 = tx * TW;
       // patch rows [ylo, yhi) and columns [xlo, xhi) lie inside the image (all wave-uniform)
       const int live = tile < total_tiles;
-      const int ylo = (live && y0 == 0) ? 1 : 0, yhi = live ? min(18, q.H - y0 + 1) : 0, xlo = x0 == 0 ? 1 : 0, xhi = min(18, q.W - x0 + 1);
+      const int ylo = (live && y0 == 0) ? 1 : 0, yhi = live ? min(PH, q.H - y0 + 1) : 0, xlo = x0 == 0 ? 1 : 0, xhi = min(PW, q.W - x0 + 1);
       const unsigned base = (unsigned)((((long long)b * q.H + y0) * q.W + x0) * 256) + half * 128;
       r.ok = 0u;
 #pragma unroll
@@ -915,7 +921,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
       }
     };
     auto convert = [&](int half, int i, const Raw& r) {
-      if ((pyx[i] & 255) < 18) {   // (the eleventh trip covers 4 pixels only)
+      if ((pyx[i] & 255) < 64) {   // (the eleventh trip covers 4 or 20 pixels only)
         u32x4 v = r.v[i];
         if (!(WS_LAB & 1) && norm) {   // branch-free: computed for every pixel, zeroed outside the image
           const unsigned keep = (r.ok >> i & 1u) ? 0xFFFFFFFFu : 0u;
@@ -1077,18 +1083,20 @@ int launch_fused_wide_t(const FusedConvParams& q0, int B, hipStream_t s) {
   }
   return melgpt_launch_status();
 }
-int launch_fused_ws(const FusedConvParams& q0, int B, hipStream_t s) {
+template <bool W8>
+int launch_fused_ws_t(const FusedConvParams& q0, int B, hipStream_t s) {
+  typedef WsTile<W8> WT;
   FusedConvParams q = q0;
-  q.tiles_x = (q.W + 15) / 16;
-  q.tiles_y = (q.H + 15) / 16;
+  q.tiles_x = (q.W + WT::TW - 1) / WT::TW;
+  q.tiles_y = (q.H + WT::TH - 1) / WT::TH;
   static int ncu = 0;
   if (!ncu) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
       return MELGPT_ERR_LAUNCH;
-    if (hipFuncSetAttribute((const void*)conv3x3_gn_ws_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv3x3_gn_ws_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3x3_gn_ws_kernel<false, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, WT::LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv3x3_gn_ws_kernel<true, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, WT::LDS) != hipSuccess)
       return MELGPT_ERR_LAUNCH;
     ncu = n;
   }
@@ -1096,9 +1104,12 @@ int launch_fused_ws(const FusedConvParams& q0, int B, hipStream_t s) {
   if (total > 0x3FFFFFFF) return MELGPT_ERR_UNSUPPORTED;
   const int avail = ncu - melgpt_get_reserved_cus() >= 8 ? ncu - melgpt_get_reserved_cus() : ncu;
   const int gx = (int)(total < avail ? total : avail);
-  if (q.stat_part) hipLaunchKernelGGL((conv3x3_gn_ws_kernel<true>), dim3(gx), dim3(512), WS_LDS, s, q, (int)total);
-  else hipLaunchKernelGGL((conv3x3_gn_ws_kernel<false>), dim3(gx), dim3(512), WS_LDS, s, q, (int)total);
+  if (q.stat_part) hipLaunchKernelGGL((conv3x3_gn_ws_kernel<true, W8>), dim3(gx), dim3(512), WT::LDS, s, q, (int)total);
+  else hipLaunchKernelGGL((conv3x3_gn_ws_kernel<false, W8>), dim3(gx), dim3(512), WT::LDS, s, q, (int)total);
   return melgpt_launch_status();
+}
+int launch_fused_ws(const FusedConvParams& q, int B, hipStream_t s) {
+  return wide_w8(q.H, q.W) ? launch_fused_ws_t<true>(q, B, s) : launch_fused_ws_t<false>(q, B, s);
 }
 int launch_fused_wide(const FusedConvParams& q, int B, hipStream_t s) {
   // (Cin = 128 is checked by the caller; the wave-specialised kernel also wants exactly 128 output channels)
