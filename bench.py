@@ -163,6 +163,26 @@ def e2e_fp16_child(timeout=420):
     if b128:
         out.update({"batch128_clips_per_s": b128["clips_per_s"], "batch128_latency_ms": b128["latency_ms"],
                     "batch128_stage_ms": b128["stage_ms_median"]})
+
+    # HBM fractions of the two HBM-bound stages (peak 8 TB/s).  Decode: per sampled token the step streams the 16-bit
+    # weights once (302.6 M parameters) and, per sequence, the K and V rows cached so far in all 24 layers (mean position
+    # 133 of 265: 24 x 2 x 133 x 1024 x 2 bytes).  Mel frontend: 220 500 f32 PCM samples in, one 80 x 848 16-bit tile out.
+    def decode_frac(batch, ms):
+        bytes_per_token = 2 * 302.6e6 + batch * 24 * 2 * 133 * 1024 * 2
+        return round(bytes_per_token / (ms * 1e-3 / 265) / 8e12, 4)
+
+    def mel_frac(batch, ms):
+        return round(batch * (220500 * 4 + 80 * 848 * 2) / (ms * 1e-3) / 8e12, 4)
+
+    out["decode_frac_hbm"] = {"batch1": decode_frac(1, b1["stage_ms_median"]["gpt_sample_265"]),
+                              "batch64": decode_frac(64, b64["stage_ms_median"]["gpt_sample_265"])}
+    out["mel_frac_hbm"] = {"batch1": mel_frac(1, b1["stage_ms_median"]["mel_frontend"]),
+                           "batch64": mel_frac(64, b64["stage_ms_median"]["mel_frontend"])}
+    if b128:
+        out["decode_frac_hbm"]["batch128"] = decode_frac(128, b128["stage_ms_median"]["gpt_sample_265"])
+        out["mel_frac_hbm"]["batch128"] = mel_frac(128, b128["stage_ms_median"]["mel_frontend"])
+    out["ms_per_token"] = {"batch1": round(b1["stage_ms_median"]["gpt_sample_265"] / 265, 4),
+                           "batch64": round(b64["stage_ms_median"]["gpt_sample_265"] / 265, 4)}
     return out
 
 
