@@ -611,6 +611,10 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const bool norm = q.mean != nullptr;
   const int tiles_img = q.tiles_x * q.tiles_y, G = gridDim.x;
+  // a workgroup walks a CONTIGUOUS run of tiles (row-major over image, tile row, tile column): the next tile is the right
+  // neighbour except at the end of a tile row, and its two left halo columns are the two right columns already staged
+  const int t_per = total_tiles / G, t_rem = total_tiles - t_per * G;
+  const int t_first = (int)blockIdx.x * t_per + min((int)blockIdx.x, t_rem), t_last = t_first + t_per + ((int)blockIdx.x < t_rem ? 1 : 0);
   if (t < 128) {
     gb[2 * t] = norm ? q.gamma[t] : 1.f;
     gb[2 * t + 1] = norm ? q.beta[t] : 0.f;
@@ -689,9 +693,9 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
       }
     };
     unsigned kg = 0;  // K-steps multiplied so far (over all tiles)
-    fetch_res(blockIdx.x);
+    fetch_res(t_first);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // half 0 of the first tile is staged
-    for (int tile = blockIdx.x; tile < total_tiles; tile += G) {
+    for (int tile = t_first; tile < t_last; ++tile) {
 #if CONVW_LAB
       unsigned long long ws_t[8];
       ws_t[0] = __builtin_amdgcn_s_memtime();
@@ -758,7 +762,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
       ws_t[3] = __builtin_amdgcn_s_memtime();
 #endif
       // ---- epilogue: the next tile's residual first (into registers the K loop does not hold)
-      fetch_res(tile + G);
+      fetch_res(tile + 1 < t_last ? tile + 1 : total_tiles);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -814,7 +818,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
 #if CONVW_LAB
       ws_t[5] = __builtin_amdgcn_s_memtime();
       if (blockIdx.x == 7 && t == 0) {
-        const int k = (tile - 7) / G;
+        const int k = tile - t_first;
         if (k < 16) {
           for (int e = 0; e < 6; ++e) melgpt_convws_dbg[0][k][e] = ws_t[e];
           melgpt_convws_dbg[0][k][6] = spins;
@@ -865,25 +869,54 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
     };
     // raw chunks of one channel half of a tile: 11 trips of 32 pixels x 8 chunks (+ the image's rstd / mean pairs of this
     // thread's two groups): 13 vector-memory operations per call, whatever the tile (the waits below count on it).
+    // Trips 0 .. NEWT-1 cover patch columns 2 .. PW-1 (TW columns x PH rows: exactly NEWT x 32 pixels); the remaining
+    // EDGE trips cover columns 0 and 1, which a tile whose left neighbour was staged just before it does not need (they
+    // are copied from that neighbour's columns TW, TW + 1 inside the LDS) - their loads are then out of range and cost
+    // an issue slot, their conversion is skipped.
     // Tile-invariant per trip: the pixel's patch coordinates and its byte offset relative to the tile's origin pixel.
-    int pyx[11], poff[11];
+    constexpr int NEWT = PH * TW / 32;        // 9 (16 x 16 tiles) / 10 (8 x 32)
+    int pyx[11], poff[11], doff[11];
 #pragma unroll
     for (int i = 0; i < 11; ++i) {
-      const int pix = prow + 32 * i, py = pix / PW, px = pix - py * PW;
-      pyx[i] = pix < WS_NPIX ? (py << 8 | px) : 0x7F7F;
+      int py, px;
+      bool in;
+      if (i < NEWT) {
+        const int n = prow + 32 * i;
+        py = n / TW;
+        px = 2 + n - py * TW;
+        in = true;
+      } else {
+        const int m = prow + 32 * (i - NEWT);
+        py = m >> 1;
+        px = m & 1;
+        in = m < 2 * PH;
+      }
+      pyx[i] = in ? (py << 8 | px) : 0x7F7F;
       poff[i] = ((py - 1) * q.W + (px - 1)) * 256 + ch * 16;
+      doff[i] = (py * PW + px) * PP + ch * 16;
     }
+    // (the patch column of a thread's pixels in the trips 0 .. NEWT-1 is the same in every trip: 2 + prow mod TW.)  The
+    // threads of columns TW, TW + 1 copy the previous tile's values of those columns to columns 0, 1 - in one burst at the
+    // head of a phase, before their own conversions overwrite the sources: no ordering between the staging waves is needed.
+    const bool cp_thread = 2 + (prow % TW) >= TW;
     struct Raw {
       u32x4 v[11];
       u32x2 rs, mn;
       unsigned ok;  // bit i: pixel of trip i lies inside the image
+    };
+    // shared(tile): its columns 0, 1 come out of the LDS (the tile staged before it in this workgroup is its left neighbour)
+    int tx_of_first = (t_first % tiles_img) % q.tiles_x;   // tile column of the run's first tile; tile k of the run: (tx_of_first + k) mod tiles_x
+    auto shared_halo = [&](int tile) -> bool {
+      if (tile <= t_first || tile >= t_last) return false;
+      return ((unsigned)(tx_of_first + (tile - t_first))) % (unsigned)q.tiles_x != 0u;
     };
     auto load_raw = [&](int tile, int half, Raw& r) {
       const int b = tile / tiles_img, rt = tile - b * tiles_img, ty = rt / q.tiles_x, tx = rt - ty * q.tiles_x;
       const int y0 = ty * TH, x0 = tx * TW;
       // patch rows [ylo, yhi) and columns [xlo, xhi) lie inside the image (all wave-uniform)
       const int live = tile < total_tiles;
-      const int ylo = (live && y0 == 0) ? 1 : 0, yhi = live ? min(PH, q.H - y0 + 1) : 0, xlo = x0 == 0 ? 1 : 0, xhi = min(PW, q.W - x0 + 1);
+      const int ylo = (live && y0 == 0) ? 1 : 0, yhi = live ? min(PH, q.H - y0 + 1) : 0;
+      const int xlo = shared_halo(tile) ? 2 : (x0 == 0 ? 1 : 0), xhi = min(PW, q.W - x0 + 1);
       const unsigned base = (unsigned)((((long long)b * q.H + y0) * q.W + x0) * 256) + half * 128;
       r.ok = 0u;
 #pragma unroll
@@ -920,8 +953,9 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
         cb[e] = norm ? gb[2 * c + 1] - mn * a : 0.f;
       }
     };
-    auto convert = [&](int half, int i, const Raw& r) {
-      if ((pyx[i] & 255) < 64) {   // (the eleventh trip covers 4 or 20 pixels only)
+    auto convert = [&](int half, int i, const Raw& r, bool shared) {
+      if (i >= NEWT && shared) return;   // (wave-uniform) columns 0, 1 are copied below instead
+      if ((pyx[i] & 255) < 64) {   // (the last edge trip covers 4 or 20 pixels only)
         u32x4 v = r.v[i];
         if (!(WS_LAB & 1) && norm) {   // branch-free: computed for every pixel, zeroed outside the image
           const unsigned keep = (r.ok >> i & 1u) ? 0xFFFFFFFFu : 0u;
@@ -943,8 +977,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = pack_bf16x2(o[2 * e], o[2 * e + 1]) & keep;
         }
-        const int pix = prow + 32 * i;
-        *(u32x4*)(patch + pix * PP + half * 128 + ch * 16) = v;   // (outside the image: the load returned zeros)
+        *(u32x4*)(patch + doff[i] + half * 128) = v;   // (outside the image: the load returned zeros)
       }
     };
 #if CONVW_LAB
@@ -961,7 +994,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
 #else
 #define WS_T(k)
 #endif
-    auto phase = [&](int half, Raw& use, int next_tile, int next_half, Raw& next, unsigned sigma0, int kt0) {
+    auto phase = [&](int half, Raw& use, bool use_shared, int next_tile, int next_half, Raw& next, unsigned sigma0, int kt0) {
 #if CONVW_LAB
       unsigned long long tl = __builtin_amdgcn_s_memtime();
 #endif
@@ -996,10 +1029,19 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
         issue_w(kt, (sigma + 3u) & 3u);
         WS_T(2)
         pf_free = cnt4[1];
-        if (j == 0) affine(half, use);
-        convert(half, j, use);
-        if (j == 2) convert(half, 9, use);
-        if (j == 5) convert(half, 10, use);
+        if (j == 0) {
+          affine(half, use);
+          if (use_shared && cp_thread) {   // columns TW, TW + 1 of the previous tile -> columns 0, 1 of this one
+            u32x4 tmp[NEWT];
+#pragma unroll
+            for (int i = 0; i < NEWT; ++i) tmp[i] = *(const u32x4*)(patch + doff[i] + half * 128);
+#pragma unroll
+            for (int i = 0; i < NEWT; ++i) *(u32x4*)(patch + doff[i] - TW * PP + half * 128) = tmp[i];
+          }
+        }
+        convert(half, j, use, use_shared);
+        if (j == 2) convert(half, 9, use, use_shared);
+        if (j == 5) convert(half, 10, use, use_shared);
         WS_T(4)
       }
 #if CONVW_LAB
@@ -1010,31 +1052,32 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
     };
     Raw r0, r1;
     // prologue: both halves of the first tile requested, K-steps 0, 1, 2 requested, half 0 staged, K-step 0 published
-    load_raw(blockIdx.x, 0, r0);
-    load_raw(blockIdx.x, 1, r1);
+    load_raw(t_first, 0, r0);
+    load_raw(t_first, 1, r1);
     issue_w(0, 0u);
     issue_w(1, 1u);
     issue_w(2, 2u);
     wait_raw(std::integral_constant<int, 25>{}, r0);   // younger than r0's 13: r1's 13 + 12 pieces
     affine(0, r0);
 #pragma unroll
-    for (int i = 0; i < 11; ++i) convert(0, i, r0);
+    for (int i = 0; i < 11; ++i) convert(0, i, r0, false);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // K-step 0 (and r1) landed
     if (lane == 0) cnt[s] = 1u;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     unsigned sigma0 = 0;
-    for (int tile = blockIdx.x; tile < total_tiles; tile += G) {
+    for (int tile = t_first; tile < t_last; ++tile) {
+      const int nxt = tile + 1 < t_last ? tile + 1 : total_tiles;
 #if CONVW_LAB
       const unsigned long long sa = __builtin_amdgcn_s_memtime();
 #endif
-      phase(1, r1, tile + G, 0, r0, sigma0, 3);        // A(t): stage half 1 of t, request half 0 of the next tile
+      phase(1, r1, shared_halo(tile), nxt, 0, r0, sigma0, 3);        // A(t): stage half 1 of t, request half 0 of the next tile
 #if CONVW_LAB
       const unsigned long long sb = __builtin_amdgcn_s_memtime();
 #endif
-      phase(0, r0, tile + G, 1, r1, sigma0 + 9u, 12);  // B(t): stage half 0 of the next tile, request its half 1
+      phase(0, r0, shared_halo(nxt), nxt, 1, r1, sigma0 + 9u, 12);  // B(t): stage half 0 of the next tile, request its half 1
 #if CONVW_LAB
       if (blockIdx.x == 7 && t == 256) {
-        const int k = (tile - 7) / G;
+        const int k = tile - t_first;
         if (k < 15) {
           melgpt_convws_dbg[1][k][0] = sa; melgpt_convws_dbg[1][k][1] = ws_pre; melgpt_convws_dbg[1][k][2] = sb;
           melgpt_convws_dbg[1][k][3] = ws_pre2; melgpt_convws_dbg[1][k][4] = __builtin_amdgcn_s_memtime(); melgpt_convws_dbg[1][k][5] = ws_spin;
