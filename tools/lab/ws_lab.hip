@@ -32,8 +32,11 @@ __global__ __launch_bounds__(512) void ws_kernel(const unsigned short* __restric
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   if (w < 4 && SHAPE32) {
-    // timing form of the 32x32x16 variant: wave tile 64 pixels x 128 channels = 2 x 4 tiles of 32 x 32 (16 accumulator
-    // registers each), per 16-wide k-step 2 patch + 4 weight fragments (ds_read_b128) and 8 MFMAs of 32 cycles
+    // the shipped kernel's multiplying loop (v_mfma_f32_32x32x16, wave tile 64 pixels x 128 channels = 2 x 4 tiles, per
+    // 16-wide step 2 patch + 4 weight fragments and 8 MFMAs of 32 cycles), without hand-offs.  SHAPE32 variants:
+    //   1 as shipped (next step's patch fragments up front, each weight fragment re-requested behind its two MFMAs, fences)
+    //   2 the same without scheduling fences        3 MFMAs only, on register contents (no LDS reads at all)
+    //   4 LDS reads as shipped, but every weight fragment from ONE address (no bank spread)   5 as 1, weights only (no patch reads)
     if (!(mode & 1)) return;
     if (prio) __builtin_amdgcn_s_setprio(1);
     typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -46,59 +49,62 @@ __global__ __launch_bounds__(512) void ws_kernel(const unsigned short* __restric
         for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     const int wm = w, r32 = lane & 31, h2 = lane >> 5;
     constexpr int PP = 272;
-    // rows 0-15 of a fragment = row-block 2 mt, rows 16-31 = row-block 2 mt + 1 (one patch row further down)
-    const char* abase = patch + (wm * 4 * 18 + (r32 >> 4) * 18 + (r32 & 15)) * PP + h2 * 16;
-    const char* bbase = ring + row_off(r32, h2);   // (the XOR term moves with the k-step: close enough for timing)
+    const char* abase = patch + ((wm * 4 + (r32 >> 4)) * 18 + (r32 & 15)) * PP + h2 * 16;
+    const int perm = 16 * ((r32 >> 2) & 1) + 4 * (r32 >> 3) + (r32 & 3);
+    const char* bb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bb[ks] = ring + row_off(perm, 2 * ks + h2);
     u32x4 fa0[2], fa1[2], fb[4];
     auto loadA = [&](const char* ab, int kx, int ks, u32x4 (&fa)[2]) {
+      if (SHAPE32 == 3 || SHAPE32 == 5) return;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) fa[mt] = *(const u32x4*)(ab + (mt * 36 + kx) * PP + ks * 32);
+      for (int f = 0; f < 2; ++f) fa[f] = *(const u32x4*)(ab + (f * 36 + kx) * PP + ks * 32);
     };
-    auto loadB = [&](const char* sb, int ks) {
+    auto step = [&](u32x4 (&fc)[2], const char* sbn) {
+      if (SHAPE32 != 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) fb[nt] = *(const u32x4*)(sb + nt * 4096 + ks * 32);
+      for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+          acc[f][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, fb[nt]), __builtin_bit_cast(s16x8, fc[f]), acc[f][nt], 0, 0, 0);
+        if (SHAPE32 != 3) fb[nt] = *(const u32x4*)(sbn + (SHAPE32 == 4 ? 0 : nt * 4096));
+        if (SHAPE32 != 2) __builtin_amdgcn_sched_barrier(0);
+      }
     };
-    auto mm = [&](u32x4 (&fc)[2]) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+    for (int f = 0; f < 2; ++f) fa0[f] = fa1[f] = u32x4{(unsigned)lane, 1u, 2u, 3u};
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, fb[nt]), __builtin_bit_cast(s16x8, fc[mt]), acc[mt][nt], 0, 0, 0);
-    };
-    int kg = 0;
-    loadA(abase, 0, 0, fa0);
-    loadB(bbase, 0);
+    for (int nt = 0; nt < 4; ++nt) fb[nt] = u32x4{(unsigned)lane * 3u, 5u, 7u, 9u};
+    unsigned kg = 0;
     for (int tile = 0; tile < tiles; ++tile) {
+#pragma unroll 1
       for (int hk = 0; hk < 6; ++hk) {
-        const int half = hk / 3, ky = hk - 3 * half;
+        const int half = hk >= 3 ? 1 : 0, ky = hk - 3 * half;
         const char* ab = abase + ky * 18 * PP + half * 128;
-        const int hkn = hk + 1 == 6 ? 0 : hk + 1, hn = hkn / 3, kyn = hkn - 3 * hn;
-        const char* abn = abase + kyn * 18 * PP + hn * 128;
+        const char* abn = hk == 2 || hk == 5 ? abase + (half ^ 1) * 128 : ab + 18 * PP;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx, ++kg) {
-          const char* sb = bbase + (kg & 3) * 16384, *sbn = bbase + ((kg + 1) & 3) * 16384;
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {   // four 16-wide k-steps per 64-channel K-step
-            u32x4 (&fc)[2] = (ks & 1) ? fa1 : fa0;
-            u32x4 (&fn)[2] = (ks & 1) ? fa0 : fa1;
-            if (ks < 3) loadA(ab, kx, ks + 1, fn);
-            else if (kx < 2) loadA(ab, kx + 1, 0, fn);
-            else loadA(abn, 0, 0, fn);
-            mm(fc);
-            if (ks < 3) loadB(sb, ks + 1);
-            else loadB(sbn, 0);
-          }
+          const unsigned so = (kg & 3u) << 14, son = ((kg + 1u) & 3u) << 14;
+          loadA(ab, kx, 1, fa1);
+          step(fa0, bb[1] + so);
+          loadA(ab, kx, 2, fa0);
+          step(fa1, bb[2] + so);
+          loadA(ab, kx, 3, fa1);
+          step(fa0, bb[3] + so);
+          if (kx < 2) loadA(ab, kx + 1, 0, fa0);
+          else loadA(abn, 0, 0, fa0);
+          step(fa1, bb[0] + son);
         }
       }
     }
-    float s = 0.f;
+    float sres = 0.f;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s += acc[a][b][e];
-    if (s == 12345.678f) sink[t] = s;
+        for (int e = 0; e < 16; ++e) sres += acc[a][b][e];
+    if (sres == 12345.678f) sink[t] = sres;
     if (blockIdx.x == 17 && t == 0) { stamps[0] = t0; stamps[1] = __builtin_amdgcn_s_memtime(); }
   } else if (w < 4) {
     if (!(mode & 1)) return;
@@ -204,25 +210,31 @@ int main(int argc, char** argv) {
   for (auto& v : h) { sd = sd * 1664525u + 1013904223u; v = (unsigned short)(0x3c00u + ((sd >> 9) & 0x3ffu) + ((sd >> 20 & 1u) << 15) - 0x0200u); }
   hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
   const size_t lds = 324 * 272 + 4 * 16384 + 4 * 1024;
-  hipFuncSetAttribute((const void*)ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipFuncSetAttribute((const void*)ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  for (int shape = 0; shape <= 1; ++shape)
-  for (int prio = 0; prio <= 0; ++prio)
-    for (int mode = 1; mode <= 3; ++mode) {
+  auto run = [&](auto sh_c) {
+    constexpr int SH = decltype(sh_c)::value;
+    hipFuncSetAttribute((const void*)ws_kernel<SH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int mode = 1; mode <= 3; mode += 2) {
       for (int rep = 0; rep < 2; ++rep) {
         hipMemset(stamps, 0, 64);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0, 0);
-        if (shape) hipLaunchKernelGGL(ws_kernel<1>, dim3(256), dim3(512), lds, 0, src, sink, stamps, tiles, mode, prio);
-        else hipLaunchKernelGGL(ws_kernel<0>, dim3(256), dim3(512), lds, 0, src, sink, stamps, tiles, mode, prio);
+        hipLaunchKernelGGL(ws_kernel<SH>, dim3(256), dim3(512), lds, 0, src, sink, stamps, tiles, mode, 0);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned long long s[8];
         hipMemcpy(s, stamps, 64, hipMemcpyDeviceToHost);
         if (rep == 1)
-          printf("%s prio %d mode %d: %.3f ms | matrix waves %7.0f cycles/tile (ideal 18432: %.2f) | staging waves %7.0f cycles/tile\n", shape ? "32x32x16" : "16x16x32", prio, mode, ms,
-                 (double)(s[1] - s[0]) / tiles, s[1] > s[0] ? 18432.0 * tiles / (double)(s[1] - s[0]) : 0.0, (double)(s[3] - s[2]) / tiles);
+          printf("variant %d mode %d: %.3f ms | matrix waves %7.0f cycles/tile (ideal 18432: %.2f) | staging waves %7.0f cycles/tile | clock %.2f GHz\n", SH, mode, ms,
+                 (double)(s[1] - s[0]) / tiles, s[1] > s[0] ? 18432.0 * tiles / (double)(s[1] - s[0]) : 0.0, (double)(s[3] - s[2]) / tiles,
+                 (double)(s[1] - s[0]) / (ms * 1e6));
       }
     }
+  };
+  run(std::integral_constant<int, 0>{});
+  run(std::integral_constant<int, 1>{});
+  run(std::integral_constant<int, 2>{});
+  run(std::integral_constant<int, 3>{});
+  run(std::integral_constant<int, 4>{});
+  run(std::integral_constant<int, 5>{});
   return 0;
 }
