@@ -318,6 +318,17 @@ def test_fused_conv_also_yields_groupnorm_stats_of_its_output(H, W, B, with_res)
     assert float((mean - m2).abs().max()) < 2e-5 * max(1.0, float(m2.abs().max()))
     assert float(((rstd - r2) / r2).abs().max()) < 1e-4
     assert ops.conv3x3_gn_with_out_stats(x.float(), None, None, None, wp.float(), bias, 1e-6, swish=False) is None
+    # the same launch geometry without a norm in front (plain 3 x 3 convolution of the raw activation), and with the norm
+    # but without swish: both staging branches of the wave-specialised kernel
+    y3 = ops.conv3x3_gn(x, None, None, None, wp, bias, swish=False, residual=res)
+    ref3 = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().to(DEV), bias, padding=1).permute(0, 2, 3, 1)
+    if with_res:
+        ref3 = ref3 + res.float()
+    assert rel_err(y3.float().cpu().numpy(), ref3.cpu().numpy()) < 8e-3
+    y4 = ops.conv3x3_gn(x, stats, gm, bt, wp, bias, swish=False)
+    h4 = F.group_norm(x.float().permute(0, 3, 1, 2), 32, gm, bt, eps=1e-6).to(torch.bfloat16).float()
+    ref4 = F.conv2d(h4, w.float().to(DEV), bias, padding=1).permute(0, 2, 3, 1)
+    assert rel_err(y4.float().cpu().numpy(), ref4.cpu().numpy()) < 8e-3
 
 
 def test_extract_codes_writes_reference_named_files(tmp_path):
