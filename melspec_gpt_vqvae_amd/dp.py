@@ -202,6 +202,7 @@ class DataParallel:
         # through a pinned host flag read at the next finish() (no extra host synchronisation per step).
         self._mask_steps = 0
         self._mask_flag = None        # (pinned host tensor, event) of the previous step's check
+        self._mask_host = None
         self._segs = {}
         self.blocks = [m for m in module.modules() if hasattr(m, "_layer_index") and hasattr(m, "attn")]
         if active and self.overlap:
@@ -259,7 +260,9 @@ class DataParallel:
         dist.all_reduce(has, op=dist.ReduceOp.SUM, group=self.ex.group)
         bad = ((has != 0) & (has != float(self.world))).any().to(torch.int32).reshape(1)
         if self._on_gpu:
-            host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            if self._mask_host is None:
+                self._mask_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]   # (allocated once)
+            host = self._mask_host[self._mask_steps & 1]
             host.copy_(bad, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
