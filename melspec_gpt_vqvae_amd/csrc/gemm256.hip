@@ -618,6 +618,10 @@ int launch_tm(const GemmParams& p, int batch, int ncu, hipStream_t s) {
   int* sched = nullptr;
   if (melgpt_get_dynamic_tiles() && 256 + 2 * grid <= MELGPT_TILE_CELL_INTS)
     sched = melgpt_tile_cell();  // claimed tiles: this launch's counters + mailboxes (abi.hip); nullptr -> static lists
+  if (!sched) {  // static lists: the ping-pong K loop where it is built (gemm8p.hip), the ring otherwise
+    const int st = launch_gemm8p(p, ALAY, BLAY, MODE, TM, tiles_m, tiles_n, batch, RN, grid, s);
+    if (st != MELGPT_ERR_UNSUPPORTED) return st;
+  }
   if (sched) {
     static bool attr_dyn = false;
     if (!attr_dyn) {

@@ -1,0 +1,502 @@
+// 256 x 256 bf16 MFMA GEMM for gfx950, second structure: persistent 512-thread workgroups as gemm256.hip (same tile
+// lists, operand layouts, LDS swizzles, fragment maps and fused epilogue), but the K loop is a two-group PING-PONG over
+// 16 KiB half-tiles instead of a lockstep walk over a ring of 32 KiB half-units (the guide's "256^2 8-phase" schedule,
+// cdna_hip_programming.md; measured against the ring in one process: profiles/r04_gemm_lab.md section 4).
+//
+// A K tile (64 of K) is four half-tiles: A0 / A1 = the rows of the output tile that belong to accumulator row-quadrant
+// 0 / 1 of every wave, B0 / B1 likewise for columns; two K tiles are resident (2 x 64 KiB of LDS) + a 32 KiB block that
+// only the epilogue stages through (160 KiB in all).  8 waves = 2 groups (wr) x 4 (wc); a wave's 128 x 64 accumulator block
+// is four 64 x 32 quadrants, and a PHASE multiplies one quadrant over the K tile (16 MFMAs) out of a register subtile:
+//   phase 1 (A0,B0): reads B sub 0 + A0 | 2 (A0,B1): reads B sub 1 | 3 (A1,B1): reads A1 | 4 (A1,B0): reads nothing
+// Every phase: { this phase's fragment reads; ONE half-tile of LDS-DMA (2 pieces per wave) } barrier { 16 MFMAs } barrier.
+// Group 1 runs one barrier behind group 0, so on every SIMD one wave multiplies while the other reads and requests: the
+// LDS-DMA issue slots and the read latency of one wave sit under the MFMAs of the other (in the ring kernel both waves
+// of a SIMD do the same thing at the same time).
+//
+// Request stream (continuous across tiles, as the ring's): half-tiles of K tile tau are requested in phases 2, 3, 4 of
+// K tile tau - 2 and phase 1 of K tile tau - 1, into the buffer that is being multiplied, each slot after its last read:
+//   B row-major (rows of a wave's quadrant nq live in B half nq: 32-row slabs, permuted by the SOURCE address):
+//     order B0, A0, B1, A1; B0's reads of phase 1 are retired by a counted lgkmcnt before that phase's first barrier
+//   B K-major (natural columns - a k-row of a half-tile is 256 contiguous bytes; wave wc reads half wc >> 1 only, sub
+//     0 in phase 1, sub 1 in phase 2): order A0, B0, B1, A1; A0's reads are retired in phase 1, B's in phase 2
+// ONE counted wait per K tile (phase 4, vmcnt(6): the three youngest half-tiles stay in flight), in front of a barrier;
+// a landed half-tile is read one phase after that barrier at the earliest.
+// A half-tiles are always slab-permuted (a wave's rows of quadrant mq live in A half mq: 64-row slabs, 48 of them used
+// by the 192-row tile), so a wave still owns a CONTIGUOUS 128 (96) x 64 block of C and the epilogue is gemm_common.h's.
+#include <cstdlib>
+
+#include "gemm_common.h"
+
+using namespace gemmk;
+
+namespace {
+
+constexpr int KU = 64;
+
+template <int MN>
+__device__ __forceinline__ int kmaj_off(int krow, int lc) {  // as gemm256.hip: 32-byte column blocks XOR-ed per k-row
+  const int s = (krow & 3) | (((krow >> 3) & 1) << 2);
+  return krow * (MN * 2) + ((lc ^ (s << 1)) << 4);
+}
+
+template <int LAY>
+__device__ __forceinline__ u32x4 load_frag(const char* half, int st, int ks, int lane) {  // 16-row tile st of a half-tile
+  const int i = lane & 15, g = lane >> 4;
+  if constexpr (LAY != LAY_KMAJ) {
+    return *(const u32x4*)(half + row_off(st * 16 + i, 4 * ks + g));
+  } else {
+    const int q = i >> 2, pp = i & 3;
+    const int k0 = 32 * ks + 8 * g + q;
+    const int lc = 2 * st + (pp >> 1);
+    const char* a0 = half + kmaj_off<128>(k0, lc) + (pp & 1) * 8;
+    const char* a1 = half + kmaj_off<128>(k0 + 4, lc) + (pp & 1) * 8;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
+    s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(u32x4, f);
+  }
+}
+
+// One LDS-DMA piece (inline asm on purpose, see gemm256.hip: the compiler must not see an LDS store it would guard with
+// vmcnt(0)).  `s_nop 4`: the resource SGPRs may have been written by a VALU instruction (v_readlane out of a spill lane)
+// right in front of the block - 5 wait states before a VMEM instruction reads them.
+typedef u32x4 rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc4(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  return rsrc_t{(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ void dma16(rsrc_t rs, char* lds_wave_base, unsigned voff) {
+  const unsigned m0v = (unsigned)(size_t)LDS_PTR(char, lds_wave_base);
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :
+               : "s"(m0v), "v"(voff), "s"(rs)
+               : "memory", "m0");
+}
+
+#define P8_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+#ifdef P8_LAB  // lab build only (tools/lab/build_lab_lib.py ... -DP8_LAB): s_memtime stamps of workgroup 17, wave 0
+__device__ unsigned long long p8_dbg[64 * 24];  // per tile: start, K loop done, drained, epilogue done, then one stamp per K tile (<= 20)
+#endif
+
+template <int ALAY, int BLAY, int MODE, int TM>
+__global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, int tiles_n, int batch, int RN) {
+  constexpr int MT = TM / 2, TN = 4, BM = 32 * TM, BN = 256;
+  constexpr int SLAB = 16 * MT;                      // rows of one wave's quadrant (64 or 48)
+  constexpr int HT = 16384, BUF = 4 * HT;            // half-tile, one K tile's buffer
+  constexpr int S_A0 = 0, S_A1 = HT, S_B0 = 2 * HT, S_B1 = 3 * HT;
+  constexpr bool BNAT = BLAY == LAY_KMAJ;            // B in natural column order (see the header)
+  static_assert(TM == 8 || (TM == 6 && ALAY != LAY_KMAJ), "the K-major A image assumes 64-row slabs");
+  static_assert(ALAY != LAY_CONV, "the implicit-GEMM convolution stays on the ring kernel");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A0 A1 B0 B1][16 KiB] + 32 KiB epilogue staging
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = w >> 2, wc = w & 3;
+  const int G = gridDim.x;
+  const int nu = (p.K + KU - 1) / KU;
+  const int rows_m = tiles_m * batch;
+
+  // ---- this workgroup's tile list: the static XCD-block lists of gemm256.hip (the 32 workgroups of an XCD take an
+  // RM x RN block of tiles per item).  This kernel is launched only with RN > 0 (a full grid, a multiple of 8
+  // workgroups) and batch == 1; everything else stays on the ring kernel.
+  // Two cursors walk the list: the multiplying one and, up to two K tiles ahead, the requesting one.  A step is a few
+  // scalar additions (block row / column of the XCD's next block kept incrementally): with the ring kernel's
+  // decode-by-division (and its linear-order and batch branches) the plan of a tile switch cost 1.2 - 1.6 k cycles in
+  // the read phase it sits in - every wave of the workgroup waits for it at the next barrier.
+  const int RM = (G >> 3) / RN;
+  const int blocks_n = (tiles_n + RN - 1) / RN;
+  const int nblocks = ((rows_m + RM - 1) / RM) * blocks_n;
+  const int xcd = blockIdx.x & 7, jslot = blockIdx.x >> 3;
+  const int jm = jslot / RN, jn = jslot - jm * RN;
+  struct Walk {
+    int blk, bm, bn;  // block number of this XCD's current item, its block row / column
+  };
+  auto walk_live = [&](const Walk& k) { return k.blk < nblocks; };
+  auto walk_tile = [&](const Walk& k, int& m0, int& n0) -> bool {
+    const int tm = k.bm * RM + jm, tn = k.bn * RN + jn;
+    m0 = tm * BM;
+    n0 = tn * BN;
+    return tm < rows_m && tn < tiles_n;
+  };
+  auto walk_next = [&](Walk& k) {  // the next item that is a tile, or the first dead one
+    int m0, n0;
+    do {
+      k.blk += 8;
+      k.bn += 8;
+      while (k.bn >= blocks_n) {
+        k.bn -= blocks_n;
+        ++k.bm;
+      }
+    } while (walk_live(k) && !walk_tile(k, m0, n0));
+  };
+  auto walk_first = [&](Walk& k) {
+    k.blk = xcd - 8;
+    k.bm = 0;
+    k.bn = xcd - 8;  // (walk_next takes the first step: block xcd, reduced to its block row / column)
+    walk_next(k);
+  };
+
+  // ---- request cursor: the tile and K tile whose half-tiles are being requested.  A wave issues pieces w and w + 8 of
+  // every half-tile (1 KiB each: 8 rows of 128 B, or 4 k-rows of 256 B).  A piece's source offset is ONE add in the loop:
+  // a per-lane running offset (a_run / b_run: this lane's chunk at the cursor's K tile; K-major operands keep one per
+  // piece j because their K tail cuts k-rows) + a wave-uniform constant per (half, j).  Lanes that must not load carry
+  // MARK (2 GiB: past any operand this kernel accepts, and MARK + constants does not wrap), rows / columns past the
+  // operand's end fall to the buffer's own range check (zeros), a ragged K tail is cut when the cursor enters the tile's
+  // last K tile.
+  constexpr unsigned MARK = 0x80000000u;
+  constexpr int AJ = ALAY == LAY_KMAJ ? 2 : 1, BJ = BLAY == LAY_KMAJ ? 2 : 1;
+  rsrc_t ra, rb;
+  unsigned a_run[AJ], b_run[BJ];
+  int pn0 = 0;
+  const int l3 = lane >> 3;
+  // row-major half-tiles: LDS row 8 (w + 8 j) + l3 holds, at physical chunk lane & 7, logical chunk r_c (row_off's swizzle)
+  const int r_c = (lane & 7) ^ ((4 * w + (lane >> 4)) & 7);
+  const int a_row0 = 8 * w + l3;                        // row inside the slab (used while < SLAB); slab j = piece j
+  const int b_row0 = (w >> 2) * 64 + 8 * (w & 3) + l3;  // tile column of B piece (half 0, j = 0): slabs of 32, j adds 128
+  // K-major half-tiles: k-rows 4 (w + 8 j) + (lane >> 4), 16 chunks of 8 columns, logical = physical ^ (s << 1)
+  const int k_row0 = 4 * w + (lane >> 4);
+  const int k_lc = (lane & 15) ^ (((lane >> 4) | (((w >> 1) & 1) << 2)) << 1);
+  const int ka_mn0 = (k_lc >> 3) * 128 + (k_lc & 7) * 8;  // K-major A: tile row of the chunk in half 0 (slab-permuted)
+  // wave-uniform byte offsets of piece (h, j) from piece (0, 0), and of one K tile
+  unsigned ca[2][2], cb[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      ca[h][j] = ALAY == LAY_KMAJ ? (unsigned)(h * 128) : (unsigned)((long long)(j * (BM / 2) + h * SLAB) * p.lda * 2);
+      cb[h][j] = BLAY == LAY_KMAJ ? (unsigned)(h * 256) : (unsigned)((long long)(j * 128 + h * 32) * p.ldb * 2);
+    }
+  const unsigned a_kstep = ALAY == LAY_KMAJ ? (unsigned)(64 * p.lda * 2) : 128u;
+  const unsigned b_kstep = BLAY == LAY_KMAJ ? (unsigned)(64 * p.ldb * 2) : 128u;
+  const bool ktail = (p.K & 63) != 0;
+  unsigned bh_mark[2] = {0u, 0u};  // K-major B: MARK when half h of the planned tile lies past column N (N % 128 == 0)
+  int iu = 0;                      // K tile of the request cursor inside its item
+  auto cut_tail = [&]() {          // the cursor is in the last, ragged K tile: lanes past K do not load
+    const int k0 = iu * KU;
+    if constexpr (ALAY == LAY_KMAJ) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) a_run[j] = k0 + k_row0 + 32 * j < p.K ? a_run[j] : MARK;
+    } else {
+      a_run[0] = k0 * 2 + r_c * 16 < p.K * 2 ? a_run[0] : MARK;
+    }
+    if constexpr (BLAY == LAY_KMAJ) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b_run[j] = k0 + k_row0 + 32 * j < p.K ? b_run[j] : MARK;
+    } else {
+      b_run[0] = k0 * 2 + r_c * 16 < p.K * 2 ? b_run[0] : MARK;
+    }
+  };
+  // per-lane parts of the source offsets that do not depend on the tile
+  const unsigned a_lane = ALAY == LAY_KMAJ ? (unsigned)(((long long)k_row0 * p.lda + ka_mn0) * 2)
+                                           : (unsigned)((long long)a_row0 * p.lda * 2) + r_c * 16;
+  const unsigned b_lane = BLAY == LAY_KMAJ ? (unsigned)(((long long)k_row0 * p.ldb + k_lc * 8) * 2)
+                                           : (unsigned)((long long)b_row0 * p.ldb * 2) + r_c * 16;
+  ra = make_rsrc4(p.A, p.a_bytes);
+  rb = make_rsrc4(p.B, p.b_bytes);
+  Walk kc;  // the requesting cursor's item
+  auto plan = [&]() {
+    int pm0 = 0;
+    pn0 = 0;
+    const bool pok = walk_live(kc) && walk_tile(kc, pm0, pn0);  // dead: every request is out of range (zero fills nobody reads)
+    if constexpr (ALAY == LAY_KMAJ) {
+      const unsigned b0 = (pok && pm0 + ka_mn0 < p.M) ? a_lane + (unsigned)(pm0 * 2) : MARK;  // (M % 128 == 0)
+      a_run[0] = b0;
+      a_run[1] = b0 == MARK ? MARK : b0 + (unsigned)(32 * p.lda * 2);
+    } else {
+      a_run[0] = (pok && a_row0 < SLAB) ? a_lane + (unsigned)((long long)pm0 * p.lda * 2) : MARK;
+    }
+    if constexpr (BLAY == LAY_KMAJ) {
+      const unsigned b0 = pok ? b_lane + (unsigned)(pn0 * 2) : MARK;
+      b_run[0] = b0;
+      b_run[1] = b0 == MARK ? MARK : b0 + (unsigned)(32 * p.ldb * 2);
+      bh_mark[0] = pn0 < p.N ? 0u : MARK;
+      bh_mark[1] = pn0 + 128 < p.N ? 0u : MARK;
+    } else {
+      b_run[0] = pok ? b_lane + (unsigned)((long long)pn0 * p.ldb * 2) : MARK;
+    }
+  };
+  // half-tile h of A / B for the cursor's K tile -> slot (wave-uniform LDS address)
+  auto issue_a = [&](int h, char* slot) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma16(ra, slot + (w + 8 * j) * 1024, a_run[AJ == 2 ? j : 0] + ca[h][j]);
+  };
+  auto issue_b = [&](int h, char* slot) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      dma16(rb, slot + (w + 8 * j) * 1024, (b_run[BJ == 2 ? j : 0] + cb[h][j]) | (BLAY == LAY_KMAJ ? bh_mark[h] : 0u));
+  };
+
+  walk_first(kc);
+  plan();
+  if (ktail && nu == 1) cut_tail();
+  auto advance = [&]() {
+    if (++iu == nu) {
+#ifdef P8_LAB
+      const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
+#endif
+      iu = 0;
+      walk_next(kc);
+      plan();
+#ifdef P8_LAB
+      if (blockIdx.x == 17 && t == 0) p8_dbg[64 * 24 - 1] = __builtin_amdgcn_s_memtime() - tp0;
+#endif
+    } else {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) a_run[j] += a_kstep;
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) b_run[j] += b_kstep;
+    }
+    if (ktail && iu == nu - 1) cut_tail();
+  };
+  // prologue: the first K tile complete, the next one without its A1 half (that is phase 1's request)
+  issue_b(0, smem + S_B0);
+  issue_a(0, smem + S_A0);
+  issue_b(1, smem + S_B1);
+  issue_a(1, smem + S_A1);
+  advance();
+  issue_a(0, smem + BUF + S_A0);
+  issue_b(0, smem + BUF + S_B0);
+  issue_b(1, smem + BUF + S_B1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  P8_BARRIER();
+  int par = 0;  // buffer of the K tile that is multiplied next
+  int xa[2], xb[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    xa[ks] = row_off(wr * 64 + (lane & 15), 4 * ks + (lane >> 4));
+    xb[ks] = row_off(wc * 32 + (lane & 15), 4 * ks + (lane >> 4));
+  }
+#ifdef P8_LAB
+  int lab_tile = 0;
+#endif
+
+  Walk km;  // the multiplying cursor's item
+  for (walk_first(km); walk_live(km); walk_next(km)) {
+    constexpr int bz = 0;
+    int m0, n0;
+    walk_tile(km, m0, n0);
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 fa[MT][2], fb0[2][2], fb1[2][2];
+
+    // fragment reads.  Row-major half-tiles: the lane's chunk address for k-step 0 / 1 at row tile 0 of the wave's slab
+    // is kept in a register (xa / xb, flipped between the two buffers once per K tile); slot and row tile are immediates.
+    auto ld_a = [&](int slot) {  // this wave's quadrant rows of an A half-tile (slab wr)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          if constexpr (ALAY == LAY_KMAJ) fa[mt][ks] = load_frag<ALAY>(smem + par * BUF + slot, wr * 4 + mt, ks, lane);
+          else fa[mt][ks] = *(const u32x4*)(smem + (xa[ks] + slot + mt * 2048));
+        }
+    };
+    auto ld_b = [&](int slot, int st0, u32x4 (&fb)[2][2]) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          if constexpr (BLAY == LAY_KMAJ) fb[nt][ks] = load_frag<BLAY>(smem + par * BUF + slot, st0 + nt, ks, lane);
+          else fb[nt][ks] = *(const u32x4*)(smem + (xb[ks] + slot + nt * 2048));
+        }
+    };
+    auto mul = [&](auto mq_c, auto nq_c, u32x4 (&fb)[2][2]) {
+      constexpr int MQ = decltype(mq_c)::value, NQ = decltype(nq_c)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) mma<bf16_t>(acc[MQ * MT + mt][NQ * 2 + nt], fb[nt][ks], fa[mt][ks]);  // rows = n, cols = m
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    constexpr int RD_A = (ALAY == LAY_KMAJ ? 4 : 2) * MT;  // LDS read instructions of an A subtile / a B subtile
+    constexpr int RD_B = (BLAY == LAY_KMAJ ? 8 : 4);
+    static_assert(RD_A <= 15 || BNAT, "lgkmcnt is a 4-bit counter");
+
+    auto ktile = [&]() {
+      char* cur = smem + par * BUF;
+      char* oth = smem + (BUF - par * BUF);
+      if constexpr (!BNAT) {
+        // phase 1: (A0, B0); B0's reads first - retired before the barrier, its slot is requested again in phase 2
+        ld_b(S_B0, wc * 2, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_a(S_A0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_a(1, oth + S_A1);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD_A) : "memory");
+        P8_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mul(c0{}, c0{}, fb0);
+        P8_BARRIER();
+        // phase 2: (A0, B1)
+        ld_b(S_B1, wc * 2, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+        issue_b(0, cur + S_B0);
+        P8_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mul(c0{}, c1{}, fb1);
+        P8_BARRIER();
+        // phase 3: (A1, B1)
+        ld_a(S_A1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_a(0, cur + S_A0);
+        P8_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mul(c1{}, c1{}, fb1);
+        P8_BARRIER();
+        // phase 4: (A1, B0); the K tile's counted wait
+        issue_b(1, cur + S_B1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        P8_BARRIER();
+        mul(c1{}, c0{}, fb0);
+        P8_BARRIER();
+      } else {
+        const int bh = wc >> 1 ? S_B1 : S_B0;
+        const int st0 = (wc & 1) * 4;
+        // phase 1: (A0, sub 0); A0's reads first - retired before the barrier, its slot is requested again in phase 2
+        ld_a(S_A0);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_b(bh, st0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_a(1, oth + S_A1);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD_B) : "memory");
+        P8_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mul(c0{}, c0{}, fb0);
+        P8_BARRIER();
+        // phase 2: (A0, sub 1); B's reads retired before the barrier, its slots are requested again in phases 3 and 4
+        ld_b(bh, st0 + 2, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+        issue_a(0, cur + S_A0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        P8_BARRIER();
+        mul(c0{}, c1{}, fb1);
+        P8_BARRIER();
+        // phase 3: (A1, sub 1)
+        ld_a(S_A1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_b(0, cur + S_B0);
+        P8_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mul(c1{}, c1{}, fb1);
+        P8_BARRIER();
+        // phase 4: (A1, sub 0); the K tile's counted wait
+        issue_b(1, cur + S_B1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        P8_BARRIER();
+        mul(c1{}, c0{}, fb0);
+        P8_BARRIER();
+      }
+    };
+
+#ifdef P8_LAB
+    const bool stamp = blockIdx.x == 17 && t == 0 && lab_tile < 64;
+    if (stamp) p8_dbg[lab_tile * 24 + 0] = __builtin_amdgcn_s_memtime();
+#endif
+    if (wr == 1) P8_BARRIER();  // group 1 runs one barrier behind group 0 inside a tile
+    for (int u = 0; u < nu; ++u) {
+      ktile();
+      par ^= 1;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        xa[ks] ^= BUF;
+        xb[ks] ^= BUF;
+      }
+#ifdef P8_LAB
+      if (stamp && u < 20) p8_dbg[lab_tile * 24 + 4 + u] = __builtin_amdgcn_s_memtime();
+#endif
+    }
+    if (wr == 0) P8_BARRIER();  // both groups run the epilogue together
+#ifdef P8_LAB
+    if (stamp) p8_dbg[lab_tile * 24 + 1] = __builtin_amdgcn_s_memtime();
+#endif
+    // the next tile's first K tile has landed (phase 4's wait), three half-tiles of its second are in flight: drained
+    // here with the builtin (see gemm256.hip) - the epilogue's own loads are counted by the compiler from zero
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#ifdef P8_LAB
+    if (stamp) p8_dbg[lab_tile * 24 + 2] = __builtin_amdgcn_s_memtime();
+#endif
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    epilogue<bf16_t, TM, TN, MODE, ALAY != LAY_CONV>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, bz, lane_e,
+                                                      smem + 2 * BUF + w * 4096);
+#ifdef P8_LAB
+    if (stamp) p8_dbg[lab_tile * 24 + 3] = __builtin_amdgcn_s_memtime();
+    ++lab_tile;
+#endif
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+template <int ALAY, int BLAY, int MODE, int TM>
+int launch8p(const GemmParams& p, int tiles_m, int tiles_n, int batch, int RN, int grid, hipStream_t s) {
+  constexpr int LDS = 160 * 1024;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)gemm8p_kernel<ALAY, BLAY, MODE, TM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS) != hipSuccess)
+      return MELGPT_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm8p_kernel<ALAY, BLAY, MODE, TM>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n, batch, RN);
+  return melgpt_launch_status();
+}
+
+template <int ALAY, int BLAY, int MODE>
+int launch8p_tm(const GemmParams& p, int tm, int tiles_m, int tiles_n, int batch, int RN, int grid, hipStream_t s) {
+  if (tm == 8) return launch8p<ALAY, BLAY, MODE, 8>(p, tiles_m, tiles_n, batch, RN, grid, s);
+  if constexpr (ALAY != LAY_KMAJ) {
+    if (tm == 6) return launch8p<ALAY, BLAY, MODE, 6>(p, tiles_m, tiles_n, batch, RN, grid, s);
+  }
+  return MELGPT_ERR_UNSUPPORTED;
+}
+
+template <int ALAY, int BLAY>
+int launch8p_mode(const GemmParams& p, int mode, int tm, int tiles_m, int tiles_n, int batch, int RN, int grid, hipStream_t s) {
+  switch (mode) {
+    case EPI_PLAIN16: return launch8p_tm<ALAY, BLAY, EPI_PLAIN16>(p, tm, tiles_m, tiles_n, batch, RN, grid, s);
+    case EPI_PLAIN16N: return launch8p_tm<ALAY, BLAY, EPI_PLAIN16N>(p, tm, tiles_m, tiles_n, batch, RN, grid, s);
+    case EPI_DACT16:
+      if constexpr (ALAY == LAY_ROW && BLAY == LAY_ROW) return launch8p_tm<ALAY, BLAY, EPI_DACT16>(p, tm, tiles_m, tiles_n, batch, RN, grid, s);
+      break;
+    case EPI_DROPR16:
+      if constexpr (ALAY == LAY_ROW && BLAY == LAY_ROW) return launch8p_tm<ALAY, BLAY, EPI_DROPR16>(p, tm, tiles_m, tiles_n, batch, RN, grid, s);
+      break;
+    default: break;
+  }
+  return MELGPT_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+#ifdef P8_LAB
+extern "C" int melgpt_p8_dbg(unsigned long long* out) {  // lab build only
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(p8_dbg), sizeof(unsigned long long) * 64 * 24) == hipSuccess ? 0 : -1;
+}
+#endif
+
+// The ping-pong form of one (layout, epilogue mode, tile height) of the persistent GEMM, or MELGPT_ERR_UNSUPPORTED when
+// that combination is served by the ring kernel only (gemm256.hip then launches its own).  MELGPT_GEMM_8P=0 keeps every
+// launch on the ring.
+int gemmk::launch_gemm8p(const GemmParams& p, int alay, int blay, int mode, int tm, int tiles_m, int tiles_n, int batch,
+                         int RN, int grid, hipStream_t s) {
+  const char* e = getenv("MELGPT_GEMM_8P");  // (read per launch: A/B runs flip it inside one process)
+  if ((e && atoi(e) == 0) || p.a_rowsum) return MELGPT_ERR_UNSUPPORTED;
+  if (p.a_bytes >= 0x80000000u || p.b_bytes >= 0x80000000u) return MELGPT_ERR_UNSUPPORTED;  // (the kernel's MARK offset)
+  if (RN <= 0 || batch != 1) return MELGPT_ERR_UNSUPPORTED;                                   // (its tile walk)
+  if (alay == LAY_ROW && blay == LAY_ROW) return launch8p_mode<LAY_ROW, LAY_ROW>(p, mode, tm, tiles_m, tiles_n, batch, RN, grid, s);
+  if (alay == LAY_ROW && blay == LAY_KMAJ && p.N % 128 == 0)
+    return launch8p_mode<LAY_ROW, LAY_KMAJ>(p, mode, tm, tiles_m, tiles_n, batch, RN, grid, s);
+  return MELGPT_ERR_UNSUPPORTED;
+}

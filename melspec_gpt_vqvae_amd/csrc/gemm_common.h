@@ -610,5 +610,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x4 (&acc)[
 
 // implemented in gemm256.hip: returns MELGPT_ERR_UNSUPPORTED when the shape/layout is not covered
 int launch_gemm256(const GemmParams& p, int alay, int blay, int batch, int tile_cfg, hipStream_t s);
+// gemm8p.hip: the ping-pong K loop for one (layout, epilogue mode, tile height) of the persistent GEMM, same tile lists
+int launch_gemm8p(const GemmParams& p, int alay, int blay, int mode, int tm, int tiles_m, int tiles_n, int batch, int RN,
+                  int grid, hipStream_t s);
 
 }  // namespace gemmk

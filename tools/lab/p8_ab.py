@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""A/B of the persistent GEMM's two K loops on the training step's shapes: MELGPT_GEMM_8P=0 (five-slot ring, gemm256.hip)
+against =1 (ping-pong over half-tiles, gemm8p.hip; combinations it does not serve fall through to the ring in both arms).
+RANDOM operands, arms interleaved in ONE process, median / minimum of per-launch HIP-event times; outputs compared bit for bit."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+
+from melspec_gpt_vqvae_amd import ops
+
+DEV = "cuda:0"
+M = int(os.environ.get("M", "33920"))
+ROUNDS = int(os.environ.get("ROUNDS", "7"))
+REPS = int(os.environ.get("REPS", "6"))
+
+
+def cases():
+    g = torch.Generator(device=DEV).manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    x1 = rnd(M, 1024).to(torch.bfloat16)
+    x4 = rnd(M, 4096).to(torch.bfloat16)
+    res = rnd(M, 1024).to(torch.bfloat16)
+    w = {n: (rnd(*s) * 0.02).to(torch.bfloat16) for n, s in
+         (("qkv", (3072, 1024)), ("proj", (1024, 1024)), ("fc1", (4096, 1024)), ("fc2", (1024, 4096)))}
+    b = {n: rnd(w[n].shape[0]) * 0.02 for n in w}
+    pre = torch.empty(M, 4096, device=DEV, dtype=torch.bfloat16)
+    if os.environ.get("SQUARES", "1") == "1":
+        for n in (4096, 8192):
+            sa = (torch.rand(n, n, device=DEV, generator=g) * 2 - 1).to(torch.bfloat16)
+            sb = (torch.rand(n, n, device=DEV, generator=g) * 2 - 1).to(torch.bfloat16)
+            yield f"square {n}", n, n, n, (lambda sa=sa, sb=sb: ops.gemm(sa, sb))
+        del sa, sb
+    yield "qkv fwd (bias)", M, 3072, 1024, lambda: ops.gemm(x1, w["qkv"], bias=b["qkv"])
+    yield "proj + dropout + residual", M, 1024, 1024, lambda: ops.gemm(x1, w["proj"], bias=b["proj"], residual=res, drop_p=0.5, seed=7, stream_id=3)
+    yield "fc1 + GELU + derivative", M, 4096, 1024, lambda: ops.gemm(x1, w["fc1"], bias=b["fc1"], act=ops.ACT_GELU_DACT, pre_out=pre)
+    yield "fc2 + dropout + residual", M, 1024, 4096, lambda: ops.gemm(x4, w["fc2"], bias=b["fc2"], residual=res, drop_p=0.5, seed=7, stream_id=5)
+    yield "fc1 plain + residual-free", M, 4096, 1024, lambda: ops.gemm(x1, w["fc1"])
+    yield "dgrad NN K=4096 (dfc1: dY W)", M, 1024, 4096, lambda: ops.gemm(x4, w["fc1"], b_kmajor=True)
+    yield "dgrad NN K=1024 (dfc2)", M, 4096, 1024, lambda: ops.gemm(x1, w["fc2"], b_kmajor=True)
+    yield "dgrad NN K=3072 (dqkv)", M, 1024, 3072, lambda: ops.gemm(torch.cat([x1, x1, x1], 1), w["qkv"], b_kmajor=True)
+
+
+def main():
+    only = os.environ.get("ONLY")
+    for name, m, n, k, fn in cases():
+        if only and only not in name:
+            continue
+        outs, times = {}, {"0": [], "1": []}
+        for arm in "01":
+            os.environ["MELGPT_GEMM_8P"] = arm
+            outs[arm] = fn().clone()
+        torch.cuda.synchronize()
+        same = bool(torch.equal(outs["0"], outs["1"]))
+        nbad = int((outs["0"] != outs["1"]).sum()) if not same else 0
+        stable = True
+        os.environ["MELGPT_GEMM_8P"] = "1"
+        for _ in range(int(os.environ.get("SCREEN", "6"))):
+            stable = stable and bool(torch.equal(fn(), outs["1"]))
+        for r in range(ROUNDS):
+            for arm in ("01" if r % 2 == 0 else "10"):
+                os.environ["MELGPT_GEMM_8P"] = arm
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(REPS):
+                    fn()
+                e.record()
+                torch.cuda.synchronize()
+                times[arm].append(s.elapsed_time(e) / REPS)
+        fl = 2.0 * m * n * k
+        rec = {"shape": f"{name} {m}x{n}x{k}", "bit_identical": same, "differing": nbad, "p8_repeatable": stable}
+        for arm, tag in (("0", "ring"), ("1", "p8")):
+            t = sorted(times[arm])
+            rec[tag + "_ms_med"] = round(t[len(t) // 2], 4)
+            rec[tag + "_ms_min"] = round(t[0], 4)
+            rec[tag + "_tflops_med"] = round(fl / t[len(t) // 2] / 1e9, 1)
+        rec["speedup_med"] = round(rec["ring_ms_med"] / rec["p8_ms_med"], 4)
+        print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()
