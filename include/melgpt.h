@@ -50,6 +50,15 @@ int melgpt_get_reserved_cus(void);
  * same results bit for bit.  Default 0 (MELGPT_DYNAMIC_TILES=1 in the environment turns it on); per process. */
 int melgpt_set_dynamic_tiles(int on);
 int melgpt_get_dynamic_tiles(void);
+/* The persistent GEMM has two K loops: a lockstep walk over a ring of five 32 KiB slots (csrc/gemm256.hip; every layout,
+ * epilogue and tile-list form) and a two-group ping-pong over 16 KiB half-tiles (csrc/gemm8p.hip; static tile lists,
+ * row-major A with either B layout and the weight-gradient form; faster where it applies).  1 (default;
+ * MELGPT_GEMM_8P=0 in the environment turns it off) lets a launch take the ping-pong loop when its combination is built,
+ * 0 keeps every launch on the ring; same results bit for bit; per process.  The counters say which loop the launches
+ * since load took. */
+int melgpt_set_gemm_pingpong(int on);
+int melgpt_get_gemm_pingpong(void);
+int melgpt_gemm_loop_launches(long long* ring, long long* pingpong);
 
 /* ===================================================================== mel frontend
  * wav -> log-mel in one kernel = MelSpectrogram.__call__ + TRANSFORMS

@@ -39,6 +39,9 @@ _PROTOS = {
     "melgpt_get_reserved_cus": [],
     "melgpt_set_dynamic_tiles": [_i],
     "melgpt_get_dynamic_tiles": [],
+    "melgpt_set_gemm_pingpong": [_i],
+    "melgpt_get_gemm_pingpong": [],
+    "melgpt_gemm_loop_launches": [_p, _p],
     "melgpt_vq_argmin_fwd": [_p, _i, _l, _i, _l, _l, _l, _l, _p, _i, _p, _p, _p, _p, _p, _p],
     "melgpt_vq_argmin_fwd_ex": [_p, _i, _l, _i, _l, _l, _l, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "melgpt_vq_max_grid": [],

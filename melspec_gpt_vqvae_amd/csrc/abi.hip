@@ -45,6 +45,28 @@ extern "C" int melgpt_get_dynamic_tiles(void) {
   return g_dynamic_tiles;
 }
 
+// K loop of the persistent GEMM: 1 = the ping-pong loop of gemm8p.hip where it is built, 0 = the ring of gemm256.hip only.
+static int g_pingpong = -1;
+static std::atomic<long long> g_loop_launches[2];
+extern "C" int melgpt_set_gemm_pingpong(int on) {
+  g_pingpong = on != 0;
+  return MELGPT_OK;
+}
+extern "C" int melgpt_get_gemm_pingpong(void) {
+  if (g_pingpong < 0) {
+    const char* e = getenv("MELGPT_GEMM_8P");
+    g_pingpong = e ? atoi(e) != 0 : 1;
+  }
+  return g_pingpong;
+}
+extern "C" int melgpt_gemm_loop_launches(long long* ring, long long* pingpong) {
+  if (!ring || !pingpong) return MELGPT_ERR_BAD_ARG;
+  *ring = g_loop_launches[0].load();
+  *pingpong = g_loop_launches[1].load();
+  return MELGPT_OK;
+}
+void melgpt_count_gemm_loop(int pingpong) { g_loop_launches[pingpong != 0].fetch_add(1); }  // (launchers of the two kernels)
+
 // Scheduler cells of the claimed-tile launches: MELGPT_TILE_CELL_INTS ints each (counter + per-workgroup mailboxes), handed
 // out round-robin from one pool so that launches in flight on different streams never share a counter; a cell puts its
 // counter back to 0 with the launch's last draw.  The pool is allocated on first use and zeroed BEFORE the first cell is

@@ -22,6 +22,8 @@ typedef unsigned short bf16_t;  // raw bf16 bits
     if (!(cond)) return (code);  \
   } while (0)
 
+void melgpt_count_gemm_loop(int pingpong);  // abi.hip: launch counters behind melgpt_gemm_loop_launches
+
 static inline int melgpt_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MELGPT_OK : MELGPT_ERR_LAUNCH;

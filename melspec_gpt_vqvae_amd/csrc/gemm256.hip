@@ -622,6 +622,7 @@ int launch_tm(const GemmParams& p, int batch, int ncu, hipStream_t s) {
     const int st = launch_gemm8p(p, ALAY, BLAY, MODE, TM, tiles_m, tiles_n, batch, RN, grid, s);
     if (st != MELGPT_ERR_UNSUPPORTED) return st;
   }
+  melgpt_count_gemm_loop(0);
   if (sched) {
     static bool attr_dyn = false;
     if (!attr_dyn) {

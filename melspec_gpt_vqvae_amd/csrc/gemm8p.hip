@@ -33,30 +33,6 @@ namespace {
 
 constexpr int KU = 64;
 
-template <int MN>
-__device__ __forceinline__ int kmaj_off(int krow, int lc) {  // as gemm256.hip: 32-byte column blocks XOR-ed per k-row
-  const int s = (krow & 3) | (((krow >> 3) & 1) << 2);
-  return krow * (MN * 2) + ((lc ^ (s << 1)) << 4);
-}
-
-template <int LAY>
-__device__ __forceinline__ u32x4 load_frag(const char* half, int st, int ks, int lane) {  // 16-row tile st of a half-tile
-  const int i = lane & 15, g = lane >> 4;
-  if constexpr (LAY != LAY_KMAJ) {
-    return *(const u32x4*)(half + row_off(st * 16 + i, 4 * ks + g));
-  } else {
-    const int q = i >> 2, pp = i & 3;
-    const int k0 = 32 * ks + 8 * g + q;
-    const int lc = 2 * st + (pp >> 1);
-    const char* a0 = half + kmaj_off<128>(k0, lc) + (pp & 1) * 8;
-    const char* a1 = half + kmaj_off<128>(k0 + 4, lc) + (pp & 1) * 8;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a0));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
-    s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(u32x4, f);
-  }
-}
-
 // One LDS-DMA piece (inline asm on purpose, see gemm256.hip: the compiler must not see an LDS store it would guard with
 // vmcnt(0)).  `s_nop 4`: the resource SGPRs may have been written by a VALU instruction (v_readlane out of a spill lane)
 // right in front of the block - 5 wait states before a VMEM instruction reads them.
@@ -74,6 +50,12 @@ __device__ __forceinline__ void dma16(rsrc_t rs, char* lds_wave_base, unsigned v
 }
 
 #define P8_BARRIER() asm volatile("s_barrier" ::: "memory")
+#ifndef P8_ORDER
+#define P8_ORDER 0  // 1: an XCD takes a contiguous run of blocks; 0: every eighth block (the ring kernel's order)
+#endif
+#ifndef P8_BNAT_EARLY
+#define P8_BNAT_EARLY 0  // lab: K-major B read whole in phase 1
+#endif
 
 #ifdef P8_LAB  // lab build only (tools/lab/build_lab_lib.py ... -DP8_LAB): s_memtime stamps of workgroup 17, wave 0
 __device__ unsigned long long p8_dbg[64 * 24];  // per tile: start, K loop done, drained, epilogue done, then one stamp per K tile (<= 20)
@@ -86,6 +68,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   constexpr int HT = 16384, BUF = 4 * HT;            // half-tile, one K tile's buffer
   constexpr int S_A0 = 0, S_A1 = HT, S_B0 = 2 * HT, S_B1 = 3 * HT;
   constexpr bool BNAT = BLAY == LAY_KMAJ;            // B in natural column order (see the header)
+  constexpr bool BATCHED = ALAY == LAY_KMAJ && BLAY == LAY_KMAJ;  // the weight gradients' split-K batches; others: batch == 1
   static_assert(TM == 8 || (TM == 6 && ALAY != LAY_KMAJ), "the K-major A image assumes 64-row slabs");
   static_assert(ALAY != LAY_CONV, "the implicit-GEMM convolution stays on the ring kernel");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A0 A1 B0 B1][16 KiB] + 32 KiB epilogue staging
@@ -104,36 +87,54 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   // scalar additions (block row / column of the XCD's next block kept incrementally): with the ring kernel's
   // decode-by-division (and its linear-order and batch branches) the plan of a tile switch cost 1.2 - 1.6 k cycles in
   // the read phase it sits in - every wave of the workgroup waits for it at the next barrier.
-  const int RM = (G >> 3) / RN;
-  const int blocks_n = (tiles_n + RN - 1) / RN;
-  const int nblocks = ((rows_m + RM - 1) / RM) * blocks_n;
-  const int xcd = blockIdx.x & 7, jslot = blockIdx.x >> 3;
-  const int jm = jslot / RN, jn = jslot - jm * RN;
+  // (RN == 0: a launch of at most one tile per workgroup - fewer tiles than CUs - in the linear XCD-remapped order; it
+  // is walked as ONE item whose "block" is the tile itself)
+  const bool single = RN == 0;
+  const int RNe = single ? 1 : RN;
+  const int RM = single ? 1 : (G >> 3) / RNe;
+  const int blocks_n = single ? tiles_n : (tiles_n + RNe - 1) / RNe;
+  const int nblocks = single ? 1 : ((rows_m + RM - 1) / RM) * blocks_n;
+  const int xcd = single ? 0 : blockIdx.x & 7, jslot = blockIdx.x >> 3;
+  const int jm = single ? 0 : jslot / RNe, jn = single ? 0 : jslot - (jslot / RNe) * RNe;
   struct Walk {
     int blk, bm, bn;  // block number of this XCD's current item, its block row / column
   };
-  auto walk_live = [&](const Walk& k) { return k.blk < nblocks; };
-  auto walk_tile = [&](const Walk& k, int& m0, int& n0) -> bool {
-    const int tm = k.bm * RM + jm, tn = k.bn * RN + jn;
-    m0 = tm * BM;
+  // Which blocks an XCD takes: a CONTIGUOUS run of the row-major block order (P8_ORDER 1: consecutive items of a
+  // workgroup then share their A row panel and only the B panel changes), or every eighth block as gemm256.hip (0).
+  const int blk_first = P8_ORDER ? (int)(((long long)xcd * nblocks) >> 3) : xcd;
+  const int blk_end = P8_ORDER ? (int)(((long long)(xcd + 1) * nblocks) >> 3) : nblocks;
+  constexpr int BSTEP = P8_ORDER ? 1 : 8;
+  auto walk_live = [&](const Walk& k) { return k.blk < blk_end; };
+  auto walk_tile = [&](const Walk& k, int& bz, int& m0, int& n0) -> bool {
+    const int tm = k.bm * RM + jm, tn = k.bn * RNe + jn;
+    bz = BATCHED ? tm / tiles_m : 0;
+    m0 = (tm - bz * tiles_m) * BM;
     n0 = tn * BN;
     return tm < rows_m && tn < tiles_n;
   };
   auto walk_next = [&](Walk& k) {  // the next item that is a tile, or the first dead one
-    int m0, n0;
+    int bz, m0, n0;
     do {
-      k.blk += 8;
-      k.bn += 8;
+      k.blk += BSTEP;
+      k.bn += BSTEP;
       while (k.bn >= blocks_n) {
         k.bn -= blocks_n;
         ++k.bm;
       }
-    } while (walk_live(k) && !walk_tile(k, m0, n0));
+    } while (walk_live(k) && !walk_tile(k, bz, m0, n0));
   };
   auto walk_first = [&](Walk& k) {
-    k.blk = xcd - 8;
-    k.bm = 0;
-    k.bn = xcd - 8;  // (walk_next takes the first step: block xcd, reduced to its block row / column)
+    if (single) {
+      const int tl = xcd_remap(blockIdx.x, G);
+      k.blk = 0;
+      k.bm = tl / tiles_n;
+      k.bn = tl - k.bm * tiles_n;
+      return;
+    }
+    const int b0 = blk_first - BSTEP;  // (walk_next takes the first step)
+    k.blk = b0;
+    k.bm = b0 >= 0 ? b0 / blocks_n : 0;
+    k.bn = b0 - k.bm * blocks_n;
     walk_next(k);
   };
 
@@ -196,9 +197,13 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   rb = make_rsrc4(p.B, p.b_bytes);
   Walk kc;  // the requesting cursor's item
   auto plan = [&]() {
-    int pm0 = 0;
+    int bz = 0, pm0 = 0;
     pn0 = 0;
-    const bool pok = walk_live(kc) && walk_tile(kc, pm0, pn0);  // dead: every request is out of range (zero fills nobody reads)
+    const bool pok = walk_live(kc) && walk_tile(kc, bz, pm0, pn0);  // dead: every request is out of range (zero fills nobody reads)
+    if constexpr (BATCHED) {
+      ra = make_rsrc4((const char*)p.A + (long long)bz * p.sA * 2, p.a_bytes);
+      rb = make_rsrc4((const char*)p.B + (long long)bz * p.sB * 2, p.b_bytes);
+    }
     if constexpr (ALAY == LAY_KMAJ) {
       const unsigned b0 = (pok && pm0 + ka_mn0 < p.M) ? a_lane + (unsigned)(pm0 * 2) : MARK;  // (M % 128 == 0)
       a_run[0] = b0;
@@ -261,11 +266,18 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   P8_BARRIER();
   int par = 0;  // buffer of the K tile that is multiplied next
-  int xa[2], xb[2];
+  int xa[4], xb[4];
+  {
+    const int i = lane & 15, g = lane >> 4, q = i >> 2, pp = i & 3;
+    const int sw = q | ((g & 1) << 2);                                                  // kmaj_off's s for this lane's k-rows
+    const int kbase = (8 * g + q) * 256 + (pp >> 1) * 16 + (pp & 1) * 8;
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    xa[ks] = row_off(wr * 64 + (lane & 15), 4 * ks + (lane >> 4));
-    xb[ks] = row_off(wc * 32 + (lane & 15), 4 * ks + (lane >> 4));
+    for (int e = 0; e < 4; ++e) {
+      if constexpr (ALAY == LAY_KMAJ) xa[e] = kbase + 128 * (wr ^ (sw >> 2)) + 32 * (e ^ (sw & 3));          // tile wr * 4 + e
+      else xa[e] = row_off(wr * 64 + i, 4 * (e & 1) + g);
+      if constexpr (BLAY == LAY_KMAJ) xb[e] = kbase + 128 * ((wc & 1) ^ (sw >> 2)) + 32 * (e ^ (sw & 3));    // tile (wc & 1) * 4 + e
+      else xb[e] = row_off(wc * 32 + i, 4 * (e & 1) + g);
+    }
   }
 #ifdef P8_LAB
   int lab_tile = 0;
@@ -273,35 +285,68 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
 
   Walk km;  // the multiplying cursor's item
   for (walk_first(km); walk_live(km); walk_next(km)) {
-    constexpr int bz = 0;
-    int m0, n0;
-    walk_tile(km, m0, n0);
+    int bz, m0, n0;
+    walk_tile(km, bz, m0, n0);
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
       for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     u32x4 fa[MT][2], fb0[2][2], fb1[2][2];
+    // ROW SUMS OF A (p.a_rowsum, weight-gradient instantiation only; see gemm256.hip): tile column tn takes K tiles tn,
+    // tn + tiles_n, ...; wave wc the 16-row fragments 2 wc, 2 wc + 1 of its group's 8 - they sit in A half wc >> 1, so
+    // the two MFMAs per k-step against a fragment of ones ride on the phase that has just read that half (1 or 3).
+    constexpr bool CS = BATCHED && MODE == EPI_PLAIN32N && TM == 8;
+    f32x4 cs[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    int cs_next = 0x7FFFFFFF;
+    if constexpr (CS) {
+      if (p.a_rowsum) cs_next = n0 >> 8;
+    }
+    auto row_sums = [&](auto mq_c, int u) {
+      if constexpr (CS) {
+        constexpr int MQ = decltype(mq_c)::value;
+        if (u == cs_next && (wc >> 1) == MQ) {  // (wave-uniform)
+          const unsigned one2 = pack_bf16x2(1.0f, 1.0f);
+          const u32x4 ones = {one2, one2, one2, one2};
+          static_for<2>([&](auto h_c) {
+            constexpr int H = decltype(h_c)::value;
+            if ((wc & 1) == H) {
+#pragma unroll
+              for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) mma<bf16_t>(cs[a], ones, fa[H * 2 + a][ks]);
+            }
+          });
+        }
+      }
+    };
 
-    // fragment reads.  Row-major half-tiles: the lane's chunk address for k-step 0 / 1 at row tile 0 of the wave's slab
-    // is kept in a register (xa / xb, flipped between the two buffers once per K tile); slot and row tile are immediates.
+    // fragment reads: the lane's address inside the buffer of `par` is kept in registers (xa / xb, flipped between the
+    // two buffers once per K tile); slot, row tile / k-step are immediates.  Row-major half-tiles: one register per
+    // k-step (row tiles 2 KiB apart).  K-major half-tiles: one per 16-column tile (the swizzle XORs the tile index into
+    // address bits 5-6), k-steps 8 KiB apart, the fragment's second four k-rows 1 KiB on.
+    auto rd = [&](auto lay_c, const int (&x)[4], int e, int ks, int slot) -> u32x4 {
+      if constexpr (decltype(lay_c)::value == LAY_KMAJ) {
+        const char* a0 = smem + (x[e] + slot + ks * 8192);
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a0 + 1024));
+        s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(u32x4, f);
+      } else {
+        return *(const u32x4*)(smem + (x[ks] + slot + e * 2048));
+      }
+    };
     auto ld_a = [&](int slot) {  // this wave's quadrant rows of an A half-tile (slab wr)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          if constexpr (ALAY == LAY_KMAJ) fa[mt][ks] = load_frag<ALAY>(smem + par * BUF + slot, wr * 4 + mt, ks, lane);
-          else fa[mt][ks] = *(const u32x4*)(smem + (xa[ks] + slot + mt * 2048));
-        }
+        for (int ks = 0; ks < 2; ++ks) fa[mt][ks] = rd(std::integral_constant<int, ALAY>{}, xa, mt, ks, slot);
     };
-    auto ld_b = [&](int slot, int st0, u32x4 (&fb)[2][2]) {
+    auto ld_b = [&](int slot, int e0, u32x4 (&fb)[2][2]) {  // (e0: K-major B, natural order: first tile of the subtile)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          if constexpr (BLAY == LAY_KMAJ) fb[nt][ks] = load_frag<BLAY>(smem + par * BUF + slot, st0 + nt, ks, lane);
-          else fb[nt][ks] = *(const u32x4*)(smem + (xb[ks] + slot + nt * 2048));
-        }
+        for (int ks = 0; ks < 2; ++ks) fb[nt][ks] = rd(std::integral_constant<int, BLAY>{}, xb, e0 + nt, ks, slot);
     };
     auto mul = [&](auto mq_c, auto nq_c, u32x4 (&fb)[2][2]) {
       constexpr int MQ = decltype(mq_c)::value, NQ = decltype(nq_c)::value;
@@ -322,12 +367,12 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
     constexpr int RD_B = (BLAY == LAY_KMAJ ? 8 : 4);
     static_assert(RD_A <= 15 || BNAT, "lgkmcnt is a 4-bit counter");
 
-    auto ktile = [&]() {
+    auto ktile = [&](int u) {
       char* cur = smem + par * BUF;
       char* oth = smem + (BUF - par * BUF);
       if constexpr (!BNAT) {
         // phase 1: (A0, B0); B0's reads first - retired before the barrier, its slot is requested again in phase 2
-        ld_b(S_B0, wc * 2, fb0);
+        ld_b(S_B0, 0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         ld_a(S_A0);
         __builtin_amdgcn_sched_barrier(0);
@@ -338,7 +383,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         mul(c0{}, c0{}, fb0);
         P8_BARRIER();
         // phase 2: (A0, B1)
-        ld_b(S_B1, wc * 2, fb1);
+        ld_b(S_B1, 0, fb1);
         __builtin_amdgcn_sched_barrier(0);
         advance();
         issue_b(0, cur + S_B0);
@@ -360,22 +405,58 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         P8_BARRIER();
         mul(c1{}, c0{}, fb0);
         P8_BARRIER();
+      } else if constexpr (P8_BNAT_EARLY) {
+        // lab: both B subtiles read in phase 1 (B first, retired before the barrier), request order as for row-major B
+        const int bh = wc >> 1 ? S_B1 : S_B0;
+        ld_b(bh, 0, fb0);
+        ld_b(bh, 2, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_a(S_A0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_a(1, oth + S_A1);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD_A < 15 ? RD_A : 15) : "memory");
+        P8_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mul(c0{}, c0{}, fb0);
+        row_sums(c0{}, u);
+        P8_BARRIER();
+        advance();
+        issue_b(0, cur + S_B0);
+        P8_BARRIER();
+        mul(c0{}, c1{}, fb1);
+        P8_BARRIER();
+        ld_a(S_A1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_a(0, cur + S_A0);
+        P8_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mul(c1{}, c1{}, fb1);
+        row_sums(c1{}, u);
+        P8_BARRIER();
+        issue_b(1, cur + S_B1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        P8_BARRIER();
+        mul(c1{}, c0{}, fb0);
+        if constexpr (CS) {
+          if (u == cs_next) cs_next += tiles_n;
+        }
+        P8_BARRIER();
       } else {
         const int bh = wc >> 1 ? S_B1 : S_B0;
-        const int st0 = (wc & 1) * 4;
         // phase 1: (A0, sub 0); A0's reads first - retired before the barrier, its slot is requested again in phase 2
         ld_a(S_A0);
         __builtin_amdgcn_sched_barrier(0);
-        ld_b(bh, st0, fb0);
+        ld_b(bh, 0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         issue_a(1, oth + S_A1);
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD_B) : "memory");
         P8_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         mul(c0{}, c0{}, fb0);
+        row_sums(c0{}, u);
         P8_BARRIER();
         // phase 2: (A0, sub 1); B's reads retired before the barrier, its slots are requested again in phases 3 and 4
-        ld_b(bh, st0 + 2, fb1);
+        ld_b(bh, 2, fb1);
         __builtin_amdgcn_sched_barrier(0);
         advance();
         issue_a(0, cur + S_A0);
@@ -390,12 +471,16 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         P8_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         mul(c1{}, c1{}, fb1);
+        row_sums(c1{}, u);
         P8_BARRIER();
         // phase 4: (A1, sub 0); the K tile's counted wait
         issue_b(1, cur + S_B1);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         P8_BARRIER();
         mul(c1{}, c0{}, fb0);
+        if constexpr (CS) {
+          if (u == cs_next) cs_next += tiles_n;
+        }
         P8_BARRIER();
       }
     };
@@ -406,12 +491,12 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
 #endif
     if (wr == 1) P8_BARRIER();  // group 1 runs one barrier behind group 0 inside a tile
     for (int u = 0; u < nu; ++u) {
-      ktile();
+      ktile(u);
       par ^= 1;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        xa[ks] ^= BUF;
-        xb[ks] ^= BUF;
+      for (int e = 0; e < 4; ++e) {
+        if (ALAY == LAY_KMAJ || e < 2) xa[e] ^= BUF;
+        if (BLAY == LAY_KMAJ || e < 2) xb[e] ^= BUF;
       }
 #ifdef P8_LAB
       if (stamp && u < 20) p8_dbg[lab_tile * 24 + 4 + u] = __builtin_amdgcn_s_memtime();
@@ -431,6 +516,16 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
     asm volatile("" : "+v"(lane_e));
     epilogue<bf16_t, TM, TN, MODE, ALAY != LAY_CONV>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, bz, lane_e,
                                                       smem + 2 * BUF + w * 4096);
+    if constexpr (CS) {
+      if (p.a_rowsum && (lane_e >> 4) == 0) {  // every tile writes its slice, zeros when it took no K tile
+        float* dst = p.a_rowsum + ((long long)bz * tiles_n + (n0 >> 8)) * p.ld_rowsum;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int m = m0 + wr * 128 + (wc * 2 + a) * 16 + (lane_e & 15);
+          if (m < p.M) dst[m] = cs[a][0];
+        }
+      }
+    }
 #ifdef P8_LAB
     if (stamp) p8_dbg[lab_tile * 24 + 3] = __builtin_amdgcn_s_memtime();
     ++lab_tile;
@@ -450,6 +545,7 @@ int launch8p(const GemmParams& p, int tiles_m, int tiles_n, int batch, int RN, i
     attr = true;
   }
   hipLaunchKernelGGL((gemm8p_kernel<ALAY, BLAY, MODE, TM>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n, batch, RN);
+  melgpt_count_gemm_loop(1);
   return melgpt_launch_status();
 }
 
@@ -473,6 +569,12 @@ int launch8p_mode(const GemmParams& p, int mode, int tm, int tiles_m, int tiles_
     case EPI_DROPR16:
       if constexpr (ALAY == LAY_ROW && BLAY == LAY_ROW) return launch8p_tm<ALAY, BLAY, EPI_DROPR16>(p, tm, tiles_m, tiles_n, batch, RN, grid, s);
       break;
+    case EPI_PLAIN32:
+      if constexpr (ALAY == LAY_KMAJ && BLAY == LAY_KMAJ) return launch8p_tm<ALAY, BLAY, EPI_PLAIN32>(p, tm, tiles_m, tiles_n, batch, RN, grid, s);
+      break;
+    case EPI_PLAIN32N:
+      if constexpr (ALAY == LAY_KMAJ && BLAY == LAY_KMAJ) return launch8p_tm<ALAY, BLAY, EPI_PLAIN32N>(p, tm, tiles_m, tiles_n, batch, RN, grid, s);
+      break;
     default: break;
   }
   return MELGPT_ERR_UNSUPPORTED;
@@ -491,10 +593,12 @@ extern "C" int melgpt_p8_dbg(unsigned long long* out) {  // lab build only
 // launch on the ring.
 int gemmk::launch_gemm8p(const GemmParams& p, int alay, int blay, int mode, int tm, int tiles_m, int tiles_n, int batch,
                          int RN, int grid, hipStream_t s) {
-  const char* e = getenv("MELGPT_GEMM_8P");  // (read per launch: A/B runs flip it inside one process)
-  if ((e && atoi(e) == 0) || p.a_rowsum) return MELGPT_ERR_UNSUPPORTED;
+  if (!melgpt_get_gemm_pingpong()) return MELGPT_ERR_UNSUPPORTED;
   if (p.a_bytes >= 0x80000000u || p.b_bytes >= 0x80000000u) return MELGPT_ERR_UNSUPPORTED;  // (the kernel's MARK offset)
-  if (RN <= 0 || batch != 1) return MELGPT_ERR_UNSUPPORTED;                                   // (its tile walk)
+  if (RN <= 0 && (long long)grid != (long long)tiles_m * tiles_n * batch) return MELGPT_ERR_UNSUPPORTED;  // (its tile walk)
+  if (alay == LAY_KMAJ && blay == LAY_KMAJ && p.M % 128 == 0 && p.N % 128 == 0)                // (whole slabs / halves)
+    return launch8p_mode<LAY_KMAJ, LAY_KMAJ>(p, mode, tm, tiles_m, tiles_n, batch, RN, grid, s);
+  if (batch != 1 || p.a_rowsum) return MELGPT_ERR_UNSUPPORTED;
   if (alay == LAY_ROW && blay == LAY_ROW) return launch8p_mode<LAY_ROW, LAY_ROW>(p, mode, tm, tiles_m, tiles_n, batch, RN, grid, s);
   if (alay == LAY_ROW && blay == LAY_KMAJ && p.N % 128 == 0)
     return launch8p_mode<LAY_ROW, LAY_KMAJ>(p, mode, tm, tiles_m, tiles_n, batch, RN, grid, s);

@@ -1,0 +1,142 @@
+"""GPU parity of the persistent GEMM's ping-pong K loop (csrc/gemm8p.hip) at sizes where every workgroup walks several
+256 x 256 (192 x 256) tiles: against an fp32 matmul of the same bf16 operands on the CPU (1e-5 relative-to-max before
+the output rounding, 2^-8 after it), and BIT FOR BIT against the ring kernel (csrc/gemm256.hip) - both loops add the
+same products in the same order.  Every case also checks, through the launch counters, that the loop it means to test
+is the one that ran (a silent fall-back to the other kernel would make the comparison empty).
+Reference call sites: the Linear layers of transformer/minGPT.py:76-88,100-117 (forward, input and weight gradients)."""
+import ctypes
+
+import pytest
+import torch
+
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _launches():
+    from melspec_gpt_vqvae_amd import _ffi
+
+    r, p = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    assert _ffi.lib().melgpt_gemm_loop_launches(ctypes.byref(r), ctypes.byref(p)) == 0
+    return r.value, p.value
+
+
+def _both(fn):
+    """fn() on the ring and on the ping-pong loop -> (ring output, ping-pong output), with the counters checked."""
+    from melspec_gpt_vqvae_amd import _ffi
+
+    L = _ffi.lib()
+    was = L.melgpt_get_gemm_pingpong()
+    try:
+        L.melgpt_set_gemm_pingpong(0)
+        r0, p0 = _launches()
+        ring = fn()
+        ring = [x.clone() for x in ring] if isinstance(ring, (list, tuple)) else ring.clone()
+        r1, p1 = _launches()
+        assert r1 > r0 and p1 == p0, "with the switch off every persistent launch takes the ring"
+        L.melgpt_set_gemm_pingpong(1)
+        pp = fn()
+        pp = [x.clone() for x in pp] if isinstance(pp, (list, tuple)) else pp.clone()
+        r2, p2 = _launches()
+        assert p2 > p1, "this shape was meant to run on the ping-pong loop"
+    finally:
+        L.melgpt_set_gemm_pingpong(was)
+    torch.cuda.synchronize()
+    return ring, pp
+
+
+def _ops(seed, M, N, K, b_kmajor=False):
+    torch.manual_seed(seed)
+    a = (torch.randn(M, K) * 0.5).to(torch.bfloat16)
+    b = (torch.randn(*((K, N) if b_kmajor else (N, K))) * 0.25).to(torch.bfloat16)
+    ref = a.float() @ (b.float() if b_kmajor else b.float().t())
+    return a.to(DEV), b.to(DEV), ref
+
+
+# >= 256 tiles (a full grid: the ping-pong kernel walks XCD blocks), ragged M / N / K edges, both tile heights
+# (MELGPT_GEMM_TM is read once per process, so the height is whatever the launch's cost model picks: N = 1024 -> 192 rows)
+@pytest.mark.parametrize("form,M,N,K", [("nt", 9000, 4096, 328), ("nt", 33920, 1024, 264), ("nt", 20000, 1272, 384),
+                                        ("nn", 24576, 1024, 320), ("nn", 8500, 4096, 328), ("nt", 8192, 8192, 512)])
+def test_plain_store_matches_reference_and_ring(form, M, N, K):
+    from melspec_gpt_vqvae_amd import ops
+
+    a, b, ref = _ops(M + N + K, M, N, K, b_kmajor=form == "nn")
+    # (an f32 output of an NT / NN product is a ring-only mode: the bf16 store is what the ping-pong kernel builds)
+    ring, pp = _both(lambda: ops.gemm(a, b, b_kmajor=form == "nn"))
+    assert torch.equal(ring, pp)
+    assert rel_err(pp.float().cpu().numpy(), ref.numpy()) < 2 ** -8
+
+
+def test_fused_epilogues_match_reference_and_ring():
+    import torch.nn.functional as F
+
+    from melspec_gpt_vqvae_amd import ops
+
+    M, N, K = 17000, 4096, 264      # 67 x 16 tiles: five rounds, ragged last tile row and a ragged K tile
+    a, b, ref = _ops(5, M, N, K)
+    bias = (torch.randn(N) * 0.1)
+    res = torch.randn(M, N).to(torch.bfloat16)
+    bd, rd = bias.to(DEV), res.to(DEV)
+    pre_ref = ref + bias
+    # bias only (qkv), bias + residual (eval-mode projection)
+    ring, pp = _both(lambda: ops.gemm(a, b, bias=bd))
+    assert torch.equal(ring, pp) and rel_err(pp.float().cpu().numpy(), pre_ref.numpy()) < 2 ** -8
+    ring, pp = _both(lambda: ops.gemm(a, b, bias=bd, residual=rd))
+    assert torch.equal(ring, pp) and rel_err(pp.float().cpu().numpy(), (pre_ref + res.float()).numpy()) < 2 ** -8
+    # Linear -> GELU with the saved derivative (fc1 in training)
+    def fc1():
+        pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        act = ops.gemm(a, b, bias=bd, act=ops.ACT_GELU_DACT, pre_out=pre)
+        return [act, pre]
+    ring, pp = _both(fc1)
+    assert torch.equal(ring[0], pp[0]) and torch.equal(ring[1], pp[1])
+    assert rel_err(pp[0].float().cpu().numpy(), F.gelu(pre_ref).numpy()) < 2 ** -8
+    x = pre_ref
+    gprime = 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+    assert rel_err(pp[1].float().cpu().numpy(), gprime.numpy()) < 2 ** -7
+    # Linear -> dropout -> + residual (projection / fc2 in training); the mask is the one dropout_apply replays
+    ring, pp = _both(lambda: ops.gemm(a, b, bias=bd, residual=rd, drop_p=0.25, seed=77, stream_id=5))
+    assert torch.equal(ring, pp)
+    mask = ops.dropout_apply(torch.ones(M, N, dtype=torch.bfloat16, device=DEV), 0.25, 77, 5).float().cpu()
+    assert rel_err(pp.float().cpu().numpy(), (pre_ref * mask + res.float()).numpy()) < 2 ** -7
+    # input gradient through the saved GELU derivative: (dY W) * R, K-major B
+    a2, b2, ref2 = _ops(6, M, N, K, b_kmajor=True)
+    ring, pp = _both(lambda: ops.gemm(a2, b2, b_kmajor=True, act=ops.ACT_MUL, residual=rd))
+    assert torch.equal(ring, pp) and rel_err(pp.float().cpu().numpy(), (ref2 * res.float()).numpy()) < 2 ** -7
+
+
+@pytest.mark.parametrize("N,K,M", [(4096, 1024, 33920), (1024, 4096, 16960), (3072, 1024, 33920), (1024, 1024, 33920)])
+def test_weight_gradient_with_bias_gradient_matches_reference_and_ring(N, K, M):
+    """dW (N x K) = dY^T X and db = column sums of dY over M rows in split-K batches (both operands K-major, ragged K
+    tiles per batch, the row sums riding on the A fragments): ops.wgrad as the training step calls it."""
+    from melspec_gpt_vqvae_amd import ops
+
+    torch.manual_seed(N + K)
+    dy = (torch.randn(M, N) * 0.5).to(torch.bfloat16)
+    x = (torch.randn(M, K) * 0.5).to(torch.bfloat16)
+    dyd, xd = dy.to(DEV), x.to(DEV)
+
+    def run():
+        w = torch.empty(N, K, device=DEV)
+        bgrad = torch.empty(N, device=DEV)
+        ops.wgrad(dyd, xd, w, False, bias_out=bgrad)
+        return [w, bgrad]
+    ring, pp = _both(run)
+    assert torch.equal(ring[0], pp[0]) and torch.equal(ring[1], pp[1])
+    assert rel_err(pp[0].cpu().numpy(), (dy.float().t() @ x.float()).numpy()) < 1e-5
+    assert rel_err(pp[1].cpu().numpy(), dy.float().sum(0).numpy()) < 1e-5
+
+
+def test_ping_pong_loop_is_bit_reproducible():
+    """LDS-DMA data is ordered for its readers only by the counted waits and barriers: a read placed too early passes
+    most runs.  Twenty launches of a multi-round shape must give the same bits."""
+    from melspec_gpt_vqvae_amd import ops
+
+    a, b, _ = _ops(9, 16384, 4096, 1024)
+    _, p0 = _launches()
+    first = ops.gemm(a, b).clone()
+    for _ in range(20):
+        assert torch.equal(ops.gemm(a, b), first)
+    assert _launches()[1] >= p0 + 21

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of the persistent GEMM's two K loops on the training step's shapes: MELGPT_GEMM_8P=0 (five-slot ring, gemm256.hip)
-against =1 (ping-pong over half-tiles, gemm8p.hip; combinations it does not serve fall through to the ring in both arms).
+"""A/B of the persistent GEMM's two K loops on the training step's shapes: melgpt_set_gemm_pingpong(0) (five-slot ring, gemm256.hip)
+against (1) (ping-pong over half-tiles, gemm8p.hip; combinations it does not serve fall through to the ring in both arms).
 RANDOM operands, arms interleaved in ONE process, median / minimum of per-launch HIP-event times; outputs compared bit for bit."""
 import json
 import os
@@ -9,7 +9,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
-from melspec_gpt_vqvae_amd import ops
+from melspec_gpt_vqvae_amd import _ffi, ops
 
 DEV = "cuda:0"
 M = int(os.environ.get("M", "33920"))
@@ -40,7 +40,19 @@ def cases():
     yield "fc1 plain + residual-free", M, 4096, 1024, lambda: ops.gemm(x1, w["fc1"])
     yield "dgrad NN K=4096 (dfc1: dY W)", M, 1024, 4096, lambda: ops.gemm(x4, w["fc1"], b_kmajor=True)
     yield "dgrad NN K=1024 (dfc2)", M, 4096, 1024, lambda: ops.gemm(x1, w["fc2"], b_kmajor=True)
-    yield "dgrad NN K=3072 (dqkv)", M, 1024, 3072, lambda: ops.gemm(torch.cat([x1, x1, x1], 1), w["qkv"], b_kmajor=True)
+    x3 = torch.cat([x1, x1, x1], 1)
+    yield "dgrad NN K=3072 (dqkv)", M, 1024, 3072, lambda: ops.gemm(x3, w["qkv"], b_kmajor=True)
+    dmul = rnd(M, 4096).to(torch.bfloat16)
+    yield "GELU' dgrad (mul) K=1024", M, 4096, 1024, lambda: ops.gemm(x1, w["fc2"], b_kmajor=True, act=ops.ACT_MUL, residual=dmul)
+    for nm, dy, x in (("fc1 4096x1024", x4, x1), ("fc2 1024x4096", x1, x4), ("qkv 3072x1024", x3, x1), ("proj 1024x1024", x1, res)):
+        n, k = dy.shape[1], x.shape[1]
+        wg = torch.zeros(n, k, device=DEV)
+        bg = torch.zeros(n, device=DEV)
+
+        def run(dy=dy, x=x, wg=wg, bg=bg):
+            ops.wgrad(dy, x, wg, False, bias_out=bg)
+            return torch.cat([wg.flatten(), bg])
+        yield "wgrad + bias " + nm, n, k, M, run
 
 
 def main():
@@ -50,18 +62,18 @@ def main():
             continue
         outs, times = {}, {"0": [], "1": []}
         for arm in "01":
-            os.environ["MELGPT_GEMM_8P"] = arm
+            _ffi.lib().melgpt_set_gemm_pingpong(int(arm))
             outs[arm] = fn().clone()
         torch.cuda.synchronize()
         same = bool(torch.equal(outs["0"], outs["1"]))
         nbad = int((outs["0"] != outs["1"]).sum()) if not same else 0
         stable = True
-        os.environ["MELGPT_GEMM_8P"] = "1"
+        _ffi.lib().melgpt_set_gemm_pingpong(1)
         for _ in range(int(os.environ.get("SCREEN", "6"))):
             stable = stable and bool(torch.equal(fn(), outs["1"]))
         for r in range(ROUNDS):
             for arm in ("01" if r % 2 == 0 else "10"):
-                os.environ["MELGPT_GEMM_8P"] = arm
+                _ffi.lib().melgpt_set_gemm_pingpong(int(arm))
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 for _ in range(REPS):

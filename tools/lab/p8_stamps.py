@@ -13,9 +13,10 @@ from melspec_gpt_vqvae_amd import _ffi, ops
 
 M, N, K = (int(v) for v in os.environ.get("SHAPE", "33920,4096,1024").split(","))
 a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
-b = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
+KM = os.environ.get("B_KMAJOR", "0") == "1"
+b = (torch.randn(*((K, N) if KM else (N, K)), device="cuda") * 0.02).to(torch.bfloat16)
 for _ in range(3):
-    ops.gemm(a, b)
+    ops.gemm(a, b, b_kmajor=KM)
 torch.cuda.synchronize()
 L = _ffi.lib()
 buf = (ctypes.c_ulonglong * (64 * 24))()
