@@ -287,11 +287,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   for (walk_first(km); walk_live(km); walk_next(km)) {
     int bz, m0, n0;
     walk_tile(km, bz, m0, n0);
+    // (not zeroed: the tile's first K tile is a copy of the loop body whose first MFMA per accumulator tile takes a zero
+    // C operand - 128 v_mov per wave and tile, ~500 cycles in front of the first phase, otherwise)
     f32x4 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     u32x4 fa[MT][2], fb0[2][2], fb1[2][2];
     // ROW SUMS OF A (p.a_rowsum, weight-gradient instantiation only; see gemm256.hip): tile column tn takes K tiles tn,
     // tn + tiles_n, ...; wave wc the 16-row fragments 2 wc, 2 wc + 1 of its group's 8 - they sit in A half wc >> 1, so
@@ -348,8 +346,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) fb[nt][ks] = rd(std::integral_constant<int, BLAY>{}, xb, e0 + nt, ks, slot);
     };
-    auto mul = [&](auto mq_c, auto nq_c, u32x4 (&fb)[2][2]) {
+    auto mul = [&](auto first_c, auto mq_c, auto nq_c, u32x4 (&fb)[2][2]) {
       constexpr int MQ = decltype(mq_c)::value, NQ = decltype(nq_c)::value;
+      constexpr bool FIRST = decltype(first_c)::value;
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -357,7 +356,13 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) mma<bf16_t>(acc[MQ * MT + mt][NQ * 2 + nt], fb[nt][ks], fa[mt][ks]);  // rows = n, cols = m
+          for (int nt = 0; nt < 2; ++nt) {
+            f32x4& c = acc[MQ * MT + mt][NQ * 2 + nt];
+            if constexpr (FIRST) {
+              if (ks == 0) c = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            mma<bf16_t>(c, fb[nt][ks], fa[mt][ks]);  // rows = n, cols = m
+          }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
     constexpr int RD_B = (BLAY == LAY_KMAJ ? 8 : 4);
     static_assert(RD_A <= 15 || BNAT, "lgkmcnt is a 4-bit counter");
 
-    auto ktile = [&](int u) {
+    auto ktile = [&](auto first_c, int u) {
       char* cur = smem + par * BUF;
       char* oth = smem + (BUF - par * BUF);
       if constexpr (!BNAT) {
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD_A) : "memory");
         P8_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mul(c0{}, c0{}, fb0);
+        mul(first_c, c0{}, c0{}, fb0);
         P8_BARRIER();
         // phase 2: (A0, B1)
         ld_b(S_B1, 0, fb1);
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         issue_b(0, cur + S_B0);
         P8_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mul(c0{}, c1{}, fb1);
+        mul(first_c, c0{}, c1{}, fb1);
         P8_BARRIER();
         // phase 3: (A1, B1)
         ld_a(S_A1);
@@ -397,13 +402,13 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         issue_a(0, cur + S_A0);
         P8_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mul(c1{}, c1{}, fb1);
+        mul(first_c, c1{}, c1{}, fb1);
         P8_BARRIER();
         // phase 4: (A1, B0); the K tile's counted wait
         issue_b(1, cur + S_B1);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         P8_BARRIER();
-        mul(c1{}, c0{}, fb0);
+        mul(first_c, c1{}, c0{}, fb0);
         P8_BARRIER();
       } else if constexpr (P8_BNAT_EARLY) {
         // lab: both B subtiles read in phase 1 (B first, retired before the barrier), request order as for row-major B
@@ -417,26 +422,26 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD_A < 15 ? RD_A : 15) : "memory");
         P8_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mul(c0{}, c0{}, fb0);
+        mul(first_c, c0{}, c0{}, fb0);
         row_sums(c0{}, u);
         P8_BARRIER();
         advance();
         issue_b(0, cur + S_B0);
         P8_BARRIER();
-        mul(c0{}, c1{}, fb1);
+        mul(first_c, c0{}, c1{}, fb1);
         P8_BARRIER();
         ld_a(S_A1);
         __builtin_amdgcn_sched_barrier(0);
         issue_a(0, cur + S_A0);
         P8_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mul(c1{}, c1{}, fb1);
+        mul(first_c, c1{}, c1{}, fb1);
         row_sums(c1{}, u);
         P8_BARRIER();
         issue_b(1, cur + S_B1);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         P8_BARRIER();
-        mul(c1{}, c0{}, fb0);
+        mul(first_c, c1{}, c0{}, fb0);
         if constexpr (CS) {
           if (u == cs_next) cs_next += tiles_n;
         }
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD_B) : "memory");
         P8_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mul(c0{}, c0{}, fb0);
+        mul(first_c, c0{}, c0{}, fb0);
         row_sums(c0{}, u);
         P8_BARRIER();
         // phase 2: (A0, sub 1); B's reads retired before the barrier, its slots are requested again in phases 3 and 4
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         issue_a(0, cur + S_A0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         P8_BARRIER();
-        mul(c0{}, c1{}, fb1);
+        mul(first_c, c0{}, c1{}, fb1);
         P8_BARRIER();
         // phase 3: (A1, sub 1)
         ld_a(S_A1);
@@ -470,14 +475,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         issue_b(0, cur + S_B0);
         P8_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mul(c1{}, c1{}, fb1);
+        mul(first_c, c1{}, c1{}, fb1);
         row_sums(c1{}, u);
         P8_BARRIER();
         // phase 4: (A1, sub 0); the K tile's counted wait
         issue_b(1, cur + S_B1);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         P8_BARRIER();
-        mul(c1{}, c0{}, fb0);
+        mul(first_c, c1{}, c0{}, fb0);
         if constexpr (CS) {
           if (u == cs_next) cs_next += tiles_n;
         }
@@ -490,8 +495,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
     if (stamp) p8_dbg[lab_tile * 24 + 0] = __builtin_amdgcn_s_memtime();
 #endif
     if (wr == 1) P8_BARRIER();  // group 1 runs one barrier behind group 0 inside a tile
-    for (int u = 0; u < nu; ++u) {
-      ktile(u);
+    auto flip = [&](int u) {  // the other buffer
       par ^= 1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -501,6 +505,12 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
 #ifdef P8_LAB
       if (stamp && u < 20) p8_dbg[lab_tile * 24 + 4 + u] = __builtin_amdgcn_s_memtime();
 #endif
+    };
+    ktile(std::true_type{}, 0);
+    flip(0);
+    for (int u = 1; u < nu; ++u) {
+      ktile(std::false_type{}, u);
+      flip(u);
     }
     if (wr == 0) P8_BARRIER();  // both groups run the epilogue together
 #ifdef P8_LAB
