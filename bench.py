@@ -407,6 +407,16 @@ class GPTVAEXLStep:
         return loss, (0.0, t2 - t0, t3 - t2, t4 - t3)
 
 
+def _gemm_loops():
+    import ctypes
+
+    from melspec_gpt_vqvae_amd import _ffi
+
+    r, p = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    _ffi.check(_ffi.lib().melgpt_gemm_loop_launches(ctypes.byref(r), ctypes.byref(p)), "melgpt_gemm_loop_launches")
+    return r.value, p.value
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -495,6 +505,7 @@ def main():
     if job.dp is not None:
         job.dp.ex.time_events = True   # two event records per step around finish()'s waits -> exposed_comm_ms
     ops.TIMER = ops.KernelTimer()
+    loops0 = _gemm_loops()
     fence()
     t0 = time.perf_counter()
     loss = None
@@ -502,6 +513,7 @@ def main():
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
+    loops1 = _gemm_loops()
     timer, ops.TIMER = ops.TIMER, None
     loss_val = float(loss.detach())
 
@@ -537,13 +549,16 @@ def main():
                 "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": job.seq_len,
                 "parallelism": f"dp{world}" if world > 1 else "single",
                 "final_loss": round(loss_val, 4),
+                # which K loop the persistent GEMM's launches of the timed region took (csrc/gemm256.hip / gemm8p.hip)
+                "gemm_launches_per_step": {"ring": (loops1[0] - loops0[0]) // max(a.steps, 1),
+                                           "pingpong": (loops1[1] - loops0[1]) // max(a.steps, 1)},
             },
             "roofline": {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc.get("traffic"),
                 "traffic_unit": "bytes/step", "traffic_source": pmc.get("traffic_source"),
                 "mfma_busy": pmc.get("mfma_busy"), "mfma_busy_by_kernel": pmc.get("mfma_busy_by_kernel"),
-                "kernel": "MFMA GEMM family (gemm256_kernel persistent 256x256 / gemm_kernel 128x128 + implicit-GEMM conv / "
+                "kernel": "MFMA GEMM family (gemm8p_kernel / gemm256_kernel persistent 256x256 / gemm_kernel 128x128 + implicit-GEMM conv / "
                           "conv3x3_gn_wide_kernel / conv3x3_gn_kernel with fused GroupNorm+swish), all launches of the timed region",
                 "launches_per_step": ks["launches"] // max(a.steps, 1),
                 "kernel_ms_per_step": round(ks["total_ms"] / max(a.steps, 1), 3),

@@ -31,7 +31,7 @@ def short(name):
             if depth == 0:
                 name = name[:i]
                 break
-    for key in ("gemm256_kernel", "gemm_kernel", "conv3x3_gn_kernel", "attn_q_kernel", "attn_dkv_kernel"):
+    for key in ("gemm8p_kernel", "gemm256_kernel", "gemm_kernel", "conv3x3_gn_kernel", "attn_q_kernel", "attn_dkv_kernel"):
         if key in name:
             # keep the template arguments: they tell layouts / modes apart
             i = name.index(key)
@@ -95,7 +95,7 @@ def main():
                       "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (four separate runs) -- " + os.environ.get(
                           "PROFILE_CMD", "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline"),
               note="hbm_read = 2 x FETCH_SIZE (gfx950 counts wide coalesced reads at half their bytes), hbm_write = "
-                   "WRITE_SIZE; KiB -> MB; GEMM family = gemm256_kernel + gemm_kernel + conv3x3_gn*_kernel")
+                   "WRITE_SIZE; KiB -> MB; GEMM family = gemm8p_kernel + gemm256_kernel + gemm_kernel + conv3x3_gn*_kernel")
     json.dump(js, open(os.path.join(root, f"summary_{tag}.json"), "w"), indent=1)
     print(open(out_csv).read()[:4000])
     print(json.dumps(js))
