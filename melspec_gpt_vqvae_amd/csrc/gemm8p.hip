@@ -53,6 +53,12 @@ __device__ __forceinline__ void dma16(rsrc_t rs, char* lds_wave_base, unsigned v
 #ifndef P8_ORDER
 #define P8_ORDER 0  // 1: an XCD takes a contiguous run of blocks; 0: every eighth block (the ring kernel's order)
 #endif
+#ifndef P8_ROW_BAL
+#define P8_ROW_BAL 1  // row-major B: fragment reads balanced over the phases (0: the guide's 12 / 4 / 8 / 0 form)
+#endif
+#ifndef P8_BNAT_BAL
+#define P8_BNAT_BAL 1  // K-major B: fragment reads balanced over the phases (0: the 16 / 8 / 8 / 0 form)
+#endif
 #ifndef P8_BNAT_EARLY
 #define P8_BNAT_EARLY 0  // lab: K-major B read whole in phase 1
 #endif
@@ -323,15 +329,15 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
     // two buffers once per K tile); slot, row tile / k-step are immediates.  Row-major half-tiles: one register per
     // k-step (row tiles 2 KiB apart).  K-major half-tiles: one per 16-column tile (the swizzle XORs the tile index into
     // address bits 5-6), k-steps 8 KiB apart, the fragment's second four k-rows 1 KiB on.
-    auto rd = [&](auto lay_c, const int (&x)[4], int e, int ks, int slot) -> u32x4 {
+    auto rd = [&](auto lay_c, const int (&x)[4], int e, int ks, int slot, int other = 0) -> u32x4 {
       if constexpr (decltype(lay_c)::value == LAY_KMAJ) {
-        const char* a0 = smem + (x[e] + slot + ks * 8192);
+        const char* a0 = smem + ((x[e] ^ other) + slot + ks * 8192);
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a0));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a0 + 1024));
         s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(u32x4, f);
       } else {
-        return *(const u32x4*)(smem + (x[ks] + slot + e * 2048));
+        return *(const u32x4*)(smem + ((x[ks] ^ other) + slot + e * 2048));
       }
     };
     auto ld_a = [&](int slot) {  // this wave's quadrant rows of an A half-tile (slab wr)
@@ -340,11 +346,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) fa[mt][ks] = rd(std::integral_constant<int, ALAY>{}, xa, mt, ks, slot);
     };
-    auto ld_b = [&](int slot, int e0, u32x4 (&fb)[2][2]) {  // (e0: K-major B, natural order: first tile of the subtile)
+    auto ld_b = [&](int slot, int e0, u32x4 (&fb)[2][2], int other = 0) {  // (e0: K-major B, natural order: first tile of the subtile; other = BUF: the buffer that is NOT being multiplied)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fb[nt][ks] = rd(std::integral_constant<int, BLAY>{}, xb, e0 + nt, ks, slot);
+        for (int ks = 0; ks < 2; ++ks) fb[nt][ks] = rd(std::integral_constant<int, BLAY>{}, xb, e0 + nt, ks, slot, other);
     };
     auto mul = [&](auto first_c, auto mq_c, auto nq_c, u32x4 (&fb)[2][2]) {
       constexpr int MQ = decltype(mq_c)::value, NQ = decltype(nq_c)::value;
@@ -372,10 +378,59 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
     constexpr int RD_B = (BLAY == LAY_KMAJ ? 8 : 4);
     static_assert(RD_A <= 15 || BNAT, "lgkmcnt is a 4-bit counter");
 
-    auto ktile = [&](auto first_c, int u) {
+    auto ktile = [&](auto first_c, auto par_c, int u) {
       char* cur = smem + par * BUF;
       char* oth = smem + (BUF - par * BUF);
-      if constexpr (!BNAT) {
+      if constexpr (!BNAT && P8_ROW_BAL) {
+        // Row-major B with the reads balanced as for K-major B below (8 / 4 / 8 / 4 instead of 12 / 4 / 8 / 0): phase 4
+        // reads the NEXT K tile's B0 subtile out of the other buffer into the registers phase 3 has finished with (the
+        // two fragment sets swap roles per K tile: PAR); B0 of the next K tile must then have landed a phase earlier:
+        // vmcnt(10) in phase 3 next to the K tile's vmcnt(6) in phase 4.  No slot is re-requested one phase after its last
+        // read any more, except B0 in a tile's first K tile (which reads it itself: the counted lgkmcnt stays there).
+        constexpr bool FIRST = decltype(first_c)::value;
+        constexpr int PAR = decltype(par_c)::value;
+        auto& fbA = PAR ? fb1 : fb0;  // B0 subtile (quadrants (A0,B0), (A1,B0)), B1 subtile
+        auto& fbB = PAR ? fb0 : fb1;
+        if constexpr (FIRST) {
+          ld_b(S_B0, 0, fbA);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        ld_a(S_A0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_a(1, oth + S_A1);
+        if constexpr (FIRST) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD_A) : "memory");
+        P8_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mul(first_c, c0{}, c0{}, fbA);
+        P8_BARRIER();
+        // phase 2: (A0, B1)
+        ld_b(S_B1, 0, fbB);
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+        issue_b(0, cur + S_B0);
+        P8_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mul(first_c, c0{}, c1{}, fbB);
+        P8_BARRIER();
+        // phase 3: (A1, B1); B0 of the next K tile has landed (read in phase 4)
+        ld_a(S_A1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_a(0, cur + S_A0);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        P8_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mul(first_c, c1{}, c1{}, fbB);
+        P8_BARRIER();
+        // phase 4: (A1, B0); reads the next K tile's B0 subtile; the K tile's counted wait (everything but the three
+        // youngest half-tiles: the rest of the next K tile)
+        ld_b(S_B0, 0, fbB, BUF);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_b(1, cur + S_B1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        P8_BARRIER();
+        mul(first_c, c1{}, c0{}, fbA);
+        P8_BARRIER();
+      } else if constexpr (!BNAT) {
         // phase 1: (A0, B0); B0's reads first - retired before the barrier, its slot is requested again in phase 2
         ld_b(S_B0, 0, fb0);
         __builtin_amdgcn_sched_barrier(0);
@@ -446,15 +501,81 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
           if (u == cs_next) cs_next += tiles_n;
         }
         P8_BARRIER();
+      } else if constexpr (P8_BNAT_BAL) {
+        // K-major B, reads BALANCED over the phases (8 / 8 / 8 / 8 instead of 16 / 8 / 8 / 0 fragment-read instructions
+        // with row-major A; `ds_read_b64_tr_b16` moves half the bytes per LDS cycle of ds_read_b128, and phase 1's burst
+        // outlasted the partner's 256 MFMA cycles: -7 % cycles per K tile with the burst ablated): phase 4 reads the NEXT
+        // K tile's first B subtile out of the other buffer into the fragment registers that phase 3 has just finished with,
+        // so the two register sets swap roles from one K tile to the next (PAR).  That read needs the next K tile's B
+        // halves one phase earlier: the counted wait moves to phase 3 (vmcnt(6): everything up to B1 of the next K tile),
+        // and A1 of the next K tile - younger than those - gets a wait of its own in phase 2 (vmcnt(10)), one phase
+        // before its reader.  A tile's first K tile reads its first subtile itself (whatever the previous tile's last
+        // phase 4 fetched is overwritten).
+        constexpr bool FIRST = decltype(first_c)::value;
+        constexpr int PAR = decltype(par_c)::value;
+        auto& fbA = PAR ? fb1 : fb0;  // first subtile (quadrants (A0,s0) and (A1,s0)), second subtile
+        auto& fbB = PAR ? fb0 : fb1;
+        const int bh = wc >> 1 ? S_B1 : S_B0;
+        // phase 1: (A0, s0); A0's reads retired before the barrier: its slot is requested again in phase 2
+        ld_a(S_A0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FIRST) {
+          ld_b(bh, 0, fbA);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        issue_a(1, oth + S_A1);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FIRST ? RD_B : 0) : "memory");
+        P8_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mul(first_c, c0{}, c0{}, fbA);
+        row_sums(c0{}, u);
+        P8_BARRIER();
+        // phase 2: (A0, s1); B's reads retired before the barrier (its slots are requested again in phases 3 and 4);
+        // A1 of this K tile has landed (read in phase 3)
+        ld_b(bh, 2, fbB);
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+        issue_a(0, cur + S_A0);
+        asm volatile("s_waitcnt lgkmcnt(0) vmcnt(10)" ::: "memory");
+        P8_BARRIER();
+        mul(first_c, c0{}, c1{}, fbB);
+        P8_BARRIER();
+        // phase 3: (A1, s1); the next K tile's A0 and B halves have landed (read from phase 4 on)
+        ld_a(S_A1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_b(0, cur + S_B0);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        P8_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mul(first_c, c1{}, c1{}, fbB);
+        row_sums(c1{}, u);
+        P8_BARRIER();
+        // phase 4: (A1, s0); reads the next K tile's s0 into the registers s1 has left
+        ld_b(bh, 0, fbB, BUF);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_b(1, cur + S_B1);
+        P8_BARRIER();
+        mul(first_c, c1{}, c0{}, fbA);
+        if constexpr (CS) {
+          if (u == cs_next) cs_next += tiles_n;
+        }
+        P8_BARRIER();
       } else {
         const int bh = wc >> 1 ? S_B1 : S_B0;
         // phase 1: (A0, sub 0); A0's reads first - retired before the barrier, its slot is requested again in phase 2
         ld_a(S_A0);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef P8_LAB_SKIPB  // lab: phase 1 without its B reads (timing only: what does the read burst of phase 1 cost?)
+        if (u < 0)
+#endif
         ld_b(bh, 0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         issue_a(1, oth + S_A1);
+#ifdef P8_LAB_SKIPB
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD_B) : "memory");
+#endif
         P8_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         mul(first_c, c0{}, c0{}, fb0);
@@ -506,11 +627,27 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
       if (stamp && u < 20) p8_dbg[lab_tile * 24 + 4 + u] = __builtin_amdgcn_s_memtime();
 #endif
     };
-    ktile(std::true_type{}, 0);
+    ktile(std::true_type{}, c0{}, 0);
     flip(0);
-    for (int u = 1; u < nu; ++u) {
-      ktile(std::false_type{}, u);
-      flip(u);
+    if constexpr ((BNAT && P8_BNAT_BAL) || (!BNAT && P8_ROW_BAL)) {
+      // (two K tiles per trip: the fragment sets swap roles from one K tile to the next, and a loop whose body picked the
+      // role at run time made the register allocator keep both sets alive over the back edge - 70-275 spilled VGPRs)
+      int u = 1;
+      for (; u + 1 < nu; u += 2) {
+        ktile(std::false_type{}, c1{}, u);
+        flip(u);
+        ktile(std::false_type{}, c0{}, u + 1);
+        flip(u + 1);
+      }
+      if (u < nu) {
+        ktile(std::false_type{}, c1{}, u);
+        flip(u);
+      }
+    } else {
+      for (int u = 1; u < nu; ++u) {
+        ktile(std::false_type{}, c0{}, u);
+        flip(u);
+      }
     }
     if (wr == 0) P8_BARRIER();  // both groups run the epilogue together
 #ifdef P8_LAB
