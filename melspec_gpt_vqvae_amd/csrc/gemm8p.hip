@@ -67,7 +67,7 @@ __device__ __forceinline__ void dma16(rsrc_t rs, char* lds_wave_base, unsigned v
 __device__ unsigned long long p8_dbg[64 * 24];  // per tile: start, K loop done, drained, epilogue done, then one stamp per K tile (<= 20)
 #endif
 
-template <int ALAY, int BLAY, int MODE, int TM>
+template <int ALAY, int BLAY, int MODE, int TM, bool EDGE = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, int tiles_n, int batch, int RN) {
   constexpr int MT = TM / 2, TN = 4, BM = 32 * TM, BN = 256;
   constexpr int SLAB = 16 * MT;                      // rows of one wave's quadrant (64 or 48)
@@ -178,6 +178,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   const unsigned b_kstep = BLAY == LAY_KMAJ ? (unsigned)(64 * p.ldb * 2) : 128u;
   const bool ktail = (p.K & 63) != 0;
   unsigned bh_mark[2] = {0u, 0u};  // K-major B: MARK when half h of the planned tile lies past column N (N % 128 == 0)
+  // EDGE (K-major operands whose M / N is not a multiple of 128 - the GPT-VAE XL widths): a half-tile can end inside a
+  // lane's columns, so every piece compares the lane's first column with what is left of the operand in that half
+  int a_lim[2] = {0, 0}, b_lim[2] = {0, 0};
   int iu = 0;                      // K tile of the request cursor inside its item
   auto cut_tail = [&]() {          // the cursor is in the last, ragged K tile: lanes past K do not load
     const int k0 = iu * KU;
@@ -211,7 +214,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
       rb = make_rsrc4((const char*)p.B + (long long)bz * p.sB * 2, p.b_bytes);
     }
     if constexpr (ALAY == LAY_KMAJ) {
-      const unsigned b0 = (pok && pm0 + ka_mn0 < p.M) ? a_lane + (unsigned)(pm0 * 2) : MARK;  // (M % 128 == 0)
+      const unsigned b0 = (pok && (EDGE || pm0 + ka_mn0 < p.M)) ? a_lane + (unsigned)(pm0 * 2) : MARK;  // (!EDGE: M % 128 == 0)
+      a_lim[0] = p.M - pm0;
+      a_lim[1] = p.M - pm0 - 64;
       a_run[0] = b0;
       a_run[1] = b0 == MARK ? MARK : b0 + (unsigned)(32 * p.lda * 2);
     } else {
@@ -223,6 +228,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
       b_run[1] = b0 == MARK ? MARK : b0 + (unsigned)(32 * p.ldb * 2);
       bh_mark[0] = pn0 < p.N ? 0u : MARK;
       bh_mark[1] = pn0 + 128 < p.N ? 0u : MARK;
+      b_lim[0] = p.N - pn0;
+      b_lim[1] = p.N - pn0 - 128;
     } else {
       b_run[0] = pok ? b_lane + (unsigned)((long long)pn0 * p.ldb * 2) : MARK;
     }
@@ -230,12 +237,20 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   // half-tile h of A / B for the cursor's K tile -> slot (wave-uniform LDS address)
   auto issue_a = [&](int h, char* slot) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) dma16(ra, slot + (w + 8 * j) * 1024, a_run[AJ == 2 ? j : 0] + ca[h][j]);
+    for (int j = 0; j < 2; ++j) {
+      unsigned off = a_run[AJ == 2 ? j : 0] + ca[h][j];
+      if constexpr (EDGE && ALAY == LAY_KMAJ) off = ka_mn0 < a_lim[h] ? off : MARK;
+      dma16(ra, slot + (w + 8 * j) * 1024, off);
+    }
   };
   auto issue_b = [&](int h, char* slot) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      dma16(rb, slot + (w + 8 * j) * 1024, (b_run[BJ == 2 ? j : 0] + cb[h][j]) | (BLAY == LAY_KMAJ ? bh_mark[h] : 0u));
+    for (int j = 0; j < 2; ++j) {
+      unsigned off = b_run[BJ == 2 ? j : 0] + cb[h][j];
+      if constexpr (EDGE && BLAY == LAY_KMAJ) off = k_lc * 8 < b_lim[h] ? off : MARK;
+      else if constexpr (BLAY == LAY_KMAJ) off |= bh_mark[h];
+      dma16(rb, slot + (w + 8 * j) * 1024, off);
+    }
   };
 
   walk_first(kc);
@@ -681,19 +696,27 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
-template <int ALAY, int BLAY, int MODE, int TM>
-int launch8p(const GemmParams& p, int tiles_m, int tiles_n, int batch, int RN, int grid, hipStream_t s) {
+template <int ALAY, int BLAY, int MODE, int TM, bool EDGE>
+int launch8p_e(const GemmParams& p, int tiles_m, int tiles_n, int batch, int RN, int grid, hipStream_t s) {
   constexpr int LDS = 160 * 1024;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)gemm8p_kernel<ALAY, BLAY, MODE, TM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)gemm8p_kernel<ALAY, BLAY, MODE, TM, EDGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS) != hipSuccess)
       return MELGPT_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL((gemm8p_kernel<ALAY, BLAY, MODE, TM>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n, batch, RN);
+  hipLaunchKernelGGL((gemm8p_kernel<ALAY, BLAY, MODE, TM, EDGE>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n, batch, RN);
   melgpt_count_gemm_loop(1);
   return melgpt_launch_status();
+}
+template <int ALAY, int BLAY, int MODE, int TM>
+int launch8p(const GemmParams& p, int tiles_m, int tiles_n, int batch, int RN, int grid, hipStream_t s) {
+  // K-major operands that do not end on a 128 boundary take the variant with per-piece column checks
+  if constexpr (BLAY == LAY_KMAJ) {
+    if ((ALAY == LAY_KMAJ && p.M % 128 != 0) || p.N % 128 != 0) return launch8p_e<ALAY, BLAY, MODE, TM, true>(p, tiles_m, tiles_n, batch, RN, grid, s);
+  }
+  return launch8p_e<ALAY, BLAY, MODE, TM, false>(p, tiles_m, tiles_n, batch, RN, grid, s);
 }
 
 template <int ALAY, int BLAY, int MODE>
@@ -743,11 +766,11 @@ int gemmk::launch_gemm8p(const GemmParams& p, int alay, int blay, int mode, int 
   if (!melgpt_get_gemm_pingpong()) return MELGPT_ERR_UNSUPPORTED;
   if (p.a_bytes >= 0x80000000u || p.b_bytes >= 0x80000000u) return MELGPT_ERR_UNSUPPORTED;  // (the kernel's MARK offset)
   if (RN <= 0 && (long long)grid != (long long)tiles_m * tiles_n * batch) return MELGPT_ERR_UNSUPPORTED;  // (its tile walk)
-  if (alay == LAY_KMAJ && blay == LAY_KMAJ && p.M % 128 == 0 && p.N % 128 == 0)                // (whole slabs / halves)
+  if (alay == LAY_KMAJ && blay == LAY_KMAJ)
     return launch8p_mode<LAY_KMAJ, LAY_KMAJ>(p, mode, tm, tiles_m, tiles_n, batch, RN, grid, s);
   if (batch != 1 || p.a_rowsum) return MELGPT_ERR_UNSUPPORTED;
   if (alay == LAY_ROW && blay == LAY_ROW) return launch8p_mode<LAY_ROW, LAY_ROW>(p, mode, tm, tiles_m, tiles_n, batch, RN, grid, s);
-  if (alay == LAY_ROW && blay == LAY_KMAJ && p.N % 128 == 0)
+  if (alay == LAY_ROW && blay == LAY_KMAJ)
     return launch8p_mode<LAY_ROW, LAY_KMAJ>(p, mode, tm, tiles_m, tiles_n, batch, RN, grid, s);
   return MELGPT_ERR_UNSUPPORTED;
 }

@@ -58,7 +58,9 @@ def _ops(seed, M, N, K, b_kmajor=False):
 # >= 256 tiles (a full grid: the ping-pong kernel walks XCD blocks), ragged M / N / K edges, both tile heights
 # (MELGPT_GEMM_TM is read once per process, so the height is whatever the launch's cost model picks: N = 1024 -> 192 rows)
 @pytest.mark.parametrize("form,M,N,K", [("nt", 9000, 4096, 328), ("nt", 33920, 1024, 264), ("nt", 20000, 1272, 384),
-                                        ("nn", 24576, 1024, 320), ("nn", 8500, 4096, 328), ("nt", 8192, 8192, 512)])
+                                        ("nn", 24576, 1024, 320), ("nn", 8500, 4096, 328), ("nt", 8192, 8192, 512),
+                                        # GPT-VAE XL widths: K-major B whose N ends inside a 128-column half-tile
+                                        ("nn", 33920, 1472, 328), ("nn", 12000, 4416, 264)])
 def test_plain_store_matches_reference_and_ring(form, M, N, K):
     from melspec_gpt_vqvae_amd import ops
 
@@ -107,7 +109,8 @@ def test_fused_epilogues_match_reference_and_ring():
     assert torch.equal(ring, pp) and rel_err(pp.float().cpu().numpy(), (ref2 * res.float()).numpy()) < 2 ** -7
 
 
-@pytest.mark.parametrize("N,K,M", [(4096, 1024, 33920), (1024, 4096, 16960), (3072, 1024, 33920), (1024, 1024, 33920)])
+@pytest.mark.parametrize("N,K,M", [(4096, 1024, 33920), (1024, 4096, 16960), (3072, 1024, 33920), (1024, 1024, 33920),
+                                   (1472, 1472, 33920), (4416, 1472, 33920), (1472, 5888, 16960)])   # XL: ragged slabs / halves
 def test_weight_gradient_with_bias_gradient_matches_reference_and_ring(N, K, M):
     """dW (N x K) = dY^T X and db = column sums of dY over M rows in split-K batches (both operands K-major, ragged K
     tiles per batch, the row sums riding on the A fragments): ops.wgrad as the training step calls it."""
