@@ -76,7 +76,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   constexpr bool BNAT = BLAY == LAY_KMAJ;            // B in natural column order (see the header)
   constexpr bool BATCHED = ALAY == LAY_KMAJ && BLAY == LAY_KMAJ;  // the weight gradients' split-K batches; others: batch == 1
   static_assert(TM == 8 || (TM == 6 && ALAY != LAY_KMAJ), "the K-major A image assumes 64-row slabs");
-  static_assert(ALAY != LAY_CONV, "the implicit-GEMM convolution stays on the ring kernel");
+  constexpr bool CONV = ALAY == LAY_CONV;  // implicit im2col (no upsampling: the launcher keeps those on the ring kernel)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A0 A1 B0 B1][16 KiB] + 32 KiB epilogue staging
 
   const int t = threadIdx.x, lane = t & 63;
@@ -181,6 +181,26 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   // EDGE (K-major operands whose M / N is not a multiple of 128 - the GPT-VAE XL widths): a half-tile can end inside a
   // lane's columns, so every piece compares the lane's first column with what is left of the operand in that half
   int a_lim[2] = {0, 0}, b_lim[2] = {0, 0};
+  // CONV: row m of A is output pixel m, a K tile is 64 channels of ONE filter tap (Cin % 64 == 0).  Per piece q = 2 h + j
+  // the lane's pixel is kept as the byte offset of its top-left tap (cv_lin, + the lane's chunk) and that tap's position
+  // (cv_yx: y + 2048 in the high half, x + 2048 in the low half; rows past M sit far outside); when the cursor enters a
+  // new tap the four running offsets are rebuilt (tap inside the image ? cv_lin + tap offset : MARK), inside a tap they
+  // advance by 128 bytes per K tile like any row-major operand.
+  int cv_lin[CONV ? 4 : 1], cv_yx[CONV ? 4 : 1];
+  unsigned a_runq[CONV ? 4 : 1];
+  int ktap = 0, kci = 0;
+  const int nci = CONV ? p.cC >> 6 : 1;
+  auto tap_setup = [&]() {
+    if constexpr (CONV) {
+      const int ky = ktap / p.KW, kx = ktap - ky * p.KW;
+      const int toff = (ky * p.cW + kx) * p.cC * 2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int y = (cv_yx[q] >> 16) - 2048 + ky, x = (cv_yx[q] & 0xFFFF) - 2048 + kx;
+        a_runq[q] = ((unsigned)y < (unsigned)p.cH && (unsigned)x < (unsigned)p.cW) ? (unsigned)(cv_lin[q] + toff) : MARK;
+      }
+    }
+  };
   int iu = 0;                      // K tile of the request cursor inside its item
   auto cut_tail = [&]() {          // the cursor is in the last, ragged K tile: lanes past K do not load
     const int k0 = iu * KU;
@@ -198,7 +218,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
     }
   };
   // per-lane parts of the source offsets that do not depend on the tile
-  const unsigned a_lane = ALAY == LAY_KMAJ ? (unsigned)(((long long)k_row0 * p.lda + ka_mn0) * 2)
+  const unsigned a_lane = CONV ? 0u : ALAY == LAY_KMAJ ? (unsigned)(((long long)k_row0 * p.lda + ka_mn0) * 2)
                                            : (unsigned)((long long)a_row0 * p.lda * 2) + r_c * 16;
   const unsigned b_lane = BLAY == LAY_KMAJ ? (unsigned)(((long long)k_row0 * p.ldb + k_lc * 8) * 2)
                                            : (unsigned)((long long)b_row0 * p.ldb * 2) + r_c * 16;
@@ -213,7 +233,21 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
       ra = make_rsrc4((const char*)p.A + (long long)bz * p.sA * 2, p.a_bytes);
       rb = make_rsrc4((const char*)p.B + (long long)bz * p.sB * 2, p.b_bytes);
     }
-    if constexpr (ALAY == LAY_KMAJ) {
+    if constexpr (CONV) {
+      const int ohw = p.OH * p.OW;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = pm0 + (q & 1) * (BM / 2) + (q >> 1) * SLAB + a_row0;
+        const int bb = m / ohw, rem = m - bb * ohw;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        const int y0 = oy * p.cstride - p.pad_t, x0 = ox * p.cstride - p.pad_l;
+        const bool ok = pok && a_row0 < SLAB && m < p.M;
+        cv_lin[q] = (int)(((long long)bb * p.cH * p.cW + (long long)y0 * p.cW + x0) * p.cC * 2) + r_c * 16;
+        cv_yx[q] = ok ? ((y0 + 2048) << 16) | (x0 + 2048) : (30000 << 16);
+      }
+      ktap = kci = 0;
+      tap_setup();
+    } else if constexpr (ALAY == LAY_KMAJ) {
       const unsigned b0 = (pok && (EDGE || pm0 + ka_mn0 < p.M)) ? a_lane + (unsigned)(pm0 * 2) : MARK;  // (!EDGE: M % 128 == 0)
       a_lim[0] = p.M - pm0;
       a_lim[1] = p.M - pm0 - 64;
@@ -239,6 +273,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       unsigned off = a_run[AJ == 2 ? j : 0] + ca[h][j];
+      if constexpr (CONV) off = a_runq[2 * h + j];
       if constexpr (EDGE && ALAY == LAY_KMAJ) off = ka_mn0 < a_lim[h] ? off : MARK;
       dma16(ra, slot + (w + 8 * j) * 1024, off);
     }
@@ -268,8 +303,19 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
       if (blockIdx.x == 17 && t == 0) p8_dbg[64 * 24 - 1] = __builtin_amdgcn_s_memtime() - tp0;
 #endif
     } else {
+      if constexpr (CONV) {
+        if (++kci == nci) {
+          kci = 0;
+          ++ktap;
+          tap_setup();
+        } else {
 #pragma unroll
-      for (int j = 0; j < AJ; ++j) a_run[j] += a_kstep;
+          for (int q = 0; q < 4; ++q) a_runq[q] += 128u;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) a_run[j] += a_kstep;
+      }
 #pragma unroll
       for (int j = 0; j < BJ; ++j) b_run[j] += b_kstep;
     }
@@ -772,5 +818,9 @@ int gemmk::launch_gemm8p(const GemmParams& p, int alay, int blay, int mode, int 
   if (alay == LAY_ROW && blay == LAY_ROW) return launch8p_mode<LAY_ROW, LAY_ROW>(p, mode, tm, tiles_m, tiles_n, batch, RN, grid, s);
   if (alay == LAY_ROW && blay == LAY_KMAJ)
     return launch8p_mode<LAY_ROW, LAY_KMAJ>(p, mode, tm, tiles_m, tiles_n, batch, RN, grid, s);
+  if (alay == LAY_CONV && blay == LAY_ROW && p.ups == 0 && p.cC % 64 == 0 && mode == EPI_PLAIN16) {
+    if (tm == 8) return launch8p<LAY_CONV, LAY_ROW, EPI_PLAIN16, 8>(p, tiles_m, tiles_n, batch, RN, grid, s);
+    if (tm == 6) return launch8p<LAY_CONV, LAY_ROW, EPI_PLAIN16, 6>(p, tiles_m, tiles_n, batch, RN, grid, s);
+  }
   return MELGPT_ERR_UNSUPPORTED;
 }

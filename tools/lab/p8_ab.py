@@ -42,6 +42,15 @@ def cases():
     yield "dgrad NN K=1024 (dfc2)", M, 4096, 1024, lambda: ops.gemm(x1, w["fc2"], b_kmajor=True)
     x3 = torch.cat([x1, x1, x1], 1)
     yield "dgrad NN K=3072 (dqkv)", M, 1024, 3072, lambda: ops.gemm(x3, w["qkv"], b_kmajor=True)
+    if os.environ.get("CONVS", "1") == "1":
+        for nm, B, H, W, Cin, Cout, stride in (("conv3x3 s1 20x212 256->256", 128, 20, 212, 256, 256, 1), ("conv3x3 s1 5x53 512->512", 128, 5, 53, 512, 512, 1),
+                                               ("conv3x3 s2 80x848 128->128", 32, 80, 848, 128, 128, 2), ("conv3x3 s1 10x106 256->256", 128, 10, 106, 256, 256, 1)):
+            xc = (rnd(B, H, W, Cin) * 0.5).to(torch.bfloat16)
+            wc = (rnd(Cout, 3, 3, Cin) * 0.05).to(torch.bfloat16)
+            bc = rnd(Cout) * 0.1
+            oh = ((H - 2) // 2 + 0, (W - 2) // 2 + 0) if stride == 2 else (H, W)
+            fn = (lambda xc=xc, wc=wc, bc=bc, stride=stride, oh=oh: ops.conv2d_nhwc(xc, wc, bc, stride=stride, pad=(0, 0) if stride == 2 else (1, 1), out_hw=(oh[0] + 1, oh[1] + 1) if stride == 2 else oh))
+            yield nm, B * (oh[0] + (1 if stride == 2 else 0)) * (oh[1] + (1 if stride == 2 else 0)), Cout, 9 * Cin, fn
     dmul = rnd(M, 4096).to(torch.bfloat16)
     yield "GELU' dgrad (mul) K=1024", M, 4096, 1024, lambda: ops.gemm(x1, w["fc2"], b_kmajor=True, act=ops.ACT_MUL, residual=dmul)
     for nm, dy, x in (("fc1 4096x1024", x4, x1), ("fc2 1024x4096", x1, x4), ("qkv 3072x1024", x3, x1), ("proj 1024x1024", x1, res)):
