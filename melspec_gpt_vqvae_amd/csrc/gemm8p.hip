@@ -76,7 +76,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   constexpr bool BNAT = BLAY == LAY_KMAJ;            // B in natural column order (see the header)
   constexpr bool BATCHED = ALAY == LAY_KMAJ && BLAY == LAY_KMAJ;  // the weight gradients' split-K batches; others: batch == 1
   static_assert(TM == 8 || (TM == 6 && ALAY != LAY_KMAJ), "the K-major A image assumes 64-row slabs");
-  constexpr bool CONV = ALAY == LAY_CONV;  // implicit im2col (no upsampling: the launcher keeps those on the ring kernel)
+  constexpr bool CONV = ALAY == LAY_CONV;  // implicit im2col
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A0 A1 B0 B1][16 KiB] + 32 KiB epilogue staging
 
   const int t = threadIdx.x, lane = t & 63;
@@ -182,9 +182,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   // lane's columns, so every piece compares the lane's first column with what is left of the operand in that half
   int a_lim[2] = {0, 0}, b_lim[2] = {0, 0};
   // CONV: row m of A is output pixel m, a K tile is 64 channels of ONE filter tap (Cin % 64 == 0).  Per piece q = 2 h + j
-  // the lane's pixel is kept as the byte offset of its top-left tap (cv_lin, + the lane's chunk) and that tap's position
+  // the lane's pixel is kept as the byte offset of its image (cv_lin, + the lane's chunk) and its top-left tap's position
   // (cv_yx: y + 2048 in the high half, x + 2048 in the low half; rows past M sit far outside); when the cursor enters a
-  // new tap the four running offsets are rebuilt (tap inside the image ? cv_lin + tap offset : MARK), inside a tap they
+  // new tap the four running offsets are rebuilt (tap inside the image ? cv_lin + its pixel's offset : MARK), inside a tap they
   // advance by 128 bytes per K tile like any row-major operand.
   int cv_lin[CONV ? 4 : 1], cv_yx[CONV ? 4 : 1];
   unsigned a_runq[CONV ? 4 : 1];
@@ -193,11 +193,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   auto tap_setup = [&]() {
     if constexpr (CONV) {
       const int ky = ktap / p.KW, kx = ktap - ky * p.KW;
-      const int toff = (ky * p.cW + kx) * p.cC * 2;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 4; ++q) {  // (nearest x2 upsampling of the input, p.ups = 1: the tap lands on pixel (y >> 1, x >> 1))
         const int y = (cv_yx[q] >> 16) - 2048 + ky, x = (cv_yx[q] & 0xFFFF) - 2048 + kx;
-        a_runq[q] = ((unsigned)y < (unsigned)p.cH && (unsigned)x < (unsigned)p.cW) ? (unsigned)(cv_lin[q] + toff) : MARK;
+        const bool ok = (unsigned)y < (unsigned)(p.cH << p.ups) && (unsigned)x < (unsigned)(p.cW << p.ups);
+        a_runq[q] = ok ? (unsigned)(cv_lin[q] + (((y >> p.ups) * p.cW + (x >> p.ups)) * p.cC) * 2) : MARK;
       }
     }
   };
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         const int oy = rem / p.OW, ox = rem - oy * p.OW;
         const int y0 = oy * p.cstride - p.pad_t, x0 = ox * p.cstride - p.pad_l;
         const bool ok = pok && a_row0 < SLAB && m < p.M;
-        cv_lin[q] = (int)(((long long)bb * p.cH * p.cW + (long long)y0 * p.cW + x0) * p.cC * 2) + r_c * 16;
+        cv_lin[q] = (int)((long long)bb * p.cH * p.cW * p.cC * 2) + r_c * 16;
         cv_yx[q] = ok ? ((y0 + 2048) << 16) | (x0 + 2048) : (30000 << 16);
       }
       ktap = kci = 0;
@@ -818,7 +818,7 @@ int gemmk::launch_gemm8p(const GemmParams& p, int alay, int blay, int mode, int 
   if (alay == LAY_ROW && blay == LAY_ROW) return launch8p_mode<LAY_ROW, LAY_ROW>(p, mode, tm, tiles_m, tiles_n, batch, RN, grid, s);
   if (alay == LAY_ROW && blay == LAY_KMAJ)
     return launch8p_mode<LAY_ROW, LAY_KMAJ>(p, mode, tm, tiles_m, tiles_n, batch, RN, grid, s);
-  if (alay == LAY_CONV && blay == LAY_ROW && p.ups == 0 && p.cC % 64 == 0 && mode == EPI_PLAIN16) {
+  if (alay == LAY_CONV && blay == LAY_ROW && p.cC % 64 == 0 && mode == EPI_PLAIN16) {
     if (tm == 8) return launch8p<LAY_CONV, LAY_ROW, EPI_PLAIN16, 8>(p, tiles_m, tiles_n, batch, RN, grid, s);
     if (tm == 6) return launch8p<LAY_CONV, LAY_ROW, EPI_PLAIN16, 6>(p, tiles_m, tiles_n, batch, RN, grid, s);
   }
