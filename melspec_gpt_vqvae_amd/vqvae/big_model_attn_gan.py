@@ -101,7 +101,11 @@ def _gn_swish_conv3x3(norm, conv, h, residual=None, stats=None, next_norm=None):
     stats: (mean, rstd) of h for `norm` if a previous launch already produced them.  next_norm: the GroupNorm that will
     be applied to THIS conv's output - returns (y, its statistics or None) instead of y."""
     out_stats = None
-    if conv.kernel_size[0] == 3 and conv.stride[0] == 1 and ops.fused_conv_supported(h.shape[-1], h.dtype, occupancy=2):
+    # (16-bit lane, Cout >= 256 - the 128 -> 256 block of a level change: the narrow fused kernel runs it at 530 TFLOP/s;
+    # one GroupNorm-apply pass + the persistent implicit GEMM, 1 200 TFLOP/s on its ping-pong loop, take half the time)
+    wide_out = h.dtype == _ffi.HALF_DTYPE and conv.out_channels >= 256
+    if (conv.kernel_size[0] == 3 and conv.stride[0] == 1 and not wide_out
+            and ops.fused_conv_supported(h.shape[-1], h.dtype, occupancy=2)):
         if stats is None:
             stats = ops.groupnorm_stats(h, norm.eps)
         args = (h, stats, _f32(norm.weight), _f32(norm.bias), _packed_weight(conv, h.dtype), _f32(conv.bias))
