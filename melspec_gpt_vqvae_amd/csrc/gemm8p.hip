@@ -7,20 +7,28 @@
 // 0 / 1 of every wave, B0 / B1 likewise for columns; two K tiles are resident (2 x 64 KiB of LDS) + a 32 KiB block that
 // only the epilogue stages through (160 KiB in all).  8 waves = 2 groups (wr) x 4 (wc); a wave's 128 x 64 accumulator block
 // is four 64 x 32 quadrants, and a PHASE multiplies one quadrant over the K tile (16 MFMAs) out of a register subtile:
-//   phase 1 (A0,B0): reads B sub 0 + A0 | 2 (A0,B1): reads B sub 1 | 3 (A1,B1): reads A1 | 4 (A1,B0): reads nothing
-// Every phase: { this phase's fragment reads; ONE half-tile of LDS-DMA (2 pieces per wave) } barrier { 16 MFMAs } barrier.
+//   phase 1 (A0,B0) | 2 (A0,B1) | 3 (A1,B1) | 4 (A1,B0)
+// Every phase: { fragment reads; ONE half-tile of LDS-DMA (2 pieces per wave) } barrier { 16 MFMAs } barrier.
 // Group 1 runs one barrier behind group 0, so on every SIMD one wave multiplies while the other reads and requests: the
 // LDS-DMA issue slots and the read latency of one wave sit under the MFMAs of the other (in the ring kernel both waves
-// of a SIMD do the same thing at the same time).
+// of a SIMD do the same thing at the same time).  With 256-cycle MFMA phases the READ phase is the critical path: one
+// v_add per LDS-DMA piece, fragment addresses in registers (flipped between the buffers by XOR once per K tile), the tile
+// walk incremental - and the fragment reads BALANCED over the phases: phase 1 reads A0, 2 the K tile's second B subtile,
+// 3 A1, 4 the NEXT K tile's first B subtile out of the other buffer, into the fragment registers phase 3 has finished
+// with - the two B fragment sets swap roles from one K tile to the next (PAR), and the loop runs two K tiles per trip.
+// A tile's first K tile reads its first B subtile itself (and takes zero C operands instead of zeroed accumulators).
 //
 // Request stream (continuous across tiles, as the ring's): half-tiles of K tile tau are requested in phases 2, 3, 4 of
 // K tile tau - 2 and phase 1 of K tile tau - 1, into the buffer that is being multiplied, each slot after its last read:
 //   B row-major (rows of a wave's quadrant nq live in B half nq: 32-row slabs, permuted by the SOURCE address):
-//     order B0, A0, B1, A1; B0's reads of phase 1 are retired by a counted lgkmcnt before that phase's first barrier
-//   B K-major (natural columns - a k-row of a half-tile is 256 contiguous bytes; wave wc reads half wc >> 1 only, sub
-//     0 in phase 1, sub 1 in phase 2): order A0, B0, B1, A1; A0's reads are retired in phase 1, B's in phase 2
-// ONE counted wait per K tile (phase 4, vmcnt(6): the three youngest half-tiles stay in flight), in front of a barrier;
-// a landed half-tile is read one phase after that barrier at the earliest.
+//     order B0, A0, B1, A1; counted waits: phase 3 vmcnt(10) (B0 of the next K tile has landed: read in phase 4),
+//     phase 4 vmcnt(6) (the rest of the next K tile; the three youngest half-tiles stay in flight)
+//   B K-major (natural columns - a k-row of a half-tile is 256 contiguous bytes; wave wc reads half wc >> 1 only):
+//     order A0, B0, B1, A1; A0's reads are retired in front of phase 1's barrier and B's in front of phase 2's (their
+//     slots are requested again one phase later); counted waits: phase 2 vmcnt(10) (this K tile's A1: read in phase 3),
+//     phase 3 vmcnt(6) (the next K tile's A0 and B halves: read from phase 4 on)
+// Every wait sits in front of a barrier, and a landed half-tile is read one phase after that barrier at the earliest.
+// P8_ROW_BAL=0 / P8_BNAT_BAL=0 build the unbalanced forms (12 / 4 / 8 / 0 reads, one vmcnt(6) per K tile in phase 4).
 // A half-tiles are always slab-permuted (a wave's rows of quadrant mq live in A half mq: 64-row slabs, 48 of them used
 // by the 192-row tile), so a wave still owns a CONTIGUOUS 128 (96) x 64 block of C and the epilogue is gemm_common.h's.
 #include <cstdlib>
@@ -58,9 +66,6 @@ __device__ __forceinline__ void dma16(rsrc_t rs, char* lds_wave_base, unsigned v
 #endif
 #ifndef P8_BNAT_BAL
 #define P8_BNAT_BAL 1  // K-major B: fragment reads balanced over the phases (0: the 16 / 8 / 8 / 0 form)
-#endif
-#ifndef P8_BNAT_EARLY
-#define P8_BNAT_EARLY 0  // lab: K-major B read whole in phase 1
 #endif
 
 #ifdef P8_LAB  // lab build only (tools/lab/build_lab_lib.py ... -DP8_LAB): s_memtime stamps of workgroup 17, wave 0
@@ -526,42 +531,6 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         P8_BARRIER();
         mul(first_c, c1{}, c0{}, fb0);
         P8_BARRIER();
-      } else if constexpr (P8_BNAT_EARLY) {
-        // lab: both B subtiles read in phase 1 (B first, retired before the barrier), request order as for row-major B
-        const int bh = wc >> 1 ? S_B1 : S_B0;
-        ld_b(bh, 0, fb0);
-        ld_b(bh, 2, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        ld_a(S_A0);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_a(1, oth + S_A1);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD_A < 15 ? RD_A : 15) : "memory");
-        P8_BARRIER();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mul(first_c, c0{}, c0{}, fb0);
-        row_sums(c0{}, u);
-        P8_BARRIER();
-        advance();
-        issue_b(0, cur + S_B0);
-        P8_BARRIER();
-        mul(first_c, c0{}, c1{}, fb1);
-        P8_BARRIER();
-        ld_a(S_A1);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_a(0, cur + S_A0);
-        P8_BARRIER();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mul(first_c, c1{}, c1{}, fb1);
-        row_sums(c1{}, u);
-        P8_BARRIER();
-        issue_b(1, cur + S_B1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        P8_BARRIER();
-        mul(first_c, c1{}, c0{}, fb0);
-        if constexpr (CS) {
-          if (u == cs_next) cs_next += tiles_n;
-        }
-        P8_BARRIER();
       } else if constexpr (P8_BNAT_BAL) {
         // K-major B, reads BALANCED over the phases (8 / 8 / 8 / 8 instead of 16 / 8 / 8 / 0 fragment-read instructions
         // with row-major A; `ds_read_b64_tr_b16` moves half the bytes per LDS cycle of ds_read_b128, and phase 1's burst
@@ -626,17 +595,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         // phase 1: (A0, sub 0); A0's reads first - retired before the barrier, its slot is requested again in phase 2
         ld_a(S_A0);
         __builtin_amdgcn_sched_barrier(0);
-#ifdef P8_LAB_SKIPB  // lab: phase 1 without its B reads (timing only: what does the read burst of phase 1 cost?)
-        if (u < 0)
-#endif
         ld_b(bh, 0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         issue_a(1, oth + S_A1);
-#ifdef P8_LAB_SKIPB
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD_B) : "memory");
-#endif
         P8_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         mul(first_c, c0{}, c0{}, fb0);
