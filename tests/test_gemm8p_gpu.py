@@ -143,3 +143,58 @@ def test_ping_pong_loop_is_bit_reproducible():
     for _ in range(20):
         assert torch.equal(ops.gemm(a, b), first)
     assert _launches()[1] >= p0 + 21
+
+
+def test_seeded_shape_sweep_matches_ring_bit_for_bit():
+    """Ragged edges in every direction at once: M, N, K drawn from a seeded generator (N a multiple of 8 - rows are
+    16-byte aligned -, K a multiple of 8, enough tiles for a full grid or, every fourth case, fewer tiles than CUs: the
+    single-round form), forward / input-gradient / weight-gradient forms in turn, with and without CUs reserved for a
+    collective (a grid of 240 or 248 workgroups walks different XCD blocks).  The ring kernel is the reference here; it is
+    itself checked against the f32 matmul in tests/test_gemm_gpu.py."""
+    import random
+
+    from melspec_gpt_vqvae_amd import _ffi, ops
+
+    rng = random.Random(20240)
+    L = _ffi.lib()
+    compared = 0
+    try:
+        for case in range(18):
+            form = ("nt", "nn", "tn")[case % 3]
+            small = case % 4 == 3
+            L.melgpt_set_reserved_cus((0, 16, 8)[case % 3] if not small else 0)
+            if form == "tn":       # dW (N x K) = dY^T X over M rows
+                N, K, M = rng.choice([1024, 1472, 2048, 3072]), rng.choice([1024, 1472, 4096]), rng.randrange(60, 140) * 256 + rng.randrange(0, 256) // 8 * 8
+                torch.manual_seed(case)
+                dy = (torch.randn(M, N, device=DEV) * 0.5).to(torch.bfloat16)
+                x = (torch.randn(M, K, device=DEV) * 0.5).to(torch.bfloat16)
+
+                def run():
+                    wg, bg = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+                    ops.wgrad(dy, x, wg, False, bias_out=bg)
+                    return [wg, bg]
+                ring, pp = _both(run)
+                assert all(torch.equal(a, b) for a, b in zip(ring, pp)), (case, form, M, N, K)
+                compared += 1
+                continue
+            N = rng.randrange(3, 18) * 256 + rng.randrange(0, 32) * 8
+            K = rng.randrange(36, 200) * 8
+            tiles_n = (N + 255) // 256
+            rows = (90 if small else rng.randrange(300, 700)) // tiles_n + 1
+            M = rows * 256 - rng.randrange(0, 255)
+            torch.manual_seed(case)
+            a = (torch.randn(M, K, device=DEV) * 0.5).to(torch.bfloat16)
+            b = (torch.randn(*((K, N) if form == "nn" else (N, K)), device=DEV) * 0.25).to(torch.bfloat16)
+            bias = torch.randn(N, device=DEV) * 0.1 if case % 2 else None
+            res = torch.randn(M, N, device=DEV).to(torch.bfloat16) if case % 5 == 0 else None
+            try:
+                ring, pp = _both(lambda: ops.gemm(a, b, b_kmajor=form == "nn", bias=bias, residual=res))
+            except AssertionError as e:
+                if "meant to run" in str(e) or "takes the ring" in str(e):
+                    continue        # (this draw fell to the 128 x 128 kernel: nothing to compare)
+                raise
+            assert torch.equal(ring, pp), (case, form, M, N, K)
+            compared += 1
+    finally:
+        L.melgpt_set_reserved_cus(0)
+    assert compared >= 12, compared
