@@ -73,7 +73,7 @@ __device__ unsigned long long p8_dbg[64 * 24];  // per tile: start, K loop done,
 #endif
 
 template <int ALAY, int BLAY, int MODE, int TM, bool EDGE = false>
-__global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, int tiles_n, int batch, int RN) {
+__global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, int tiles_n, int batch, int RN, int tail_m0) {
   constexpr int MT = TM / 2, TN = 4, BM = 32 * TM, BN = 256;
   constexpr int SLAB = 16 * MT;                      // rows of one wave's quadrant (64 or 48)
   constexpr int HT = 16384, BUF = 4 * HT;            // half-tile, one K tile's buffer
@@ -101,30 +101,55 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   // (RN == 0: a launch of at most one tile per workgroup - fewer tiles than CUs - in the linear XCD-remapped order; it
   // is walked as ONE item whose "block" is the tile itself)
   const bool single = RN == 0;
+  // HALF-HEIGHT LAST ROUND (tail_m0 > 0; row-major A, 256-row tiles, no batches): the XCD-block lists cover the rows
+  // below tail_m0 in whole rounds, and the rows from tail_m0 on - less than half a round of 256-row tiles - are cut into
+  // 128-row tiles, ONE per workgroup, walked as the workgroup's last item: such a tile has no A1 half (a wave's 64 rows
+  // are its quadrants (A0,B0), (A0,B1)), its K tiles skip phases 3 and 4's reads and MFMAs but keep their requests
+  // (A1's pieces marked), waits and barriers, so the request stream runs on into it like into any other tile.
+  constexpr bool TAILS = ALAY == LAY_ROW && TM == 8 && !BATCHED;
+  const bool tails = TAILS && tail_m0 > 0;
+  const int rows_main = tails ? tail_m0 / BM : rows_m;
   const int RNe = single ? 1 : RN;
   const int RM = single ? 1 : (G >> 3) / RNe;
   const int blocks_n = single ? tiles_n : (tiles_n + RNe - 1) / RNe;
-  const int nblocks = single ? 1 : ((rows_m + RM - 1) / RM) * blocks_n;
+  const int nblocks = single ? 1 : ((rows_main + RM - 1) / RM) * blocks_n;
   const int xcd = single ? 0 : blockIdx.x & 7, jslot = blockIdx.x >> 3;
   const int jm = single ? 0 : jslot / RNe, jn = single ? 0 : jslot - (jslot / RNe) * RNe;
+  const int tail_tl = tails ? xcd_remap(blockIdx.x, G) : 0;                      // this workgroup's 128-row tile, if it exists
+  const int tail_cnt = tails ? ((p.M - tail_m0 + 127) >> 7) * tiles_n : 0;
+  const int tail_tr = tails ? tail_tl / tiles_n : 0, tail_tc = tail_tl - tail_tr * tiles_n;
   struct Walk {
     int blk, bm, bn;  // block number of this XCD's current item, its block row / column
+    int tail;         // 0: in the block lists; 1: at the workgroup's 128-row tile; 2: past it
   };
   // Which blocks an XCD takes: a CONTIGUOUS run of the row-major block order (P8_ORDER 1: consecutive items of a
   // workgroup then share their A row panel and only the B panel changes), or every eighth block as gemm256.hip (0).
   const int blk_first = P8_ORDER ? (int)(((long long)xcd * nblocks) >> 3) : xcd;
   const int blk_end = P8_ORDER ? (int)(((long long)(xcd + 1) * nblocks) >> 3) : nblocks;
   constexpr int BSTEP = P8_ORDER ? 1 : 8;
-  auto walk_live = [&](const Walk& k) { return k.blk < blk_end; };
-  auto walk_tile = [&](const Walk& k, int& bz, int& m0, int& n0) -> bool {
+  auto walk_live = [&](const Walk& k) { return k.tail == 0 ? k.blk < blk_end : k.tail == 1; };
+  auto walk_tile = [&](const Walk& k, int& bz, int& m0, int& n0, bool& half) -> bool {
+    half = false;
+    if (TAILS && k.tail == 1) {
+      bz = 0;
+      m0 = tail_m0 + tail_tr * 128;
+      n0 = tail_tc * BN;
+      half = true;
+      return true;
+    }
     const int tm = k.bm * RM + jm, tn = k.bn * RNe + jn;
     bz = BATCHED ? tm / tiles_m : 0;
     m0 = (tm - bz * tiles_m) * BM;
     n0 = tn * BN;
-    return tm < rows_m && tn < tiles_n;
+    return tm < rows_main && tn < tiles_n;
   };
   auto walk_next = [&](Walk& k) {  // the next item that is a tile, or the first dead one
+    if (k.tail) {
+      k.tail = 2;
+      return;
+    }
     int bz, m0, n0;
+    bool half;
     do {
       k.blk += BSTEP;
       k.bn += BSTEP;
@@ -132,9 +157,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         k.bn -= blocks_n;
         ++k.bm;
       }
-    } while (walk_live(k) && !walk_tile(k, bz, m0, n0));
+    } while (k.blk < blk_end && !walk_tile(k, bz, m0, n0, half));
+    if (k.blk >= blk_end) k.tail = tail_tl < tail_cnt ? 1 : 2;
   };
   auto walk_first = [&](Walk& k) {
+    k.tail = 0;
     if (single) {
       const int tl = xcd_remap(blockIdx.x, G);
       k.blk = 0;
@@ -230,10 +257,12 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   ra = make_rsrc4(p.A, p.a_bytes);
   rb = make_rsrc4(p.B, p.b_bytes);
   Walk kc;  // the requesting cursor's item
+  bool kc_half = false;  // ... is a 128-row tile: slabs 64 rows apart, no A1 half
+  const unsigned ca_half1 = (unsigned)((long long)64 * p.lda * 2);
   auto plan = [&]() {
     int bz = 0, pm0 = 0;
     pn0 = 0;
-    const bool pok = walk_live(kc) && walk_tile(kc, bz, pm0, pn0);  // dead: every request is out of range (zero fills nobody reads)
+    const bool pok = walk_live(kc) && walk_tile(kc, bz, pm0, pn0, kc_half);  // dead: every request is out of range (zero fills nobody reads)
     if constexpr (BATCHED) {
       ra = make_rsrc4((const char*)p.A + (long long)bz * p.sA * 2, p.a_bytes);
       rb = make_rsrc4((const char*)p.B + (long long)bz * p.sB * 2, p.b_bytes);
@@ -278,6 +307,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       unsigned off = a_run[AJ == 2 ? j : 0] + ca[h][j];
+      if constexpr (TAILS) {
+        if (kc_half) off = h ? MARK : a_run[0] + (j ? ca_half1 : 0u);  // (wave-uniform)
+      }
       if constexpr (CONV) off = a_runq[2 * h + j];
       if constexpr (EDGE && ALAY == LAY_KMAJ) off = ka_mn0 < a_lim[h] ? off : MARK;
       dma16(ra, slot + (w + 8 * j) * 1024, off);
@@ -358,7 +390,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   Walk km;  // the multiplying cursor's item
   for (walk_first(km); walk_live(km); walk_next(km)) {
     int bz, m0, n0;
-    walk_tile(km, bz, m0, n0);
+    bool km_half;
+    walk_tile(km, bz, m0, n0, km_half);
     // (not zeroed: the tile's first K tile is a copy of the loop body whose first MFMA per accumulator tile takes a zero
     // C operand - 128 v_mov per wave and tile, ~500 cycles in front of the first phase, otherwise)
     f32x4 acc[TM][TN];
@@ -407,6 +440,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
       }
     };
     auto ld_a = [&](int slot) {  // this wave's quadrant rows of an A half-tile (slab wr)
+      if constexpr (TAILS) {
+        if (slot == S_A1 && km_half) return;  // (a 128-row tile has no A1 half; wave-uniform)
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -421,6 +457,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
     auto mul = [&](auto first_c, auto mq_c, auto nq_c, u32x4 (&fb)[2][2]) {
       constexpr int MQ = decltype(mq_c)::value, NQ = decltype(nq_c)::value;
       constexpr bool FIRST = decltype(first_c)::value;
+      if constexpr (TAILS && MQ == 1) {
+        if (km_half) return;  // (a 128-row tile: quadrants (A1, *) do not exist; wave-uniform)
+      }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -684,8 +723,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
 #endif
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
-    epilogue<bf16_t, TM, TN, MODE, ALAY != LAY_CONV>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, bz, lane_e,
-                                                      smem + 2 * BUF + w * 4096);
+    {
+      // (128-row tile: the wave's 64 rows are its first MT slabs, 64 rows apart between the two wave groups)
+      long long mrow[TM];
+      const int m_base = m0 + wr * ((TAILS && km_half) ? 64 : BM / 2);
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt) mrow[mt] = (TAILS && km_half && mt >= MT) ? -1ll : (long long)(m_base + mt * 16);
+      epilogue_rows<bf16_t, TM, TN, MODE, ALAY != LAY_CONV>(p, acc, mrow, 16, n0 + wc * 64, bz, lane_e, smem + 2 * BUF + w * 4096);
+    }
     if constexpr (CS) {
       if (p.a_rowsum && (lane_e >> 4) == 0) {  // every tile writes its slice, zeros when it took no K tile
         float* dst = p.a_rowsum + ((long long)bz * tiles_n + (n0 >> 8)) * p.ld_rowsum;
@@ -705,7 +750,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
 }
 
 template <int ALAY, int BLAY, int MODE, int TM, bool EDGE>
-int launch8p_e(const GemmParams& p, int tiles_m, int tiles_n, int batch, int RN, int grid, hipStream_t s) {
+int launch8p_e(const GemmParams& p, int tiles_m, int tiles_n, int batch, int RN, int grid, int tail_m0, hipStream_t s) {
   constexpr int LDS = 160 * 1024;
   static bool attr = false;
   if (!attr) {
@@ -714,17 +759,46 @@ int launch8p_e(const GemmParams& p, int tiles_m, int tiles_n, int batch, int RN,
       return MELGPT_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL((gemm8p_kernel<ALAY, BLAY, MODE, TM, EDGE>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n, batch, RN);
+  hipLaunchKernelGGL((gemm8p_kernel<ALAY, BLAY, MODE, TM, EDGE>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n, batch, RN, tail_m0);
   melgpt_count_gemm_loop(1);
   return melgpt_launch_status();
 }
+// Half-height last round (row-major A, 256-row tiles, one batch, XCD-block lists): if the block lists end with a partial
+// round, the block rows that fill whole rounds stay 256-row tiles and the rows behind them become 128-row tiles, one per
+// workgroup - returned as the first row of that tail, 0 = none.  (M = 33 920, N = 4096: 8.3 rounds of tiles = 8 rounds +
+// 144 half tiles; the ninth round of 80 full tiles on 256 CUs costs a whole tile time, the half tiles ~ 0.8 of one.)
+static int tail_rows(const GemmParams& p, int tiles_m, int tiles_n, int batch, int RN, int grid) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("MELGPT_GEMM_TAIL");
+    on = e ? atoi(e) : 1;
+  }
+  if (!on || RN <= 0 || batch != 1 || (grid & 7)) return 0;
+  const int RM = (grid >> 3) / RN;
+  const int blocks_n = (tiles_n + RN - 1) / RN, blocks_m = (tiles_m + RM - 1) / RM;
+  const int rounds = (blocks_m * blocks_n + 7) / 8;
+  for (int br = blocks_m - 1; br > 0; --br) {
+    if ((br * blocks_n) % 8 != 0) continue;
+    if (br * blocks_n / 8 + 1 != rounds) return 0;  // (more than one round would turn into half tiles)
+    const long long m0 = (long long)br * RM * 256;
+    if (m0 >= p.M) return 0;
+    const long long cnt = ((p.M - m0 + 127) / 128) * tiles_n;
+    return cnt <= grid ? (int)m0 : 0;
+  }
+  return 0;
+}
+
 template <int ALAY, int BLAY, int MODE, int TM>
 int launch8p(const GemmParams& p, int tiles_m, int tiles_n, int batch, int RN, int grid, hipStream_t s) {
   // K-major operands that do not end on a 128 boundary take the variant with per-piece column checks
   if constexpr (BLAY == LAY_KMAJ) {
-    if ((ALAY == LAY_KMAJ && p.M % 128 != 0) || p.N % 128 != 0) return launch8p_e<ALAY, BLAY, MODE, TM, true>(p, tiles_m, tiles_n, batch, RN, grid, s);
+    if ((ALAY == LAY_KMAJ && p.M % 128 != 0) || p.N % 128 != 0) {
+      const int tail = (ALAY == LAY_ROW && TM == 8) ? tail_rows(p, tiles_m, tiles_n, batch, RN, grid) : 0;
+      return launch8p_e<ALAY, BLAY, MODE, TM, true>(p, tiles_m, tiles_n, batch, RN, grid, tail, s);
+    }
   }
-  return launch8p_e<ALAY, BLAY, MODE, TM, false>(p, tiles_m, tiles_n, batch, RN, grid, s);
+  const int tail = (ALAY == LAY_ROW && TM == 8) ? tail_rows(p, tiles_m, tiles_n, batch, RN, grid) : 0;
+  return launch8p_e<ALAY, BLAY, MODE, TM, false>(p, tiles_m, tiles_n, batch, RN, grid, tail, s);
 }
 
 template <int ALAY, int BLAY, int MODE>
