@@ -29,6 +29,10 @@
 //     phase 3 vmcnt(6) (the next K tile's A0 and B halves: read from phase 4 on)
 // Every wait sits in front of a barrier, and a landed half-tile is read one phase after that barrier at the earliest.
 // P8_ROW_BAL=0 / P8_BNAT_BAL=0 build the unbalanced forms (12 / 4 / 8 / 0 reads, one vmcnt(6) per K tile in phase 4).
+// Also in here: an EDGE variant for K-major operands that end inside a 128-column half-tile (the GPT-VAE XL widths),
+// the convolutions' implicit-im2col A operand (running offsets rebuilt per filter tap), single-round launches (fewer
+// tiles than CUs), the weight gradients' split-K batches with the bias row sums on the A fragments, and a half-height
+// last round (128-row tiles behind the last whole round of 256-row tiles, same loop with the A1 half absent).
 // A half-tiles are always slab-permuted (a wave's rows of quadrant mq live in A half mq: 64-row slabs, 48 of them used
 // by the 192-row tile), so a wave still owns a CONTIGUOUS 128 (96) x 64 block of C and the epilogue is gemm_common.h's.
 #include <cstdlib>
