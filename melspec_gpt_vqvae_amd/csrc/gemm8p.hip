@@ -368,8 +368,16 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   issue_b(1, smem + S_B1);
   issue_a(1, smem + S_A1);
   advance();
-  issue_a(0, smem + BUF + S_A0);
-  issue_b(0, smem + BUF + S_B0);
+  // (IN THE STREAM'S ORDER: the loop's counted waits count the pieces issued behind the half-tile they wait for.  With A0
+  // in front of B0 for row-major B, phase 3's vmcnt(10) of a workgroup's very first K tile left B0 of the second one
+  // uncovered - phase 4 read it anyway: one launch in a few thousand came out different)
+  if constexpr (BNAT) {
+    issue_a(0, smem + BUF + S_A0);
+    issue_b(0, smem + BUF + S_B0);
+  } else {
+    issue_b(0, smem + BUF + S_B0);
+    issue_a(0, smem + BUF + S_A0);
+  }
   issue_b(1, smem + BUF + S_B1);
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   P8_BARRIER();

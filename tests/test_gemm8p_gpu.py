@@ -134,15 +134,20 @@ def test_weight_gradient_with_bias_gradient_matches_reference_and_ring(N, K, M):
 
 def test_ping_pong_loop_is_bit_reproducible():
     """LDS-DMA data is ordered for its readers only by the counted waits and barriers: a read placed too early passes
-    most runs.  Twenty launches of a multi-round shape must give the same bits."""
+    almost every run.  (It happened: with the prologue's requests out of the stream's order one launch in a few thousand
+    differed - caught by a 4 000-launch screen, tools/lab/p8_ab.py SCREEN=4000, not by twenty launches.)  2 000 launches of
+    three shapes (row-major B at both tile heights, K-major B) must give the same bits every time."""
     from melspec_gpt_vqvae_amd import ops
 
-    a, b, _ = _ops(9, 16384, 4096, 1024)
-    _, p0 = _launches()
-    first = ops.gemm(a, b).clone()
-    for _ in range(20):
-        assert torch.equal(ops.gemm(a, b), first)
-    assert _launches()[1] >= p0 + 21
+    for M, N, K, kmaj in ((8192, 4096, 256, False), (20480, 1024, 512, False), (8192, 4096, 256, True)):
+        a, b, _ = _ops(9 + N, M, N, K, b_kmajor=kmaj)
+        _, p0 = _launches()
+        first = ops.gemm(a, b, b_kmajor=kmaj).clone()
+        same = torch.ones((), dtype=torch.bool, device=DEV)
+        for _ in range(2000):
+            same &= (ops.gemm(a, b, b_kmajor=kmaj) == first).all()
+        assert bool(same), (M, N, K, kmaj)
+        assert _launches()[1] >= p0 + 2001
 
 
 def test_seeded_shape_sweep_matches_ring_bit_for_bit():
