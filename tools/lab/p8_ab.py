@@ -77,9 +77,10 @@ def main():
         same = bool(torch.equal(outs["0"], outs["1"]))
         nbad = int((outs["0"] != outs["1"]).sum()) if not same else 0
         stable = True
-        _ffi.lib().melgpt_set_gemm_pingpong(1)
+        screen_arm = os.environ.get("SCREEN_ARM", "1")      # which K loop the repeatability screen runs (1: ping-pong, 0: ring)
+        _ffi.lib().melgpt_set_gemm_pingpong(int(screen_arm))
         for _ in range(int(os.environ.get("SCREEN", "6"))):
-            stable = stable and bool(torch.equal(fn(), outs["1"]))
+            stable = stable and bool(torch.equal(fn(), outs[screen_arm]))
         for r in range(ROUNDS):
             for arm in ("01" if r % 2 == 0 else "10"):
                 _ffi.lib().melgpt_set_gemm_pingpong(int(arm))
