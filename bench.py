@@ -334,6 +334,7 @@ class ClassGPTStep:
         self.opt.grad_scale = 1.0 / world
         self.dp = DataParallel(self.gpt, grad_dtype=a.grad_dtype) if world > 1 or FORCE_DP else None
         self.full = a.layers == 24
+        self._one = torch.ones((), dtype=torch.float32, device=device)
         self.workload = ("VQ-encode (LitVQVAE encoder + 128-code L2 argmin on 80x848 mel tiles) + class-GPT VAS "
                          f"({a.layers} L, 1024, 16 H, T=265, V=128, dropout 0.5) fwd/bwd + AdamW")
         self.metric = "mel-token seqs/sec training step (VQ-encode + GPT fwd/bwd)"
@@ -352,7 +353,7 @@ class ClassGPTStep:
         loss = cross_entropy(logits.reshape(-1, logits.size(-1)), seq.reshape(-1))
         t2 = mark()
         self.opt.zero_grad()
-        loss.backward()
+        loss.backward(self._one)                                 # (a resident 1.0: autograd's own root gradient is a torch fill launch)
         if self.dp is not None:
             self.dp.finish()
         t3 = mark()
@@ -386,6 +387,7 @@ class GPTVAEXLStep:
         self.opt.grad_scale = 1.0 / world
         self.dp = DataParallel(self.vae, grad_dtype=a.grad_dtype) if world > 1 or FORCE_DP else None
         self.full = layers == 40
+        self._one = torch.ones((), dtype=torch.float32, device=device)
         self.n_params = sum(p.numel() for p in self.vae.parameters())
         self.workload = (f"GPT-VAE XL (encoder + decoder GPT, {layers}+{layers} L, 1472, 23 H, T=265, V=1024, "
                          f"{self.n_params / 1e9:.2f} B parameters) training step: ELBO fwd/bwd + AdamW, per-GPU batch "
@@ -398,7 +400,7 @@ class GPTVAEXLStep:
         loss = total.mean()
         t2 = mark()
         self.opt.zero_grad()
-        loss.backward()
+        loss.backward(self._one)
         if self.dp is not None:
             self.dp.finish()
         t3 = mark()

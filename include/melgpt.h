@@ -374,6 +374,10 @@ int melgpt_dropout_apply_colsum(const void* x, void* y, long long M, int N, floa
                                 unsigned stream_id, float* out, int accumulate, float* workspace, int dtype,
                                 void* stream);
 int melgpt_cast(const void* x, int src_dtype, void* y, int dst_dtype, long long n, void* stream);
+/* p[0 .. bytes) = 0 on `stream` (what `tensor.zero_()` does in the reference's host code, e.g. the F.pad / zero-initialised
+ * buffers around minGPT.py:170-180; here: guard rows of the AttnBlock's q|k|v buffer, the prepended positions' slice of
+ * the positional-embedding gradient) - so that no framework fill kernel runs inside a step. */
+int melgpt_zero_bytes(void* p, long long bytes, void* stream);
 /* torch.optim.AdamW step (minGPT.py:660-664) fused over a flat f32 buffer; optional bf16 shadow copy. */
 int melgpt_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16,
                  long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,

@@ -53,7 +53,12 @@ def _headers():
     return sorted(hs)
 
 
-FLAVOURS = {"bf16": ([], "libmelgpt_hip.so", ""), "fp16": (["-DMELGPT_HALF_FP16"], "libmelgpt_hip_fp16.so", "_fp16")}
+FLAVOURS = {"bf16": ([], "libmelgpt_hip.so", ""), "fp16": (["-DMELGPT_HALF_FP16"], "libmelgpt_hip_fp16.so", "_fp16"),
+            # race-screen build (csrc/common.h MELGPT_VMCNT0): every hand-counted wait is a full drain.  Test infrastructure:
+            # only the sources that count their waits are recompiled, the rest are the bf16 flavour's objects; loaded by
+            # tests/test_race_screens_gpu.py in a child process (MELGPT_LAB_LIB), never by the product
+            "vm0": (["-DMELGPT_VMCNT0"], "libmelgpt_hip_vm0.so", "_vm0")}
+VM0_SOURCES = ("gemm8p.hip", "gemm256.hip", "conv_fused.hip")
 
 
 def lib_path(flavour="bf16"):
@@ -79,8 +84,8 @@ def _compile(src, stamp, verbose, flavour="bf16"):
     return obj, True
 
 
-def build(verbose=False, force=False, jobs=None, flavours=("bf16", "fp16")):
-    """-> path of the default (bf16) library; builds every flavour in `flavours`."""
+def build(verbose=False, force=False, jobs=None, flavours=("bf16", "fp16", "vm0")):
+    """-> path of the default (bf16) library; builds every flavour in `flavours` ("vm0" needs "bf16" in front of it)."""
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = sources()
     hdr = _headers()
@@ -91,9 +96,12 @@ def build(verbose=False, force=False, jobs=None, flavours=("bf16", "fp16")):
         if force and os.path.isdir(objdir):
             shutil.rmtree(objdir)
         os.makedirs(objdir, exist_ok=True)
+        own = [s for s in srcs if fl != "vm0" or os.path.basename(s) in VM0_SOURCES]
         with cf.ThreadPoolExecutor(jobs) as ex:
-            res = list(ex.map(lambda s: _compile(s, stamps[s], verbose, fl), srcs))
+            res = list(ex.map(lambda s: _compile(s, stamps[s], verbose, fl), own))
         objs = [o for o, _ in res]
+        if fl == "vm0":
+            objs += [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in srcs if s not in own]
         lib = lib_path(fl)
         if any(ch for _, ch in res) or not os.path.exists(lib):
             cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib + ".tmp", *objs]

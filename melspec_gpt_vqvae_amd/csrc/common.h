@@ -22,6 +22,25 @@ typedef unsigned short bf16_t;  // raw bf16 bits
     if (!(cond)) return (code);  \
   } while (0)
 
+// ---------------------------------------------------------------- hand-counted waits
+// Kernels that order LDS-DMA / in-flight loads by COUNTED waits (s_waitcnt vmcnt(N) / lgkmcnt(N) with N > 0: "all but the
+// N youngest have landed") spell the count through these, so that the race-screen build (-DMELGPT_VMCNT0,
+// build.py flavour "vm0", tests/test_race_screens_gpu.py) can turn every one of them into a full drain: that build
+// cannot read a piece too early, so its outputs ARE the intended ones, and the production build must reproduce them bit
+// for bit - a miscounted wait shows up as a difference in the production arm only.
+#ifdef MELGPT_VMCNT0
+#define MELGPT_WAITN(n) 0
+#else
+#define MELGPT_WAITN(n) (n)
+#endif
+#define MELGPT_STR2(x) #x
+#define MELGPT_STR(x) MELGPT_STR2(x)
+#ifdef MELGPT_VMCNT0
+#define MELGPT_VMCNT(n) "vmcnt(0)"
+#else
+#define MELGPT_VMCNT(n) "vmcnt(" MELGPT_STR(n) ")"
+#endif
+
 void melgpt_count_gemm_loop(int pingpong);  // abi.hip: launch counters behind melgpt_gemm_loop_launches
 
 static inline int melgpt_launch_status() {

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
       // this wave's pieces of the pair have landed; after the barrier everybody's have, and everybody is past the
       // previous pair, whose two stages are refilled below.  (The next tile's MAXCH patch loads were issued just before
       // this loop: younger than the first pair's pieces - they stay in flight - and older than all later ones.)
-      if (pr == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(MAXCH) : "memory");
+      if (pr == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(MELGPT_WAITN(MAXCH)) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh, ++kg) {
@@ -939,7 +939,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
       asm volatile("s_waitcnt vmcnt(%[n])"
                    : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4]), "+v"(r.v[5]), "+v"(r.v[6]),
                      "+v"(r.v[7]), "+v"(r.v[8]), "+v"(r.v[9]), "+v"(r.v[10]), "+v"(r.rs), "+v"(r.mn)
-                   : [n] "n"(N)
+                   : [n] "n"(MELGPT_WAITN(N))
                    : "memory");
     };
     float ca[8], cb[8];  // affine of this thread's 8 channels for the half being staged
@@ -1006,8 +1006,8 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
         // FIRST the publication the multiplying waves may be waiting for: this wave's pieces of K-step sigma + 1 (requested
         // two slots ago) have landed - younger are K-step sigma + 2 (4 pieces) and, in slots 0 and 1, the 13 loads of `next`
         if (j == 0) wait_raw(std::integral_constant<int, 17>{}, use);   // ... which also covers `use` (requested a phase ago)
-        else if (j == 1) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (j == 1) asm volatile("s_waitcnt " MELGPT_VMCNT(17) ::: "memory");
+        else asm volatile("s_waitcnt " MELGPT_VMCNT(4) ::: "memory");
         if (lane == 0) cnt[s] = sigma + 2u;
         WS_T(3)
         // then the request of K-step sigma + 3, once K-step sigma - 1 is free (the counters only grow: a poll that saw the
@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
     affine(0, r0);
 #pragma unroll
     for (int i = 0; i < 11; ++i) convert(0, i, r0, false);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // K-step 0 (and r1) landed
+    asm volatile("s_waitcnt " MELGPT_VMCNT(8) ::: "memory");   // K-step 0 (and r1) landed
     if (lane == 0) cnt[s] = 1u;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     unsigned sigma0 = 0;
@@ -1221,9 +1221,8 @@ static int conv3x3_gn_impl(const void* x, int B, int H, int W, int Cin, const fl
   const long long wide_px = wide_tiles * 256, narrow_px = (long long)q.tiles_x * q.tiles_y * B * TH * TW;
   if (!wide_off && wide_lds <= 160 * 1024 && wide_tiles >= 512 && wide_px * 4 <= narrow_px * 5 && q.g.vec_io &&
       Cin == 128 &&
-      M * Cin * 2 < 0xFFFFFF00LL && (!residual || M * Cout * 2 < 0xFFFFFF00LL)) {
+      M * Cin * 2 < 0xFFFFFF00LL && M * Cout * 2 < 0xFFFFFF00LL) {   // (outputs past a descriptor's range: the narrow kernel)
     q.x_bytes = (unsigned)(M * Cin * 2);
-    if (M * Cout * 2 >= 0xFFFFFF00LL) return MELGPT_ERR_UNSUPPORTED;
     q.r_bytes = (unsigned)(M * Cout * 2);   // bytes of y (and of the residual, when there is one: same shape)
     return launch_fused_wide(q, B, s);
   }

@@ -93,7 +93,7 @@ __device__ __forceinline__ void dma16(rsrc_t rs, char* lds_wave_base, unsigned v
 template <int N>
 __device__ __forceinline__ void wait_vm_barrier() {
   static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MELGPT_WAITN(N)) : "memory");
 }
 
 // 256 x 256 output tile, 8 waves as 2 (M) x 4 (N), each wave 128 x 64 = 8 x 4 accumulator tiles of 16 x 16.

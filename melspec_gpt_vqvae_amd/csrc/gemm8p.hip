@@ -379,7 +379,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
     issue_a(0, smem + BUF + S_A0);
   }
   issue_b(1, smem + BUF + S_B1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  asm volatile("s_waitcnt " MELGPT_VMCNT(6) ::: "memory");
   P8_BARRIER();
   int par = 0;  // buffer of the K tile that is multiplied next
   int xa[4], xb[4];
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         ld_a(S_A0);
         __builtin_amdgcn_sched_barrier(0);
         issue_a(1, oth + S_A1);
-        if constexpr (FIRST) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD_A) : "memory");
+        if constexpr (FIRST) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MELGPT_WAITN(RD_A)) : "memory");
         P8_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         mul(first_c, c0{}, c0{}, fbA);
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         ld_a(S_A1);
         __builtin_amdgcn_sched_barrier(0);
         issue_a(0, cur + S_A0);
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        asm volatile("s_waitcnt " MELGPT_VMCNT(10) ::: "memory");
         P8_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         mul(first_c, c1{}, c1{}, fbB);
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         ld_b(S_B0, 0, fbB, BUF);
         __builtin_amdgcn_sched_barrier(0);
         issue_b(1, cur + S_B1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("s_waitcnt " MELGPT_VMCNT(6) ::: "memory");
         P8_BARRIER();
         mul(first_c, c1{}, c0{}, fbA);
         P8_BARRIER();
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         ld_a(S_A0);
         __builtin_amdgcn_sched_barrier(0);
         issue_a(1, oth + S_A1);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD_A) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MELGPT_WAITN(RD_A)) : "memory");
         P8_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         mul(first_c, c0{}, c0{}, fb0);
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         P8_BARRIER();
         // phase 4: (A1, B0); the K tile's counted wait
         issue_b(1, cur + S_B1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("s_waitcnt " MELGPT_VMCNT(6) ::: "memory");
         P8_BARRIER();
         mul(first_c, c1{}, c0{}, fb0);
         P8_BARRIER();
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
           __builtin_amdgcn_sched_barrier(0);
         }
         issue_a(1, oth + S_A1);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FIRST ? RD_B : 0) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MELGPT_WAITN(FIRST ? RD_B : 0)) : "memory");
         P8_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         mul(first_c, c0{}, c0{}, fbA);
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         __builtin_amdgcn_sched_barrier(0);
         advance();
         issue_a(0, cur + S_A0);
-        asm volatile("s_waitcnt lgkmcnt(0) vmcnt(10)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0) " MELGPT_VMCNT(10) ::: "memory");
         P8_BARRIER();
         mul(first_c, c0{}, c1{}, fbB);
         P8_BARRIER();
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         ld_a(S_A1);
         __builtin_amdgcn_sched_barrier(0);
         issue_b(0, cur + S_B0);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("s_waitcnt " MELGPT_VMCNT(6) ::: "memory");
         P8_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         mul(first_c, c1{}, c1{}, fbB);
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         ld_b(bh, 0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         issue_a(1, oth + S_A1);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD_B) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MELGPT_WAITN(RD_B)) : "memory");
         P8_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         mul(first_c, c0{}, c0{}, fb0);
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         P8_BARRIER();
         // phase 4: (A1, sub 0); the K tile's counted wait
         issue_b(1, cur + S_B1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("s_waitcnt " MELGPT_VMCNT(6) ::: "memory");
         P8_BARRIER();
         mul(first_c, c1{}, c0{}, fb0);
         if constexpr (CS) {

@@ -1306,6 +1306,25 @@ extern "C" int melgpt_dropout_apply_colsum(const void* x, void* y, long long M, 
   return melgpt_launch_status();
 }
 
+// ---------------------------------------------------------------- zero fill
+// (the library's own memset: the guard rows / padded slices the host code clears inside a step go through the C ABI like
+// every other tensor operation of the path - no torch fill kernel inside a training step, tests/test_step_kernels_gpu.py)
+__global__ __launch_bounds__(256) void zero_bytes_kernel(char* p, long long bytes) {
+  const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, nth = (long long)gridDim.x * 256;
+  long long head = (16 - (long long)((uintptr_t)p & 15)) & 15;  // bytes in front of the first 16-byte boundary
+  head = head < bytes ? head : bytes;
+  const long long nvec = (bytes - head) >> 4;
+  for (long long i = tid; i < nvec; i += nth) *(u32x4*)(p + head + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+  for (long long j = tid; j < head; j += nth) p[j] = 0;
+  for (long long j = head + 16 * nvec + tid; j < bytes; j += nth) p[j] = 0;
+}
+
+extern "C" int melgpt_zero_bytes(void* p, long long bytes, void* stream) {
+  MELGPT_CHECK(p && bytes > 0, MELGPT_ERR_BAD_ARG);
+  hipLaunchKernelGGL(zero_bytes_kernel, dim3(grid_for((bytes + 15) / 16, 256)), dim3(256), 0, (hipStream_t)stream, (char*)p, bytes);
+  return melgpt_launch_status();
+}
+
 extern "C" int melgpt_cast(const void* x, int src_dtype, void* y, int dst_dtype, long long n, void* stream) {
   MELGPT_CHECK(x && y && n > 0, MELGPT_ERR_BAD_ARG);
   hipStream_t s = (hipStream_t)stream;

@@ -37,8 +37,10 @@ class GradientExchange:
     wire_dtype (default None = the gradient's own f32): a 16-bit format to exchange in - SURVEY 2b C2, for the GPT-VAE XL
     job whose f32 gradient is 8.37 GB per step: a launched slice is cast into a staging buffer of that format, the
     staging slice is all-reduced, and finish() converts the sums back into the f32 buffer (moments and master weights
-    stay f32).  The reduction itself then runs in 16 bits: ~2^-9 relative per addition for bf16; tested at 1e-3 of
-    the gradient's maximum on two ranks, off by default."""
+    stay f32).  The reduction itself then runs in 16 bits: ~2^-9 relative per addition for bf16; tested on two ranks at
+    6e-3 of the gradient's maximum / 3e-3 rms (tests/test_host_cpu.py: 1e-3 would be below ONE bf16 rounding), off by
+    default.  IEEE half is refused as a wire format by DataParallel: loss-scaled gradients summed over ranks in a 5-bit
+    exponent overflow, the step is skipped and the scale drops - every step."""
 
     def __init__(self, grad: torch.Tensor, group=None, max_bucket_elems: int = 64 << 20, wire_dtype=None):
         assert grad.dim() == 1
@@ -57,6 +59,7 @@ class GradientExchange:
         self.last_wait_ms = 0.0       # host time finish() spent in the waits (GPU backends: the time to ENQUEUE them)
         self.time_events = False      # GPU: bracket finish()'s waits with stream events -> exposed_ms()
         self._events = []
+        self._ev0 = None              # mark_backward_end(): the event behind the backward pass' last kernel
 
     @property
     def bytes_per_step(self):
@@ -89,6 +92,14 @@ class GradientExchange:
         self._done.append((lo, hi))
         self._reduce(lo, hi)
 
+    def mark_backward_end(self):
+        """with time_events: record the start of the exposed window NOW (the caller is about to queue stream work that
+        waits for the collectives - DataParallel's has-gradient mask all-reduce shares the communicator with every
+        early-launched gradient all-reduce, so an event recorded after it would already sit behind the exposed wait)."""
+        if self.active and self.time_events and self.grad.is_cuda and self._ev0 is None:
+            self._ev0 = torch.cuda.Event(enable_timing=True)
+            self._ev0.record()
+
     def finish(self):
         """reduce everything not launched yet, then make the current stream wait for all of it."""
         if self.active:
@@ -103,8 +114,8 @@ class GradientExchange:
             self.launch_uncounted(pos, self.grad.numel())
             ev = None
             if self.time_events and self.grad.is_cuda:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record()                  # behind the last kernel of the backward pass
+                self.mark_backward_end()        # behind the last kernel of the backward pass (unless marked earlier)
+                ev = (self._ev0, torch.cuda.Event(enable_timing=True))
             t0 = time.perf_counter()
             for w in self._works:
                 w.wait()
@@ -114,7 +125,7 @@ class GradientExchange:
             if ev is not None:
                 ev[1].record()                  # behind the last collective (and the conversion back)
                 self._events.append(ev)
-        self._works, self._done, self._wired = [], [], []
+        self._works, self._done, self._wired, self._ev0 = [], [], [], None
 
     def launch_uncounted(self, lo, hi):
         if hi > lo:
@@ -169,8 +180,14 @@ class DataParallel:
 
         self.module = module
         self.fp = ensure_flat(module)
-        if isinstance(grad_dtype, str):      # "f32" | "bf16" | "fp16" (the library flavour's 16-bit format), as the CLIs spell it
-            grad_dtype = {"f32": None, "bf16": _ffi.HALF_DTYPE, "fp16": _ffi.HALF_DTYPE, "half": _ffi.HALF_DTYPE}[grad_dtype]
+        if isinstance(grad_dtype, str):      # "f32" | "bf16", as the CLIs spell it
+            grad_dtype = {"f32": None, "bf16": torch.bfloat16, "fp16": torch.float16, "half": _ffi.HALF_DTYPE}[grad_dtype]
+        if grad_dtype not in (None, torch.float32):
+            # the cast kernel converts to the LIBRARY's 16-bit format only, and IEEE half cannot carry loss-scaled
+            # gradients summed over ranks (GradientExchange's docstring): a 16-bit wire exists in the bf16 flavour only
+            if grad_dtype != torch.bfloat16 or _ffi.HALF_DTYPE != torch.bfloat16:
+                raise ValueError(f"gradient wire format {grad_dtype} is not supported in the "
+                                 f"{str(_ffi.HALF_DTYPE)[6:]} flavour of the library: use f32 (or bf16 in the bf16 flavour)")
         self.ex = GradientExchange(self.fp.grad, group, max_bucket_elems=max_bucket_elems, wire_dtype=grad_dtype)
         self.world = self.ex.world
         self.overlap = bool(overlap)
@@ -198,8 +215,10 @@ class DataParallel:
         # which parameters got a gradient this step must be the SAME on every rank: FusedAdamW skips a parameter whose
         # .grad is None (torch.optim.AdamW's rule) and decides that per rank, so a parameter missing on one rank only
         # would be restored there and stepped elsewhere - silently diverging replicas (the reference's DDP raises).  The
-        # has-gradient bitmask is all-reduced with the gradients; the first step is checked synchronously, later steps
-        # through a pinned host flag read at the next finish() (no extra host synchronisation per step).
+        # has-gradient bitmask is all-reduced with the gradients; the first step is checked synchronously, step N > 1 at
+        # step N + 1's finish() through a pinned host flag: ALWAYS exactly one step late (the flag's event is waited for,
+        # never polled - it is a whole step old, so the wait is free), hence on the same step on every rank - the verdict
+        # comes from the all-reduced mask, so either every rank raises there or none does; detach() reads the last one.
         self._mask_steps = 0
         self._mask_flag = None        # (pinned host tensor, event) of the previous step's check
         self._mask_host = None
@@ -232,17 +251,16 @@ class DataParallel:
         step - zeroed first so that no stale slice is summed), then wait for every launched piece."""
         if self.ex.active:
             self.fp.zero_missing_grads()
+        self.ex.mark_backward_end()     # exposed_comm_ms counts from here: the mask all-reduce below already waits
         self._check_grad_sets()
         self.ex.finish()
         self._reserve(False)  # everything launched after this is stream-ordered behind the last all-reduce
 
-    def _raise_if_flagged(self, wait):
+    def _raise_if_flagged(self):
         if self._mask_flag is None:
             return
         host, ev = self._mask_flag
         if ev is not None:
-            if not wait and not ev.query():
-                return
             ev.synchronize()
         self._mask_flag = None
         if int(host.item()) != 0:
@@ -254,7 +272,7 @@ class DataParallel:
         """all-reduce the has-gradient bitmask of the flat store's parameters; see __init__."""
         if self.world <= 1:
             return
-        self._raise_if_flagged(wait=False)
+        self._raise_if_flagged()        # the previous step's verdict, before its slot is reused
         has = torch.tensor([0.0 if p.grad is None else 1.0 for p in self.fp.params], dtype=torch.float32)
         has = has.to(self.fp.device, non_blocking=True)
         dist.all_reduce(has, op=dist.ReduceOp.SUM, group=self.ex.group)
@@ -271,7 +289,7 @@ class DataParallel:
             self._mask_flag = (bad.clone(), None)
         self._mask_steps += 1
         if self._mask_steps == 1 or not self._on_gpu:
-            self._raise_if_flagged(wait=True)
+            self._raise_if_flagged()
 
     def describe(self):
         """what a bench line needs to explain a scaling record: the exchange's size and the two persistent-kernel switches"""
@@ -280,7 +298,7 @@ class DataParallel:
                 "overlap": bool(self.overlap), "backend": dist.get_backend(self.ex.group) if dist.is_initialized() else None}
 
     def detach(self):
-        self._raise_if_flagged(wait=True)
+        self._raise_if_flagged()
         for blk in self.blocks:
             if getattr(blk, "_grad_ready_hook", None) is not None:
                 object.__setattr__(blk, "_grad_ready_hook", None)

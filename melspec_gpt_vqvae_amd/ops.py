@@ -403,6 +403,14 @@ def dropout_apply_colsum(x, drop_p, seed, stream_id, out, accumulate=False):
     return y
 
 
+def zero_(x):
+    """x.zero_() through the library (x contiguous; an empty tensor is left alone)."""
+    assert x.is_contiguous()
+    if x.numel():
+        call("melgpt_zero_bytes", ptr(x), x.numel() * x.element_size(), stream())
+    return x
+
+
 def cast(x, dtype, out=None):
     assert x.is_contiguous()
     if out is None:

@@ -383,7 +383,7 @@ class _StemFn(torch.autograd.Function):
         pg_full, acc_p = fp.grad_target(gpt.pos_emb)
         pg = pg_full.view(-1, C)
         if not acc_p:
-            pg[Ttot:].zero_()
+            ops.zero_(pg[Ttot:])
         assert acc_t == acc_p
         kw = {}
         dvals = None

@@ -27,6 +27,38 @@ def _require_cuda(x):
         raise _ffi.MelgptError("melspec_gpt_vqvae_amd runs on the GPU only (no CPU / eager fallback)")
 
 
+class _InferenceOnly(torch.autograd.Function):
+    """The VQ-VAE encoder / decoder kernels are forward-only (VQ-VAE training is out of this build's scope: the
+    reference's README trains it elsewhere); the reference's LitVQVAE.forward (big_model_attn_gan.py:622-634) is
+    differentiable end to end.  An output computed while autograd is recording from an input or parameter that requires a
+    gradient is therefore tied to this node, whose backward REFUSES - `.backward()` through encode / decode / forward
+    raises instead of silently leaving the convolutions without gradients.  Forward-only callers that never call
+    backward (feature_extraction/extract_codes.py:48-49 runs encode with autograd on) are not affected."""
+
+    @staticmethod
+    def forward(ctx, out, where, *anchors):
+        ctx.where = where
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise _ffi.MelgptError(
+            f"{ctx.where}: gradients through the VQ-VAE encoder / decoder are not implemented (inference-only HIP "
+            "path; VQ-VAE training is out of scope) - wrap the call in torch.no_grad(), or freeze the module and detach "
+            "its input")
+
+
+def _inference_only(module, where, out, *inputs):
+    if not torch.is_grad_enabled():
+        return out
+    anchors = [x for x in inputs if isinstance(x, torch.Tensor) and x.requires_grad]
+    if not anchors:
+        anchors = [p for p in module.parameters() if p.requires_grad][:1]
+    if not anchors:
+        return out
+    return _InferenceOnly.apply(out, where, *anchors)
+
+
 def _cdtype(module):
     return getattr(module, "compute_dtype", torch.float32)
 
@@ -172,7 +204,7 @@ class ResnetBlock(nn.Module):
     def forward(self, x, temb):
         assert temb is None, "the mel VQ-VAE has no timestep embedding (temb_ch = 0, reference :196)"
         _require_cuda(x)
-        return _as_nchw(self._nhwc(ops.to_nhwc(x, _cdtype(self))))
+        return _inference_only(self, "ResnetBlock.forward", _as_nchw(self._nhwc(ops.to_nhwc(x, _cdtype(self)))), x)
 
 
 class Downsample(nn.Module):
@@ -192,7 +224,7 @@ class Downsample(nn.Module):
 
     def forward(self, x):
         _require_cuda(x)
-        return _as_nchw(self._nhwc(ops.to_nhwc(x, _cdtype(self))))
+        return _inference_only(self, "Downsample.forward", _as_nchw(self._nhwc(ops.to_nhwc(x, _cdtype(self)))), x)
 
 
 class Upsample(nn.Module):
@@ -209,7 +241,7 @@ class Upsample(nn.Module):
 
     def forward(self, x):
         _require_cuda(x)
-        return _as_nchw(self._nhwc(ops.to_nhwc(x, _cdtype(self))))
+        return _inference_only(self, "Upsample.forward", _as_nchw(self._nhwc(ops.to_nhwc(x, _cdtype(self)))), x)
 
 
 class AttnBlock(nn.Module):
@@ -249,7 +281,7 @@ class AttnBlock(nn.Module):
         # q|k|v for all positions, plus 8 zeroed guard rows so that the per-batch (kp, C) windows below stay
         # inside this allocation and only ever meet finite values
         buf = torch.empty(B * n + 8, 3 * C, dtype=dt, device=x.device)
-        buf[B * n:].zero_()
+        ops.zero_(buf[B * n:])
         ops.gemm(hn.view(B * n, C), wqkv, bias=bqkv, out=buf[:B * n])
         win = lambda col, rows: torch.as_strided(buf, (B, rows, C), (n * 3 * C, 3 * C, 1), col * C)
         q, k, v = win(0, n), win(1, npad), win(2, kp)
@@ -263,7 +295,7 @@ class AttnBlock(nn.Module):
 
     def forward(self, x):
         _require_cuda(x)
-        return _as_nchw(self._nhwc(ops.to_nhwc(x, _cdtype(self))))
+        return _inference_only(self, "AttnBlock.forward", _as_nchw(self._nhwc(ops.to_nhwc(x, _cdtype(self)))), x)
 
 
 class Encoder(nn.Module):
@@ -337,7 +369,7 @@ class Encoder(nn.Module):
 
     def forward(self, x):
         _require_cuda(x)
-        return _as_nchw(self._nhwc(x))
+        return _inference_only(self, "Encoder.forward", _as_nchw(self._nhwc(x)), x)
 
 
 class Decoder(nn.Module):
@@ -414,7 +446,7 @@ class Decoder(nn.Module):
 
     def forward(self, z):
         _require_cuda(z)
-        return _as_nchw(self._nhwc(z))
+        return _inference_only(self, "Decoder.forward", _as_nchw(self._nhwc(z)), z)
 
 
 # ------------------------------------------------------------------------------ discriminator (checkpoint ABI only)
@@ -518,7 +550,7 @@ class LitVQVAE(_LitBase):
         codebook kernel wants)."""
         _require_cuda(x)
         h = self._encoder._nhwc(x)
-        return _as_nchw(_conv(self.quant_conv, h))
+        return _inference_only(self, "LitVQVAE.encode", _as_nchw(_conv(self.quant_conv, h)), x)
 
     def decode(self, quant):
         """reference :610-614."""
@@ -528,7 +560,7 @@ class LitVQVAE(_LitBase):
             return torch.cat([self.decode(quant[a:b]) for a, b in ck], 0)
         dt = _cdtype(self._decoder)
         q = _conv(self.post_quant_conv, ops.to_nhwc(quant, dt))
-        return _as_nchw(self._decoder._nhwc(_as_nchw(q)))
+        return _inference_only(self, "LitVQVAE.decode", _as_nchw(self._decoder._nhwc(_as_nchw(q))), quant)
 
     @torch.no_grad()
     def encode_to_codes(self, x, fused=None):

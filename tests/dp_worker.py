@@ -44,21 +44,32 @@ def main():
     n = next(iter(batch.values())).shape[0] // world
     local = {k: v[rank * n:(rank + 1) * n] for k, v in batch.items()}
     if os.environ.get("DP_MISMATCH") == "1":
-        # rank 1 ends its backward with one parameter (outside the Blocks) WITHOUT a gradient, rank 0 with all of them:
-        # finish() must refuse on both ranks (the sets are compared through an all-reduced bitmask)
-        loss = loss_fn(model, local)
-        loss.backward()
-        if rank == 1:
-            victim = [p for nm, p in model.named_parameters() if nm.endswith("pos_emb") or nm.endswith("head.weight")][0]
-            victim.grad = None
-        refused = False
-        try:
-            dp.finish()
-        except RuntimeError as e:
-            refused = "disagree on which parameters received a gradient" in str(e)
+        # at step DP_MISMATCH_STEP rank 1 ends its backward with one parameter (outside the Blocks) WITHOUT a gradient,
+        # rank 0 with all of them: finish() must refuse on BOTH ranks at the SAME step - that very step when it is the
+        # first (checked synchronously), exactly one step later otherwise (the verdict rides a pinned flag one step old);
+        # no host synchronisation between the steps, as in the training loop
+        at = int(os.environ.get("DP_MISMATCH_STEP", "1"))
+        refused_at = None
+        for step in range(1, at + 3):
+            for p in model.parameters():
+                p.grad = None
+            dp.fp.zero_grad()
+            loss = loss_fn(model, local)
+            loss.backward()
+            if rank == 1 and step == at:
+                victim = [p for nm, p in model.named_parameters() if nm.endswith("pos_emb") or nm.endswith("head.weight")][0]
+                victim.grad = None
+            try:
+                dp.finish()
+            except RuntimeError as e:
+                if "disagree on which parameters received a gradient" in str(e):
+                    refused_at = step
+                    break
+                raise
         torch.cuda.synchronize()
         dist.barrier()
-        torch.save({"refused": refused}, os.path.join(outdir, f"rank{rank}_mismatch.pt"))
+        torch.save({"refused": refused_at is not None, "refused_at": refused_at},
+                   os.path.join(outdir, f"rank{rank}_mismatch.pt"))
         dist.destroy_process_group()
         return
     loss = loss_fn(model, local)

@@ -147,17 +147,21 @@ def test_bench_e2e_self_launches_two_ranks_clips_sharded_no_collective():
     assert o["clip_ids_by_rank"] == [[0, 0], [1, 1]]
 
 
-def test_ranks_that_disagree_on_which_parameters_got_a_gradient_are_refused(tmp_path):
-    """One rank feeds the class token, the other does not (its class embedder gets no gradient): torch's DDP - the
-    reference - raises; here finish() raises on both ranks instead of letting the replicas diverge."""
+@pytest.mark.parametrize("at", [1, 3])
+def test_ranks_that_disagree_on_which_parameters_got_a_gradient_are_refused(tmp_path, at):
+    """One rank ends step `at` with a parameter that got no gradient, the other with all of them: torch's DDP - the
+    reference - raises; here finish() raises on BOTH ranks at the SAME step instead of letting the replicas diverge - step
+    1 is checked synchronously, a later step's verdict is read (waited for, not polled) at the next finish(), so a
+    mismatch that first appears at step 3 is refused at step 4 on every rank even when the host runs a step ahead."""
     world, port = 2, _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", DP_MISMATCH="1")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", DP_MISMATCH="1", DP_MISMATCH_STEP=str(at))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), "gptclass", str(tmp_path)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     for rnk in range(world):
-        assert torch.load(os.path.join(str(tmp_path), f"rank{rnk}_mismatch.pt"))["refused"]
+        o = torch.load(os.path.join(str(tmp_path), f"rank{rnk}_mismatch.pt"))
+        assert o["refused"] and o["refused_at"] == (1 if at == 1 else at + 1), o

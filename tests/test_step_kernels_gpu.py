@@ -1,0 +1,90 @@
+"""bench.py says "every tensor op is a hand-written HIP kernel": checked here for one training step of the metric's
+workload (bench.ClassGPTStep.step = VQ-encode + class-GPT forward / backward + fused AdamW).  Two independent views:
+(1) every aten operator dispatched during the step (forward, the autograd engine's backward thread, the optimizer) must be
+metadata-only - views, allocations, zero-sized tensors; (2) when the profiler can see device activity on this box, no
+kernel named at::native::* (torch's eager kernels), __amd_rocclr_* (runtime copy / fill blits) or a BLAS / MIOpen kernel
+ran on the device."""
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+# aten operators that launch nothing: views / metadata / allocation
+_META = {"view", "_unsafe_view", "reshape", "slice", "select", "as_strided", "permute", "transpose", "t", "unsqueeze",
+         "squeeze", "expand", "detach", "alias", "empty", "empty_like", "empty_strided", "new_empty", "new_empty_strided",
+         "unbind", "split", "split_with_sizes", "chunk", "narrow", "flatten", "unflatten", "view_as", "_reshape_alias",
+         "size", "stride", "is_contiguous", "numel", "storage_offset", "sym_size", "sym_stride", "sym_numel", "dim",
+         "lift_fresh", "_local_scalar_dense", "is_same_size", "result_type", "contiguous", "_to_copy", "to"}
+
+
+def _job(layers=2, batch=16):
+    import bench
+
+    a = SimpleNamespace(layers=layers, batch=batch, grad_dtype="f32")
+    return bench.ClassGPTStep(a, torch.device("cuda", 0), torch.bfloat16, 0, 1)
+
+
+def test_no_framework_kernel_runs_inside_the_training_step():
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    job = _job()
+    for _ in range(2):                       # warm-up: lazily built caches (packed weights, codebook image, graphs)
+        job.step(time.perf_counter)
+    torch.cuda.synchronize()
+
+    seen = []
+
+    class Census(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            out = func(*args, **(kwargs or {}))
+            name = func.overloadpacket.__name__
+            if name not in _META:
+                outs = out if isinstance(out, (tuple, list)) else (out,)
+                big = [o for o in outs if isinstance(o, torch.Tensor) and o.is_cuda and o.numel() > 0]
+                ins = [x for x in args if isinstance(x, torch.Tensor) and x.is_cuda and x.numel() > 0]
+                if big or ins:
+                    seen.append((name, [tuple(o.shape) for o in big] or [tuple(x.shape) for x in ins]))
+            elif name in ("contiguous", "_to_copy", "to"):
+                # allowed only as no-ops (already contiguous / same dtype and device): a real copy is an eager kernel
+                src = args[0]
+                if isinstance(out, torch.Tensor) and isinstance(src, torch.Tensor) and out.numel() > 0 and \
+                        out.data_ptr() != src.data_ptr():
+                    seen.append((name + " (copies)", [tuple(out.shape)]))
+            return out
+
+    with Census():
+        loss, _ = job.step(time.perf_counter)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss.detach()).all()
+    assert not seen, f"aten operators with device work inside ClassGPTStep.step: {seen[:20]} ({len(seen)} in all)"
+
+
+def test_device_trace_of_a_step_names_only_this_librarys_kernels():
+    from torch.profiler import ProfilerActivity, profile
+
+    job = _job()
+    for _ in range(2):
+        job.step(time.perf_counter)
+    torch.cuda.synchronize()
+    try:
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            job.step(time.perf_counter)
+            torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001 - a box without the tracer library: the census above is the check
+        pytest.skip(f"device tracing not available here: {type(e).__name__}: {e}")
+    names = [e.name for e in prof.events() if str(getattr(e, "device_type", "")).endswith("CUDA")]
+    if not names:
+        pytest.skip("the profiler recorded no device activity on this box (tracer unavailable): census test covers it")
+    foreign = sorted({n for n in names if any(s in n for s in ("at::native", "__amd_rocclr", "Cijk_", "rocblas", "miopen",
+                                                               "MIOpen", "hipblas", "ck::", "triton"))})
+    assert not foreign, f"framework / runtime / vendor-library kernels inside the step: {foreign}"
+    assert any("gemm8p_kernel" in n or "gemm256_kernel" in n for n in names), names[:10]

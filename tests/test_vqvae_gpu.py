@@ -102,7 +102,7 @@ def test_attn_block_vs_oracle(dt):
     y = blk(x.to(DEV))
     assert y.shape == (2, C, 5, 53)
     ref = ovq.attn_block({("a." + k): t(v) for k, v in sd.items()}, "a", x)
-    assert rel_err(y.float().cpu().numpy(), ref.numpy()) < (1e-5 if dt == "f32" else 2e-2)
+    assert rel_err(y.detach().float().cpu().numpy(), ref.numpy()) < (1e-5 if dt == "f32" else 2e-2)   # (as the reference's: requires grad)
 
 
 def test_narrow_encoder_decoder_vs_reference_golden():
@@ -359,3 +359,36 @@ def test_extract_codes_writes_reference_named_files(tmp_path):
         c = np.load(os.path.join(root, cls, "codes_10s", f"video_{i:05d}_mel_code.npy"))
         assert c.shape == (5, 53) and c.dtype == np.int64 and np.array_equal(c, ref[i])
     assert extract_all(root, m, DEV, 848) == []         # nothing left to do
+
+
+def test_backward_through_the_inference_only_vqvae_is_refused_not_silently_empty():
+    """The reference's LitVQVAE.forward is differentiable end to end (big_model_attn_gan.py:622-634); here the encoder /
+    decoder kernels are forward-only (VQ-VAE training is out of scope).  Recording autograd through them must not end in
+    silently missing gradients: `.backward()` raises MelgptError.  Forward-only use with autograd on - what
+    feature_extraction/extract_codes.py:48-49 does - keeps working and gives the no_grad bits."""
+    from melspec_gpt_vqvae_amd import _ffi
+    from melspec_gpt_vqvae_amd.vqvae.big_model_attn_gan import LitVQVAE
+
+    g = golden("vqvae_full")
+    m = LitVQVAE(num_embeddings=128, embedding_dim=256)
+    _load(m, synth.vqvae_state_dict(int(g["seed"])), allow_missing_prefix="discriminator.")
+    m.to(DEV).train()
+    x = t(g["x"][:1], DEV)
+    with torch.no_grad():
+        z0 = m.encode(x)
+    z = m.encode(x)                                  # autograd on, parameters require a gradient: forward is fine
+    assert z.requires_grad and torch.equal(z.detach(), z0)
+    loss, x_recon, info = m(x)
+    assert x_recon.shape == x.shape and x_recon.requires_grad and loss.requires_grad
+    with pytest.raises(_ffi.MelgptError, match="not implemented"):
+        (loss + x_recon.float().mean()).backward()
+    with pytest.raises(_ffi.MelgptError, match="LitVQVAE.decode"):
+        m.decode(z0.clone().requires_grad_(True)).float().sum().backward()
+    # a frozen module fed a plain input records nothing, and the quantiser alone stays differentiable (its own kernel)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    assert not m.encode(x).requires_grad
+    zl = z0.clone().requires_grad_(True)
+    l2, q, _ = m._vq_vae(zl)
+    (l2 + q.float().sum()).backward()
+    assert zl.grad is not None and torch.isfinite(zl.grad.float()).all()

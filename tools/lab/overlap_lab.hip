@@ -50,6 +50,7 @@ static int gemm(const void* A, int ak, long long lda, const void* B, int bk, lon
 // (g_ns = split-K batches of the weight gradients: 4 x 64 tiles fill 256 CUs exactly once - and take two rounds on 240 -,
 // 5 x 64 = 320 tiles are 1.25 / 1.33 rounds; ops._wgrad_split picks by the workgroups a launch gets.  0 = dgrads only.)
 static int g_ns = 4;
+static int g_wg_res = 0;  // CUs reserved around the WEIGHT-GRADIENT launches only (the single-round launches are the ones that stall)
 static void chain(const Bufs& b, hipStream_t s, int reps) {
   const int M = 33920, C = 1024, F = 4096, ns = g_ns;
   for (int r = 0; r < reps; ++r) {
@@ -57,10 +58,12 @@ static void chain(const Bufs& b, hipStream_t s, int reps) {
     st |= gemm(b.g1, 0, C, b.w2, 1, F, b.g4, F, M, F, C, 1, 0, 0, 0, 0, s);                       // dY(M,C) @ W2(C,F) -> (M,F)
     st |= gemm(b.g4, 0, F, b.w1, 1, C, b.g1, C, M, C, F, 1, 0, 0, 0, 0, s);                       // (M,F) @ W1(F,C) -> (M,C)
     if (ns > 0) {
+      if (g_wg_res) melgpt_set_reserved_cus(g_wg_res);
       st |= gemm(b.g4, 1, F, b.x, 1, C, b.dw1, C, F, C, M / ns, ns, (long long)(M / ns) * F, (long long)(M / ns) * C,
                  (long long)F * C, 1, s);                                                        // dW1 parts (ns,F,C)
       st |= gemm(b.g1, 1, C, b.y4, 1, F, b.dw2, F, C, F, M / ns, ns, (long long)(M / ns) * C, (long long)(M / ns) * F,
                  (long long)C * F, 1, s);                                                        // dW2 parts (ns,C,F)
+      if (g_wg_res) melgpt_set_reserved_cus(0);
     }
     if (st) { printf("melgpt_gemm failed: %d\n", st); exit(1); }
   }
@@ -89,12 +92,24 @@ int main(int argc, char** argv) {
   hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
   hipEvent_t e0, e1, c0, c1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&c0)); CK(hipEventCreate(&c1));
 
-  struct Mode { const char* name; int dyn, reserve; } modes[] = {{"static lists", 0, 0}, {"claimed tiles", 1, 0}, {"16 reserved CUs", 0, 16}, {"claimed + 16 reserved", 1, 16}};
+  // (round 5: the ping-pong K loop walks static lists only - claimed tiles mean the ring kernel - so the question is now
+  // "ping-pong + static lists (+ reserved CUs) against ring + claimed tiles"; ns_for[] = the weight gradients' split-K
+  // batches ops._wgrad_split picks for the workgroups such a launch gets: 4 on 256, 5 on 248 / 240 CUs)
+  struct Mode { const char* name; int pp, dyn, reserve, wg_res; } modes[] = {
+      {"pingpong, static lists", 1, 0, 0, 0},        {"pingpong, static, 8 reserved CUs", 1, 0, 8, 0},
+      {"pingpong, static, 16 reserved CUs", 1, 0, 16, 0}, {"pingpong, static, 32 reserved CUs", 1, 0, 32, 0},
+      {"pingpong, static, 16 reserved for wgrads only", 1, 0, 0, 16}, {"pingpong, static, 32 reserved for wgrads only", 1, 0, 0, 32},
+      {"ring, claimed tiles", 0, 1, 0, 0},           {"ring, claimed + 16 reserved", 0, 1, 16, 0},
+      {"ring, static lists", 0, 0, 0, 0}};
+  const int ns_arg = g_ns;
   printf("{\"bench\": \"backward MLP GEMM chain (2 dgrads%s) x %d beside a stand-in collective of %d channels x 256 threads over 50 MB\", \"wgrad_batches\": %d, \"rows\": [\n", g_ns ? " + 2 wgrads" : "", REPS, G, g_ns);
   for (int round = 0; round < 2; ++round)
     for (auto& m : modes) {
+      melgpt_set_gemm_pingpong(m.pp);
       melgpt_set_dynamic_tiles(m.dyn);
       melgpt_set_reserved_cus(m.reserve);
+      g_wg_res = m.wg_res;
+      if (ns_arg < 0) g_ns = (m.reserve || m.wg_res) ? 5 : 4;   // (-1: the split the host picks for the grid the launch gets)
       chain(b, sa, 2);
       CK(hipStreamSynchronize(sa));
       float alone, beside, coll;
@@ -109,11 +124,12 @@ int main(int argc, char** argv) {
       *stop = 1;
       CK(hipStreamSynchronize(sb));
       CK(hipEventElapsedTime(&beside, e0, e1)); CK(hipEventElapsedTime(&coll, c0, c1));
-      printf("  {\"mode\": \"%s\", \"round\": %d, \"chain_alone_ms\": %.3f, \"chain_beside_collective_ms\": %.3f, \"ratio\": %.3f, \"collective_resident_ms\": %.2f},\n",
-             m.name, round, alone / REPS, beside / REPS, beside / alone, coll);
+      printf("  {\"mode\": \"%s\", \"wgrad_batches\": %d, \"round\": %d, \"chain_alone_ms\": %.3f, \"chain_beside_collective_ms\": %.3f, \"ratio\": %.3f, \"collective_resident_ms\": %.2f},\n",
+             m.name, g_ns, round, alone / REPS, beside / REPS, beside / alone, coll);
     }
   melgpt_set_dynamic_tiles(0);
   melgpt_set_reserved_cus(0);
+  melgpt_set_gemm_pingpong(1);
   printf("  {}]}\n");
   return 0;
 }
