@@ -472,6 +472,9 @@ def main():
         if share:
             dist.init_process_group("gloo")
         else:
+            from melspec_gpt_vqvae_amd.dp import pin_rccl_channels
+
+            pin_rccl_channels()      # a small, KNOWN RCCL footprint; DataParallel reserves that many CUs (dp.py)
             dist.init_process_group("nccl", device_id=device)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 

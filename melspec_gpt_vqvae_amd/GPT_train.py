@@ -114,6 +114,10 @@ def init_distributed(args):
         args.device = "cpu"
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.cuda:
+            from .dp import pin_rccl_channels
+
+            pin_rccl_channels()
         dist.init_process_group("nccl" if args.cuda else "gloo")
     return world
 

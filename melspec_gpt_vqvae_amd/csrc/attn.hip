@@ -155,9 +155,10 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 // Both tiles of a workgroup staged with every global load in flight at once (a load -> store loop pays the memory
 // latency once per iteration: 20 of the forward's 118 us at the training shape).
-template <typename T, bool SWZ0, bool SWZ1>
+template <typename T, bool SWZ0, bool SWZ1, int NTH = 512>
 __device__ __forceinline__ void load_tiles(char* t0, const T* b0, long long ld0, char* t1, const T* b1, long long ld1,
                                            int nvalid, int nfill, int t) {
+  constexpr int NTHREADS = NTH;
   constexpr int CP = AT<T>::CP, VEC = AT<T>::VEC, NIT = (MAXT * CP + NTHREADS - 1) / NTHREADS;
   u32x4 v0[NIT], v1[NIT];
 #pragma unroll
@@ -640,6 +641,186 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_dkv_ker
  }  // tile loop
 }
 
+// ====================================================================== forward on 32-row query tiles (16-bit lane)
+// The structure DESIGN section 4 specified in round 2 (built in round 5): v_mfma_f32_32x32x16, a wave owns a 32-query tile
+// and keeps the WHOLE row of logits in registers (9 key tiles x 16 accumulator registers at T <= 288), so there is no
+// pass 1 and nothing is recomputed: S^T = K Q^T (4 MFMAs per 32 x 32 block, the query on the lane), row maximum in
+// registers (v_max3 + ONE cross-half exchange), e = 2^(s c - m c), row sum, dropout, and the converted accumulators ARE the
+// B operand of O^T = V^T P^T (guide: "an accumulator tile as the next MFMA's operand" - element j of lane half hh of k-step s
+// is key 16 s + 8 (j >> 2) + 4 hh + (j & 3) of the tile, so V^T's fragment takes its two 4-key blocks 8 keys apart, by
+// ds_read_b64_tr_b16 from the same swizzled V image the 16-row kernel uses).  Against the 16-row kernel per 1 024
+// probabilities: 8 MFMAs of 32 issue-blocking cycles instead of 24 of 16 (no recompute), half the K / V^T fragment bytes
+// from LDS, and half the per-tile fixed cost (9 tiles instead of 17: Q fetch, exchanges, 1 / l, lse, stores).
+// 256 threads = 4 waves = one (batch, head); two workgroups per CU (2 x 72 KB of LDS, 256 registers per lane).
+// The dropout masks are the SAME bits as everywhere else (header): a lane's keys of a 32-key tile are 8 j + 4 hh + r,
+// i.e. gk = 2 (j & 1) + hh of 16-key tile 2 kt + (j >> 1): p = 1/2 takes two hash words per 128 keys, all 32 bits of each used.
+template <int DM>
+__global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnParams p) {
+  using T = bf16_t;
+  constexpr int MAXKT32 = MAXT / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, r32 = lane & 31, hh = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z, Tn = p.T, nu = p.n_unmasked;
+  const int TP = rup(Tn, 32);
+  char* Kt = smem;
+  char* Vt = smem + (size_t)TP * 128;
+  int* ctr = (int*)(smem + 2 * (size_t)TP * 128);
+  const T* Kg = (const T*)p.K + (long long)b * Tn * p.ld + h * HS;
+  const T* Vg = (const T*)p.V + (long long)b * Tn * p.ld + h * HS;
+  load_tiles<T, false, true, 256>(Kt, Kg, p.ld, Vt, Vg, p.ld, Tn, TP, t);
+  if (t == 0) *ctr = 0;
+  __syncthreads();
+  const long long bh = (long long)b * p.H + h;
+  const int ntiles = (Tn + 31) / 32;
+  const float c2 = p.scale * LOG2E;
+  const float dsc = DM != DM_NONE ? p.drop_scale : 1.f;
+  const DropKeys dkeys = drop_keys(p.seed, p.stream_id, (unsigned)bh, p.drop_thresh);
+  // this lane's addresses inside a 32-key tile: K rows by ds_read_b128 (row r32, chunk 2 ks + hh), V^T by transposed reads
+  // (16-lane group: row q4 of the 4-key block, 4 columns from 16 g1 + 4 p4 of the 32-column block db)
+  const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+
+  auto grab = [&]() {
+    int j = 0;
+    if (lane == 0) j = atomicAdd(ctr, 1);
+    return __builtin_amdgcn_readfirstlane(j);
+  };
+  auto fetch = [&](int job, u32x4 (&qf)[4]) {
+    const int qc = min(32 * (ntiles - 1 - job) + r32, Tn - 1);
+    const T* qp = (const T*)p.Q + ((long long)b * Tn + qc) * p.ld + h * HS;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const u32x4*)(qp + 16 * ks + 8 * hh);   // B[k = 8 hh + j][query]: d = 16 ks + 8 hh + j
+  };
+
+  int job = grab();
+  u32x4 qf[4];
+  fetch(min(job, ntiles - 1), qf);
+  while (job < ntiles) {
+    const int q0 = 32 * (ntiles - 1 - job);
+    const int q = q0 + r32, qc = min(q, Tn - 1);
+    const int lim = vis_keys(qc, Tn, nu) - 4 * hh;                        // key 32 kt + 8 j + 4 hh + r visible <=> 32 kt + 8 j + r < lim
+    const int nkt = (vis_keys(min(q0 + 31, Tn - 1), Tn, nu) + 31) / 32;   // key tiles any row of the tile sees (wave-uniform)
+    const int nfull = vis_keys(q0, Tn, nu) / 32;                          // key tiles every row sees whole
+
+    // ---- S^T tiles: keys on the accumulator rows, the query on the lane
+    f32x16 S[MAXKT32];
+#pragma unroll
+    for (int kt = 0; kt < MAXKT32; ++kt) {
+      if (kt < nkt) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const u32x4 kf = *(const u32x4*)(Kt + offK<T>(32 * kt + r32, 2 * ks + hh));
+          acc = MELGPT_MFMA_32x32x16(kf, qf[ks], acc);
+        }
+        if (kt >= nfull) {
+          const int lk = lim - 32 * kt;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[i] = (8 * (i >> 2) + (i & 3) < lk) ? acc[i] : -__builtin_inff();
+        }
+        S[kt] = acc;
+      }
+    }
+    // the logits are in registers and the Q fragments dead: the NEXT tile's rows are requested into them now and land
+    // under the softmax / P V phase (a second register set for them spilled)
+    const int njob = grab();
+    fetch(min(njob, ntiles - 1), qf);
+    // ---- row maximum (every query sees key 0: never -inf)
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int kt = 0; kt < MAXKT32; ++kt) {
+      if (kt < nkt) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2)   // (asm: fmaxf on MFMA results makes hipcc canonicalise every operand with a v_max of its own)
+          asm("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(S[kt][i]), "v"(S[kt][i + 1]));
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float mc = m * c2;
+    // p = 1/2: hash word a of key block kb (128 keys, drawn when the loop below enters it) serves keys
+    // 128 kb + 16 tt + 4 (2 a + hh) + r, bit 4 tt + r
+    int hw[2] = {0, 0};
+    const unsigned ch = (unsigned)q * 16u + 4u * (unsigned)hh + dkeys.k0;
+    // ---- e = 2^(s c - m c), row sum, dropout, O^T += V^T e
+    f32x16 o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+    float ls[4] = {0.f, 0.f, 0.f, 0.f};   // four partial row sums (independent chains)
+#pragma unroll
+    for (int kt = 0; kt < MAXKT32; ++kt) {
+      if (kt < nkt) {
+        if constexpr (DM == DM_HALF) {
+          if ((kt & 3) == 0) {
+            hw[0] = (int)hash32(ch + (unsigned)(kt >> 2));
+            hw[1] = (int)hash32(ch + 8u + (unsigned)(kt >> 2));
+          }
+        }
+        float e[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kt][i], c2, -mc));
+          asm("v_add_f32 %0, %0, %1" : "+v"(ls[i & 3]) : "v"(e[i]));   // (asm: hipcc SLP-packs plain adds into v_pk_add_f32, slower beside MFMAs)
+        }
+        if constexpr (DM == DM_HALF) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int j = i >> 2, r = i & 3;
+            // keep-mask = the hash bit sign-extended (asm: written with the builtin, hipcc turns sbfe + and into and + cmp + cndmask)
+            unsigned km;
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(km) : "v"(hw[j & 1]), "n"(8 * (kt & 3) + 4 * (j >> 1) + r));
+            e[i] = __uint_as_float(__float_as_uint(e[i]) & km);
+          }
+        } else if constexpr (DM == DM_ANY) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            bool keep[4];
+            drop_keep4(dkeys, (unsigned)q * 128u + (unsigned)(8 * kt + 2 * j + hh), keep);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[4 * j + r] = keep[r] ? e[4 * j + r] : 0.f;
+          }
+        }
+        u32x4 pb[2];
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx)
+          pb[sx] = u32x4{pack_bf16x2(e[8 * sx + 0], e[8 * sx + 1]), pack_bf16x2(e[8 * sx + 2], e[8 * sx + 3]),
+                         pack_bf16x2(e[8 * sx + 4], e[8 * sx + 5]), pack_bf16x2(e[8 * sx + 6], e[8 * sx + 7])};
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            // A[row d = 32 db + r32][k = 8 hh + j] = V[key 32 kt + 16 sx + 8 (j >> 2) + 4 hh + (j & 3)][d]
+            const int row = 32 * kt + 16 * sx + 4 * hh + q4, c = 4 * db + 2 * g1 + (p4 >> 1);
+            const char* a0 = Vt + offV<T>(row, c) + 8 * (p4 & 1);
+            const char* a1 = Vt + offV<T>(row + 8, c) + 8 * (p4 & 1);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a0));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
+            const s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            o[db] = MELGPT_MFMA_32x32x16(__builtin_bit_cast(u32x4, f), pb[sx], o[db]);
+          }
+        }
+      }
+    }
+    const float lsum = (ls[0] + ls[1]) + (ls[2] + ls[3]);
+    const float l = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / l;
+    const float oscale = inv * dsc;
+    if (q < Tn) {
+      if (hh == 0) p.lse[bh * Tn + q] = m * p.scale + __logf(l);
+      T* op = (T*)p.O + ((long long)b * Tn + q) * p.ldo + h * HS;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)   // registers 4 jj .. 4 jj + 3: d = 32 db + 8 jj + 4 hh + 0..3
+          store4<T>(op + 32 * db + 8 * jj + 4 * hh,
+                    f32x4{o[db][4 * jj], o[db][4 * jj + 1], o[db][4 * jj + 2], o[db][4 * jj + 3]} * oscale);
+    }
+    job = njob;
+  }
+}
+
 #ifndef ATTN_LAB_LDSPAD
 #define ATTN_LAB_LDSPAD 0  // lab: extra dynamic LDS per workgroup (90000 forces ONE workgroup per CU: what a persistent
 #endif                     // workgroup with double-buffered K/V would run at - profiles/r03_attn_lab.md)
@@ -697,6 +878,18 @@ int launch_dkv(const AttnParams& p, hipStream_t s) {
   hipLaunchKernelGGL((attn_dkv_kernel<T, DM>), dim3(1, p.H, p.B), dim3(NTHREADS), lds_bytes<T>(p.T, true), s, p);
   return MELGPT_OK;
 }
+template <int DM>
+int launch_fwd32(const AttnParams& p, hipStream_t s) {
+  const size_t lds = 2 * (size_t)((p.T + 31) / 32 * 32) * 128 + 16;
+  static bool attr = false;
+  if (!attr) {
+    if (set_lds(attn_fwd32_kernel<DM>, 2 * (size_t)MAXT * 128 + 16) != MELGPT_OK) return MELGPT_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL((attn_fwd32_kernel<DM>), dim3(1, p.H, p.B), dim3(256), lds, s, p);
+  return MELGPT_OK;
+}
+
 template <typename T, bool BWD>
 int launch_q_mode(const AttnParams& p, hipStream_t s) {
   switch (drop_mode(p)) {
@@ -1048,6 +1241,13 @@ int launch_bwd1(const AttnParams& p, hipStream_t s) {
 
 }  // namespace
 
+static int g_fwd32 = -1;
+extern "C" int melgpt_set_attn_fwd32(int on) {
+  const int prev = g_fwd32 != 0;
+  g_fwd32 = on != 0;
+  return prev;
+}
+
 extern "C" int melgpt_attn_fwd(const void* q, const void* k, const void* v, long long ld, void* out, long long ldo,
                                float* lse, float* att, int B, int H, int T, int head_size, int n_unmasked,
                                float drop_p, unsigned long long seed, unsigned stream_id, int dtype, void* stream) {
@@ -1062,6 +1262,20 @@ extern "C" int melgpt_attn_fwd(const void* q, const void* k, const void* v, long
   MELGPT_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0, MELGPT_ERR_ALIGN);
   set_dropout(p, drop_p, seed, stream_id);
   hipStream_t s = (hipStream_t)stream;
+  // 16-bit lane without the attention map: 32-row query tiles (attn_fwd32_kernel); MELGPT_ATTN_FWD32=0 /
+  // melgpt_set_attn_fwd32(0) keep the 16-row kernel (which also serves the f32 parity lane and the `att` output)
+  if (g_fwd32 < 0) {
+    const char* e = getenv("MELGPT_ATTN_FWD32");
+    g_fwd32 = e ? atoi(e) != 0 : 1;
+  }
+  if (ATTN_LAB == 0 && g_fwd32 && dtype == MELGPT_BF16 && !att) {
+    switch (drop_mode(p)) {
+      case DM_NONE: st = launch_fwd32<DM_NONE>(p, s); break;
+      case DM_HALF: st = launch_fwd32<DM_HALF>(p, s); break;
+      default: st = launch_fwd32<DM_ANY>(p, s); break;
+    }
+    return st != MELGPT_OK ? st : melgpt_launch_status();
+  }
   st = dtype == MELGPT_F32 ? launch_q_mode<float, false>(p, s) : launch_q_mode<bf16_t, false>(p, s);
   return st != MELGPT_OK ? st : melgpt_launch_status();
 }

@@ -21,6 +21,37 @@ import torch
 import torch.distributed as dist
 
 
+RCCL_CHANNELS_DEFAULT = 16
+
+
+def pin_rccl_channels(n=None):
+    """Bound RCCL's footprint BEFORE the process group is created: NCCL_MAX_NCHANNELS = n (one persistent workgroup = one
+    CU per channel).  Call from every rank before dist.init_process_group("nccl").  Why: the persistent GEMM / conv grids own
+    one CU per workgroup and walk static tile lists, so a CU held by an all-reduce kernel costs the launch beside it one
+    workgroup's WHOLE list (stand-in collective, tools/lab/overlap_lab.hip, profiles/r05_overlap_lab_*.jsonl: the backward
+    MLP chain of a Block 0.96 -> 1.35-1.43 ms beside 16 or 32 channels with static lists - claimed tiles on the ring loop
+    are no better, 1.42 - but 0.99 -> 1.06 when as many CUs are RESERVED as the collective has channels, and 1.73 when it
+    has twice as many).  The exchange needs little bandwidth (1.2 GB per ~60 ms backward pass for the class-GPT, 8.4 GB per
+    ~300 ms for GPT-VAE XL: < 60 GB/s of bus bandwidth), so a small, KNOWN channel count + the same number of reserved CUs
+    is the robust pairing.  n = None: MELGPT_RCCL_CHANNELS, else 16; 0: leave RCCL alone (DataParallel then reserves nothing
+    unless MELGPT_RESERVE_CUS says so).  A value the user already exported (NCCL_MAX_NCHANNELS) is respected.  -> the pin."""
+    if n is None:
+        n = int(os.environ.get("MELGPT_RCCL_CHANNELS", str(RCCL_CHANNELS_DEFAULT)))
+    if n > 0:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(n))
+        if int(os.environ.get("NCCL_MIN_NCHANNELS", "1")) > int(os.environ["NCCL_MAX_NCHANNELS"]):
+            os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"]
+    return pinned_rccl_channels()
+
+
+def pinned_rccl_channels():
+    """the channel bound RCCL was started under (NCCL_MAX_NCHANNELS), 0 = unknown / unbounded"""
+    try:
+        return max(0, int(os.environ.get("NCCL_MAX_NCHANNELS", "0")))
+    except ValueError:
+        return 0
+
+
 def _convert(src, dst):
     """dtype-converting copy dst <- src: the library's cast kernel on the GPU, a torch copy on the CPU rig of the tests."""
     if src.is_cuda:
@@ -192,19 +223,24 @@ class DataParallel:
         self.world = self.ex.world
         self.overlap = bool(overlap)
         # The persistent GEMM / conv kernels own one CU per workgroup for a whole launch; an RCCL kernel that holds a CU
-        # when such a launch starts would leave one workgroup waiting for another one's ENTIRE static tile list.  While an
-        # (overlapped) all-reduce can be in flight - from the first Block's early launch to finish() - the persistent GEMM
-        # therefore draws its tiles from counters (`dynamic_tiles`, csrc/gemm256.hip: whoever has a CU takes the next tile;
-        # default when the exchange really runs over RCCL), and/or leaves `reserve_cus` CUs free (default 0:
-        # reserving 16 of 256 costs the weight-gradient GEMMs, whose 256 tiles are one round on 256 CUs, a second round).
+        # when such a launch starts leaves one workgroup waiting for another one's ENTIRE static tile list.  While an
+        # (overlapped) all-reduce can be in flight - from the first Block's early launch to finish() - the persistent grids
+        # therefore leave `reserve_cus` CUs to RCCL: by default as many as RCCL has channels WHEN THAT IS KNOWN
+        # (pin_rccl_channels(): NCCL_MAX_NCHANNELS, rounded up to a multiple of 8 - the grids are XCD-blocked), else none.
+        # Round 5 (profiles/r05_overlap_lab_*.jsonl): beside a stand-in collective the ping-pong K loop on STATIC lists
+        # (1.35-1.43 ms per backward MLP chain) is never slower than the ring loop drawing CLAIMED tiles (1.42-1.46), and
+        # faster alone (0.94-0.96 against 0.96-1.07) - so claimed tiles (`dynamic_tiles`, csrc/gemm256.hip: whoever has a
+        # CU takes the next tile; they force the ring loop) are OFF by default now and the data-parallel backward runs the
+        # same ping-pong GEMM as a single GPU; a reservation that matches the channel count brings the chain to 1.06.
         # MELGPT_DP_DYNAMIC_TILES / MELGPT_RESERVE_CUS override.  The forward pass, the head's and the last Block's
-        # backward and the optimizer run on the whole chip with static lists.
+        # backward and the optimizer run on the whole chip.
         active = self.ex.active
         on_rccl = active and self.overlap and dist.get_backend(group) == "nccl"
         if reserve_cus is None:
-            reserve_cus = int(os.environ.get("MELGPT_RESERVE_CUS", "0"))
+            ch = pinned_rccl_channels() if on_rccl else 0
+            reserve_cus = int(os.environ.get("MELGPT_RESERVE_CUS", str((ch + 7) // 8 * 8 if 0 < ch <= 64 else 0)))
         if dynamic_tiles is None:
-            dynamic_tiles = int(os.environ.get("MELGPT_DP_DYNAMIC_TILES", "1" if on_rccl else "0")) != 0
+            dynamic_tiles = int(os.environ.get("MELGPT_DP_DYNAMIC_TILES", "0")) != 0
         self.reserve_cus = int(reserve_cus)
         self.dynamic_tiles = bool(dynamic_tiles)
         self._reserved = False
@@ -295,6 +331,7 @@ class DataParallel:
         """what a bench line needs to explain a scaling record: the exchange's size and the two persistent-kernel switches"""
         return {"exchange_bytes": int(self.ex.bytes_per_step), "exchange_dtype": str(self.ex.wire_dtype or torch.float32)[6:],
                 "dp_tiles": "claimed" if self.dynamic_tiles else "static", "reserved_cus": int(self.reserve_cus),
+                "rccl_channels_pinned": pinned_rccl_channels(),
                 "overlap": bool(self.overlap), "backend": dist.get_backend(self.ex.group) if dist.is_initialized() else None}
 
     def detach(self):

@@ -34,8 +34,10 @@ def main():
     # the window in which RCCL kernels may share the chip (claimed tiles + reserved CUs on): claimed tiles are what an
     # RCCL run gets by default (checked below); asked for explicitly when this rendezvous is gloo
     if backend == "nccl":
-        dp = DataParallel(model)      # no reserved CUs: they change the weight gradients' split-K factor, hence the bits
-        assert dp.ex.active and dp.dynamic_tiles, "over RCCL the exchange is live and claimed tiles are the default"
+        dp = DataParallel(model)      # no reserved CUs (no channel pin in this child): they change the weight gradients' split-K factor, hence the bits
+        claimed = os.environ.get("MELGPT_DP_DYNAMIC_TILES") == "1"
+        assert dp.ex.active and dp.dynamic_tiles == claimed and dp.reserve_cus == 0, \
+            "over RCCL the exchange is live; static lists (the ping-pong GEMM) are the default, claimed tiles the switch"
     else:
         dp = DataParallel(model, dynamic_tiles=True, reserve_cus=8)
     L = _ffi.lib()

@@ -94,7 +94,7 @@ FORMS = {
     "gemm NN 8192x4096x256 (K-major B)": ("gemm8p", _gemm(8192, 4096, 256, kmaj=True, seed=12)),
     "gemm NN 24576x1024x320 (K-major B, 192-row tiles, ragged K)": ("gemm8p", _gemm(24576, 1024, 320, kmaj=True, seed=13)),
     "gemm NN 16960x1472x328 (EDGE: N ends inside a half-tile)": ("gemm8p", _gemm(16960, 1472, 328, kmaj=True, seed=14)),
-    "gemm NT 33920x4096x136 (half-height last round, ragged K)": ("gemm8p", _gemm(33920, 4096, 136, seed=15)),
+    "gemm NT 33920x4096x264 (half-height last round, ragged K)": ("gemm8p", _gemm(33920, 4096, 264, seed=15)),
     "gemm NT 4000x2048x512 (single round: fewer tiles than CUs)": ("gemm8p", _gemm(4000, 2048, 512, seed=16)),
     "gemm NT 8192x4096x256 + bias + GELU + derivative": ("gemm8p", _gemm(8192, 4096, 256, seed=17, bias=True, dact=True)),
     "gemm NT 20480x1024x512 + bias + dropout + residual": ("gemm8p", _gemm(20480, 1024, 512, seed=18, bias=True, drop=True, residual=True)),

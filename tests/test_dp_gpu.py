@@ -64,18 +64,24 @@ def test_two_ranks_share_one_gpu_gradients_equal_single_process(which, tmp_path)
         assert torch.load(os.path.join(str(tmp_path), f"rank{rnk}_guard.pt"))["refused"]
 
 
-def test_one_rank_over_a_real_rccl_group_bit_identical_to_no_dp(tmp_path):
+@pytest.mark.parametrize("claimed", [False, True])
+def test_one_rank_over_a_real_rccl_group_bit_identical_to_no_dp(tmp_path, claimed):
     """The `nccl` backend (= RCCL) itself: a child rank initialises a real RCCL process group (size 1 - RCCL does not
     allow two ranks on one device), forces the exchange on (MELGPT_DP_FORCE_EXCHANGE=1) and runs the 16-bit-lane backward of
     a VAS-width model through DataParallel with its RCCL defaults: every Block's two slices are all-reduced on RCCL's
-    stream while the earlier Blocks' GEMMs - drawing CLAIMED tiles - are still running.  The flat gradient must equal the
-    no-DP run of this process bit for bit, the hooks fire, and the window is (0,0) -> (1,0) -> (0,0) (claimed tiles on, no
-    reserved CUs: a smaller grid changes the weight gradients' split-K factor and with it the summation order)."""
+    stream while the earlier Blocks' GEMMs are still running - on STATIC tile lists (the ping-pong GEMM, the default since
+    round 5: window (0,0) throughout) or, with MELGPT_DP_DYNAMIC_TILES=1, drawing CLAIMED tiles on the ring loop (window
+    (0,0) -> (1,0) -> (0,0)).  The flat gradient must equal the no-DP run of this process bit for bit and the hooks fire
+    (no reserved CUs here: a smaller grid changes the weight gradients' split-K factor and with it the summation order)."""
     from melspec_gpt_vqvae_amd.flat import ensure_flat
 
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY="0", DP_BACKEND="nccl", MELGPT_DP_FORCE_EXCHANGE="1")
     env.pop("MELGPT_DP_DYNAMIC_TILES", None)
+    env.pop("NCCL_MAX_NCHANNELS", None)
+    env.pop("MELGPT_RESERVE_CUS", None)
+    if claimed:
+        env["MELGPT_DP_DYNAMIC_TILES"] = "1"
     proc = subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), "gptclass_vas16", str(tmp_path)], env=env,
                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     model, batch, loss_fn = dp_models.build("gptclass_vas16", "cuda:0")
@@ -89,7 +95,7 @@ def test_one_rank_over_a_real_rccl_group_bit_identical_to_no_dp(tmp_path):
     r = torch.load(os.path.join(str(tmp_path), "rank0.pt"))
     assert r["backend"] == "nccl"
     assert r["hook_calls"] == 2 and r["launched_early"] == 4
-    assert [tuple(w) for w in r["window"]] == [(0, 0), (1, 0), (0, 0)]
+    assert [tuple(w) for w in r["window"]] == [(0, 0), (1 if claimed else 0, 0), (0, 0)]
     assert r["names"] == fp.names and r["offsets"] == fp.offsets
     assert float(loss) == r["loss"]
     assert torch.equal(r["grad"], want), float((r["grad"] - want).abs().max())

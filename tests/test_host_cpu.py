@@ -219,3 +219,23 @@ def test_c_abi_host_paths_under_address_sanitizer(tmp_path):
                        timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "asan host driver: ok" in r.stdout
+
+
+def test_rccl_channel_pin_respects_the_users_environment(monkeypatch):
+    """dp.pin_rccl_channels: a small known RCCL footprint (NCCL_MAX_NCHANNELS) so that DataParallel can reserve exactly
+    that many CUs for it; a value the user exported wins, MELGPT_RCCL_CHANNELS=0 leaves RCCL alone."""
+    from melspec_gpt_vqvae_amd import dp
+
+    for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "MELGPT_RCCL_CHANNELS"):
+        monkeypatch.delenv(k, raising=False)
+    assert dp.pinned_rccl_channels() == 0
+    assert dp.pin_rccl_channels() == dp.RCCL_CHANNELS_DEFAULT == 16 and os.environ["NCCL_MAX_NCHANNELS"] == "16"
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "24")
+    assert dp.pin_rccl_channels(8) == 24, "the user's bound is respected"
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS")
+    monkeypatch.setenv("MELGPT_RCCL_CHANNELS", "0")
+    assert dp.pin_rccl_channels() == 0 and "NCCL_MAX_NCHANNELS" not in os.environ
+    monkeypatch.setenv("MELGPT_RCCL_CHANNELS", "32")
+    monkeypatch.setenv("NCCL_MIN_NCHANNELS", "64")
+    assert dp.pin_rccl_channels() == 32 and os.environ["NCCL_MIN_NCHANNELS"] == "32"
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS")

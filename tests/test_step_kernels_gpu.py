@@ -49,8 +49,11 @@ def test_no_framework_kernel_runs_inside_the_training_step():
             name = func.overloadpacket.__name__
             if name not in _META:
                 outs = out if isinstance(out, (tuple, list)) else (out,)
-                big = [o for o in outs if isinstance(o, torch.Tensor) and o.is_cuda and o.numel() > 0]
-                ins = [x for x in args if isinstance(x, torch.Tensor) and x.is_cuda and x.numel() > 0]
+                touts = [o for o in outs if isinstance(o, torch.Tensor)]
+                big = [o for o in touts if o.is_cuda and o.numel() > 0]
+                # (an operator WITH tensor results launches for them only - x.new_zeros(0) is no kernel -, one without, e.g.
+                # an in-place op returning None, for its device arguments)
+                ins = [] if touts else [x for x in args if isinstance(x, torch.Tensor) and x.is_cuda and x.numel() > 0]
                 if big or ins:
                     seen.append((name, [tuple(o.shape) for o in big] or [tuple(x.shape) for x in ins]))
             elif name in ("contiguous", "_to_copy", "to"):
