@@ -474,7 +474,7 @@ def main():
         else:
             from melspec_gpt_vqvae_amd.dp import pin_rccl_channels
 
-            pin_rccl_channels()      # a small, KNOWN RCCL footprint; DataParallel reserves that many CUs (dp.py)
+            pin_rccl_channels()      # opt-in (MELGPT_RCCL_CHANNELS=n): a known RCCL footprint + that many reserved CUs (dp.py)
             dist.init_process_group("nccl", device_id=device)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 

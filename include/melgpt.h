@@ -282,10 +282,12 @@ int melgpt_attn_bwd(const void* q, const void* k, const void* v, long long ld, c
  * probabilities once (dK / dV in registers, dS through LDS for dQ).  on != 0 keeps the two-kernel path (dQ, then dK / dV)
  * that every other case uses; returns the previous setting.  MELGPT_ATTN_BWD_TWO_PASS=1 in the environment does the same. */
 int melgpt_set_attn_bwd_two_pass(int on);
-/* Forward kernel of the 16-bit lane when no attention map is asked for: 1 (default) = 32-row query tiles with the logits of
- * a tile row kept in registers (no recompute), 0 = the 16-row two-pass kernel (which always serves the f32 lane and the `att`
- * output).  Returns the previous setting; MELGPT_ATTN_FWD32=0 in the environment sets the default.  Same dropout bits. */
-int melgpt_set_attn_fwd32(int on);
+/* Forward kernel of the 16-bit lane when no attention map is asked for: -1 (default) = by shape - 32-row query tiles with
+ * the logits of a tile row kept in registers (attn_fwd32_kernel) for the full-square mask (n_unmasked >= T: the GPT-VAE
+ * encoder, encoders.py:21-30), the 16-row two-pass kernel under the causal mask, where the two tie; 1 / 0 = force the
+ * 32-row / the 16-row kernel for every shape (the 16-row one always serves the f32 lane and the `att` output).  Returns the
+ * previous mode; MELGPT_ATTN_FWD32=0|1 in the environment sets the initial one.  Same dropout bits from either kernel. */
+int melgpt_set_attn_fwd32(int mode);
 
 /* ===================================================================== row kernels
  * nn.LayerNorm(C, eps) (minGPT.py:97-98,141): y = (x-mean)*rstd*gamma+beta; mean/rstd (M,) f32 saved. */

@@ -37,6 +37,15 @@
 __device__ unsigned long long melgpt_attn_dbg[256 + 4 * 4096];  // lab build only: phase stamps of one wave of one workgroup
 #endif
 
+MELGPT_CLK_DECL(clk_attn_fwd)
+MELGPT_CLK_DECL(clk_attn_bwd)
+MELGPT_CLK_DECL(clk_attn32_ph)   // phase stamps of the four waves of workgroup (head 5, batch 3) of attn_fwd32_kernel: 64 slots per wave
+#ifdef MELGPT_CLOCK_STAMPS
+#define PH32_STAMP() do { if (ph_on && ph_n < 62) ph[ph_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PH32_STAMP() do { } while (0)
+#endif
+
 namespace {
 
 constexpr int HS = 64;
@@ -665,13 +674,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnParams p) {
   char* Kt = smem;
   char* Vt = smem + (size_t)TP * 128;
   int* ctr = (int*)(smem + 2 * (size_t)TP * 128);
+#ifdef MELGPT_CLOCK_STAMPS
+  const bool ph_on = blockIdx.y == 5 && blockIdx.z == 3 && lane == 0;
+  unsigned long long* ph = clk_attn32_ph + (t >> 6) * 64;
+  int ph_n = 0;
+#endif
+  MELGPT_CLK_BEGIN();
+  PH32_STAMP();   // [0] entry
+  const int ntiles = (Tn + 31) / 32;
+  // The four waves' FIRST query tiles are fixed (jobs 0-3, the heaviest) and their Q rows requested before K / V: behind
+  // the staging barrier the first tile waited a whole memory round trip for them (3 k of a workgroup's ~23 k cycles,
+  // tools/lab/clock_lab.py stamps); the work counter hands out jobs from 4 on.
+  int job = __builtin_amdgcn_readfirstlane(t >> 6);   // (wave-uniform: in a VGPR every branch on a tile count became an EXEC-mask region)
+  u32x4 qf[4];
+  {
+    const int qc = min(32 * (ntiles - 1 - min(job, ntiles - 1)) + r32, Tn - 1);
+    const T* qp = (const T*)p.Q + ((long long)b * Tn + qc) * p.ld + h * HS;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const u32x4*)(qp + 16 * ks + 8 * hh);
+  }
   const T* Kg = (const T*)p.K + (long long)b * Tn * p.ld + h * HS;
   const T* Vg = (const T*)p.V + (long long)b * Tn * p.ld + h * HS;
   load_tiles<T, false, true, 256>(Kt, Kg, p.ld, Vt, Vg, p.ld, Tn, TP, t);
-  if (t == 0) *ctr = 0;
+  if (t == 0) *ctr = 4;
   __syncthreads();
+  PH32_STAMP();   // [1] K / V staged
   const long long bh = (long long)b * p.H + h;
-  const int ntiles = (Tn + 31) / 32;
   const float c2 = p.scale * LOG2E;
   const float dsc = DM != DM_NONE ? p.drop_scale : 1.f;
   const DropKeys dkeys = drop_keys(p.seed, p.stream_id, (unsigned)bh, p.drop_thresh);
@@ -691,37 +719,58 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnParams p) {
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const u32x4*)(qp + 16 * ks + 8 * hh);   // B[k = 8 hh + j][query]: d = 16 ks + 8 hh + j
   };
 
-  int job = grab();
-  u32x4 qf[4];
-  fetch(min(job, ntiles - 1), qf);
   while (job < ntiles) {
+    PH32_STAMP();   // per tile: start
     const int q0 = 32 * (ntiles - 1 - job);
     const int q = q0 + r32, qc = min(q, Tn - 1);
     const int lim = vis_keys(qc, Tn, nu) - 4 * hh;                        // key 32 kt + 8 j + 4 hh + r visible <=> 32 kt + 8 j + r < lim
     const int nkt = (vis_keys(min(q0 + 31, Tn - 1), Tn, nu) + 31) / 32;   // key tiles any row of the tile sees (wave-uniform)
     const int nfull = vis_keys(q0, Tn, nu) / 32;                          // key tiles every row sees whole
 
-    // ---- S^T tiles: keys on the accumulator rows, the query on the lane
+    // ---- S^T tiles: keys on the accumulator rows, the query on the lane.  Key tiles go in PAIRS through one basic block
+    // (a wave-uniform branch per pair, the masks afterwards): the two 4-MFMA chains and their eight fragment reads are
+    // independent, so the compiler interleaves them - tile by tile every chain waited for its own LDS round trip
+    PH32_STAMP();   // tile bounds known
     f32x16 S[MAXKT32];
+    auto s_chain = [&](int kt) -> f32x16 {
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const u32x4 kf = *(const u32x4*)(Kt + offK<T>(32 * kt + r32, 2 * ks + hh));
+        acc = MELGPT_MFMA_32x32x16(kf, qf[ks], acc);
+      }
+      return acc;
+    };
+#pragma unroll
+    for (int kp = 0; kp < (MAXKT32 + 1) / 2; ++kp) {
+      const int k0 = 2 * kp, k1 = 2 * kp + 1;
+      if (k1 < MAXKT32 && k1 < nkt) {
+        S[k0] = s_chain(k0);
+        S[k1 < MAXKT32 ? k1 : k0] = s_chain(k1);
+      } else if (k0 < nkt) {
+        S[k0] = s_chain(k0);
+      }
+#ifdef MELGPT_CLOCK_STAMPS
+      if (kp == 0) {
+        asm volatile("" ::"v"(S[0]));
+        PH32_STAMP();   // first pair of key tiles issued
+      }
+#endif
+    }
 #pragma unroll
     for (int kt = 0; kt < MAXKT32; ++kt) {
-      if (kt < nkt) {
-        f32x16 acc;
+      if (kt >= nfull && kt < nkt) {   // (the tiles the causal frontier or the end of the sequence cuts: one or two per query tile)
+        const int lk = lim - 32 * kt;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const u32x4 kf = *(const u32x4*)(Kt + offK<T>(32 * kt + r32, 2 * ks + hh));
-          acc = MELGPT_MFMA_32x32x16(kf, qf[ks], acc);
-        }
-        if (kt >= nfull) {
-          const int lk = lim - 32 * kt;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[i] = (8 * (i >> 2) + (i & 3) < lk) ? acc[i] : -__builtin_inff();
-        }
-        S[kt] = acc;
+        for (int i = 0; i < 16; ++i) S[kt][i] = (8 * (i >> 2) + (i & 3) < lk) ? S[kt][i] : -__builtin_inff();
       }
     }
+#ifdef MELGPT_CLOCK_STAMPS
+    asm volatile("" ::"v"(S[0]));
+#endif
+    PH32_STAMP();   // S tiles issued
     // the logits are in registers and the Q fragments dead: the NEXT tile's rows are requested into them now and land
     // under the softmax / P V phase (a second register set for them spilled)
     const int njob = grab();
@@ -738,6 +787,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnParams p) {
     }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     const float mc = m * c2;
+#ifdef MELGPT_CLOCK_STAMPS
+    asm volatile("" ::"v"(mc));
+#endif
+    PH32_STAMP();   // row maximum known
     // p = 1/2: hash word a of key block kb (128 keys, drawn when the loop below enters it) serves keys
     // 128 kb + 16 tt + 4 (2 a + hh) + r, bit 4 tt + r
     int hw[2] = {0, 0};
@@ -749,64 +802,79 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnParams p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
     float ls[4] = {0.f, 0.f, 0.f, 0.f};   // four partial row sums (independent chains)
-#pragma unroll
-    for (int kt = 0; kt < MAXKT32; ++kt) {
-      if (kt < nkt) {
-        if constexpr (DM == DM_HALF) {
-          if ((kt & 3) == 0) {
-            hw[0] = (int)hash32(ch + (unsigned)(kt >> 2));
-            hw[1] = (int)hash32(ch + 8u + (unsigned)(kt >> 2));
-          }
-        }
-        float e[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kt][i], c2, -mc));
-          asm("v_add_f32 %0, %0, %1" : "+v"(ls[i & 3]) : "v"(e[i]));   // (asm: hipcc SLP-packs plain adds into v_pk_add_f32, slower beside MFMAs)
-        }
-        if constexpr (DM == DM_HALF) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int j = i >> 2, r = i & 3;
-            // keep-mask = the hash bit sign-extended (asm: written with the builtin, hipcc turns sbfe + and into and + cmp + cndmask)
-            unsigned km;
-            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(km) : "v"(hw[j & 1]), "n"(8 * (kt & 3) + 4 * (j >> 1) + r));
-            e[i] = __uint_as_float(__float_as_uint(e[i]) & km);
-          }
-        } else if constexpr (DM == DM_ANY) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            bool keep[4];
-            drop_keep4(dkeys, (unsigned)q * 128u + (unsigned)(8 * kt + 2 * j + hh), keep);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) e[4 * j + r] = keep[r] ? e[4 * j + r] : 0.f;
-          }
-        }
-        u32x4 pb[2];
-#pragma unroll
-        for (int sx = 0; sx < 2; ++sx)
-          pb[sx] = u32x4{pack_bf16x2(e[8 * sx + 0], e[8 * sx + 1]), pack_bf16x2(e[8 * sx + 2], e[8 * sx + 3]),
-                         pack_bf16x2(e[8 * sx + 4], e[8 * sx + 5]), pack_bf16x2(e[8 * sx + 6], e[8 * sx + 7])};
-#pragma unroll
-        for (int sx = 0; sx < 2; ++sx) {
-#pragma unroll
-          for (int db = 0; db < 2; ++db) {
-            // A[row d = 32 db + r32][k = 8 hh + j] = V[key 32 kt + 16 sx + 8 (j >> 2) + 4 hh + (j & 3)][d]
-            const int row = 32 * kt + 16 * sx + 4 * hh + q4, c = 4 * db + 2 * g1 + (p4 >> 1);
-            const char* a0 = Vt + offV<T>(row, c) + 8 * (p4 & 1);
-            const char* a1 = Vt + offV<T>(row + 8, c) + 8 * (p4 & 1);
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a0));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
-            const s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            o[db] = MELGPT_MFMA_32x32x16(__builtin_bit_cast(u32x4, f), pb[sx], o[db]);
-          }
+    // probabilities of key tile kt as the two B operands (k-steps) of the P V product
+    auto probs = [&](int kt, u32x4 (&pb)[2]) {
+      if constexpr (DM == DM_HALF) {
+        if ((kt & 3) == 0) {
+          hw[0] = (int)hash32(ch + (unsigned)(kt >> 2));
+          hw[1] = (int)hash32(ch + 8u + (unsigned)(kt >> 2));
         }
       }
+      float e[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kt][i], c2, -mc));
+        asm("v_add_f32 %0, %0, %1" : "+v"(ls[i & 3]) : "v"(e[i]));   // (asm: hipcc SLP-packs plain adds into v_pk_add_f32, slower beside MFMAs)
+      }
+      if constexpr (DM == DM_HALF) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int j = i >> 2, r = i & 3;
+          // keep-mask = the hash bit sign-extended (asm: written with the builtin, hipcc turns sbfe + and into and + cmp + cndmask)
+          unsigned km;
+          asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(km) : "v"(hw[j & 1]), "n"(8 * (kt & 3) + 4 * (j >> 1) + r));
+          e[i] = __uint_as_float(__float_as_uint(e[i]) & km);
+        }
+      } else if constexpr (DM == DM_ANY) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bool keep[4];
+          drop_keep4(dkeys, (unsigned)q * 128u + (unsigned)(8 * kt + 2 * j + hh), keep);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) e[4 * j + r] = keep[r] ? e[4 * j + r] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx)
+        pb[sx] = u32x4{pack_bf16x2(e[8 * sx + 0], e[8 * sx + 1]), pack_bf16x2(e[8 * sx + 2], e[8 * sx + 3]),
+                       pack_bf16x2(e[8 * sx + 4], e[8 * sx + 5]), pack_bf16x2(e[8 * sx + 6], e[8 * sx + 7])};
+    };
+    auto pv = [&](int kt, const u32x4 (&pb)[2]) {
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          // A[row d = 32 db + r32][k = 8 hh + j] = V[key 32 kt + 16 sx + 8 (j >> 2) + 4 hh + (j & 3)][d]
+          const int row = 32 * kt + 16 * sx + 4 * hh + q4, c = 4 * db + 2 * g1 + (p4 >> 1);
+          const char* a0 = Vt + offV<T>(row, c) + 8 * (p4 & 1);
+          const char* a1 = Vt + offV<T>(row + 8, c) + 8 * (p4 & 1);
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
+          const s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[db] = MELGPT_MFMA_32x32x16(__builtin_bit_cast(u32x4, f), pb[sx], o[db]);
+        }
+      }
+    };
+#pragma unroll
+    for (int kt = 0; kt < MAXKT32; ++kt) {   // (tile by tile here: a pair's 32 probabilities + two operand sets do not fit beside the logits)
+      if (kt < nkt) {
+        u32x4 pb[2];
+        probs(kt, pb);
+        pv(kt, pb);
+      }
     }
+#ifdef MELGPT_CLOCK_STAMPS
+    asm volatile("" ::"v"(o[0]), "v"(o[1]));
+#endif
+    PH32_STAMP();   // softmax + P V done
     const float lsum = (ls[0] + ls[1]) + (ls[2] + ls[3]);
     const float l = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / l;
     const float oscale = inv * dsc;
+    // The next tile's Q rows (requested a whole softmax / P V phase ago) are taken HERE, in front of this tile's stores:
+    // vmcnt counts stores too and in order, so a wait for them placed at the top of the next tile (where the compiler puts
+    // it) also waited for the nine stores below - ~1.9 k cycles per tile, whatever its size (clock_lab.py stamps).
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
     if (q < Tn) {
       if (hh == 0) p.lse[bh * Tn + q] = m * p.scale + __logf(l);
       T* op = (T*)p.O + ((long long)b * Tn + q) * p.ldo + h * HS;
@@ -818,7 +886,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnParams p) {
                     f32x4{o[db][4 * jj], o[db][4 * jj + 1], o[db][4 * jj + 2], o[db][4 * jj + 3]} * oscale);
     }
     job = njob;
+#ifdef MELGPT_CLOCK_STAMPS
+    if (ph_on && ph_n < 62) ph[ph_n++] = (unsigned long long)nkt;   // (key tiles of the tile just done)
+#endif
   }
+  PH32_STAMP();   // this wave is done
+#ifdef MELGPT_CLOCK_STAMPS
+  if (ph_on) ph[63] = (unsigned long long)ph_n;
+#endif
+  MELGPT_CLK_END(clk_attn_fwd);
 }
 
 #ifndef ATTN_LAB_LDSPAD
@@ -936,6 +1012,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void attn_bwd1_kernel(AttnParams p) {
   float* del_s = lse_s + TP;                                  // delta * (1 - p)
   int* ctr = (int*)(del_s + TP);                              // [0] phase 1, [1] phase 2
   char* dsb = (char*)(ctr + 4);                               // dS tiles (16-byte aligned: TP is a multiple of 32)
+  MELGPT_CLK_BEGIN();
   const float dsc = DM != DM_NONE ? p.drop_scale : 1.f;
   const f32x4 c2v = splat4(p.scale * LOG2E);
   const int qsh = 8 * (lane & 3);
@@ -1212,6 +1289,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void attn_bwd1_kernel(AttnParams p) {
   __syncthreads();  // the next item's rows replace K / dO / the statistics / the counters
   LAB_STAMP(6);
  }  // item loop
+  MELGPT_CLK_END(clk_attn_bwd);
 }
 
 static size_t bwd1_lds_bytes(int Tn) {
@@ -1241,10 +1319,28 @@ int launch_bwd1(const AttnParams& p, hipStream_t s) {
 
 }  // namespace
 
-static int g_fwd32 = -1;
-extern "C" int melgpt_set_attn_fwd32(int on) {
-  const int prev = g_fwd32 != 0;
-  g_fwd32 = on != 0;
+#ifdef MELGPT_CLOCK_STAMPS
+// (diagnostic build only) workgroups of attn_fwd32_kernel<DM_HALF> the runtime will keep resident per CU at sequence length T
+extern "C" int melgpt_clk_attn_fwd32_occupancy(int T) {
+  int n = -1;
+  const size_t lds = 2 * (size_t)((T + 31) / 32 * 32) * 128 + 16;
+  set_lds(attn_fwd32_kernel<DM_HALF>, 2 * (size_t)MAXT * 128 + 16);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)attn_fwd32_kernel<DM_HALF>, 256, lds) != hipSuccess) return -1;
+  return n;
+}
+#endif
+
+static int g_fwd32 = -2;   // -2: environment not read yet; -1: by shape (default); 0 / 1: forced off / on
+static void fwd32_env() {
+  if (g_fwd32 == -2) {
+    const char* e = getenv("MELGPT_ATTN_FWD32");
+    g_fwd32 = e ? (atoi(e) != 0 ? 1 : 0) : -1;
+  }
+}
+extern "C" int melgpt_set_attn_fwd32(int mode) {
+  fwd32_env();
+  const int prev = g_fwd32;
+  g_fwd32 = mode < 0 ? -1 : (mode != 0 ? 1 : 0);
   return prev;
 }
 
@@ -1262,13 +1358,15 @@ extern "C" int melgpt_attn_fwd(const void* q, const void* k, const void* v, long
   MELGPT_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0, MELGPT_ERR_ALIGN);
   set_dropout(p, drop_p, seed, stream_id);
   hipStream_t s = (hipStream_t)stream;
-  // 16-bit lane without the attention map: 32-row query tiles (attn_fwd32_kernel); MELGPT_ATTN_FWD32=0 /
-  // melgpt_set_attn_fwd32(0) keep the 16-row kernel (which also serves the f32 parity lane and the `att` output)
-  if (g_fwd32 < 0) {
-    const char* e = getenv("MELGPT_ATTN_FWD32");
-    g_fwd32 = e ? atoi(e) != 0 : 1;
-  }
-  if (ATTN_LAB == 0 && g_fwd32 && dtype == MELGPT_BF16 && !att) {
+  // 16-bit lane without the attention map: attn_fwd32_kernel (32-row query tiles, the row of logits in registers) where
+  // it is the faster one - measured against the 16-row kernel in one process (profiles/r05_attn_lab.md): the full-square
+  // mask of the GPT-VAE encoder (n_unmasked >= T: 126.6 against 138.1 us per layer at 128 x 23 x 265 without dropout,
+  // 144 against 144-150 with dropout 1/2); under the causal mask the two tie within 2 % either way (71.3 / 72.5 us
+  // without, 75.7-76.9 / 73.7-75.2 with dropout 1/2 at 128 x 16 x 265) and the 16-row kernel keeps the launch.
+  // MELGPT_ATTN_FWD32=0 / 1 or melgpt_set_attn_fwd32 force one kernel for every shape (tests run both on every shape).
+  fwd32_env();
+  const bool use32 = g_fwd32 == 1 || (g_fwd32 == -1 && n_unmasked >= T);
+  if (ATTN_LAB == 0 && use32 && dtype == MELGPT_BF16 && !att) {
     switch (drop_mode(p)) {
       case DM_NONE: st = launch_fwd32<DM_NONE>(p, s); break;
       case DM_HALF: st = launch_fwd32<DM_HALF>(p, s); break;

@@ -41,6 +41,35 @@ typedef unsigned short bf16_t;  // raw bf16 bits
 #define MELGPT_VMCNT(n) "vmcnt(" MELGPT_STR(n) ")"
 #endif
 
+// ---------------------------------------------------------------- in-kernel clock (diagnostic build only)
+// -DMELGPT_CLOCK_STAMPS (tools/lab/build_clock_lib.py -> tools/lab/clock_lab.py): thread 0 of every workgroup stamps
+// s_memtime (shader cycles) and s_memrealtime (100 MHz, one clock for the whole chip) at the top of the kernel and when it
+// leaves; in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz, median over workgroups, after >= 2 s of back-to-back
+// launches on random data (MI355X_MICROARCH "DVFS give-back" item 6).  The stamps go to a buffer of their own that no kernel
+// reads; in the product build the macros are empty and no stamp executes.
+#ifdef MELGPT_CLOCK_STAMPS
+#define MELGPT_CLK_SLOTS 2048
+#define MELGPT_CLK_DECL(name)                                                                                     \
+  __device__ unsigned long long name[MELGPT_CLK_SLOTS * 2];                                                       \
+  extern "C" int melgpt_##name(unsigned long long* out) {                                                         \
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(name), sizeof(unsigned long long) * MELGPT_CLK_SLOTS * 2) == hipSuccess ? 0 : -1; \
+  }
+#define MELGPT_CLK_BEGIN() \
+  const unsigned long long clk_c0_ = __builtin_amdgcn_s_memtime(), clk_r0_ = __builtin_amdgcn_s_memrealtime()
+#define MELGPT_CLK_END(name)                                                                                      \
+  do {                                                                                                            \
+    const unsigned slot_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                        \
+    if (threadIdx.x == 0 && slot_ < MELGPT_CLK_SLOTS) {                                                           \
+      name[2 * slot_] = __builtin_amdgcn_s_memtime() - clk_c0_;                                                   \
+      name[2 * slot_ + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0_;                                           \
+    }                                                                                                             \
+  } while (0)
+#else
+#define MELGPT_CLK_DECL(name)
+#define MELGPT_CLK_BEGIN() do { } while (0)
+#define MELGPT_CLK_END(name) do { } while (0)
+#endif
+
 void melgpt_count_gemm_loop(int pingpong);  // abi.hip: launch counters behind melgpt_gemm_loop_launches
 
 static inline int melgpt_launch_status() {

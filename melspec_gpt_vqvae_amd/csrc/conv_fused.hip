@@ -19,6 +19,8 @@
 
 using namespace gemmk;
 
+MELGPT_CLK_DECL(clk_conv_ws)
+
 namespace {
 
 constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW;  // 180 patch pixels
@@ -591,7 +593,7 @@ constexpr float LOG2E_F = 1.4426950408889634f;
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <bool STATS, bool W8>
+template <bool STATS, bool W8, bool M16>
 __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, int total_tiles) {
   typedef WsTile<W8> WT;
   constexpr int PP = WS_PP, PW = WT::PW, PH = WT::PH, TH = WT::TH, TW = WT::TW, WS_NPIX = WT::NPIX, WS_PATCH = WT::PATCH;
@@ -615,6 +617,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
   // neighbour except at the end of a tile row, and its two left halo columns are the two right columns already staged
   const int t_per = total_tiles / G, t_rem = total_tiles - t_per * G;
   const int t_first = (int)blockIdx.x * t_per + min((int)blockIdx.x, t_rem), t_last = t_first + t_per + ((int)blockIdx.x < t_rem ? 1 : 0);
+  MELGPT_CLK_BEGIN();
   if (t < 128) {
     gb[2 * t] = norm ? q.gamma[t] : 1.f;
     gb[2 * t + 1] = norm ? q.beta[t] : 0.f;
@@ -626,7 +629,163 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
     return (unsigned)__builtin_amdgcn_readfirstlane((int)min(min(v[0], v[1]), min(v[2], v[3])));
   };
 
-  if (w < 4) {
+  if (w < 4 && M16) {
+    // ================================================================== multiplying waves, v_mfma_f32_16x16x32 form (round 5)
+    // The same roles, protocol and phases as the 32x32x16 form below, with the K-step's 64 channels as TWO 32-wide sub-steps
+    // of 32 MFMAs (4 pixel fragments of 16 x 8 channel fragments of 16).  Why a second form: on random operands the chip
+    // holds a higher clock under the 16x16x32 instruction than under 32x32x16 at equal cycles per FLOP (guide, "DVFS
+    // give-back" item 7: 1.12-1.15 x the FLOP/s; this kernel's own harness, profiles/r04_conv_lab.md section 8: 0.486
+    // against 0.622 ms for the bare multiplying loops) - and this kernel ran at the lowest clock of the step.
+    //   patch fragment mt (16 pixels of one patch row): lane = pixel i16, 16-byte k-chunk 4 ks + g of the K-step's 64 channels
+    //   weight fragment nt: lane = ring row 16 nt + i16, chunk 4 ks + g (natural rows: conflict-free with row_off); the
+    //     staging waves request channel chan(R) = 32 (R >> 5) + 8 ((R >> 2) & 3) + 4 ((R >> 4) & 1) + (R & 3) into ring row R,
+    //     so that accumulator rows 4 g + r of fragments 2 u, 2 u + 1 are the 8 CONSECUTIVE channels 32 u + 8 g + 0..7 of
+    //     the lane's pixel: one 16-byte store / residual load per (pixel fragment, u), 64 contiguous bytes per pixel.
+    const int wm = w, i16 = lane & 15, g = lane >> 4;
+    auto foff = [](int mt) { return W8 ? (mt >> 1) * PW + 16 * (mt & 1) : mt * PW; };   // patch pixels from fragment 0 to fragment mt
+    const char* abase = patch + ((W8 ? wm * 2 : wm * 4) * PW + i16) * PP + g * 16;
+    const char* bb[2] = {ring + row_off(i16, g), ring + row_off(i16, 4 + g)};           // sub-step ks; fragment nt: + nt * 2048
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.R, p.R ? q.r_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.C, q.r_bytes);
+    auto out_off = [&](int tile, int mt) -> unsigned {  // byte offset of (this lane's pixel of fragment mt, channel 8 g) in y / R
+      const int b = tile / tiles_img, r = tile - b * tiles_img, ty = r / q.tiles_x, tx = r - ty * q.tiles_x;
+      const int y = W8 ? ty * 8 + wm * 2 + (mt >> 1) : ty * 16 + wm * 4 + mt, x = W8 ? tx * 32 + 16 * (mt & 1) + i16 : tx * 16 + i16;
+      const bool ok = tile < total_tiles && y < q.H && x < q.W;
+      return ok ? (unsigned)(((((long long)b * q.H + y) * q.W + x) * 128 + 8 * g) * 2) : OOB;
+    };
+    u32x4 rr[4][4];  // residual of the tile about to be multiplied: piece (mt, u) = channels 32 u + 8 g + 0..7 of the lane's pixel
+    auto fetch_res = [&](int tile) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const unsigned o = out_off(tile, mt);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rr[mt][u] = (p.R && o != OOB) ? buf_load16(rres, o + u * 64) : u32x4{0u, 0u, 0u, 0u};
+      }
+    };
+    auto wait_full = [&](unsigned k) {   // K-step k has landed for every staging wave
+      if (!(WS_LAB & 4)) {
+        for (int it = 0; min4(cnt4[0]) <= k && it < WS_SPIN; ++it) __builtin_amdgcn_s_sleep(1);
+      }
+      asm volatile("" ::: "memory");
+    };
+    u32x4 fa0[4], fa1[4], fb[8];
+    auto loadA = [&](const char* ab, int kx, int ks, u32x4 (&fa)[4]) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) fa[mt] = *(const u32x4*)(ab + (foff(mt) + kx) * PP + ks * 64);
+    };
+    f32x4 acc[4][8];
+    // one 32-wide sub-step: channel fragment by channel fragment - a weight fragment is re-requested (for the next sub-step:
+    // `sbn`) as soon as its four MFMAs are out; the fences pin the order as written (see the 32x32x16 form)
+    // (NO scheduling fences here, unlike the 32x32x16 form: pinned fragment by fragment the reloads took fresh registers
+    // while the old fragments were still allocated and the loop spilled 57-73 VGPRs - reloads between the MFMAs; the
+    // 32x32x16 harness measured the unfenced order at the same wall time, profiles/r04_conv_lab.md section 8)
+    auto step = [&](u32x4 (&fc)[4], const char* sbn, bool reload) {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = MELGPT_MFMA_16x16x32(fb[nt], fc[mt], acc[mt][nt]);
+        if (reload) fb[nt] = *(const u32x4*)(sbn + nt * 2048);
+      }
+    };
+    unsigned kg = 0;  // K-steps multiplied so far (over all tiles)
+    fetch_res(t_first);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // half 0 of the first tile is staged
+    for (int tile = t_first; tile < t_last; ++tile) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const f32x4 b0 = *(const f32x4*)(bias_l + 32 * u + 8 * g), b1 = *(const f32x4*)(bias_l + 32 * u + 8 * g + 4);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const u32x4 pk = rr[mt][u];
+          acc[mt][2 * u] = f32x4{bf16lo(pk[0]) + b0[0], bf16hi(pk[0]) + b0[1], bf16lo(pk[1]) + b0[2], bf16hi(pk[1]) + b0[3]};
+          acc[mt][2 * u + 1] = f32x4{bf16lo(pk[2]) + b1[0], bf16hi(pk[2]) + b1[1], bf16lo(pk[3]) + b1[2], bf16hi(pk[3]) + b1[3]};
+        }
+      }
+#pragma unroll 1
+      for (int hk = 0; hk < 6; ++hk) {  // (channel half, filter row): three K-steps (kx = 0, 1, 2) each
+        const int half = hk >= 3 ? 1 : 0, ky = hk - 3 * half;
+        const char* ab = abase + ky * PW * PP + half * 128;
+        if (hk == 0 || hk == 3) {
+          // a phase starts: (hk == 3) everybody is done with half 0 and half 1 is staged
+          if (hk == 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          wait_full(kg);
+          loadA(ab, 0, 0, fa0);
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) fb[nt] = *(const u32x4*)(bb[0] + ((kg & 3u) << 14) + nt * 2048);
+        }
+        const bool last_hk = hk == 2 || hk == 5;
+        const char* abn = ab + PW * PP;  // (not used behind the phase's last filter row)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx, ++kg) {
+          const unsigned so = (kg & 3u) << 14, son = ((kg + 1u) & 3u) << 14;
+          const bool last = last_hk && kx == 2;  // the phase's last K-step: nothing of the next one may be touched yet
+          const u32x4 pf = cnt4[0];               // the NEXT K-step's counters, looked at a sub-step later (they only grow)
+          loadA(ab, kx, 1, fa1);
+          step(fa0, bb[1] + so, true);
+          asm volatile("" ::: "memory");          // (no fragment load of this stage may sink below its release)
+          if (lane == 0) cnt[4 + wm] = kg + 1u;   // behind this wave's last read of the stage (LDS runs a wave's ops in order)
+          if (!last) {
+            if ((WS_LAB & 4) || min4(pf) > kg + 1u) asm volatile("" ::: "memory");
+            else wait_full(kg + 1u);
+            if (kx < 2) loadA(ab, kx + 1, 0, fa0);
+            else loadA(abn, 0, 0, fa0);
+          }
+          step(fa1, bb[0] + son, !last);
+        }
+      }
+      // ---- epilogue: the next tile's residual first (into registers the K loop does not hold)
+      fetch_res(tile + 1 < t_last ? tile + 1 : total_tiles);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const u32x4 pk = {pack_bf16x2(acc[mt][2 * u][0], acc[mt][2 * u][1]), pack_bf16x2(acc[mt][2 * u][2], acc[mt][2 * u][3]),
+                            pack_bf16x2(acc[mt][2 * u + 1][0], acc[mt][2 * u + 1][1]), pack_bf16x2(acc[mt][2 * u + 1][2], acc[mt][2 * u + 1][3])};
+          const unsigned o = out_off(tile, mt);
+          if (o != OOB)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, pk), ry, o + u * 64, 0, 0);
+          if constexpr (STATS) {
+            // GroupNorm(32) statistics of THIS conv's output on the values as stored: the lane's words 2 j, 2 j + 1 are group
+            // 8 u + 2 g + j of its pixel
+            if (o != OOB) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float v0 = bf16lo(pk[e]), v1 = bf16hi(pk[e]);
+                s1[e >> 1] += v0 + v1;
+                s2[e >> 1] = fmaf(v1, v1, fmaf(v0, v0, s2[e >> 1]));
+              }
+            }
+          }
+        }
+        if constexpr (STATS) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {   // over the 16 pixels of the lane's DPP row: four DPP steps
+            float a = s1[j], c = s2[j];
+            a += dpp_move<0xB1>(a);
+            c += dpp_move<0xB1>(c);
+            a += dpp_move<0x4E>(a);
+            c += dpp_move<0x4E>(c);
+            a += dpp_move<0x141>(a);
+            c += dpp_move<0x141>(c);
+            a += dpp_move<0x140>(a);
+            c += dpp_move<0x140>(c);
+            if (i16 == 0) {
+              stp[(wm * 32 + 8 * u + 2 * g + j) * 2] = a;
+              stp[(wm * 32 + 8 * u + 2 * g + j) * 2 + 1] = c;
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // half 1 is free; half 0 of the next tile is staged
+      if constexpr (STATS) {
+        if (wm == 0) {
+          const float v = ((stp[lane] + stp[64 + lane]) + stp[128 + lane]) + stp[192 + lane];
+          q.stat_part[(long long)tile * 64 + lane] = v;  // tile = (b * tiles_y + ty) * tiles_x + tx
+        }
+      }
+    }
+  } else if (w < 4) {
     // ================================================================== multiplying waves
     const int wm = w, r32 = lane & 31, h = lane >> 5;
     // patch fragment f (32 pixels = row-blocks 4 wm + 2 f, + 1): lane = pixel r32 of it, 16-byte k-chunk h of the step
@@ -852,7 +1011,9 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int piece = s + 4 * i, row = piece * 8 + (lane >> 3), chs = (lane & 7) ^ ((row >> 1) & 7);
-      b_base[i] = (row < p.N && !(WS_LAB & 2)) ? (unsigned)(((long long)row * p.ldb) * 2) + chs * 16 : OOB;
+      // (the 16x16x32 form reads ring rows in natural order: ring row R then holds channel chan(R), see the multiplying waves)
+      const int src = M16 ? 32 * (row >> 5) + 8 * ((row >> 2) & 3) + 4 * ((row >> 4) & 1) + (row & 3) : row;
+      b_base[i] = (row < p.N && !(WS_LAB & 2)) ? (unsigned)(((long long)src * p.ldb) * 2) + chs * 16 : OOB;
     }
     auto issue_w = [&](int kt, unsigned stage) {  // K-step kt of a tile (channel-half-major)
       const int half = kt >= 9 ? 1 : 0, tap = kt - 9 * half;
@@ -1089,6 +1250,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
   }
+  MELGPT_CLK_END(clk_conv_ws);
 }
 
 template <bool W8>
@@ -1138,8 +1300,10 @@ int launch_fused_ws_t(const FusedConvParams& q0, int B, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
       return MELGPT_ERR_LAUNCH;
-    if (hipFuncSetAttribute((const void*)conv3x3_gn_ws_kernel<false, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, WT::LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv3x3_gn_ws_kernel<true, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, WT::LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3x3_gn_ws_kernel<false, W8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WT::LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv3x3_gn_ws_kernel<true, W8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WT::LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv3x3_gn_ws_kernel<false, W8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WT::LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv3x3_gn_ws_kernel<true, W8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WT::LDS) != hipSuccess)
       return MELGPT_ERR_LAUNCH;
     ncu = n;
   }
@@ -1147,8 +1311,17 @@ int launch_fused_ws_t(const FusedConvParams& q0, int B, hipStream_t s) {
   if (total > 0x3FFFFFFF) return MELGPT_ERR_UNSUPPORTED;
   const int avail = ncu - melgpt_get_reserved_cus() >= 8 ? ncu - melgpt_get_reserved_cus() : ncu;
   const int gx = (int)(total < avail ? total : avail);
-  if (q.stat_part) hipLaunchKernelGGL((conv3x3_gn_ws_kernel<true, W8>), dim3(gx), dim3(512), WT::LDS, s, q, (int)total);
-  else hipLaunchKernelGGL((conv3x3_gn_ws_kernel<false, W8>), dim3(gx), dim3(512), WT::LDS, s, q, (int)total);
+  // the multiplying waves' MFMA shape: 16x16x32 (default) or the round-4 32x32x16 form (MELGPT_CONV_WS_M16=0); same results
+  // up to the accumulation order of a 16- or a 32-wide k-slice
+  static int m16 = -1;
+  if (m16 < 0) m16 = !(getenv("MELGPT_CONV_WS_M16") && atoi(getenv("MELGPT_CONV_WS_M16")) == 0);
+  if (m16) {
+    if (q.stat_part) hipLaunchKernelGGL((conv3x3_gn_ws_kernel<true, W8, true>), dim3(gx), dim3(512), WT::LDS, s, q, (int)total);
+    else hipLaunchKernelGGL((conv3x3_gn_ws_kernel<false, W8, true>), dim3(gx), dim3(512), WT::LDS, s, q, (int)total);
+  } else {
+    if (q.stat_part) hipLaunchKernelGGL((conv3x3_gn_ws_kernel<true, W8, false>), dim3(gx), dim3(512), WT::LDS, s, q, (int)total);
+    else hipLaunchKernelGGL((conv3x3_gn_ws_kernel<false, W8, false>), dim3(gx), dim3(512), WT::LDS, s, q, (int)total);
+  }
   return melgpt_launch_status();
 }
 int launch_fused_ws(const FusedConvParams& q, int B, hipStream_t s) {

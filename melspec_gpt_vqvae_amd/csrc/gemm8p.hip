@@ -41,6 +41,8 @@
 
 using namespace gemmk;
 
+MELGPT_CLK_DECL(clk_gemm8p)
+
 namespace {
 
 constexpr int KU = 64;
@@ -94,6 +96,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   const int G = gridDim.x;
   const int nu = (p.K + KU - 1) / KU;
   const int rows_m = tiles_m * batch;
+  MELGPT_CLK_BEGIN();
 
   // ---- this workgroup's tile list: the static XCD-block lists of gemm256.hip (the 32 workgroups of an XCD take an
   // RM x RN block of tiles per item).  This kernel is launched only with RN > 0 (a full grid, a multiple of 8
@@ -759,6 +762,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
 #endif
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  MELGPT_CLK_END(clk_gemm8p);
 }
 
 template <int ALAY, int BLAY, int MODE, int TM, bool EDGE>

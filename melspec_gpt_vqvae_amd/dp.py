@@ -21,26 +21,33 @@ import torch
 import torch.distributed as dist
 
 
-RCCL_CHANNELS_DEFAULT = 16
+RCCL_CHANNELS_DEFAULT = 0      # 0: RCCL picks its own channel count and no CU is reserved (see pin_rccl_channels)
 
 
 def pin_rccl_channels(n=None):
-    """Bound RCCL's footprint BEFORE the process group is created: NCCL_MAX_NCHANNELS = n (one persistent workgroup = one
-    CU per channel).  Call from every rank before dist.init_process_group("nccl").  Why: the persistent GEMM / conv grids own
-    one CU per workgroup and walk static tile lists, so a CU held by an all-reduce kernel costs the launch beside it one
-    workgroup's WHOLE list (stand-in collective, tools/lab/overlap_lab.hip, profiles/r05_overlap_lab_*.jsonl: the backward
-    MLP chain of a Block 0.96 -> 1.35-1.43 ms beside 16 or 32 channels with static lists - claimed tiles on the ring loop
-    are no better, 1.42 - but 0.99 -> 1.06 when as many CUs are RESERVED as the collective has channels, and 1.73 when it
-    has twice as many).  The exchange needs little bandwidth (1.2 GB per ~60 ms backward pass for the class-GPT, 8.4 GB per
-    ~300 ms for GPT-VAE XL: < 60 GB/s of bus bandwidth), so a small, KNOWN channel count + the same number of reserved CUs
-    is the robust pairing.  n = None: MELGPT_RCCL_CHANNELS, else 16; 0: leave RCCL alone (DataParallel then reserves nothing
-    unless MELGPT_RESERVE_CUS says so).  A value the user already exported (NCCL_MAX_NCHANNELS) is respected.  -> the pin."""
+    """OPT-IN pairing for real multi-GPU nodes: bound RCCL's footprint BEFORE the process group is created
+    (NCCL_MAX_NCHANNELS = n: one persistent workgroup = one CU per channel) so that DataParallel can RESERVE exactly that
+    many CUs for it while an exchange can be in flight.  Call from every rank before dist.init_process_group("nccl");
+    n = None reads MELGPT_RCCL_CHANNELS (default 0 = leave RCCL alone, reserve nothing); a value the user already exported
+    (NCCL_MAX_NCHANNELS) is respected and returned.
+    Why it exists, and why it is not the default (tools/lab/overlap_lab.hip beside a stand-in collective,
+    profiles/r05_overlap_lab_*.jsonl; one rank through a real RCCL group, profiles/r05_c_bench_dp.json): the persistent
+    GEMM / conv grids own one CU per workgroup and walk static tile lists, so a CU held by an all-reduce kernel costs the
+    launch beside it one workgroup's WHOLE list: the backward MLP chain of a Block 0.94-0.96 -> 1.35-1.43 ms while 16 or 32
+    channels are resident (claimed tiles on the ring loop: 1.42-1.46 - no better), but 0.98 -> 1.06 when as many CUs are
+    reserved as the collective has channels (and 1.73 when it has twice as many: the count must be KNOWN, hence the pin).
+    The reservation is paid all the time, though: the split-K weight gradients lose their exact one-round fit (256 tiles on
+    256 CUs -> 10 batches on 240), +5.7 % on the whole step with nothing resident (94.4 -> 99.7 ms), against +35-47 % on the
+    backward GEMMs only WHILE a collective is resident - the exchange is 1.2 GB per ~55 ms backward pass (8.4 GB per ~300 ms
+    for GPT-VAE XL), i.e. resident for 15-25 % of it at 100-150 GB/s, which prices both choices within a millisecond of each
+    other.  Without a node to measure on, the default is the one whose cost is zero when RCCL is idle."""
     if n is None:
         n = int(os.environ.get("MELGPT_RCCL_CHANNELS", str(RCCL_CHANNELS_DEFAULT)))
     if n > 0:
         os.environ.setdefault("NCCL_MAX_NCHANNELS", str(n))
         if int(os.environ.get("NCCL_MIN_NCHANNELS", "1")) > int(os.environ["NCCL_MAX_NCHANNELS"]):
             os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"]
+        os.environ.setdefault("MELGPT_RESERVE_CUS", str((pinned_rccl_channels() + 7) // 8 * 8))
     return pinned_rccl_channels()
 
 
@@ -223,22 +230,20 @@ class DataParallel:
         self.world = self.ex.world
         self.overlap = bool(overlap)
         # The persistent GEMM / conv kernels own one CU per workgroup for a whole launch; an RCCL kernel that holds a CU
-        # when such a launch starts leaves one workgroup waiting for another one's ENTIRE static tile list.  While an
-        # (overlapped) all-reduce can be in flight - from the first Block's early launch to finish() - the persistent grids
-        # therefore leave `reserve_cus` CUs to RCCL: by default as many as RCCL has channels WHEN THAT IS KNOWN
-        # (pin_rccl_channels(): NCCL_MAX_NCHANNELS, rounded up to a multiple of 8 - the grids are XCD-blocked), else none.
-        # Round 5 (profiles/r05_overlap_lab_*.jsonl): beside a stand-in collective the ping-pong K loop on STATIC lists
-        # (1.35-1.43 ms per backward MLP chain) is never slower than the ring loop drawing CLAIMED tiles (1.42-1.46), and
-        # faster alone (0.94-0.96 against 0.96-1.07) - so claimed tiles (`dynamic_tiles`, csrc/gemm256.hip: whoever has a
-        # CU takes the next tile; they force the ring loop) are OFF by default now and the data-parallel backward runs the
-        # same ping-pong GEMM as a single GPU; a reservation that matches the channel count brings the chain to 1.06.
-        # MELGPT_DP_DYNAMIC_TILES / MELGPT_RESERVE_CUS override.  The forward pass, the head's and the last Block's
-        # backward and the optimizer run on the whole chip.
+        # when such a launch starts leaves one workgroup waiting for another one's ENTIRE static tile list.  Two switches
+        # act while an (overlapped) all-reduce can be in flight - from the first Block's early launch to finish() - and
+        # both are OFF by default since round 5 (measurements: pin_rccl_channels' docstring):
+        #  * `reserve_cus` (MELGPT_RESERVE_CUS; set by pin_rccl_channels together with RCCL's channel bound): the
+        #    persistent grids leave that many CUs to RCCL - the remedy that works (1.35-1.43 -> 1.06 ms per backward MLP
+        #    chain beside a collective) when the collective's channel count is known, at +5.7 % on the step when it is idle;
+        #  * `dynamic_tiles` (MELGPT_DP_DYNAMIC_TILES=1; csrc/gemm256.hip: whoever has a CU takes the next tile): claimed
+        #    tiles force the RING K loop, which beside a collective is no faster (1.42-1.46) than the ping-pong loop on
+        #    static lists (1.35-1.43) and slower alone (0.96-1.07 against 0.94-0.96) - so the data-parallel backward now
+        #    runs the same ping-pong GEMM as a single GPU (`gemm_launches_per_step` in the bench line says which loop ran).
+        # The forward pass, the head's and the last Block's backward and the optimizer run on the whole chip.
         active = self.ex.active
-        on_rccl = active and self.overlap and dist.get_backend(group) == "nccl"
         if reserve_cus is None:
-            ch = pinned_rccl_channels() if on_rccl else 0
-            reserve_cus = int(os.environ.get("MELGPT_RESERVE_CUS", str((ch + 7) // 8 * 8 if 0 < ch <= 64 else 0)))
+            reserve_cus = int(os.environ.get("MELGPT_RESERVE_CUS", "0"))
         if dynamic_tiles is None:
             dynamic_tiles = int(os.environ.get("MELGPT_DP_DYNAMIC_TILES", "0")) != 0
         self.reserve_cus = int(reserve_cus)

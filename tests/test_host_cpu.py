@@ -222,20 +222,20 @@ def test_c_abi_host_paths_under_address_sanitizer(tmp_path):
 
 
 def test_rccl_channel_pin_respects_the_users_environment(monkeypatch):
-    """dp.pin_rccl_channels: a small known RCCL footprint (NCCL_MAX_NCHANNELS) so that DataParallel can reserve exactly
-    that many CUs for it; a value the user exported wins, MELGPT_RCCL_CHANNELS=0 leaves RCCL alone."""
+    """dp.pin_rccl_channels (opt-in, MELGPT_RCCL_CHANNELS=n): a known RCCL footprint (NCCL_MAX_NCHANNELS) together with that
+    many reserved CUs (MELGPT_RESERVE_CUS, a multiple of 8); off by default; a value the user exported wins."""
     from melspec_gpt_vqvae_amd import dp
 
-    for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "MELGPT_RCCL_CHANNELS"):
+    for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "MELGPT_RCCL_CHANNELS", "MELGPT_RESERVE_CUS"):
         monkeypatch.delenv(k, raising=False)
     assert dp.pinned_rccl_channels() == 0
-    assert dp.pin_rccl_channels() == dp.RCCL_CHANNELS_DEFAULT == 16 and os.environ["NCCL_MAX_NCHANNELS"] == "16"
-    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "24")
-    assert dp.pin_rccl_channels(8) == 24, "the user's bound is respected"
-    monkeypatch.delenv("NCCL_MAX_NCHANNELS")
-    monkeypatch.setenv("MELGPT_RCCL_CHANNELS", "0")
-    assert dp.pin_rccl_channels() == 0 and "NCCL_MAX_NCHANNELS" not in os.environ
-    monkeypatch.setenv("MELGPT_RCCL_CHANNELS", "32")
+    assert dp.pin_rccl_channels() == 0 and "NCCL_MAX_NCHANNELS" not in os.environ and "MELGPT_RESERVE_CUS" not in os.environ
+    monkeypatch.setenv("MELGPT_RCCL_CHANNELS", "12")
     monkeypatch.setenv("NCCL_MIN_NCHANNELS", "64")
-    assert dp.pin_rccl_channels() == 32 and os.environ["NCCL_MIN_NCHANNELS"] == "32"
-    monkeypatch.delenv("NCCL_MAX_NCHANNELS")
+    assert dp.pin_rccl_channels() == 12 and os.environ["NCCL_MAX_NCHANNELS"] == "12"
+    assert os.environ["NCCL_MIN_NCHANNELS"] == "12" and os.environ["MELGPT_RESERVE_CUS"] == "16"
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "24")
+    monkeypatch.setenv("MELGPT_RESERVE_CUS", "8")
+    assert dp.pin_rccl_channels(16) == 24 and os.environ["MELGPT_RESERVE_CUS"] == "8", "what the user exported is respected"
+    for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "MELGPT_RESERVE_CUS"):
+        monkeypatch.delenv(k, raising=False)
