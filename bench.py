@@ -214,6 +214,8 @@ def pmc_summary(workload="class_gpt"):
     if j.get("gemm_family_mfma_busy") is not None:
         out["mfma_busy"] = j["gemm_family_mfma_busy"]
         out["mfma_busy_by_kernel"] = j.get("mfma_busy_by_kernel")
+    if j.get("in_kernel_clock_GHz"):      # the shader clock the chip HELD inside the big kernels (stamped diagnostic build)
+        out["in_kernel_clock_GHz"] = {k: v["GHz"] for k, v in j["in_kernel_clock_GHz"].items()}
     return out
 
 
@@ -563,6 +565,7 @@ def main():
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc.get("traffic"),
                 "traffic_unit": "bytes/step", "traffic_source": pmc.get("traffic_source"),
                 "mfma_busy": pmc.get("mfma_busy"), "mfma_busy_by_kernel": pmc.get("mfma_busy_by_kernel"),
+                "in_kernel_clock_GHz": pmc.get("in_kernel_clock_GHz"),
                 "kernel": "MFMA GEMM family (gemm8p_kernel / gemm256_kernel persistent 256x256 / gemm_kernel 128x128 + implicit-GEMM conv / "
                           "conv3x3_gn_wide_kernel / conv3x3_gn_kernel with fused GroupNorm+swish), all launches of the timed region",
                 "launches_per_step": ks["launches"] // max(a.steps, 1),

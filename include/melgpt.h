@@ -423,6 +423,10 @@ int melgpt_softmax_rows(const float* scores, long long ld_scores, int n, long lo
 int melgpt_repack_conv_weight(const float* w_oihw, void* out_ohwi, int out_dtype, int O, int I, int KH, int KW,
                               void* stream);
 
+/* MFMA shape of the multiplying waves of the wave-specialised fused conv (bf16, Cin = Cout = 128 layers): 1 (default) =
+ * v_mfma_f32_16x16x32, 0 = the round-4 v_mfma_f32_32x32x16 path; same results up to the accumulation order inside a k-slice.
+ * Returns the previous setting; MELGPT_CONV_WS_M16=0 in the environment sets the initial one. */
+int melgpt_set_conv_ws_mfma16(int on);
 /* ResnetBlock's  norm -> swish -> conv3x3  (big_model_attn_gan.py:117-127) as ONE kernel: halo-tiled 3x3 conv
  * (stride 1, pad 1) whose input patch is normalised (GroupNorm(32) statistics from melgpt_groupnorm_stats, affine
  * gamma/beta) and swish-ed while it is staged into LDS; mean == NULL -> plain convolution.  residual/bias as in

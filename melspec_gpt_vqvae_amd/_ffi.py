@@ -75,6 +75,7 @@ _PROTOS = {
                         _i, _p],
     "melgpt_set_attn_bwd_two_pass": [_i],
     "melgpt_set_attn_fwd32": [_i],
+    "melgpt_set_conv_ws_mfma16": [_i],
     "melgpt_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _l, _i, _f, _i, _p],
     "melgpt_layernorm_bwd_nwaves": [_l],
     "melgpt_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _l, _i, _i, _p],

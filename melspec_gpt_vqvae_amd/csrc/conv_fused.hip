@@ -1288,6 +1288,7 @@ int launch_fused_wide_t(const FusedConvParams& q0, int B, hipStream_t s) {
   }
   return melgpt_launch_status();
 }
+int g_ws_m16 = -1;   // MFMA shape of the wave-specialised conv's multiplying waves: 1 = 16x16x32 (default), 0 = 32x32x16
 template <bool W8>
 int launch_fused_ws_t(const FusedConvParams& q0, int B, hipStream_t s) {
   typedef WsTile<W8> WT;
@@ -1313,9 +1314,8 @@ int launch_fused_ws_t(const FusedConvParams& q0, int B, hipStream_t s) {
   const int gx = (int)(total < avail ? total : avail);
   // the multiplying waves' MFMA shape: 16x16x32 (default) or the round-4 32x32x16 form (MELGPT_CONV_WS_M16=0); same results
   // up to the accumulation order of a 16- or a 32-wide k-slice
-  static int m16 = -1;
-  if (m16 < 0) m16 = !(getenv("MELGPT_CONV_WS_M16") && atoi(getenv("MELGPT_CONV_WS_M16")) == 0);
-  if (m16) {
+  if (g_ws_m16 < 0) g_ws_m16 = !(getenv("MELGPT_CONV_WS_M16") && atoi(getenv("MELGPT_CONV_WS_M16")) == 0);
+  if (g_ws_m16) {
     if (q.stat_part) hipLaunchKernelGGL((conv3x3_gn_ws_kernel<true, W8, true>), dim3(gx), dim3(512), WT::LDS, s, q, (int)total);
     else hipLaunchKernelGGL((conv3x3_gn_ws_kernel<false, W8, true>), dim3(gx), dim3(512), WT::LDS, s, q, (int)total);
   } else {
@@ -1401,6 +1401,13 @@ static int conv3x3_gn_impl(const void* x, int B, int H, int W, int Cin, const fl
   }
   if (stat_part) return MELGPT_ERR_UNSUPPORTED;
   return launch_fused<bf16_t>(q, B, s);
+}
+
+extern "C" int melgpt_set_conv_ws_mfma16(int on) {
+  if (g_ws_m16 < 0) g_ws_m16 = !(getenv("MELGPT_CONV_WS_M16") && atoi(getenv("MELGPT_CONV_WS_M16")) == 0);
+  const int prev = g_ws_m16;
+  g_ws_m16 = on != 0;
+  return prev;
 }
 
 extern "C" int melgpt_conv3x3_gn_nhwc(const void* x, int B, int H, int W, int Cin, const float* mean, const float* rstd,

@@ -52,6 +52,24 @@ def _wgrad(M, N, K, seed=2):
     return build
 
 
+def _switched(build, setter, value):
+    """the same form with a library switch held at `value` for every call (melgpt_set_attn_fwd32 / melgpt_set_conv_ws_mfma16)"""
+    def build2(torch, ops, dev):
+        from melspec_gpt_vqvae_amd import _ffi
+
+        fn = build(torch, ops, dev)
+        set_ = getattr(_ffi.lib(), setter)
+
+        def held():
+            prev = set_(value)
+            try:
+                return fn()
+            finally:
+                set_(prev)
+        return held
+    return build2
+
+
 def _conv(B, H, W, *, stats_out=False, residual=False, seed=3):
     def build(torch, ops, dev):
         C = 128
@@ -106,9 +124,13 @@ FORMS = {
     "conv3x3+gn 6x80x848 + residual + output statistics": ("conv_ws", _conv(6, 80, 848, stats_out=True, residual=True, seed=31)),
     "conv3x3+gn 12x40x424 (8x32 tiles)": ("conv_ws", _conv(12, 40, 424, seed=32)),
     "conv3x3+gn 12x40x424 + output statistics": ("conv_ws", _conv(12, 40, 424, stats_out=True, seed=33)),
-    # ---- attention (forward; backward in one launch for the causal 16-bit lane)
-    "attention forward 32x16x265 dropout 0.5": ("attn", _attn(32, 16, 265, 0.5)),
-    "attention forward 32x16x265 dropout 0, bidirectional": ("attn", _attn(32, 16, 265, 0.0, n_unmasked=265, seed=51)),
+    "conv3x3+gn 6x80x848 + residual + output statistics, 32x32x16 multiplying waves":
+        ("conv_ws", _switched(_conv(6, 80, 848, stats_out=True, residual=True, seed=34), "melgpt_set_conv_ws_mfma16", 0)),
+    "conv3x3+gn 12x40x424, 32x32x16 multiplying waves": ("conv_ws", _switched(_conv(12, 40, 424, seed=35), "melgpt_set_conv_ws_mfma16", 0)),
+    # ---- attention (forward: the 16-row and the 32-row kernel, each forced; backward in one launch for the causal 16-bit lane)
+    "attention forward 32x16x265 dropout 0.5 (16-row kernel)": ("attn", _switched(_attn(32, 16, 265, 0.5), "melgpt_set_attn_fwd32", 0)),
+    "attention forward 32x16x265 dropout 0.5 (32-row kernel)": ("attn", _switched(_attn(32, 16, 265, 0.5, seed=50), "melgpt_set_attn_fwd32", 1)),
+    "attention forward 32x16x265 dropout 0, bidirectional (32-row kernel)": ("attn", _attn(32, 16, 265, 0.0, n_unmasked=265, seed=51)),
     "attention backward 32x16x265 dropout 0.5 (single pass)": ("attn", _attn(32, 16, 265, 0.5, bwd=True, seed=52)),
     "attention backward 32x16x265 dropout 0 (single pass)": ("attn", _attn(32, 16, 265, 0.0, bwd=True, seed=53)),
     "attention backward 16x23x265 bidirectional, dropout 0.3": ("attn", _attn(16, 23, 265, 0.3, n_unmasked=265, bwd=True, seed=54)),

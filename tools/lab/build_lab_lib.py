@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build a LAB flavour of libmelgpt_hip.so in which one source of csrc/ is replaced by a lab copy (same C ABI), for A/B runs
 through MELGPT_LAB_LIB (see _ffi.py): the other objects are the ones of the in-tree build.
-  python tools/lab/build_lab_lib.py gemm256=tools/lab/gemm256_r04.hip tools/lab/bin/libmelgpt_r04gemm.so [-DFLAG ...]"""
+  python tools/lab/build_lab_lib.py gemm8p=melspec_gpt_vqvae_amd/csrc/gemm8p.hip tools/lab/bin/libmelgpt_p8lab.so -DP8_LAB [-DFLAG ...]"""
 import os
 import subprocess
 import sys

@@ -19,6 +19,12 @@ timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/write" -o write -
 # matrix-pipe busy: SQ_VALU_MFMA_BUSY_CYCLES (cycles an MFMA occupies a SIMD's matrix pipe, summed over SIMDs) against
 # GRBM_GUI_ACTIVE (shader clock cycles of the dispatch, summed over the 8 XCDs) - SQ and GRBM slots are independent
 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/mfma" -o mfma --output-format csv -- $CMD > "$OUT/mfma.log" 2>&1
-cd "$REPO" && PROFILE_STEPS=5 python3 tools/profile_summary.py "$OUT" "$TAG"
+# the in-kernel shader clock of the step's big kernels (diagnostic build with s_memtime / s_memrealtime stamps, built in the
+# build container by tools/lab/build_clock_lib.py; MI355X_MICROARCH "DVFS give-back" item 6) -> summary "in_kernel_clock_GHz"
+cd "$REPO"
+if [ -f tools/lab/bin/libmelgpt_clock.so ] && [ -z "$EXTRA" ]; then
+  MELGPT_LAB_LIB=$REPO/tools/lab/bin/libmelgpt_clock.so timeout 600 python3 tools/lab/clock_lab.py > "$OUT/clock_lab_$TAG.jsonl" 2> "$OUT/clock_lab.log"
+fi
+PROFILE_STEPS=5 python3 tools/profile_summary.py "$OUT" "$TAG"
 find "$OUT" -name "*.csv" -size +4M -delete   # the per-dispatch counter tables are too big to ship back
 ls -la "$OUT"

@@ -96,6 +96,21 @@ def main():
                           "PROFILE_CMD", "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline"),
               note="hbm_read = 2 x FETCH_SIZE (gfx950 counts wide coalesced reads at half their bytes), hbm_write = "
                    "WRITE_SIZE; KiB -> MB; GEMM family = gemm8p_kernel + gemm256_kernel + gemm_kernel + conv3x3_gn*_kernel")
+    # in-kernel clocks (tools/lab/clock_lab.py on the stamped diagnostic build of the same sources), when collected
+    cl = os.path.join(root, f"clock_lab_{tag}.jsonl")
+    if os.path.exists(cl):
+        clocks = {}
+        for ln in open(cl):
+            try:
+                r = json.loads(ln)
+            except ValueError:
+                continue
+            if "in_kernel_clock_GHz" in r:
+                clocks[r["kernel"]] = {"GHz": r["in_kernel_clock_GHz"], "TFLOPs": r.get("TFLOPs"),
+                                       "frac_of_peak_at_that_clock": r.get("frac_of_peak_at_that_clock")}
+        js["in_kernel_clock_GHz"] = clocks
+        js["in_kernel_clock_source"] = ("d(s_memtime) / d(s_memrealtime) x 100 MHz per workgroup, median over workgroups, after 2 s of "
+                                        "back-to-back launches on random data (tools/lab/clock_lab.py, -DMELGPT_CLOCK_STAMPS build)")
     json.dump(js, open(os.path.join(root, f"summary_{tag}.json"), "w"), indent=1)
     print(open(out_csv).read()[:4000])
     print(json.dumps(js))
