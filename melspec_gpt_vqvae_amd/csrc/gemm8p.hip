@@ -97,7 +97,6 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   const int nu = (p.K + KU - 1) / KU;
   const int rows_m = tiles_m * batch;
   MELGPT_CLK_BEGIN();
-
   // ---- this workgroup's tile list: the static XCD-block lists of gemm256.hip (the 32 workgroups of an XCD take an
   // RM x RN block of tiles per item).  This kernel is launched only with RN > 0 (a full grid, a multiple of 8
   // workgroups) and batch == 1; everything else stays on the ring kernel.

@@ -15,9 +15,16 @@ M, N, K = (int(v) for v in os.environ.get("SHAPE", "33920,4096,1024").split(",")
 a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
 KM = os.environ.get("B_KMAJOR", "0") == "1"
 b = (torch.randn(*((K, N) if KM else (N, K)), device="cuda") * 0.02).to(torch.bfloat16)
+MODE = os.environ.get("MODE", "plain")      # plain | bias | drop_res | gelu_dact | mul : the epilogue the launch carries
+bias = torch.randn(N, device="cuda") * 0.1
+res = torch.randn(M, N, device="cuda").to(torch.bfloat16)
+pre = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+kw = {"plain": {}, "bias": dict(bias=bias), "drop_res": dict(bias=bias, drop_p=0.5, seed=3, stream_id=2, residual=res),
+      "gelu_dact": dict(bias=bias, act=ops.ACT_GELU_DACT, pre_out=pre), "mul": dict(act=ops.ACT_MUL, residual=res)}[MODE]
 for _ in range(3):
-    ops.gemm(a, b, b_kmajor=KM)
+    ops.gemm(a, b, b_kmajor=KM, **kw)
 torch.cuda.synchronize()
+print(f"shape {M}x{N}x{K} b_kmajor={int(KM)} mode={MODE}")
 L = _ffi.lib()
 buf = (ctypes.c_ulonglong * (64 * 24))()
 L.melgpt_p8_dbg.argtypes = [ctypes.c_void_p]
