@@ -686,6 +686,15 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
         for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = MELGPT_MFMA_16x16x32(fb[nt], fc[mt], acc[mt][nt]);
         if (reload) fb[nt] = *(const u32x4*)(sbn + nt * 2048);
       }
+      // scheduling GROUPS instead of fences: four MFMAs, then one LDS read, eight times - each weight reload right behind
+      // its fragment's MFMAs (the fenced form's order) without pinning anything else
+      if (reload) {
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+        }
+      }
     };
     unsigned kg = 0;  // K-steps multiplied so far (over all tiles)
     fetch_res(t_first);
