@@ -403,6 +403,12 @@ int melgpt_groupnorm_stats(const void* x, int B, int HW, int C, float eps, float
 /* y = act((x - mean)*rstd*gamma + beta), act = swish x*sigmoid(x) (:164-166) when swish != 0 */
 int melgpt_groupnorm_apply(const void* x, const float* mean, const float* rstd, const float* gamma,
                            const float* beta, void* y, int B, int HW, int C, int swish, int dtype, void* stream);
+/* Normalize + nonlinearity (:139-140,164-166) of a SMALL image (H W <= 1152, 128-byte channel slabs, a group >= 16 bytes:
+ * the 256 / 512-channel levels at 10 x 106 and 5 x 53) in ONE launch that reads the tensor once - statistics and
+ * normalisation out of registers; mean / rstd (B*32,) f32: optional outputs.  MELGPT_ERR_UNSUPPORTED, nothing launched, for
+ * every other shape: melgpt_groupnorm_stats + melgpt_groupnorm_apply then. */
+int melgpt_groupnorm_fused(const void* x, const float* gamma, const float* beta, void* y, int B, int HW, int C,
+                           float eps, int swish, float* mean, float* rstd, int dtype, void* stream);
 /* Encoder.conv_in (:203-207): 3x3, pad 1, ONE input channel; x (B,H,W) x_dtype; w (Cout,1,3,3) f32 as stored. */
 int melgpt_conv_in_c1(const void* x, int x_dtype, const float* w, const float* bias, void* y, int dtype, int B,
                       int H, int W, int Cout, void* stream);

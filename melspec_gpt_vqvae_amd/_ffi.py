@@ -102,6 +102,7 @@ _PROTOS = {
     "melgpt_groupnorm_nchunks": [_i],
     "melgpt_groupnorm_stats": [_p, _i, _i, _i, _f, _p, _p, _p, _i, _p],
     "melgpt_groupnorm_apply": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "melgpt_groupnorm_fused": [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _p, _i, _p],
     "melgpt_conv_in_c1": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "melgpt_conv_in_c1_stats_workspace": [_i, _i, _i],
     "melgpt_conv_in_c1_stats": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p],

@@ -1138,7 +1138,10 @@ extern "C" int melgpt_layernorm_fwd(const void* x, const float* gamma, const flo
 extern "C" int melgpt_layernorm_bwd_nwaves(long long M) {
   long long w = (M + 7) / 8;  // >= 8 rows per wave where possible
   if (w < 4) w = 4;
-  if (w > 4096) w = 4096;  // 16 waves per CU; partial rows are per BLOCK of 4 waves (<= 1024)
+  // ONE 8-wave workgroup per CU: at 33 920 x 1024 bf16 rows (+ residual gradient, + dgamma / dbeta) 1 024 waves 57.7 us,
+  // 1 536 48.0, 2 048 47.9 (5.8 TB/s), 3 072 53.8, 4 096 51.4, 8 192 and up 60.0 (tools/lab/stream_ab.py): more resident
+  // waves only lengthen the partial-row reduction and thrash the rows' lines
+  if (w > 2048) w = 2048;
   return (int)((w + 3) / 4 * 4);
 }
 

@@ -191,6 +191,112 @@ __global__ __launch_bounds__(256) void gn_apply_cols_kernel(const T* __restrict_
   }
 }
 
+// GroupNorm(32) [+ swish] of a SMALL image in ONE pass (HW <= 1152 pixels: the 10 x 106 and 5 x 53 levels of the VQ-VAE,
+// 256 / 512 channels - thirteen layers of the encoder at 12 + 5 + 10 us for three launches over 17 MB): a workgroup owns
+// one 128-byte channel slab of one image and keeps it in registers - thread (row lane r0 = t >> 3, piece j = t & 7) holds
+// the 16-byte pieces of rows r0, r0 + RL, ... (at most GNF_NP of them, all requested up front) - so the tensor is read once:
+// sums / sums of squares per thread in f32 (its pieces all belong to one group: a group is >= one piece), over the 8 row
+// lanes of a wave by shuffles, over the waves in double through LDS (wave order), var = E[x^2] - mean^2 as the
+// three-kernel path, then y = x a + b [* sigmoid] from the registers.  Needs (C / 32) sizeof(T) >= 16 (one piece never
+// straddles two groups) and C sizeof(T) % 128 == 0.
+constexpr int GNF_NP = 9;
+template <typename T, int NTH>
+__global__ __launch_bounds__(NTH) void gn_fused_small_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, T* __restrict__ y, int HW,
+                                                               int C, float eps, int swish, float* __restrict__ mean_out,
+                                                               float* __restrict__ rstd_out) {
+  constexpr int N = V16<T>::N, RL = NTH / 8, NW = NTH / 64;
+  __shared__ double red[NW][8][2];
+  __shared__ float stat[8][2];
+  const int t = threadIdx.x, j = t & 7, r0 = t >> 3, lane = t & 63, wv = t >> 6;
+  const int slab = blockIdx.x, b = blockIdx.y;
+  const int cg = C / GN_GROUPS;             // channels per group
+  const int pg = cg / N;                    // pieces per group: 1, 2 or 4
+  const int c0 = slab * (8 * N) + j * N;    // this thread's first channel
+  const T* xb = x + (long long)b * HW * C + c0;
+  T* yb = y + (long long)b * HW * C + c0;
+  float v[GNF_NP][N];
+#pragma unroll
+  for (int k = 0; k < GNF_NP; ++k) {
+    const int r = r0 + k * RL;
+    V16<T>::ld(xb + (long long)min(r, HW - 1) * C, v[k]);  // (unconditional: a branch around a load is waited for at its end)
+  }
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < GNF_NP; ++k) {
+    const bool live = r0 + k * RL < HW;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const float u = live ? v[k][e] : 0.f;
+      s += u;
+      ss = fmaf(u, u, ss);
+    }
+  }
+  // the 8 row lanes of this wave that hold piece j: lanes j + 8 m
+  s += __shfl_xor(s, 8);
+  ss += __shfl_xor(ss, 8);
+  s += __shfl_xor(s, 16);
+  ss += __shfl_xor(ss, 16);
+  s += __shfl_xor(s, 32);
+  ss += __shfl_xor(ss, 32);
+  // the pieces of a group (adjacent, aligned)
+  if (pg >= 2) {
+    s += __shfl_xor(s, 1);
+    ss += __shfl_xor(ss, 1);
+  }
+  if (pg >= 4) {
+    s += __shfl_xor(s, 2);
+    ss += __shfl_xor(ss, 2);
+  }
+  if (lane < 8) {
+    red[wv][lane][0] = (double)s;
+    red[wv][lane][1] = (double)ss;
+  }
+  __syncthreads();
+  if (t < 8) {  // piece t's group (the pieces of a group hold the same sums)
+    double a = 0.0, q = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      a += red[w][t][0];
+      q += red[w][t][1];
+    }
+    const double count = (double)HW * cg;
+    const double m = a / count;
+    double var = q / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
+    stat[t][0] = mf;
+    stat[t][1] = rf;
+    if (mean_out && (t % pg) == 0) {
+      const int g = (slab * 8 + t) / pg;
+      mean_out[b * GN_GROUPS + g] = mf;
+      rstd_out[b * GN_GROUPS + g] = rf;
+    }
+  }
+  __syncthreads();
+  const float mf = stat[j][0], rf = stat[j][1];
+  float a[N], sh[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    a[e] = rf * gamma[c0 + e];
+    sh[e] = beta[c0 + e] - mf * a[e];
+  }
+#pragma unroll
+  for (int k = 0; k < GNF_NP; ++k) {
+    const int r = r0 + k * RL;
+    if (r < HW) {
+      float o[N];
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        float u = fmaf(v[k][e], a[e], sh[e]);
+        if (swish) u = u * __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+        o[e] = u;
+      }
+      V16<T>::st(yb + (long long)r * C, o);
+    }
+  }
+}
+
 // 3x3 convolution of a single-channel image into COUT channels (NHWC out).  16 threads per pixel x 8 channels.
 template <typename TI, typename T>
 __global__ __launch_bounds__(256) void conv_in_c1_kernel(const TI* __restrict__ x, const float* __restrict__ w,
@@ -277,8 +383,21 @@ __global__ __launch_bounds__(256) void conv_in_c1_stats_kernel(const TI* __restr
   constexpr int COUT = 128;
   __shared__ float wsh[COUT * 10];
   __shared__ float red[16][16][4];  // [pixel lane][channel group of 8][s lo, ss lo, s hi, ss hi]
+  // the chunk's input window: pixels p0 - W - 1 .. p1 + W of the image in linear order (rows above / below the image: zeros),
+  // so tap (ky, kx) of pixel p is win[p - p0 + ky W + kx].  The nine taps used to be clamped global loads inside the pixel
+  // loop - every trip waited out an L1 / L2 round trip with nothing else in flight: 383 us per 64 tiles for 1.1 GB of
+  // stores; from LDS the loop is bound by its stores.
+  extern __shared__ float win[];
   for (int i = threadIdx.x; i < COUT * 9; i += 256) wsh[i] = w[i];
   for (int i = threadIdx.x; i < COUT; i += 256) wsh[COUT * 9 + i] = bias ? bias[i] : 0.f;
+  {
+    const int HWs = H * W, q0 = (int)blockIdx.x * STEM_CHUNK - W - 1, nwin = min(STEM_CHUNK, HWs - (int)blockIdx.x * STEM_CHUNK) + 2 * W + 2;
+    const TI* xs = x + (long long)blockIdx.y * HWs;
+    for (int i = threadIdx.x; i < nwin; i += 256) {
+      const int lin = q0 + i;
+      win[i] = (lin >= 0 && lin < HWs) ? Elem<TI>::ld(xs + min(max(lin, 0), HWs - 1)) : 0.f;
+    }
+  }
   __syncthreads();
   const int cgp = threadIdx.x & 15, pl = threadIdx.x >> 4;
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -292,7 +411,6 @@ __global__ __launch_bounds__(256) void conv_in_c1_stats_kernel(const TI* __restr
   }
   const int b = blockIdx.y, HW = H * W;
   const int p0 = blockIdx.x * STEM_CHUNK, p1 = min(p0 + STEM_CHUNK, HW);
-  const TI* xb = x + (long long)b * HW;
   float s[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
   int p = p0 + pl;
   int yh = p / W, xw = p - yh * W;
@@ -302,14 +420,14 @@ __global__ __launch_bounds__(256) void conv_in_c1_stats_kernel(const TI* __restr
       ++yh;
     }
     float in[9];
+    const float* wp = win + (p - p0);
+    const bool left = xw == 0, right = xw == W - 1;  // (the linear window wraps into the neighbouring rows there)
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const int iy = yh + ky - 1, ix = xw + kx - 1;
-        const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
-        const float v = Elem<TI>::ld(xb + cy * W + cx);
-        in[ky * 3 + kx] = (iy == cy && ix == cx) ? v : 0.f;
+        const float v = wp[ky * W + kx];
+        in[ky * 3 + kx] = ((kx == 0 && left) || (kx == 2 && right)) ? 0.f : v;
       }
     float o[8];
 #pragma unroll
@@ -515,6 +633,31 @@ extern "C" int melgpt_groupnorm_finalize(const float* partial, int nchunks, int 
   return melgpt_launch_status();
 }
 
+// GroupNorm(32) [+ swish] in one launch for small images (gn_fused_small_kernel); MELGPT_ERR_UNSUPPORTED - nothing launched -
+// when the shape needs the three-kernel path (melgpt_groupnorm_stats + melgpt_groupnorm_apply).  mean / rstd: optional outputs.
+extern "C" int melgpt_groupnorm_fused(const void* x, const float* gamma, const float* beta, void* y, int B, int HW, int C,
+                                      float eps, int swish, float* mean, float* rstd, int dtype, void* stream) {
+  MELGPT_CHECK(x && gamma && beta && y && B > 0 && HW > 0 && C > 0, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK((mean == nullptr) == (rstd == nullptr), MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(dtype == MELGPT_F32 || dtype == MELGPT_BF16, MELGPT_ERR_UNSUPPORTED);
+  const int es = dtype == MELGPT_F32 ? 4 : 2;
+  if (C % GN_GROUPS != 0 || (C * es) % 128 != 0 || (C / GN_GROUPS) * es < 16 || (C / GN_GROUPS) * es > 64 || B > 65535 ||
+      HW > 128 * GNF_NP || ((((uintptr_t)x | (uintptr_t)y) & 15) != 0))
+    return MELGPT_ERR_UNSUPPORTED;
+  const dim3 grid(C * es / 128, B);
+  hipStream_t s = (hipStream_t)stream;
+#define GNF_LAUNCH(T, NTH) \
+  hipLaunchKernelGGL((gn_fused_small_kernel<T, NTH>), grid, dim3(NTH), 0, s, (const T*)x, gamma, beta, (T*)y, HW, C, eps, swish, mean, rstd)
+#define GNF_PICK(T)                               \
+  if (HW <= 32 * GNF_NP) GNF_LAUNCH(T, 256);      \
+  else if (HW <= 64 * GNF_NP) GNF_LAUNCH(T, 512); \
+  else GNF_LAUNCH(T, 1024)
+  if (dtype == MELGPT_F32) { GNF_PICK(float); } else { GNF_PICK(bf16_t); }
+#undef GNF_PICK
+#undef GNF_LAUNCH
+  return melgpt_launch_status();
+}
+
 extern "C" int melgpt_groupnorm_apply(const void* x, const float* mean, const float* rstd, const float* gamma,
                                       const float* beta, void* y, int B, int HW, int C, int swish, int dtype,
                                       void* stream) {
@@ -581,9 +724,11 @@ extern "C" int melgpt_conv_in_c1_stats(const void* x, int x_dtype, const float* 
   MELGPT_CHECK(Cout == 128 && (long long)H * W < 0x7FFFFFFF / 2, MELGPT_ERR_UNSUPPORTED);
   const int nchunks = (H * W + STEM_CHUNK - 1) / STEM_CHUNK;
   hipStream_t s = (hipStream_t)stream;
+  const size_t win_bytes = (size_t)(STEM_CHUNK + 2 * W + 2) * sizeof(float);  // the chunk's input window (+ 9.2 KB static)
+  MELGPT_CHECK(win_bytes <= 48 * 1024, MELGPT_ERR_UNSUPPORTED);
 #define CIS_LAUNCH(TI, T)                                                                                             \
-  hipLaunchKernelGGL((conv_in_c1_stats_kernel<TI, T>), dim3(nchunks, B), dim3(256), 0, s, (const TI*)x, w, bias, (T*)y, \
-                     H, W, workspace)
+  hipLaunchKernelGGL((conv_in_c1_stats_kernel<TI, T>), dim3(nchunks, B), dim3(256), win_bytes, s, (const TI*)x, w, bias, \
+                     (T*)y, H, W, workspace)
   if (x_dtype == MELGPT_F32 && dtype == MELGPT_F32) CIS_LAUNCH(float, float);
   else if (x_dtype == MELGPT_F32 && dtype == MELGPT_BF16) CIS_LAUNCH(float, bf16_t);
   else if (x_dtype == MELGPT_BF16 && dtype == MELGPT_BF16) CIS_LAUNCH(bf16_t, bf16_t);

@@ -652,8 +652,15 @@ def conv3x3_gn_with_out_stats(x, stats, gamma, beta, wpack, bias, out_eps, *, sw
 def groupnorm(x, gamma, beta, eps=1e-6, swish=True):
     """x (B,H,W,C) contiguous -> GroupNorm(32) [+ swish]."""
     B, H, W, C = x.shape
-    mean, rstd = groupnorm_stats(x, eps)
+    assert x.is_contiguous()
     y = torch.empty_like(x)
+    # small images (the 10 x 106 and 5 x 53 levels): statistics + normalisation in one launch, the tensor read once
+    code = _ffi.lib().melgpt_groupnorm_fused(ptr(x), ptr(gamma), ptr(beta), ptr(y), B, H * W, C, float(eps), int(swish),
+                                             None, None, dtype_code(x.dtype), stream())
+    if code != _ffi.ERR_UNSUPPORTED:
+        _ffi.check(code, "melgpt_groupnorm_fused")
+        return y
+    mean, rstd = groupnorm_stats(x, eps)
     call("melgpt_groupnorm_apply", ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(y), B, H * W, C, int(swish),
          dtype_code(x.dtype), stream())
     return y

@@ -42,6 +42,49 @@ def test_groupnorm_swish(dt, C, HW):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("C,HW", [(256, (10, 106)), (512, (5, 53)), (256, (5, 53)), (512, (10, 106)), (128, (5, 53)),
+                                  (256, (3, 7)), (512, (9, 32)), (256, (17, 17)), (512, (24, 24)), (256, (1, 577)),
+                                  (256, (32, 36)), (512, (1, 1))])
+def test_groupnorm_in_one_launch_for_small_images(dt, C, HW):
+    """melgpt_groupnorm_fused (statistics + normalisation out of registers, the tensor read once) against torch's
+    group_norm, against the three-kernel path, and its optional mean / rstd outputs; every workgroup size's boundary
+    (288 / 289, 576 / 577, 1152 pixels); a shape it must decline (bf16 with 4-channel groups: 8 bytes per group)."""
+    from melspec_gpt_vqvae_amd import _ffi, ops
+    from melspec_gpt_vqvae_amd.ops import ptr, dtype_code, stream
+
+    B = 3
+    x = t(synth.normal(21, (B, HW[0], HW[1], C), 1.5, 0.7)).to(DT[dt]).to(DEV)
+    gm, bt = t(synth.normal(22, (C,), 0.1, 1.0)).to(DEV), t(synth.normal(23, (C,), 0.1)).to(DEV)
+    L = _ffi.lib()
+    for swish in (True, False):
+        y = torch.empty_like(x)
+        mean, rstd = torch.empty(B * 32, device=DEV), torch.empty(B * 32, device=DEV)
+        code = L.melgpt_groupnorm_fused(ptr(x), ptr(gm), ptr(bt), ptr(y), B, HW[0] * HW[1], C, 1e-6, int(swish), ptr(mean),
+                                        ptr(rstd), dtype_code(x.dtype), stream())
+        if dt == "bf16" and C == 128:
+            assert code == _ffi.ERR_UNSUPPORTED
+            continue
+        assert code == 0
+        ref = F.group_norm(x.float().cpu().permute(0, 3, 1, 2), 32, gm.cpu(), bt.cpu(), eps=1e-6)
+        if swish:
+            ref = ref * torch.sigmoid(ref)
+        ref = ref.permute(0, 2, 3, 1)
+        tol = 2e-5 if dt == "f32" else 8e-3
+        assert rel_err(y.float().cpu().numpy(), ref.numpy()) < tol
+        m3, r3 = ops.groupnorm_stats(x, 1e-6)
+        assert rel_err(mean.cpu().numpy(), m3.cpu().numpy()) < 1e-5 and rel_err(rstd.cpu().numpy(), r3.cpu().numpy()) < 1e-5
+        y3 = torch.empty_like(x)
+        _ffi.call("melgpt_groupnorm_apply", ptr(x), ptr(m3), ptr(r3), ptr(gm), ptr(bt), ptr(y3), B, HW[0] * HW[1], C, int(swish),
+                  dtype_code(x.dtype), stream())
+        assert rel_err(y.float().cpu().numpy(), y3.float().cpu().numpy()) < tol
+        assert torch.equal(ops.groupnorm(x, gm, bt, 1e-6, swish=swish), y)      # ... and it is what ops.groupnorm runs
+    # one pixel more than the largest workgroup holds: declined, nothing launched
+    xb = torch.zeros(1, 1, 1153, C, dtype=DT[dt], device=DEV)
+    assert L.melgpt_groupnorm_fused(ptr(xb), ptr(gm), ptr(bt), ptr(torch.empty_like(xb)), 1, 1153, C, 1e-6, 1, None, None,
+                                    dtype_code(xb.dtype), stream()) == _ffi.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_conv_in_out_single_channel_and_permute(dt):
     from melspec_gpt_vqvae_amd import ops
 
