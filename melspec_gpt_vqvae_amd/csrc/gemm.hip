@@ -441,6 +441,28 @@ extern "C" int melgpt_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, c
   p.ups = upsample; p.KW = KW;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MELGPT_F32) return dispatch<float>(p, LAY_CONV, LAY_ROW, 1, s);
+  if (Cout <= 128 && p.K >= 512 && p.vec_io) {
+    // at most 128 output channels (the stride-2 Downsample layers): 256 x 128 tiles of the ping-pong loop (gemm8p.hip),
+    // whose 32-bit operand offsets end at 2 GiB - whole images per launch (128 tiles of 80 x 848 x 128: two launches)
+    const long long per_img = (long long)H * W * Cin * es;
+    const int nlaunch = (int)((in_bytes + 0x7FFFFFFFLL - 1) / 0x7FFFFFFFLL);
+    const int per = (B + nlaunch - 1) / nlaunch;
+    if (per_img < 0x7FFFFFFFLL && per * per_img < 0x7FFFFFFFLL) {
+      for (int b0 = 0; b0 < B; b0 += per) {
+        const int bn = B - b0 < per ? B - b0 : per;
+        GemmParams q = p;
+        q.A = (const char*)x + b0 * per_img;
+        q.C = (char*)y + (long long)b0 * OH * OW * Cout * es;
+        if (residual) q.R = (const char*)residual + (long long)b0 * OH * OW * Cout * es;
+        q.M = bn * OH * OW;
+        q.a_bytes = (unsigned)(bn * per_img);
+        int st = launch_conv8p_n128(q, s);
+        if (st == MELGPT_ERR_UNSUPPORTED) st = dispatch<bf16_t>(q, LAY_CONV, LAY_ROW, 1, s);
+        if (st != MELGPT_OK) return st;
+      }
+      return MELGPT_OK;
+    }
+  }
   const int cfg = pick_tile(p, 1);
   if (cfg != 1) {
     int st = launch_gemm256(p, LAY_CONV, LAY_ROW, 1, cfg, s);

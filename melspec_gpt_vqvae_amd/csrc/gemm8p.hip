@@ -33,6 +33,10 @@
 // the convolutions' implicit-im2col A operand (running offsets rebuilt per filter tap), single-round launches (fewer
 // tiles than CUs), the weight gradients' split-K batches with the bias row sums on the A fragments, and a half-height
 // last round (128-row tiles behind the last whole round of 256-row tiles, same loop with the A1 half absent).
+// NHALF (the implicit-GEMM convolutions with Cout <= 128: the stride-2 Downsample layers): a 256 x 128 output tile - the
+// B1 half does not exist (its pieces are requested out of range so that the counted waits keep their meaning, quadrants
+// (*, B1) are neither read nor multiplied), B0 holds weight rows 0 .. 127 (wave column wc: rows 32 wc .. 32 wc + 31) and a
+// wave owns a contiguous 128 x 32 block of C.
 // A half-tiles are always slab-permuted (a wave's rows of quadrant mq live in A half mq: 64-row slabs, 48 of them used
 // by the 192-row tile), so a wave still owns a CONTIGUOUS 128 (96) x 64 block of C and the epilogue is gemm_common.h's.
 #include <cstdlib>
@@ -78,7 +82,7 @@ __device__ __forceinline__ void dma16(rsrc_t rs, char* lds_wave_base, unsigned v
 __device__ unsigned long long p8_dbg[64 * 24];  // per tile: start, K loop done, drained, epilogue done, then one stamp per K tile (<= 20)
 #endif
 
-template <int ALAY, int BLAY, int MODE, int TM, bool EDGE = false>
+template <int ALAY, int BLAY, int MODE, int TM, bool EDGE = false, bool NHALF = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, int tiles_n, int batch, int RN, int tail_m0) {
   constexpr int MT = TM / 2, TN = 4, BM = 32 * TM, BN = 256;
   constexpr int SLAB = 16 * MT;                      // rows of one wave's quadrant (64 or 48)
@@ -87,6 +91,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   constexpr bool BNAT = BLAY == LAY_KMAJ;            // B in natural column order (see the header)
   constexpr bool BATCHED = ALAY == LAY_KMAJ && BLAY == LAY_KMAJ;  // the weight gradients' split-K batches; others: batch == 1
   static_assert(TM == 8 || (TM == 6 && ALAY != LAY_KMAJ), "the K-major A image assumes 64-row slabs");
+  static_assert(!NHALF || (BLAY == LAY_ROW && !EDGE), "the 128-column tile exists for row-major B only");
   constexpr bool CONV = ALAY == LAY_CONV;  // implicit im2col
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A0 A1 B0 B1][16 KiB] + 32 KiB epilogue staging
 
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   // row-major half-tiles: LDS row 8 (w + 8 j) + l3 holds, at physical chunk lane & 7, logical chunk r_c (row_off's swizzle)
   const int r_c = (lane & 7) ^ ((4 * w + (lane >> 4)) & 7);
   const int a_row0 = 8 * w + l3;                        // row inside the slab (used while < SLAB); slab j = piece j
-  const int b_row0 = (w >> 2) * 64 + 8 * (w & 3) + l3;  // tile column of B piece (half 0, j = 0): slabs of 32, j adds 128
+  const int b_row0 = (w >> 2) * (NHALF ? 32 : 64) + 8 * (w & 3) + l3;  // tile column of B piece (half 0, j = 0): slabs of 32, j adds 128 (NHALF: 64)
   // K-major half-tiles: k-rows 4 (w + 8 j) + (lane >> 4), 16 chunks of 8 columns, logical = physical ^ (s << 1)
   const int k_row0 = 4 * w + (lane >> 4);
   const int k_lc = (lane & 15) ^ (((lane >> 4) | (((w >> 1) & 1) << 2)) << 1);
@@ -210,7 +215,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       ca[h][j] = ALAY == LAY_KMAJ ? (unsigned)(h * 128) : (unsigned)((long long)(j * (BM / 2) + h * SLAB) * p.lda * 2);
-      cb[h][j] = BLAY == LAY_KMAJ ? (unsigned)(h * 256) : (unsigned)((long long)(j * 128 + h * 32) * p.ldb * 2);
+      cb[h][j] = BLAY == LAY_KMAJ ? (unsigned)(h * 256)
+                                  : (unsigned)((long long)(NHALF ? j * 64 : j * 128 + h * 32) * p.ldb * 2);
     }
   const unsigned a_kstep = ALAY == LAY_KMAJ ? (unsigned)(64 * p.lda * 2) : 128u;
   const unsigned b_kstep = BLAY == LAY_KMAJ ? (unsigned)(64 * p.ldb * 2) : 128u;
@@ -325,6 +331,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       unsigned off = b_run[BJ == 2 ? j : 0] + cb[h][j];
+      if constexpr (NHALF) off = h ? MARK : off;  // (no B1 half: requested out of range, the request stream keeps its count)
       if constexpr (EDGE && BLAY == LAY_KMAJ) off = k_lc * 8 < b_lim[h] ? off : MARK;
       else if constexpr (BLAY == LAY_KMAJ) off |= bh_mark[h];
       dma16(rb, slot + (w + 8 * j) * 1024, off);
@@ -463,6 +470,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         for (int ks = 0; ks < 2; ++ks) fa[mt][ks] = rd(std::integral_constant<int, ALAY>{}, xa, mt, ks, slot);
     };
     auto ld_b = [&](int slot, int e0, u32x4 (&fb)[2][2], int other = 0) {  // (e0: K-major B, natural order: first tile of the subtile; other = BUF: the buffer that is NOT being multiplied)
+      if constexpr (NHALF) {
+        if (slot == S_B1) return;  // (compile-time at every call site)
+      }
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -474,6 +484,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
       if constexpr (TAILS && MQ == 1) {
         if (km_half) return;  // (a 128-row tile: quadrants (A1, *) do not exist; wave-uniform)
       }
+      if constexpr (NHALF && NQ == 1) return;  // (a 128-column tile: quadrants (*, B1) do not exist)
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -743,7 +754,17 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
       const int m_base = m0 + wr * ((TAILS && km_half) ? 64 : BM / 2);
 #pragma unroll
       for (int mt = 0; mt < TM; ++mt) mrow[mt] = (TAILS && km_half && mt >= MT) ? -1ll : (long long)(m_base + mt * 16);
-      epilogue_rows<bf16_t, TM, TN, MODE, ALAY != LAY_CONV>(p, acc, mrow, 16, n0 + wc * 64, bz, lane_e, smem + 2 * BUF + w * 4096);
+      if constexpr (NHALF) {
+        // the wave's 64-column block of the shared epilogue with its columns cut behind the 32 that exist (column tiles 2
+        // and 3 of the accumulator block were never multiplied; the epilogue's own range checks drop them)
+        GemmParams pw = p;
+        pw.N = min(p.N, n0 + wc * 32 + 32);
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) acc[mt][2] = acc[mt][3] = f32x4{0.f, 0.f, 0.f, 0.f};
+        epilogue_rows<bf16_t, TM, TN, MODE, false>(pw, acc, mrow, 16, n0 + wc * 32, bz, lane_e, smem + 2 * BUF + w * 4096);
+      } else {
+        epilogue_rows<bf16_t, TM, TN, MODE, ALAY != LAY_CONV>(p, acc, mrow, 16, n0 + wc * 64, bz, lane_e, smem + 2 * BUF + w * 4096);
+      }
     }
     if constexpr (CS) {
       if (p.a_rowsum && (lane_e >> 4) == 0) {  // every tile writes its slice, zeros when it took no K tile
@@ -764,17 +785,17 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   MELGPT_CLK_END(clk_gemm8p);
 }
 
-template <int ALAY, int BLAY, int MODE, int TM, bool EDGE>
+template <int ALAY, int BLAY, int MODE, int TM, bool EDGE, bool NHALF = false>
 int launch8p_e(const GemmParams& p, int tiles_m, int tiles_n, int batch, int RN, int grid, int tail_m0, hipStream_t s) {
   constexpr int LDS = 160 * 1024;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)gemm8p_kernel<ALAY, BLAY, MODE, TM, EDGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm8p_kernel<ALAY, BLAY, MODE, TM, EDGE, NHALF>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return MELGPT_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL((gemm8p_kernel<ALAY, BLAY, MODE, TM, EDGE>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n, batch, RN, tail_m0);
+  hipLaunchKernelGGL((gemm8p_kernel<ALAY, BLAY, MODE, TM, EDGE, NHALF>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n, batch, RN, tail_m0);
   melgpt_count_gemm_loop(1);
   return melgpt_launch_status();
 }
@@ -874,4 +895,30 @@ int gemmk::launch_gemm8p(const GemmParams& p, int alay, int blay, int mode, int 
     if (tm == 6) return launch8p<LAY_CONV, LAY_ROW, EPI_PLAIN16, 6>(p, tiles_m, tiles_n, batch, RN, grid, s);
   }
   return MELGPT_ERR_UNSUPPORTED;
+}
+
+// The implicit-GEMM convolutions with at most 128 output channels (Downsample: 3x3, stride 2, 128 -> 128 at 80 x 848 and
+// 40 x 424 - 631 TFLOP/s on the 128 x 128 kernel) as 256 x 128 tiles of the ping-pong loop (NHALF).  One tile column, the
+// block lists degenerate to RM = workgroups per XCD consecutive tile rows; fewer tiles than CUs: one tile per workgroup.
+// MELGPT_ERR_UNSUPPORTED: the caller's 128 x 128 kernel serves the launch.  MELGPT_CONV_N128=0 switches the form off.
+int gemmk::launch_conv8p_n128(const GemmParams& p, hipStream_t s) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("MELGPT_CONV_N128");
+    on = e ? atoi(e) : 1;
+  }
+  if (!on || !melgpt_get_gemm_pingpong() || melgpt_get_dynamic_tiles()) return MELGPT_ERR_UNSUPPORTED;
+  if (p.N > 128 || p.cC % 64 != 0 || p.K < 512 || !p.vec_io || p.out_f32 || p.accumulate || p.C2 || p.drop_scale != 0.f ||
+      p.act != MELGPT_ACT_NONE || p.a_bytes >= 0x80000000u || p.b_bytes >= 0x80000000u)
+    return MELGPT_ERR_UNSUPPORTED;
+  int ncu = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+    return MELGPT_ERR_LAUNCH;
+  if (ncu - melgpt_get_reserved_cus() >= 8) ncu -= melgpt_get_reserved_cus();
+  const int tiles_m = (p.M + 255) / 256;
+  if (tiles_m < ncu / 2) return MELGPT_ERR_UNSUPPORTED;  // (a small image: the 128 x 128 kernel's two workgroups per CU)
+  int grid = tiles_m < ncu ? tiles_m : ncu, RN = 0;
+  if (grid == ncu && ncu % 8 == 0) RN = 1;
+  else if (grid != tiles_m) return MELGPT_ERR_UNSUPPORTED;
+  return launch8p_e<LAY_CONV, LAY_ROW, EPI_PLAIN16, 8, false, true>(p, tiles_m, 1, 1, RN, grid, 0, s);
 }

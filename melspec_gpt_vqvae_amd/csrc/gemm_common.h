@@ -614,4 +614,5 @@ int launch_gemm256(const GemmParams& p, int alay, int blay, int batch, int tile_
 int launch_gemm8p(const GemmParams& p, int alay, int blay, int mode, int tm, int tiles_m, int tiles_n, int batch, int RN,
                   int grid, hipStream_t s);
 
+int launch_conv8p_n128(const GemmParams& p, hipStream_t s);  // gemm8p.hip: Cout <= 128 convolutions as 256 x 128 tiles
 }  // namespace gemmk

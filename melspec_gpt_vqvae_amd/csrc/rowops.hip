@@ -1359,7 +1359,7 @@ extern "C" int melgpt_adamw(float* param, const float* grad, float* exp_avg, flo
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   // one 16-byte chunk of each of the seven streams per thread, no grid cap: a 4 096-workgroup grid walking the buffer in
   // two-chunk trips ran the 302.85 M-parameter step at 4.67 TB/s, 65 536 workgroups at 5.13, one chunk per thread
-  // (296 k workgroups) at 5.45 (tools/lab/adamw_ab.py: 1.945 -> 1.667 ms)
+  // (296 k workgroups) at 5.45 (1.945 -> 1.667 ms; tools/lab/stream_ab.py)
   constexpr int cap = 1 << 22;
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4, 256, cap)), dim3(256), 0, (hipStream_t)stream, param,
                      grad, exp_avg, exp_avg_sq, (bf16_t*)param_bf16, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,

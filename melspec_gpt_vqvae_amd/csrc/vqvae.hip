@@ -100,31 +100,41 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
   }
 }
 
-// stage 2: chunks are combined in double, var = E[x^2] - mean^2 (biased), rstd = 1/sqrt(var + eps)
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunks, int B, double count, float eps,
-                                   float* __restrict__ mean, float* __restrict__ rstd) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (b, g)
-  if (i >= B * GN_GROUPS) return;
-  const int b = i / GN_GROUPS, g = i % GN_GROUPS;
+// stage 2: chunks are combined in double, var = E[x^2] - mean^2 (biased), rstd = 1/sqrt(var + eps).  16 lanes per
+// (image, group): lane l adds chunks l, l + 16, ... (four requested per trip), then the 16 partial sums meet in a fixed
+// shuffle tree - behind the fused conv an image has 265 chunks, and one thread walking them took 22 us per layer.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nchunks, int B, double count,
+                                                          float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+  const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gi >> 4, l = gi & 15;  // (b, g), lane of its 16
+  const bool live = i < B * GN_GROUPS;
+  const int ic = live ? i : B * GN_GROUPS - 1;  // (dead lanes shadow the last pair: every lane reaches the shuffles)
+  const int b = ic / GN_GROUPS, g = ic % GN_GROUPS;
   double a = 0.0, q = 0.0;
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
   const f32x2_t* o = (const f32x2_t*)partial + ((long long)b * nchunks) * GN_GROUPS + g;
-  int c = 0;
-  for (; c + 7 < nchunks; c += 8) {  // eight chunks requested together, added in chunk order (same bits as one by one)
-    f32x2_t v[8];
+  int c = l;
+  for (; c + 48 < nchunks; c += 64) {
+    f32x2_t v[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = o[(long long)(c + j) * GN_GROUPS];
+    for (int j = 0; j < 4; ++j) v[j] = o[(long long)(c + 16 * j) * GN_GROUPS];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 4; ++j) {
       a += (double)v[j][0];
       q += (double)v[j][1];
     }
   }
-  for (; c < nchunks; ++c) {
+  for (; c < nchunks; c += 16) {
     const f32x2_t v = o[(long long)c * GN_GROUPS];
     a += (double)v[0];
     q += (double)v[1];
   }
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) {
+    a += __shfl_xor(a, m);
+    q += __shfl_xor(q, m);
+  }
+  if (!live || l != 0) return;
   const double m = a / count;
   double var = q / count - m * m;
   if (var < 0.0) var = 0.0;
@@ -620,7 +630,7 @@ extern "C" int melgpt_groupnorm_stats(const void* x, int B, int HW, int C, float
   else
     hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, dim3(nchunks, B), dim3(256), lds, s, (const bf16_t*)x, HW, C,
                        workspace);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * GN_GROUPS + 255) / 256), dim3(256), 0, s, workspace, nchunks, B,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * GN_GROUPS * 16 + 255) / 256), dim3(256), 0, s, workspace, nchunks, B,
                      (double)HW * (C / GN_GROUPS), eps, mean, rstd);
   return melgpt_launch_status();
 }
@@ -628,7 +638,7 @@ extern "C" int melgpt_groupnorm_stats(const void* x, int B, int HW, int C, float
 extern "C" int melgpt_groupnorm_finalize(const float* partial, int nchunks, int B, double count, float eps, float* mean,
                                          float* rstd, void* stream) {
   MELGPT_CHECK(partial && mean && rstd && nchunks > 0 && B > 0 && count > 0, MELGPT_ERR_BAD_ARG);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * GN_GROUPS + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * GN_GROUPS * 16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial,
                      nchunks, B, count, eps, mean, rstd);
   return melgpt_launch_status();
 }

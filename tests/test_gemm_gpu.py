@@ -318,7 +318,8 @@ def test_wide_kernel_fused_epilogues_and_split_k_at_size():
     assert rel_err(gw.cpu().numpy(), (dy.float().cpu().t() @ xw.float().cpu()).numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("case", ["s1_256", "s1_512", "s2", "up", "1x1"])
+@pytest.mark.parametrize("case", ["s1_256", "s1_512", "s2", "up", "1x1", "s2_128", "s2_128_one_round", "up_128", "s1_64out",
+                                  "s1_128_ragged"])
 def test_conv_on_wide_kernel_at_size(case):
     """implicit-GEMM convolutions big enough for the persistent 256-wide kernel (im2col rows fetched by LDS-DMA with
     address predicates for the padding / stride-2 pad / nearest x2 upsampling) == F.conv2d on CPU."""
@@ -333,8 +334,20 @@ def test_conv_on_wide_kernel_at_size(case):
         B, H, W, Cin, Cout, k, stride, up = 6, 80, 424, 256, 256, 3, 2, False
     elif case == "up":
         B, H, W, Cin, Cout, k, stride, up = 4, 40, 106, 256, 256, 3, 1, True
-    else:
+    elif case == "1x1":
         B, H, W, Cin, Cout, k, stride, up = 10, 40, 212, 256, 512, 1, 1, False
+    # at most 128 output channels: 256 x 128 tiles of the ping-pong loop (csrc/gemm8p.hip, NHALF) - several rounds of the
+    # block lists, one round (fewer tiles than CUs), nearest x2 upsampling, half the tile's columns, a ragged last tile
+    elif case == "s2_128":
+        B, H, W, Cin, Cout, k, stride, up = 6, 80, 848, 128, 128, 3, 2, False
+    elif case == "s2_128_one_round":
+        B, H, W, Cin, Cout, k, stride, up = 3, 80, 848, 128, 128, 3, 2, False
+    elif case == "up_128":
+        B, H, W, Cin, Cout, k, stride, up = 4, 40, 212, 256, 128, 3, 1, True
+    elif case == "s1_64out":
+        B, H, W, Cin, Cout, k, stride, up = 4, 80, 424, 128, 64, 3, 1, False
+    else:
+        B, H, W, Cin, Cout, k, stride, up = 5, 77, 431, 64, 104, 3, 1, False
     x = (torch.randn(B, H, W, Cin) * 0.5).to(torch.bfloat16)
     w = (torch.randn(Cout, Cin, k, k) * 0.05).to(torch.bfloat16)
     bias = torch.randn(Cout) * 0.1
