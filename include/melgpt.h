@@ -328,6 +328,11 @@ int melgpt_onehot_rows(const long long* idx, long long idx_ld, int B, int Tt, in
 /* out[c] (+)= scale * sum_{r<R} partials[r*ld + c], fixed summation order (split-K / two-stage reductions) */
 int melgpt_reduce_rows(const float* partials, int R, long long ld, long long ncols, float* out, int accumulate,
                        float scale, void* stream);
+/* melgpt_reduce_rows for TWO jobs in one launch (scale 1): a weight gradient's split-K slabs and the row-sum partials of its
+ * bias gradient behind melgpt_wgrad_rowsum (transformer/minGPT.py:56-63,100-105 backward).  The same bits as two calls. */
+int melgpt_reduce_rows_pair(const float* part_a, int Ra, long long lda, long long ncols_a, float* out_a, int accumulate_a,
+                            const float* part_b, int Rb, long long ldb, long long ncols_b, float* out_b, int accumulate_b,
+                            void* stream);
 /* F.cross_entropy pieces (minGPT.py:197,416; decoders.py:64-68): loss_rows[m] = lse[m] - logits[m,target[m]] */
 int melgpt_cross_entropy_fwd(const float* logits, long long ld, const long long* target, long long M, int V,
                              float* loss_rows, float* lse, void* stream);

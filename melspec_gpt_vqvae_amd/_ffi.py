@@ -113,6 +113,7 @@ _PROTOS = {
     "melgpt_codes_permute": [_p, _p, _i, _i, _i, _i, _p],
     "melgpt_onehot_rows": [_p, _l, _i, _i, _i, _i, _p, _i, _p],
     "melgpt_reduce_rows": [_p, _i, _l, _l, _p, _i, _f, _p],
+    "melgpt_reduce_rows_pair": [_p, _i, _l, _l, _p, _i, _p, _i, _l, _l, _p, _i, _p],
     "melgpt_mel_frontend_fwd": [_p, _i, _l, _i, _i, _p, _p, _p, _i, _f, _f, _f, _f, _f, _f, _f, _p, _i, _p, _i, _i, _i,
                                 _p],
     "melgpt_mel_transforms_fwd": [_p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _p, _i, _p, _i, _i, _i, _p],

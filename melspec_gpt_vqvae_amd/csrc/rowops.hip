@@ -300,13 +300,13 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 // rows, which a block of 4 phases walks latency-bound.  Optional second destination: columns >= split go to
 // out2[c - split] (LayerNorm's [dgamma | dbeta] partial rows are reduced by one launch).
 // Fixed summation order (phase-major, then the four chains, then the phases pairwise) => deterministic.
-__global__ __launch_bounds__(256) void reduce_rows4_kernel(const float* __restrict__ part, int R, long long ld,
-                                                           long long ncols, float* __restrict__ out,
-                                                           float* __restrict__ out2, long long split, int accumulate,
-                                                           float scale) {
+__device__ __forceinline__ void reduce_rows4_body(int blk, const float* __restrict__ part, int R, long long ld,
+                                                  long long ncols, float* __restrict__ out,
+                                                  float* __restrict__ out2, long long split, int accumulate,
+                                                  float scale) {
   __shared__ f32x4 sh[16][16];
   const int lc = threadIdx.x & 15, ph = threadIdx.x >> 4;
-  const long long c = ((long long)blockIdx.x * 16 + lc) * 4;
+  const long long c = ((long long)blk * 16 + lc) * 4;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
   if (c < ncols) {
     int r = ph;
@@ -331,17 +331,24 @@ __global__ __launch_bounds__(256) void reduce_rows4_kernel(const float* __restri
   }
 }
 
+__global__ __launch_bounds__(256) void reduce_rows4_kernel(const float* __restrict__ part, int R, long long ld,
+                                                           long long ncols, float* __restrict__ out,
+                                                           float* __restrict__ out2, long long split, int accumulate,
+                                                           float scale) {
+  reduce_rows4_body((int)blockIdx.x, part, R, ld, ncols, out, out2, split, accumulate, scale);
+}
+
 // The same sum for a FEW partial rows (R <= RB <= 8: split-K slabs of a weight gradient, N K columns each): one thread
 // per 16-byte column chunk requests all its rows at once (unconditional loads, row index clamped - a branch around a load
 // would be waited for at its end) and adds them in the order reduce_rows4_kernel does (phase sums, then the pair tree),
 // so both kernels give the same bits.  reduce_rows4_kernel spends a 256-thread workgroup on 64 columns and keeps
 // R of its 16 row phases busy: 3 TB/s on 4 x 16 MB slabs.
 template <int RB>  // row phases in use: 2, 4 or 8 (R <= RB)
-__global__ __launch_bounds__(256) void reduce_few_rows_kernel(const float* __restrict__ part, int R, long long ld,
-                                                              long long ncols, float* __restrict__ out,
-                                                              float* __restrict__ out2, long long split, int accumulate,
-                                                              float scale) {
-  const long long c = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+__device__ __forceinline__ void reduce_few_rows_body(int blk, const float* __restrict__ part, int R, long long ld,
+                                                     long long ncols, float* __restrict__ out,
+                                                     float* __restrict__ out2, long long split, int accumulate,
+                                                     float scale) {
+  const long long c = ((long long)blk * 256 + threadIdx.x) * 4;
   if (c >= ncols) return;
   float* dst = (out2 && c >= split) ? out2 + (c - split) : out + c;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -357,6 +364,35 @@ __global__ __launch_bounds__(256) void reduce_few_rows_kernel(const float* __res
   f32x4 sum = (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) * scale;
   if (accumulate) sum += prev;
   *(f32x4*)dst = sum;
+}
+
+template <int RB>
+__global__ __launch_bounds__(256) void reduce_few_rows_kernel(const float* __restrict__ part, int R, long long ld,
+                                                              long long ncols, float* __restrict__ out,
+                                                              float* __restrict__ out2, long long split, int accumulate,
+                                                              float scale) {
+  reduce_few_rows_body<RB>((int)blockIdx.x, part, R, ld, ncols, out, out2, split, accumulate, scale);
+}
+
+// TWO sums in one launch (a weight gradient's split-K slabs and the bias gradient's row-sum partials behind the same
+// GEMM: 96 launches of ~4 us per training step otherwise): workgroups [0, g1) run the first job - the few-rows form when
+// RB > 0, else the 16-phase form -, the rest the second job in the 16-phase form.  The bodies are the stand-alone
+// kernels': same bits.
+struct ReduceJob {
+  const float* part;
+  int R;
+  long long ld, ncols;
+  float* out;
+  int accumulate;
+};
+template <int RB>
+__global__ __launch_bounds__(256) void reduce_pair_kernel(ReduceJob a, int g1, ReduceJob b) {
+  if ((int)blockIdx.x < g1) {
+    if constexpr (RB > 0) reduce_few_rows_body<RB>((int)blockIdx.x, a.part, a.R, a.ld, a.ncols, a.out, nullptr, 0, a.accumulate, 1.0f);
+    else reduce_rows4_body((int)blockIdx.x, a.part, a.R, a.ld, a.ncols, a.out, nullptr, 0, a.accumulate, 1.0f);
+  } else {
+    reduce_rows4_body((int)blockIdx.x - g1, b.part, b.R, b.ld, b.ncols, b.out, nullptr, 0, b.accumulate, 1.0f);
+  }
 }
 
 // picks the vectorised form when columns, leading dimension, split and pointers allow 16-byte accesses
@@ -1388,6 +1424,33 @@ extern "C" int melgpt_reduce_rows(const float* partials, int R, long long ld, lo
                                   int accumulate, float scale, void* stream) {
   MELGPT_CHECK(partials && out && R > 0 && ncols > 0 && ld >= ncols, MELGPT_ERR_BAD_ARG);
   launch_reduce_rows(partials, R, ld, ncols, out, nullptr, 0, accumulate, scale, (hipStream_t)stream);
+  return melgpt_launch_status();
+}
+
+// melgpt_reduce_rows twice in ONE launch (jobs a, b; scale 1): out_x[c] (+)= sum_r part_x[r * ld_x + c].  The same bits as two
+// calls.  Operands that do not allow 16-byte accesses: two launches.
+extern "C" int melgpt_reduce_rows_pair(const float* part_a, int Ra, long long lda, long long ncols_a, float* out_a,
+                                       int accumulate_a, const float* part_b, int Rb, long long ldb, long long ncols_b,
+                                       float* out_b, int accumulate_b, void* stream) {
+  MELGPT_CHECK(part_a && out_a && Ra > 0 && ncols_a > 0 && lda >= ncols_a, MELGPT_ERR_BAD_ARG);
+  MELGPT_CHECK(part_b && out_b && Rb > 0 && ncols_b > 0 && ldb >= ncols_b, MELGPT_ERR_BAD_ARG);
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = ncols_a % 4 == 0 && lda % 4 == 0 && ncols_b % 4 == 0 && ldb % 4 == 0 &&
+                   ((((uintptr_t)part_a | (uintptr_t)out_a | (uintptr_t)part_b | (uintptr_t)out_b) & 15) == 0);
+  const long long ga4 = (ncols_a / 4 + 15) / 16, gafew = (ncols_a / 4 + 255) / 256, gb = (ncols_b / 4 + 15) / 16;
+  if (!vec || ga4 + gb > 0x7FFFFFFF) {
+    launch_reduce_rows(part_a, Ra, lda, ncols_a, out_a, nullptr, 0, accumulate_a, 1.0f, s);
+    launch_reduce_rows(part_b, Rb, ldb, ncols_b, out_b, nullptr, 0, accumulate_b, 1.0f, s);
+    return melgpt_launch_status();
+  }
+  const ReduceJob a{part_a, Ra, lda, ncols_a, out_a, accumulate_a}, b{part_b, Rb, ldb, ncols_b, out_b, accumulate_b};
+  const bool few = Ra <= 8 && ncols_a >= (1 << 16);  // (launch_reduce_rows' rule)
+  const int g1 = (int)(few ? gafew : ga4);
+  const dim3 grid((unsigned)(g1 + gb));
+  if (!few) hipLaunchKernelGGL(reduce_pair_kernel<0>, grid, dim3(256), 0, s, a, g1, b);
+  else if (Ra <= 2) hipLaunchKernelGGL(reduce_pair_kernel<2>, grid, dim3(256), 0, s, a, g1, b);
+  else if (Ra <= 4) hipLaunchKernelGGL(reduce_pair_kernel<4>, grid, dim3(256), 0, s, a, g1, b);
+  else hipLaunchKernelGGL(reduce_pair_kernel<8>, grid, dim3(256), 0, s, a, g1, b);
   return melgpt_launch_status();
 }
 

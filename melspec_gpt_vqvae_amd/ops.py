@@ -303,8 +303,8 @@ def wgrad(dy, x, out, accumulate, bias_out=None, bias_accumulate=None):
                 tm.cancel()
         if code != _ffi.ERR_UNSUPPORTED:
             _ffi.check(code, "melgpt_wgrad_rowsum")
-            call("melgpt_reduce_rows", ptr(part), ns, N * K, N * K, ptr(out), int(accumulate), 1.0, stream())
-            call("melgpt_reduce_rows", ptr(rpart), nrs, N, N, ptr(bias_out), int(bias_accumulate), 1.0, stream())
+            call("melgpt_reduce_rows_pair", ptr(part), ns, N * K, N * K, ptr(out), int(accumulate),
+                 ptr(rpart), nrs, N, N, ptr(bias_out), int(bias_accumulate), stream())
             return out
     if bias_out is not None:
         colsum(dy, bias_out, accumulate=bias_accumulate)
