@@ -231,6 +231,15 @@ int melgpt_attn_fwd(const void* q, const void* k, const void* v, long long ld, v
  * decoding step) and `pos` is ignored. */
 int melgpt_attn_decode(const void* qkv, long long ld, void* kcache, void* vcache, int B, int H, int head_size,
                        int Tmax, int pos, const int* pos_dev, void* out, float* att_row, int dtype, void* stream);
+/* The qkv projection (Block.ln1 folded in: minGPT.py:108-112, 76-78) and the KV-cached attention step of one decode position
+ * for 1 .. 4 sequences in ONE launch, one workgroup per (head, sequence): x (B, C) rows of the residual stream, W (3C, C) rows
+ * [key | query | value] (the packed view of the three nn.Linear weights), bias (3C) f32 or null; the rest as
+ * melgpt_attn_decode.  Bit-identical to melgpt_gemv_rows (with LayerNorm) + melgpt_attn_decode.  MELGPT_ERR_UNSUPPORTED,
+ * nothing launched: f32 lane, head size != 64, C > 1536, B > 4. */
+int melgpt_qkv_attn_decode(const void* x, long long ldx, const void* W, long long ldw, const float* bias,
+                           const float* ln_gamma, const float* ln_beta, float ln_eps, void* kcache, void* vcache, int B,
+                           int H, int head_size, int Tmax, int pos, const int* pos_dev, void* out, float* att_row,
+                           int dtype, void* stream);
 /* skinny-M linear layer of a decode step: y (M,N) = epi(x (M,K) @ W (N,K)^T + bias) (+ residual), W = nn.Linear.weight
  * layout; act in {MELGPT_ACT_NONE, MELGPT_ACT_GELU (exact erf)}; y in `dtype`, or f32 when out_f32 (always f32 for
  * dtype f32).  One wave per 4 output columns streams the weights once with every CU busy; M is walked 16 rows at a

@@ -59,6 +59,7 @@ _PROTOS = {
     "melgpt_conv2d_nhwc": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],
     "melgpt_attn_fwd": [_p, _p, _p, _l, _p, _l, _p, _p, _i, _i, _i, _i, _i, _f, _u64, C.c_uint, _i, _p],
     "melgpt_attn_decode": [_p, _l, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],
+    "melgpt_qkv_attn_decode": [_p, _l, _p, _l, _p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],
     "melgpt_embed_decode": [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p],
     "melgpt_incr_i32": [_p, _p],
     "melgpt_pad1d_act": [_p, _p, _i, _i, _i, _i, _i, _f, _i, _p],

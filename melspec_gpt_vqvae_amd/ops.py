@@ -456,6 +456,34 @@ def attn_decode(qkv, kcache, vcache, n_head, pos, att_row=None, pos_dev=None, ou
     return out
 
 
+# OFF by default: built as the review proposed (one workgroup per (head, sequence)) and MEASURED SLOWER - 0.93 against
+# 0.58 ms per token at one sequence (profiles/r05_decode_lab.md): 16 workgroups cannot pull a layer's 6.3 MB of qkv weights
+# at more than ~0.4 TB/s (per-CU memory-level parallelism), the weight-streaming GEMV uses all 256 CUs.  Kept as a tested,
+# bit-identical alternative behind the switch.
+QKV_ATTN_FUSED = os.environ.get("MELGPT_DECODE_QKV_ATTN", "0") == "1"
+
+
+def qkv_attn_decode(x, w_qkv, b_qkv, ln, kcache, vcache, n_head, pos, att_row=None, pos_dev=None, force=False):
+    """ln1 -> qkv projection -> KV-cached attention step for 1 .. 4 sequences in ONE launch (melgpt_qkv_attn_decode; the
+    bits of linear_rows(..., ln=...) + attn_decode).  x (B, C), w_qkv (3C, C) rows [key | query | value], caches
+    (B, Tmax, C).  Returns None - nothing launched - where the two-launch path has to serve (the switch is off and not
+    `force`, f32 lane, B > 4, ...)."""
+    B, C = x.shape
+    if not (QKV_ATTN_FUSED or force) or x.dtype != _ffi.HALF_DTYPE or B > 4 or C != 64 * n_head or C > 1536 or x.stride(1) != 1:
+        return None
+    assert w_qkv.shape == (3 * C, C) and w_qkv.stride(1) == 1 and w_qkv.dtype == x.dtype
+    assert kcache.shape == vcache.shape and kcache.shape[0] == B and kcache.shape[2] == C and kcache.is_contiguous()
+    g, b, eps = ln
+    out = torch.empty(B, C, dtype=x.dtype, device=x.device)
+    code = _ffi.lib().melgpt_qkv_attn_decode(ptr(x), x.stride(0), ptr(w_qkv), w_qkv.stride(0), ptr(b_qkv), ptr(g), ptr(b),
+                                            float(eps), ptr(kcache), ptr(vcache), B, n_head, 64, kcache.shape[1], int(pos),
+                                            ptr(pos_dev), ptr(out), ptr(att_row), dtype_code(x.dtype), stream())
+    if code == _ffi.ERR_UNSUPPORTED:
+        return None
+    _ffi.check(code, "melgpt_qkv_attn_decode")
+    return out
+
+
 SKINNY_LN_MAX_ROWS = int(os.environ.get("MELGPT_SKINNY_LN_MAX_ROWS", "64"))  # lab switch (0: never fuse)
 LDS_LINEAR_MIN_ROWS = int(os.environ.get("MELGPT_LDS_LINEAR_MIN_ROWS", "5"))  # lab switch (999: never).  Default from the
 # end-to-end chain (profiles/r03_decode_lab.md): sampling 265 tokens at 16 sequences 238.8 -> 210.5 ms, at 8 sequences
