@@ -705,9 +705,11 @@ def conv_in_c1(x, w, bias, dtype, stats_eps=None):
         ws = workspace(_ffi.lib().melgpt_conv_in_c1_stats_workspace(B, H, W), x.device)
         mean = torch.empty(B * 32, dtype=torch.float32, device=x.device)
         rstd = torch.empty(B * 32, dtype=torch.float32, device=x.device)
-        call("melgpt_conv_in_c1_stats", ptr(x), dtype_code(x.dtype), ptr(w), ptr(bias), ptr(y), dtype_code(dtype), B, H, W,
-             Cout, float(stats_eps), ptr(mean), ptr(rstd), ptr(ws), stream())
-        return y, (mean, rstd)
+        code = _ffi.lib().melgpt_conv_in_c1_stats(ptr(x), dtype_code(x.dtype), ptr(w), ptr(bias), ptr(y), dtype_code(dtype), B, H,
+                                                  W, Cout, float(stats_eps), ptr(mean), ptr(rstd), ptr(ws), stream())
+        if code != _ffi.ERR_UNSUPPORTED:   # (an image too wide for the kernel's LDS window: the plain stem, statistics by the caller)
+            _ffi.check(code, "melgpt_conv_in_c1_stats")
+            return y, (mean, rstd)
     call("melgpt_conv_in_c1", ptr(x), dtype_code(x.dtype), ptr(w), ptr(bias), ptr(y), dtype_code(dtype), B, H, W, Cout,
          stream())
     return y, None

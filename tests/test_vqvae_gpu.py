@@ -114,6 +114,12 @@ def test_conv_in_out_single_channel_and_permute(dt):
         gn = yn.float().cpu().reshape(B, hn * wn, 32, 4).permute(0, 2, 1, 3).reshape(B * 32, -1).double()
         assert rel_err(mn.cpu().numpy(), gn.mean(1).numpy()) < 1e-5, (hn, wn)
         assert rel_err(rn.cpu().numpy(), (1.0 / torch.sqrt(gn.var(1, unbiased=False) + 1e-6)).numpy()) < 1e-5, (hn, wn)
+    # an image too wide for the statistics kernel's LDS window (2 048 + 2 W + 2 pixels): the plain stem serves, no statistics
+    xw = t(synth.normal(13, (1, 3, 6000)))
+    yw, none_w = ops.conv_in_c1(xw.to(DEV), w.to(DEV), b.to(DEV), DT[dt], stats_eps=1e-6)
+    assert none_w is None
+    refw = F.conv2d(xw.to(DT[dt]).float()[:, None], w, b, padding=1).permute(0, 2, 3, 1)
+    assert rel_err(yw.float().cpu().numpy(), refw.numpy()) < (1e-6 if dt == "f32" else 8e-3)
     # 128 -> 1
     h = t(synth.normal(8, (B, 20, 53, C))).to(DT[dt])
     wo = t(synth.uniform(9, (1, C, 3, 3), -0.05, 0.05))
