@@ -303,7 +303,7 @@ bool fits32(long long rows, long long ld, int es) { return (rows + 260) * ld * e
 
 // tile configuration for the bf16 lane: 1 = 128x128 (this file), 2 = 256x128, 3 = 256x256 (gemm256.hip).
 // MELGPT_GEMM_TILE=1|2|3 forces one (development / A-B timing).
-int pick_tile(const GemmParams& p, int batch) {
+int pick_tile(const GemmParams& p, int batch, int kmin = 256) {
   static int forced = -1;
   if (forced < 0) {
     const char* e = getenv("MELGPT_GEMM_TILE");
@@ -314,7 +314,7 @@ int pick_tile(const GemmParams& p, int batch) {
   // tile grid is not mostly padding; small or skinny problems stay on the 128 x 128 kernel (two workgroups per CU).
   const long long tiles256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch;
   const double fill = (double)p.M * p.N / ((double)((p.M + 191) / 192) * 192.0 * ((p.N + 255) / 256) * 256.0);
-  if (tiles256 >= 192 && fill >= 0.8 && p.K >= 256) return 3;
+  if (tiles256 >= 192 && fill >= 0.8 && p.K >= kmin) return 3;
   // Fewer tiles than CUs but a LONG K loop (the VQ-VAE's 5 x 53 / 512-channel layers at 64 clips: M = 16 960, N = 512,
   // K = 4 608 -> 178 tiles of 192 x 256): one partial round of the persistent kernel (72 K units x 2.9 k cycles = 92 us)
   // still beats this kernel's 532 workgroups at 263 TFLOP/s (304 us per layer, 16 % of the decoder at batch 64).
@@ -463,7 +463,10 @@ extern "C" int melgpt_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, c
       return MELGPT_OK;
     }
   }
-  const int cfg = pick_tile(p, 1);
+  // (1 x 1 convolutions with K = 128 - the 128 -> 256 nin_shortcut at 20 x 212 - are pure streams: 208 MB at 64 tiles; the
+  // persistent kernel's request stream runs across tile boundaries, the 128 x 128 kernel's workgroups each wait out their own
+  // load -> multiply -> store chain: 92 us there)
+  const int cfg = pick_tile(p, 1, 128);
   if (cfg != 1) {
     int st = launch_gemm256(p, LAY_CONV, LAY_ROW, 1, cfg, s);
     if (st != MELGPT_ERR_UNSUPPORTED) return st;

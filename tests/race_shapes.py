@@ -90,16 +90,16 @@ def _conv(B, H, W, *, stats_out=False, residual=False, seed=3):
     return build
 
 
-def _conv_plain(B, H, W, Cin, Cout, *, stride=1, upsample=False, residual=False, seed=40):
+def _conv_plain(B, H, W, Cin, Cout, *, stride=1, upsample=False, residual=False, seed=40, k=3):
     """implicit-GEMM convolution without a norm in front (Downsample / Upsample: big_model_attn_gan.py:145-186)"""
     def build(torch, ops, dev):
         r = _rnd(torch, dev, seed)
         x = r(B, H, W, Cin, scale=1.0)
-        w = r(Cout, 3, 3, Cin, scale=0.05)
+        w = r(Cout, k, k, Cin, scale=0.05)
         bias = r(Cout, scale=0.1, dtype=torch.float32)
         oh = (H // 2, W // 2) if stride == 2 else ((2 * H, 2 * W) if upsample else (H, W))
         res = r(B, oh[0], oh[1], Cout, scale=1.0) if residual else None
-        pad = (0, 0) if stride == 2 else (1, 1)
+        pad = (0, 0) if stride == 2 else (k // 2, k // 2)
         return lambda: [ops.conv2d_nhwc(x, w, bias, stride=stride, pad=pad, out_hw=oh, upsample=upsample, residual=res)]
     return build
 
@@ -139,6 +139,7 @@ FORMS = {
         ("gemm8p", _conv_plain(3, 80, 848, 128, 128, stride=2, residual=True, seed=41)),
     "conv3x3 x2-upsampled 4x40x212 128->64 (256 x 128 tiles, half the columns)":
         ("gemm8p", _conv_plain(4, 40, 212, 128, 64, upsample=True, seed=42)),
+    "conv1x1 10x40x212 128->256 (two K tiles per tile)": ("gemm8p", _conv_plain(10, 40, 212, 128, 256, k=1, seed=43)),
     # ---- fused GroupNorm + swish + conv3x3, wave-specialised: both tile shapes, with / without output statistics
     "conv3x3+gn 6x80x848 (16x16 tiles)": ("conv_ws", _conv(6, 80, 848)),
     "conv3x3+gn 6x80x848 + residual + output statistics": ("conv_ws", _conv(6, 80, 848, stats_out=True, residual=True, seed=31)),
