@@ -661,7 +661,11 @@ int launch_mode(const GemmParams& p, int batch, hipStream_t s) {
   if constexpr (ALAY != LAY_KMAJ) {
     // cost of a launch = tile rounds x cycles of one tile.  A 192-row tile is NOT 3/4 of a 256-row one: its K unit takes
     // 2.9 k cycles against 3.45 k (the B half-unit is staged for fewer rows) and its epilogue 6.3 k against 8 k, + ~2 k of
-    // drain and tile switch either way (s_memtime stamps, profiles/r03_gemm_lab.md).  Counting rounds x rows - the first
+    // drain and tile switch either way (s_memtime stamps, profiles/r03_gemm_lab.md).  These are the RING loop's cycles; the
+    // ping-pong loop (gemm8p.hip: 2.25-2.45 k per K tile, the default since round 4) keeps the same RATIO between the two
+    // heights - a re-fit to its own stamps chose the same heights for the class-GPT shapes and worse ones at the GPT-VAE XL
+    // widths (profiles/r04_gemm_lab.md) - and its choices were re-checked launch by launch in round 5 (tools/lab/tail_ab.py,
+    // profiles/r05_n_tail_ab.jsonl: N = 1024 -> 192 rows, N = 3072 / 4096 -> 256 rows + half-height tail, as picked).  Counting rounds x rows - the first
     // model - put the qkv projection (N = 3072: 9 rounds of 192 rows against 7 of 256) on the wrong side: 5.10 -> 4.72 ms
     // per step with 256 rows.
     const long long nu = (p.K + KU - 1) / KU;
