@@ -1196,7 +1196,9 @@ extern "C" int melgpt_layernorm_bwd_masked(const void* dy, const void* x, const 
   MELGPT_CHECK(C % vec == 0 && C / vec <= 64 * LN_MAXCH, MELGPT_ERR_UNSUPPORTED);
   const int nwaves = melgpt_layernorm_bwd_nwaves(M);
   hipStream_t s = (hipStream_t)stream;
-  const bool wide = nwaves % 8 == 0 && (size_t)8 * 2 * C * sizeof(float) <= 64 * 1024;  // 8 waves per workgroup
+  // 8 waves per workgroup where their partial rows fit 64 KiB (C <= 1024); at the GPT-VAE XL width (1472: 94 KB) the
+  // 8-wave form was measured at 189 us against the 4-wave form's 87 (tools/lab/stream_ab.py)
+  const bool wide = nwaves % 8 == 0 && (size_t)8 * 2 * C * sizeof(float) <= 64 * 1024;
   const int wpb = wide ? 8 : 4;
   const size_t lds = dgamma ? (size_t)wpb * 2 * C * sizeof(float) : 0;
   MELGPT_CHECK(lds <= 64 * 1024, MELGPT_ERR_UNSUPPORTED);
