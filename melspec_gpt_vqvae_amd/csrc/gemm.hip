@@ -319,9 +319,10 @@ int pick_tile(const GemmParams& p, int batch, int kmin = 256) {
   // K = 4 608 -> 178 tiles of 192 x 256): one partial round of the persistent kernel (72 K units x 2.9 k cycles = 92 us)
   // still beats this kernel's 532 workgroups at 263 TFLOP/s (304 us per layer, 16 % of the decoder at batch 64).
   const long long tiles192 = (long long)((p.M + 191) / 192) * ((p.N + 255) / 256) * batch;
+  // (80 tiles: Encoder.conv_out at 64 clips - 512 -> 256 channels, 89 tiles - 94 -> 80 us)
   // (the ping-pong loop's K tile is a third shorter: K >= 512 pays there; launches that will take the RING loop - the switch
   // off, or claimed tiles on - keep the ring's threshold)
-  if (tiles192 >= 96 && fill >= 0.8 && p.K >= ((melgpt_get_gemm_pingpong() && !melgpt_get_dynamic_tiles()) ? 512 : 1024)) return 3;
+  if (tiles192 >= 80 && fill >= 0.8 && p.K >= ((melgpt_get_gemm_pingpong() && !melgpt_get_dynamic_tiles()) ? 512 : 1024)) return 3;
   return 1;
 }
 

@@ -319,7 +319,7 @@ def test_wide_kernel_fused_epilogues_and_split_k_at_size():
 
 
 @pytest.mark.parametrize("case", ["s1_256", "s1_512", "s2", "up", "1x1", "s2_128", "s2_128_one_round", "up_128", "s1_64out",
-                                  "s1_128_ragged", "1x1_k128"])
+                                  "s1_128_ragged", "1x1_k128", "conv_out_64_tiles"])
 def test_conv_on_wide_kernel_at_size(case):
     """implicit-GEMM convolutions big enough for the persistent 256-wide kernel (im2col rows fetched by LDS-DMA with
     address predicates for the padding / stride-2 pad / nearest x2 upsampling) == F.conv2d on CPU."""
@@ -346,6 +346,8 @@ def test_conv_on_wide_kernel_at_size(case):
         B, H, W, Cin, Cout, k, stride, up = 4, 40, 212, 256, 128, 3, 1, True
     elif case == "1x1_k128":      # two K tiles per output tile (the 128 -> 256 nin_shortcut at 20 x 212)
         B, H, W, Cin, Cout, k, stride, up = 10, 40, 212, 128, 256, 1, 1, False
+    elif case == "conv_out_64_tiles":   # Encoder.conv_out at 64 tiles: 89 tiles of 192 x 256, ONE partial round of the persistent kernel
+        B, H, W, Cin, Cout, k, stride, up = 64, 5, 53, 512, 256, 3, 1, False
     elif case == "s1_64out":
         B, H, W, Cin, Cout, k, stride, up = 4, 80, 424, 128, 64, 3, 1, False
     else:
