@@ -303,7 +303,7 @@ bool fits32(long long rows, long long ld, int es) { return (rows + 260) * ld * e
 
 // tile configuration for the bf16 lane: 1 = 128x128 (this file), 2 = 256x128, 3 = 256x256 (gemm256.hip).
 // MELGPT_GEMM_TILE=1|2|3 forces one (development / A-B timing).
-int pick_tile(const GemmParams& p, int batch, int kmin = 256) {
+int pick_tile(const GemmParams& p, int batch, int kmin = 256, int kmin_partial = 512) {
   static int forced = -1;
   if (forced < 0) {
     const char* e = getenv("MELGPT_GEMM_TILE");
@@ -322,7 +322,7 @@ int pick_tile(const GemmParams& p, int batch, int kmin = 256) {
   // (80 tiles: Encoder.conv_out at 64 clips - 512 -> 256 channels, 89 tiles - 94 -> 80 us)
   // (the ping-pong loop's K tile is a third shorter: K >= 512 pays there; launches that will take the RING loop - the switch
   // off, or claimed tiles on - keep the ring's threshold)
-  if (tiles192 >= 80 && fill >= 0.8 && p.K >= ((melgpt_get_gemm_pingpong() && !melgpt_get_dynamic_tiles()) ? 512 : 1024)) return 3;
+  if (tiles192 >= 80 && fill >= 0.8 && p.K >= ((melgpt_get_gemm_pingpong() && !melgpt_get_dynamic_tiles()) ? kmin_partial : 1024)) return 3;
   return 1;
 }
 
@@ -467,7 +467,7 @@ extern "C" int melgpt_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, c
   // (1 x 1 convolutions with K = 128 - the 128 -> 256 nin_shortcut at 20 x 212 - are pure streams: 208 MB at 64 tiles; the
   // persistent kernel's request stream runs across tile boundaries, the 128 x 128 kernel's workgroups each wait out their own
   // load -> multiply -> store chain: 92 us there)
-  const int cfg = pick_tile(p, 1, 128);
+  const int cfg = pick_tile(p, 1, 128, 256);   // (... and the 256 -> 512 nin_shortcut at 5 x 53: one partial round of four K tiles)
   if (cfg != 1) {
     int st = launch_gemm256(p, LAY_CONV, LAY_ROW, 1, cfg, s);
     if (st != MELGPT_ERR_UNSUPPORTED) return st;
