@@ -43,19 +43,65 @@ def vas_args(**kw):
     return SimpleNamespace(**d)  # config/config_GPT_vas.py:1-18
 
 
-def build_models(device, dtype, args):
+def balanced_rows(lat, k=128, iters=400, seed=SEED):
+    """Pick k rows of `lat` (N, D) f32 CPU - every row stays an actual sample - so that nearest-row assignment of `lat`
+    spreads over the rows: start from k random samples (already mass-proportional), then `iters` times replace the
+    least-used row by a random member of the most-used row's cell.  Bench-side set-up arithmetic (host torch), not
+    part of the path.  -> (k, D) tensor, perplexity of the assignment on `lat`."""
+    g = torch.Generator().manual_seed(seed)
+    E = lat[torch.randperm(lat.shape[0], generator=g)[:k]].clone()
+    l2 = (lat * lat).sum(1, keepdim=True)
+
+    def assign():
+        return (l2 + (E * E).sum(1)[None] - 2.0 * lat @ E.t()).argmin(1)
+
+    for _ in range(iters):
+        idx = assign()
+        cnt = torch.bincount(idx, minlength=k)
+        members = torch.nonzero(idx == int(cnt.argmax())).flatten()
+        E[int(cnt.argmin())] = lat[members[int(torch.randint(0, len(members), (1,), generator=g))]]
+    p = torch.bincount(assign(), minlength=k).double() / lat.shape[0]
+    return E, float(torch.exp(-(p * torch.log(p + 1e-10)).sum()))
+
+
+def spread_codebook(vqvae, device, tiles=32):
+    """A frozen VQ-VAE whose codes SPREAD over the 128 entries, as a trained one's do and as BASELINE.md 4 asks of the
+    GPT leg's tokens: the codebook's rows are the encoder's own latents (LitVQVAE.encode of `tiles` synthetic mel tiles
+    drawn from another seed than any step's batch), chosen by `balanced_rows`.  A random encoder maps these tiles to a
+    tight cluster far from a N(0,1) codebook: that pairing gives 8-11 distinct codes, perplexity 3.2 (--codebook normal)."""
+    x, _ = synthetic_batch(tiles, 2000, device)
+    with torch.no_grad():
+        z = vqvae.encode(x)                                                    # (tiles,256,5,53): quant_conv(encoder(x))
+        lat = z.float().permute(0, 2, 3, 1).reshape(-1, z.shape[1]).cpu()
+        rows, perp = balanced_rows(lat)
+        vqvae._vq_vae._embedding.weight.copy_(rows.to(device))
+    return perp
+
+
+def code_perplexity(codes, k=128):
+    """exp(entropy) of the code histogram of one batch (VectorQuantizer.forward's `perplexity`, big_model_attn_gan.py:50-51)."""
+    p = torch.bincount(codes.reshape(-1).cpu(), minlength=k).double()
+    p = p / p.sum()
+    return {"perplexity": round(float(torch.exp(-(p * torch.log(p + 1e-10)).sum())), 2), "distinct": int((p > 0).sum()),
+            "top_share": round(float(p.max()), 4)}
+
+
+def build_models(device, dtype, args, codebook="latents"):
     from melspec_gpt_vqvae_amd.transformer import minGPT
     from melspec_gpt_vqvae_amd.vqvae import big_model_attn_gan as vq
 
     torch.manual_seed(SEED)  # identical initial weights on every rank (no start-up broadcast needed)
     gpt = minGPT.GPTClass(args)
     vqvae = vq.LitVQVAE(num_embeddings=128, embedding_dim=256)
-    with torch.no_grad():  # spread the codebook so that codes are not degenerate with a random encoder
-        vqvae._vq_vae._embedding.weight.normal_(0.0, 1.0)
+    if codebook == "normal":  # rounds 1-5: N(0,1) rows - with a random encoder the step's tokens collapse onto a few codes
+        with torch.no_grad():
+            vqvae._vq_vae._embedding.weight.normal_(0.0, 1.0)
     gpt.to(device).train()
     vqvae.to(device).eval()
     minGPT.set_compute_dtype(gpt, dtype)
     vq.set_compute_dtype(vqvae, dtype)
+    if codebook == "latents":  # deterministic given the seed: every rank computes the same rows
+        spread_codebook(vqvae, device)
     return gpt, vqvae
 
 
@@ -96,14 +142,39 @@ def vq_encode_b64(job, device, reps=5):
         e1.record()
         e1.synchronize()
         lookup_us = 1e3 * e0.elapsed_time(e1) / n_l
+        sweep = lookup_sweep(job, h)
     lookup_bytes = n_vec * 520 + 66048      # 512 B bf16 latent + 8 B index per vector, + the prepared image
     ms = 1e3 * sorted(ts)[len(ts) // 2]
     return {"workload": "VQ-encode + argmin, 64 tiles (1,80,848), 16-bit lane", "ms": round(ms, 3),
+            "code_stats": code_perplexity(codes), "lookup_sweep": sweep,
             "tiles_per_s": round(64 / (ms * 1e-3), 1), "encoder_tflops": round(64 * 142.57e9 / (ms * 1e-3) / 1e12, 1),
             "codes_shape": list(codes.shape), "lookup_us": round(lookup_us, 2), "lookup_vectors": n_vec,
             "lookup_bytes": lookup_bytes, "lookup_frac_hbm": round(lookup_bytes / (lookup_us * 1e-6) / 8e12, 4),
             "lookup_note": "in-stream average of 50 back-to-back launches incl. the Python launch path; 8.9 MB is 1.1 us "
                            "at 8 TB/s - below any stand-alone launch (DESIGN 4)"}
+
+
+def lookup_sweep(job, h64, batches=(64, 256, 1024, 4096), n_l=50):
+    """the codebook lookup alone over a batch sweep - latents of B tiles (the B = 64 encoder
+    output tiled along the batch axis: real latents, so the codes are the step's codes), the fused lookup launched `n_l`
+    times back to back, HIP events on the launch stream; bytes = 520 per vector + the prepared image."""
+    out = {}
+    for b in batches:
+        h = h64 if b == 64 else h64.permute(0, 2, 3, 1).repeat(b // 64, 1, 1, 1).permute(0, 3, 1, 2)   # channels-last strides kept
+        n_vec = h.shape[0] * h.shape[2] * h.shape[3]
+        job.vqvae._vq_vae.encode_indices_fused(h, job.vqvae.quant_conv)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n_l):
+            job.vqvae._vq_vae.encode_indices_fused(h, job.vqvae.quant_conv)
+        e1.record()
+        e1.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / n_l
+        nbytes = n_vec * 520 + 66048
+        out[f"B{b}"] = {"vectors": n_vec, "us": round(us, 2), "GBps": round(nbytes / (us * 1e-6) / 1e9, 1),
+                        "frac_hbm": round(nbytes / (us * 1e-6) / 8e12, 4)}
+        del h
+    return out
 
 
 def gpt_vae_xl_rank(a, device, dtype, steps=3):
@@ -214,6 +285,8 @@ def pmc_summary(workload="class_gpt"):
     if j.get("gemm_family_mfma_busy") is not None:
         out["mfma_busy"] = j["gemm_family_mfma_busy"]
         out["mfma_busy_by_kernel"] = j.get("mfma_busy_by_kernel")
+    if j.get("attention_hbm_MB_per_launch"):
+        out["attention_hbm_MB_per_launch"] = j["attention_hbm_MB_per_launch"]
     if j.get("in_kernel_clock_GHz"):      # the shader clock the chip HELD inside the big kernels (stamped diagnostic build)
         out["in_kernel_clock_GHz"] = {k: v["GHz"] for k, v in j["in_kernel_clock_GHz"].items()}
     return out
@@ -302,6 +375,127 @@ def cpu_baseline(batch=8, reps=3):
                       f"AdamW, fp32, torch threads = usable cores (affinity / cgroup quota) = {threads} of os.cpu_count() = {os.cpu_count()}, {dt:.2f} s/step"}
 
 
+def torch_baseline_child(batch, steps=3):
+    """The body of `torch_gpu_baseline`, run in a CHILD process (stock torch-ROCm's allocator, MIOpen and rocBLAS/hipBLASLt
+    state never share a process with the measured path): the oracle's functional restatement of the step - the same
+    functions `cpu_baseline` times, pinned to the reference by tests/golden - on cuda:0 under bf16 autocast, f32
+    parameters, torch.optim.AdamW with the reference's two parameter groups.  One JSON line per stage on stdout."""
+    import synth
+    from oracle import gpt as ogpt
+    from oracle import vqvae as ovq
+
+    dev = torch.device("cuda", 0)
+    a = vas_args()
+    C, L, V = a.n_embd, a.n_layer, a.vocab_size
+    g = torch.Generator().manual_seed(1)
+
+    def rn(*s, std=0.02):
+        return (torch.randn(*s, generator=g) * std).to(dev).requires_grad_(True)
+
+    def const(n, v):
+        return torch.full((n,), v, device=dev).requires_grad_(True)
+
+    sd = {"pos_emb": rn(1, 266, C), "tok_emb.weight": rn(V, C), "ln_f.weight": const(C, 1.0), "ln_f.bias": const(C, 0.0),
+          "head.weight": rn(V, C), "embedder.weight": rn(8, C, std=1.0)}
+    for i in range(L):
+        p = f"blocks.{i}."
+        for ln in ("ln1", "ln2"):
+            sd[p + ln + ".weight"], sd[p + ln + ".bias"] = const(C, 1.0), const(C, 0.0)
+        for nm in ("key", "query", "value", "proj"):
+            sd[p + f"attn.{nm}.weight"], sd[p + f"attn.{nm}.bias"] = rn(C, C), const(C, 0.0)
+        sd[p + "mlp.0.weight"], sd[p + "mlp.0.bias"] = rn(4 * C, C), const(4 * C, 0.0)
+        sd[p + "mlp.2.weight"], sd[p + "mlp.2.bias"] = rn(C, 4 * C), const(C, 0.0)
+    decay = [v for k, v in sd.items() if k.endswith(".weight") and v.dim() == 2 and "emb" not in k]   # nn.Linear weights
+    decay_ids = {id(v) for v in decay}
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.01},
+                             {"params": [v for v in sd.values() if id(v) not in decay_ids], "weight_decay": 0.0}],
+                            lr=1e-6, betas=(0.9, 0.95))                       # minGPT.py:618-665
+    vsd = {k: torch.from_numpy(v).to(dev) for k, v in synth.vqvae_state_dict(50).items()}
+    mel = torch.from_numpy(synth.mel_tiles(3, batch)).to(dev)
+    c = torch.from_numpy(synth.randint(4, 0, 8, (batch, 1))).to(dev)
+    # the codebook spread as in the measured job (rows = the encoder's own latents)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        z = ovq.vqvae_encode(vsd, (2 * torch.from_numpy(synth.mel_tiles(2000, 32)).to(dev)[:, :, 6:854] - 1).unsqueeze(1))
+    rows, _ = balanced_rows(z.float().permute(0, 2, 3, 1).reshape(-1, 256).cpu())
+    vsd["_vq_vae._embedding.weight"] = rows.to(dev)
+
+    def encode():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            x = (2 * mel[:, :, 6:854] - 1).unsqueeze(1)
+            zq = ovq.vqvae_encode(vsd, x).float()
+            flat = zq.permute(0, 2, 3, 1).reshape(-1, 256)
+            idx = torch.argmin(ovq.vq_distances(flat, vsd["_vq_vae._embedding.weight"]), dim=1)   # big_model_attn_gan.py:28-33
+        return idx.view(batch, 5, 53)
+
+    def gpt_step(codes):
+        x = ogpt.codes_to_sequence(codes)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss, _, _ = ogpt.class_gpt_loss(sd, x, c, L, a.n_head, pdrop=(0.5, 0.5, 0.5), train=True)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    def timed(fn, *args):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn(*args)
+        torch.cuda.synchronize()
+        return r, time.perf_counter() - t0
+
+    codes, warm_e = timed(encode)
+    print(json.dumps({"stage": "encode_warmup", "s": round(warm_e, 2)}), flush=True)
+    te = sorted(timed(encode)[1] for _ in range(steps))[steps // 2]
+    print(json.dumps({"stage": "encode", "ms": round(1e3 * te, 2), "code_stats": code_perplexity(codes)}), flush=True)
+    _, warm_g = timed(gpt_step, codes)
+    print(json.dumps({"stage": "gpt_warmup", "s": round(warm_g, 2)}), flush=True)
+    ts, loss = [], None
+    for _ in range(steps):
+        loss, dt = timed(gpt_step, codes)
+        ts.append(dt)
+    tg = sorted(ts)[steps // 2]
+    print(json.dumps({"stage": "gpt_step", "ms": round(1e3 * tg, 2), "loss": round(float(loss), 4),
+                      "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1)}), flush=True)
+
+
+def torch_gpu_baseline(batch=128, timeout=420):
+    """What a user of the reference gets from stock PyTorch-ROCm on THIS box, beside `cpu_baseline`: the same functional
+    step (oracle/gpt.py + oracle/vqvae.py = the reference's modules restated) on cuda through torch's own kernels
+    (rocBLAS / hipBLASLt / MIOpen / ATen), bf16 autocast, batch 128, 1 warm-up + median of 3, in a child process started
+    after this process's GPU work is done.  A baseline, not a target; the measured path never imports any of it."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--torch-baseline-child", "--batch", str(batch)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MELGPT_HALF")}
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        stdout, rc, err = r.stdout, r.returncode, r.stderr[-300:]
+    except subprocess.TimeoutExpired as e:
+        stdout = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        rc, err = "timeout", f"child did not finish in {timeout} s"
+    st = {}
+    for ln in stdout.splitlines():
+        if ln.startswith("{"):
+            try:
+                j = json.loads(ln)
+                st[j.pop("stage")] = j
+            except (ValueError, KeyError):
+                pass
+    out = {"kind": "stock PyTorch-ROCm (torch %s) eager, the oracle's functional step on cuda:0, bf16 autocast, f32 master "
+                   "weights, torch.optim.AdamW; random-init weights, same synthetic tiles" % torch.__version__,
+           "batch": batch, "sample": "1 warm-up + median of 3 per stage; VQ-encode and GPT step timed separately, value = batch / their sum"}
+    if "encode" in st and "gpt_step" in st:
+        ms = st["encode"]["ms"] + st["gpt_step"]["ms"]
+        out.update({"value": round(batch / (ms * 1e-3), 2), "unit": "seq/s", "ms_per_step": round(ms, 2),
+                    "encode_ms": st["encode"]["ms"], "gpt_step_ms": st["gpt_step"]["ms"],
+                    "code_stats": st["encode"].get("code_stats"), "final_loss": st["gpt_step"].get("loss"),
+                    "peak_mem_GB": st["gpt_step"].get("peak_mem_GB"),
+                    "warmup_s": {"encode": st.get("encode_warmup", {}).get("s"), "gpt": st.get("gpt_warmup", {}).get("s")}})
+    else:
+        out.update({"error": f"rc {rc}", "stages_done": sorted(st), "stderr_tail": err})
+    return out
+
+
 def xl_args(**kw):
     from types import SimpleNamespace
 
@@ -330,8 +524,9 @@ class ClassGPTStep:
 
         self.a = a
         gargs = vas_args(n_layer=a.layers)
-        self.gpt, self.vqvae = build_models(device, dtype, gargs)
+        self.gpt, self.vqvae = build_models(device, dtype, gargs, getattr(a, "codebook", "latents"))
         self.x_mel, self.c = synthetic_batch(a.batch, rank, device)
+        self.codes = None                                        # the last step's codes (code_perplexity of the line)
         self.opt = FusedAdamW(self.gpt, lr=gargs.learning_rate, betas=(0.9, 0.95), weight_decay=0.01)
         self.opt.grad_scale = 1.0 / world
         self.dp = DataParallel(self.gpt, grad_dtype=a.grad_dtype) if world > 1 or FORCE_DP else None
@@ -349,6 +544,7 @@ class ClassGPTStep:
         with torch.no_grad():
             codes = self.vqvae.encode_to_codes(self.x_mel)       # (B,5,53) int64
             seq = ops.codes_permute(codes, 5, 53)                # (B,265) time-major (get_x)
+        self.codes = codes
         t1 = mark()
         with self.gpt.discard_att():                             # as Lit_minGPT.forward does: the (B,H,T,T) map it
             logits, _, _ = self.gpt(seq[:, :-1], self.c)         # ignores (`logits, _, _ = transformer(...)`) is not written
@@ -434,6 +630,12 @@ def main():
     ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"],
                     help="wire format of the data-parallel gradient exchange (N > 1): f32 (default) | bf16 = cast slice -> "
                          "all-reduce -> back into the f32 buffer (half the bytes: 8.37 -> 4.18 GB per step for GPT-VAE XL)")
+    ap.add_argument("--codebook", default="latents", choices=["latents", "normal"],
+                    help="frozen VQ-VAE codebook of the class_gpt workload: latents (default) = rows sampled from the encoder's "
+                         "own outputs, usage-balanced -> the step's tokens spread over the 128 codes (BASELINE.md 4 asks for "
+                         "uniform codes); normal = N(0,1) rows as in rounds 1-5 (tokens collapse: perplexity ~3)")
+    ap.add_argument("--no-torch-baseline", action="store_true", help="skip torch_gpu_baseline (stock PyTorch-ROCm, same box)")
+    ap.add_argument("--torch-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--layers", type=int, default=24, help="debug only; anything but the configuration's depth is flagged")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -443,6 +645,11 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="print per-phase timings to stderr")
     a = ap.parse_args()
 
+    if a.torch_baseline_child:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py --torch-baseline-child needs a GPU")
+        torch_baseline_child(a.batch)
+        return
     if a.dtype == "fp16":  # the 16-bit format is a property of the library flavour: choose it before the package loads
         os.environ["MELGPT_HALF"] = "fp16"
     share = os.environ.get("MELGPT_BENCH_SHARE_GPU") == "1"
@@ -539,6 +746,21 @@ def main():
     achieved = ks["flops"] / (ks["total_ms"] * 1e-3) / 1e12 if ks["total_ms"] > 0 else 0.0
     if rank == 0:
         pmc = pmc_summary(job.name)
+        # attention (HBM-bound at T = 265, hs = 64: DESIGN 4): per launch form, live HIP-event time against the algorithmic
+        # bytes (ops.attn_fwd / attn_bwd) and, when the committed PMC pass has them, against the counted bytes
+        aux = timer.aux_by_tag()
+        attn_flops = sum(v[3] for v in aux.values())
+        attn = {}
+        for tag, (n, ms, nbytes, fl) in sorted(aux.items()):
+            us = 1e3 * ms / n
+            row = {"launches_per_step": round(n / a.steps, 2), "us": round(us, 2), "algorithmic_MB": round(nbytes / n / 1e6, 1),
+                   "frac_hbm": round(nbytes / n / (us * 1e-6) / 8e12, 4), "tflops": round(fl / n / (us * 1e-6) / 1e12, 1)}
+            counted = (pmc.get("attention_hbm_MB_per_launch") or {}).get("fwd" if " fwd " in tag else "bwd")
+            if counted and " full" not in tag and job.name == "class_gpt":
+                row["counted_MB"] = counted
+                row["frac_hbm_counted"] = round(counted * 1e6 / (us * 1e-6) / 8e12, 4)
+            attn[tag] = row
+        step_flops = (ks["flops"] + attn_flops) / max(a.steps, 1)
         # per-instantiation table: one row per (layout, shape, epilogue) of the GEMM family, slowest rate first among
         # the rows that matter (>= 0.5 % of the family's time) - names the shape the family's `frac` is held down by
         rows = [{"shape": tag, "calls_per_step": round(n / a.steps, 2), "ms_per_step": round(ms / a.steps, 3),
@@ -556,13 +778,22 @@ def main():
                 "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": job.seq_len,
                 "parallelism": f"dp{world}" if world > 1 else "single",
                 "final_loss": round(loss_val, 4),
+                "codebook": getattr(a, "codebook", None) if job.name == "class_gpt" else None,
+                "code_perplexity": code_perplexity(job.codes) if getattr(job, "codes", None) is not None else None,
                 # which K loop the persistent GEMM's launches of the timed region took (csrc/gemm256.hip / gemm8p.hip)
                 "gemm_launches_per_step": {"ring": (loops1[0] - loops0[0]) // max(a.steps, 1),
                                            "pingpong": (loops1[1] - loops0[1]) // max(a.steps, 1)},
             },
             "roofline": {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc.get("traffic"),
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                # the same peak over the WHOLE timed step: every algorithmic FLOP of the step (GEMM family + attention on
+                # the full T x T square, backward = 2 x forward: BASELINE.md 3) / ms_per_step - what `frac` leaves out is
+                # the time of everything that is not a family launch
+                "step_frac": round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                "step_algorithmic_tflop": round(step_flops / 1e12, 3),
+                "attn_frac_hbm": attn,
+                "traffic": pmc.get("traffic"),
                 "traffic_unit": "bytes/step", "traffic_source": pmc.get("traffic_source"),
                 "mfma_busy": pmc.get("mfma_busy"), "mfma_busy_by_kernel": pmc.get("mfma_busy_by_kernel"),
                 "in_kernel_clock_GHz": pmc.get("in_kernel_clock_GHz"),
@@ -615,6 +846,38 @@ def main():
             out["config5_e2e_fp16"] = side(e2e_fp16_child)
         if world == 1 and not a.no_cpu_baseline and out["metric"].startswith("mel-token seqs/sec training step (VQ"):
             out["cpu_baseline"] = side(cpu_baseline)
+        if extras and not a.no_torch_baseline:
+            tb = out["torch_gpu_baseline"] = side(torch_gpu_baseline)
+            if tb.get("value"):
+                tb["this_over_torch"] = round(out["value"] / tb["value"], 2)
+        # Scalars a reader of the record needs without the nested tables (a driver that keeps only flat fields of
+        # `roofline` / `config` still holds them), and one compact `summary` object as the LAST key of the line.
+        rf, cfg = out["roofline"], out["config"]
+        cp = cfg.get("code_perplexity")
+        if isinstance(cp, dict):
+            cfg["code_perplexity"], cfg["code_distinct"], cfg["code_top_share"] = cp["perplexity"], cp["distinct"], cp["top_share"]
+        for tag, row in attn.items():
+            key = "attn_" + ("fwd" if " fwd " in tag else "bwd") + ("_full" if " full" in tag else "")
+            rf[key + "_us"], rf[key + "_frac_hbm"] = row["us"], row.get("frac_hbm_counted", row["frac_hbm"])
+        c2 = out.get("config2_vq_encode") or {}
+        for k, v in (c2.get("lookup_sweep") or {}).items():
+            rf[f"vq_lookup_frac_hbm_{k}"] = v["frac_hbm"]
+        if (out.get("torch_gpu_baseline") or {}).get("value"):
+            rf["torch_rocm_same_box_seq_per_s"] = out["torch_gpu_baseline"]["value"]
+            rf["this_over_torch_rocm"] = out["torch_gpu_baseline"]["this_over_torch"]
+        c5 = out.get("config5_e2e_fp16") or {}
+        out["summary"] = {
+            "seq_per_s": out["value"], "ms_per_step": out["ms_per_step"], "frac": rf["frac"], "step_frac": rf["step_frac"],
+            "code_perplexity": cfg.get("code_perplexity"),
+            "attn": {k: [v["us"], v.get("frac_hbm_counted", v["frac_hbm"])] for k, v in attn.items()},
+            "vq_lookup_frac_hbm": {k: v["frac_hbm"] for k, v in (c2.get("lookup_sweep") or {}).items()},
+            "config2_ms": c2.get("ms"), "config4_rank_ms": (out.get("config4_gpt_vae_xl_rank") or {}).get("ms_per_step"),
+            "config5": {"b1_p50_ms": (c5.get("batch1_latency_ms") or {}).get("p50"), "b64_clips_per_s": c5.get("batch64_clips_per_s"),
+                        "ms_per_token": c5.get("ms_per_token"), "decode_frac_hbm": c5.get("decode_frac_hbm")},
+            "torch_rocm_seq_per_s": (out.get("torch_gpu_baseline") or {}).get("value"),
+            "cpu_seq_per_s": (out.get("cpu_baseline") or {}).get("value"),
+            "per_shape_tflops": {r["shape"]: r["tflops"] for r in major[:14]},
+        }
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

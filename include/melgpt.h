@@ -44,12 +44,6 @@ const char* melgpt_strerror(int code);
  * workgroup's whole tile list.  0 (default) = use every CU; per process. */
 int melgpt_set_reserved_cus(int n);
 int melgpt_get_reserved_cus(void);
-/* Claimed tiles: with 1 the persistent GEMM's workgroups draw every tile from a per-launch counter (scalar-memory atomic
- * at L2, ticket handed to the workgroup's other waves through a mailbox in global memory) instead of walking static
- * lists, so a workgroup that starts late or runs slowly - its CU shared with an RCCL kernel - does not strand work;
- * same results bit for bit.  Default 0 (MELGPT_DYNAMIC_TILES=1 in the environment turns it on); per process. */
-int melgpt_set_dynamic_tiles(int on);
-int melgpt_get_dynamic_tiles(void);
 /* The persistent GEMM has two K loops: a lockstep walk over a ring of five 32 KiB slots (csrc/gemm256.hip; every layout,
  * epilogue and tile-list form) and a two-group ping-pong over 16 KiB half-tiles (csrc/gemm8p.hip; static tile lists,
  * row-major A with either B layout and the weight-gradient form; faster where it applies).  1 (default;
@@ -231,15 +225,6 @@ int melgpt_attn_fwd(const void* q, const void* k, const void* v, long long ld, v
  * decoding step) and `pos` is ignored. */
 int melgpt_attn_decode(const void* qkv, long long ld, void* kcache, void* vcache, int B, int H, int head_size,
                        int Tmax, int pos, const int* pos_dev, void* out, float* att_row, int dtype, void* stream);
-/* The qkv projection (Block.ln1 folded in: minGPT.py:108-112, 76-78) and the KV-cached attention step of one decode position
- * for 1 .. 4 sequences in ONE launch, one workgroup per (head, sequence): x (B, C) rows of the residual stream, W (3C, C) rows
- * [key | query | value] (the packed view of the three nn.Linear weights), bias (3C) f32 or null; the rest as
- * melgpt_attn_decode.  Bit-identical to melgpt_gemv_rows (with LayerNorm) + melgpt_attn_decode.  MELGPT_ERR_UNSUPPORTED,
- * nothing launched: f32 lane, head size != 64, C > 1536, B > 4. */
-int melgpt_qkv_attn_decode(const void* x, long long ldx, const void* W, long long ldw, const float* bias,
-                           const float* ln_gamma, const float* ln_beta, float ln_eps, void* kcache, void* vcache, int B,
-                           int H, int head_size, int Tmax, int pos, const int* pos_dev, void* out, float* att_row,
-                           int dtype, void* stream);
 /* skinny-M linear layer of a decode step: y (M,N) = epi(x (M,K) @ W (N,K)^T + bias) (+ residual), W = nn.Linear.weight
  * layout; act in {MELGPT_ACT_NONE, MELGPT_ACT_GELU (exact erf)}; y in `dtype`, or f32 when out_f32 (always f32 for
  * dtype f32).  One wave per 4 output columns streams the weights once with every CU busy; M is walked 16 rows at a
@@ -443,10 +428,6 @@ int melgpt_softmax_rows(const float* scores, long long ld_scores, int n, long lo
 int melgpt_repack_conv_weight(const float* w_oihw, void* out_ohwi, int out_dtype, int O, int I, int KH, int KW,
                               void* stream);
 
-/* MFMA shape of the multiplying waves of the wave-specialised fused conv (bf16, Cin = Cout = 128 layers): 1 (default) =
- * v_mfma_f32_16x16x32, 0 = the round-4 v_mfma_f32_32x32x16 path; same results up to the accumulation order inside a k-slice.
- * Returns the previous setting; MELGPT_CONV_WS_M16=0 in the environment sets the initial one. */
-int melgpt_set_conv_ws_mfma16(int on);
 /* ResnetBlock's  norm -> swish -> conv3x3  (big_model_attn_gan.py:117-127) as ONE kernel: halo-tiled 3x3 conv
  * (stride 1, pad 1) whose input patch is normalised (GroupNorm(32) statistics from melgpt_groupnorm_stats, affine
  * gamma/beta) and swish-ed while it is staged into LDS; mean == NULL -> plain convolution.  residual/bias as in

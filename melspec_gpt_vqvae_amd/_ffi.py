@@ -37,8 +37,6 @@ _PROTOS = {
     "melgpt_strerror": [_i],
     "melgpt_set_reserved_cus": [_i],
     "melgpt_get_reserved_cus": [],
-    "melgpt_set_dynamic_tiles": [_i],
-    "melgpt_get_dynamic_tiles": [],
     "melgpt_set_gemm_pingpong": [_i],
     "melgpt_get_gemm_pingpong": [],
     "melgpt_gemm_loop_launches": [_p, _p],
@@ -59,7 +57,6 @@ _PROTOS = {
     "melgpt_conv2d_nhwc": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],
     "melgpt_attn_fwd": [_p, _p, _p, _l, _p, _l, _p, _p, _i, _i, _i, _i, _i, _f, _u64, C.c_uint, _i, _p],
     "melgpt_attn_decode": [_p, _l, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],
-    "melgpt_qkv_attn_decode": [_p, _l, _p, _l, _p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],
     "melgpt_embed_decode": [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p],
     "melgpt_incr_i32": [_p, _p],
     "melgpt_pad1d_act": [_p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
@@ -76,7 +73,6 @@ _PROTOS = {
                         _i, _p],
     "melgpt_set_attn_bwd_two_pass": [_i],
     "melgpt_set_attn_fwd32": [_i],
-    "melgpt_set_conv_ws_mfma16": [_i],
     "melgpt_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _l, _i, _f, _i, _p],
     "melgpt_layernorm_bwd_nwaves": [_l],
     "melgpt_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _l, _i, _i, _p],

@@ -100,10 +100,18 @@ def build(verbose=False, force=False, jobs=None, flavours=("bf16", "fp16", "vm0"
         with cf.ThreadPoolExecutor(jobs) as ex:
             res = list(ex.map(lambda s: _compile(s, stamps[s], verbose, fl), own))
         objs = [o for o, _ in res]
-        if fl == "vm0":
-            objs += [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in srcs if s not in own]
         lib = lib_path(fl)
-        if any(ch for _, ch in res) or not os.path.exists(lib):
+        stale = False
+        if fl == "vm0":
+            # the sources that do not count their waits are borrowed from the bf16 flavour's objects: they must exist (build
+            # "bf16" first) and a relink is due whenever one of them is newer than the library
+            borrowed = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in srcs if s not in own]
+            missing = [o for o in borrowed if not os.path.exists(o)]
+            if missing:
+                raise RuntimeError(f"vm0 flavour borrows the bf16 flavour's objects: build 'bf16' first (missing {missing})")
+            stale = os.path.exists(lib) and any(os.path.getmtime(o) > os.path.getmtime(lib) for o in borrowed)
+            objs += borrowed
+        if any(ch for _, ch in res) or stale or not os.path.exists(lib):
             cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib + ".tmp", *objs]
             if verbose:
                 print(" ".join(cmd), flush=True)

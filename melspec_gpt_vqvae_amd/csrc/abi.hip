@@ -1,7 +1,6 @@
 // ABI bookkeeping entry points of libmelgpt_hip.so.
 #include <atomic>
 #include <cstdlib>
-#include <mutex>
 
 #include "common.h"
 
@@ -30,21 +29,6 @@ extern "C" int melgpt_set_reserved_cus(int n) {
 }
 extern "C" int melgpt_get_reserved_cus(void) { return g_reserved_cus; }
 
-// Claimed tiles for the persistent GEMM (gemm256.hip): 1 = every tile is drawn from a counter at run time instead of
-// a static per-workgroup list (data-parallel runs: a workgroup displaced by an RCCL kernel no longer strands a list).
-static int g_dynamic_tiles = -1;
-extern "C" int melgpt_set_dynamic_tiles(int on) {
-  g_dynamic_tiles = on != 0;
-  return MELGPT_OK;
-}
-extern "C" int melgpt_get_dynamic_tiles(void) {
-  if (g_dynamic_tiles < 0) {
-    const char* e = getenv("MELGPT_DYNAMIC_TILES");
-    g_dynamic_tiles = e ? atoi(e) != 0 : 0;
-  }
-  return g_dynamic_tiles;
-}
-
 // K loop of the persistent GEMM: 1 = the ping-pong loop of gemm8p.hip where it is built, 0 = the ring of gemm256.hip only.
 static int g_pingpong = -1;
 static std::atomic<long long> g_loop_launches[2];
@@ -66,34 +50,3 @@ extern "C" int melgpt_gemm_loop_launches(long long* ring, long long* pingpong) {
   return MELGPT_OK;
 }
 void melgpt_count_gemm_loop(int pingpong) { g_loop_launches[pingpong != 0].fetch_add(1); }  // (launchers of the two kernels)
-
-// Scheduler cells of the claimed-tile launches: MELGPT_TILE_CELL_INTS ints each (counter + per-workgroup mailboxes), handed
-// out round-robin from one pool so that launches in flight on different streams never share a counter; a cell puts its
-// counter back to 0 with the launch's last draw.  The pool is allocated on first use and zeroed BEFORE the first cell is
-// handed out - the fill is waited for with a device synchronisation: a launch that started on a recycled allocation's
-// old contents would draw wild tickets.  nullptr (static tile lists are used instead) if that first use falls into a
-// stream capture, where neither the allocation nor the wait is allowed.
-extern "C" int* melgpt_tile_cell(void) {
-  constexpr int NCELL = 256;
-  static int* pool = nullptr;
-  static std::atomic<unsigned> seq{0};
-  static std::mutex mu;
-  if (!pool) {
-    std::lock_guard<std::mutex> lk(mu);
-    if (!pool) {
-      int* q = nullptr;
-      const size_t bytes = (size_t)NCELL * MELGPT_TILE_CELL_INTS * sizeof(int);
-      if (hipMalloc(&q, bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-      }
-      if (hipMemset(q, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-        (void)hipGetLastError();
-        (void)hipFree(q);
-        return nullptr;
-      }
-      pool = q;
-    }
-  }
-  return pool + (size_t)(seq.fetch_add(1) % NCELL) * MELGPT_TILE_CELL_INTS;
-}

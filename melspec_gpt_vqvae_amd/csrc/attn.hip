@@ -27,15 +27,7 @@
 
 #include "mma.h"
 
-#ifndef ATTN_LAB
-#define ATTN_LAB 0  // tools/lab/attn_lab.hip ablations: 1 staging only, 2 no staging, 3 dQ kernel only, 4 dK/dV kernel only,
-// forward only: 5 no row-maximum pass, 6 no P V MFMAs, 7 no softmax arithmetic, 8 phase stamps of one wave;
-// 9 single-pass backward: phase stamps of the 8 waves of workgroup 17 over its first items
-#endif
 
-#if ATTN_LAB == 8 || ATTN_LAB == 9
-__device__ unsigned long long melgpt_attn_dbg[256 + 4 * 4096];  // lab build only: phase stamps of one wave of one workgroup
-#endif
 
 MELGPT_CLK_DECL(clk_attn_fwd)
 MELGPT_CLK_DECL(clk_attn_bwd)
@@ -238,19 +230,11 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kerne
   char* Kt = smem;
   char* Vt = smem + (size_t)TP * A::ROWB;
   int* ctr = (int*)(smem + 2 * (size_t)TP * A::ROWB);
-#if ATTN_LAB == 8
-  const unsigned long long ts_entry = __builtin_amdgcn_s_memtime();
-  const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();  // 100 MHz, one clock for the whole chip
-#endif
   const T* Kg = (const T*)p.K + (long long)b * Tn * p.ld + h * HS;
   const T* Vg = (const T*)p.V + (long long)b * Tn * p.ld + h * HS;
-  if (ATTN_LAB != 2) load_tiles<T, false, !BWD>(Kt, Kg, p.ld, Vt, Vg, p.ld, Tn, TP, t);  // fwd: V only via transposed reads
+  load_tiles<T, false, !BWD>(Kt, Kg, p.ld, Vt, Vg, p.ld, Tn, TP, t);  // fwd: V only via transposed reads
   if (t == 0) *ctr = 0;
   __syncthreads();
-  if (ATTN_LAB == 1) {
-    if (*(volatile int*)(Kt + 4 * t) == 0x12345678) p.lse[t] = 1.f;
-    return;
-  }
   const long long bh = (long long)b * p.H + h;
   const int ntiles = (Tn + 15) / 16;
   const float c2 = p.scale * LOG2E;
@@ -279,11 +263,6 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kerne
     }
   };
 
-#if ATTN_LAB == 8
-  const bool dbg_on = !BWD && b == 3 && h == 5 && (t >> 6) == 2;
-  int dbg_n = 0;
-  unsigned long long ts_k = __builtin_amdgcn_s_memtime();
-#endif
   int job = grab();
   u32x4 qf[A::NKS], dof[A::NKS], ov[A::NKS];
   float lse_q = 0.f;
@@ -296,9 +275,6 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kerne
   float nlse = 0.f;
   fetch(min(njob, ntiles - 1), nqf, ndof, nov, nlse);
 
-#if ATTN_LAB == 8
-  unsigned long long ts0 = __builtin_amdgcn_s_memtime(), ts1 = 0, ts2 = 0;
-#endif
   const int q0 = 16 * (ntiles - 1 - job);
   const int q = q0 + i16, qc = min(q, Tn - 1);
   const int lim_g = vis_keys(qc, Tn, nu) - 4 * g;                      // key 16 kt + 4 g + r visible <=> 16 kt + r < lim_g
@@ -350,7 +326,7 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kerne
     // pass 1: the row maximum alone.  The logits are NOT kept: pass 2 recomputes them (the MFMA pipe idles under the
     // softmax VALU work anyway), which frees the 72 registers a 17-tile row of scores would pin.
     float m = -__builtin_inff();
-    int kt4 = ATTN_LAB == 5 ? nkt : 0;
+    int kt4 = 0;
     for (; kt4 + 4 <= nfull; kt4 += 4) {  // four independent tiles in flight (the compiler does not unroll MFMA loops)
       const f32x4 a0 = scores(kt4, false), a1 = scores(kt4 + 1, false), a2 = scores(kt4 + 2, false),
                   a3 = scores(kt4 + 3, false);
@@ -366,12 +342,8 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kerne
       const f32x4 a = scores(kt, true);
       m = fmaxf(fmaxf(m, a[0]), fmaxf(fmaxf(a[1], a[2]), a[3]));
     }
-    if (ATTN_LAB == 5) m = 8.f;
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-#if ATTN_LAB == 8
-    ts1 = __builtin_amdgcn_s_memtime();
-#endif
     const f32x4 mcv = splat4(m * c2);
     f32x4 lv = {0.f, 0.f, 0.f, 0.f};
     float* ap = ATT ? p.att + (bh * Tn + qc) * Tn : nullptr;
@@ -381,10 +353,6 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kerne
 #pragma unroll
       for (int tt = 0; tt < A::TPS; ++tt) {
         const int kt = A::TPS * st + tt;
-        if (ATTN_LAB == 7) {
-          e[tt] = scores(kt, masked);
-          continue;
-        }
         e[tt] = exp2_4(scores(kt, masked) * c2v - mcv);
         lv += e[tt];
         if constexpr (ATT) {  // unnormalised here, rescaled below once the row sum is known
@@ -395,10 +363,6 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kerne
         e[tt] = dropped(e[tt], kt);
       }
       const u32x4 bop = pack_operand<T>(e[0], e[A::TPS - 1]);
-      if (ATTN_LAB == 6) {
-        o[0] += __builtin_bit_cast(f32x4, bop);
-        return;
-      }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) mma<T>(o[dt], frag_tr<T, true>(Xt, st, dt, lane), bop);
     };
@@ -409,10 +373,6 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kerne
     }
     if (st2 < nst_full) step(st2, false);
     for (int st = nst_full; st < nst; ++st) step(st, true);
-#if ATTN_LAB == 8
-    asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
-    ts2 = __builtin_amdgcn_s_memtime();
-#endif
     float l = (lv[0] + lv[1]) + (lv[2] + lv[3]);
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
@@ -474,14 +434,6 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kerne
     for (int dt = 0; dt < 4; ++dt) store4<T>(op + 16 * dt + 4 * g, o[dt] * oscale);
   }
 
-#if ATTN_LAB == 8
-  if (dbg_on && dbg_n < 8) {
-    unsigned long long* d = melgpt_attn_dbg + 8 * dbg_n++;
-    if (lane == 0) {
-      d[0] = ts0 - ts_k; d[1] = ts1 - ts0; d[2] = ts2 - ts1; d[3] = __builtin_amdgcn_s_memtime() - ts2; d[4] = nkt; d[5] = job;
-    }
-  }
-#endif
   job = njob;
 #pragma unroll
   for (int ks = 0; ks < A::NKS; ++ks) {
@@ -491,13 +443,6 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kerne
   }
   lse_q = nlse;
  }  // tile loop
-#if ATTN_LAB == 8
-  if (!BWD && t == 0 && bh < 4096) {
-    unsigned long long* d = melgpt_attn_dbg + 256 + 4 * bh;
-    d[0] = ts_entry; d[1] = ts_k; d[2] = __builtin_amdgcn_s_memtime();
-    d[3] = (rt_entry << 32) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull);
-  }
-#endif
 }
 
 // ============================================================================================ dK / dV
@@ -520,19 +465,14 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_dkv_ker
   int* ctr = (int*)(del_s + TP);
   const long long bh = (long long)b * p.H + h;
   const float dsc = DM != DM_NONE ? p.drop_scale : 1.f;
-  if (ATTN_LAB != 2)
-    load_tiles<T, false, false>(Qt, (const T*)p.Q + (long long)b * Tn * p.ld + h * HS, p.ld, Dt,
-                                (const T*)p.dO + (long long)b * Tn * p.ldo + h * HS, p.ldo, Tn, TP, t);
+  load_tiles<T, false, false>(Qt, (const T*)p.Q + (long long)b * Tn * p.ld + h * HS, p.ld, Dt,
+                              (const T*)p.dO + (long long)b * Tn * p.ldo + h * HS, p.ldo, Tn, TP, t);
   for (int j = t; j < TP; j += NTHREADS) {
     lse_s[j] = j < Tn ? p.lse[bh * Tn + j] * LOG2E : 0.f;
     del_s[j] = j < Tn ? p.delta[bh * Tn + j] / dsc : 0.f;
   }
   if (t == 0) *ctr = 0;
   __syncthreads();
-  if (ATTN_LAB == 1) {
-    if (*(volatile int*)(Qt + 4 * t) == 0x12345678) p.delta[t] = 1.f;
-    return;
-  }
   const int ntiles = (Tn + 15) / 16;
   const f32x4 c2v = splat4(p.scale * LOG2E);
   const DropKeys dkeys = drop_keys(p.seed, p.stream_id, (unsigned)bh, p.drop_thresh);
@@ -897,13 +837,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnParams p) {
   MELGPT_CLK_END(clk_attn_fwd);
 }
 
-#ifndef ATTN_LAB_LDSPAD
-#define ATTN_LAB_LDSPAD 0  // lab: extra dynamic LDS per workgroup (90000 forces ONE workgroup per CU: what a persistent
-#endif                     // workgroup with double-buffered K/V would run at - profiles/r03_attn_lab.md)
 template <typename T>
 size_t lds_bytes(int Tn, bool with_stats) {
   const int TP = (Tn + 31) / 32 * 32;
-  return 2 * (size_t)TP * AT<T>::ROWB + (with_stats ? 2 * (size_t)TP * 4 : 0) + 16 + ATTN_LAB_LDSPAD;
+  return 2 * (size_t)TP * AT<T>::ROWB + (with_stats ? 2 * (size_t)TP * 4 : 0) + 16;
 }
 
 int validate(const AttnParams& p, int hs, int dtype) {
@@ -1045,15 +982,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void attn_bwd1_kernel(AttnParams p) {
   };
   request(blockIdx.x);
  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-#if ATTN_LAB == 9
-  const int lab_it = (item - (int)blockIdx.x) / (int)gridDim.x;
-  unsigned long long* lab = melgpt_attn_dbg + (size_t)(lab_it * 8 + (t >> 6)) * 8;
-  const bool lab_on = blockIdx.x == 17 && lab_it < 8 && lane == 0;
-  int lab_steps = 0;
-#define LAB_STAMP(k) do { if (lab_on) lab[k] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
 #define LAB_STAMP(k) do { } while (0)
-#endif
   LAB_STAMP(0);
   const int b = item / p.H, h = item - b * p.H;
   const long long bh = item;
@@ -1205,9 +1134,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void attn_bwd1_kernel(AttnParams p) {
     const int stf1 = max(stf0, (Tn / 16) / 2);                          // .. and one past the last
     for (int st = st0; st < st1; ++st) {
       step(st, st < stf0 || st >= stf1);
-#if ATTN_LAB == 9
-      ++lab_steps;
-#endif
     }
 
     if (key < Tn) {
@@ -1228,9 +1154,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void attn_bwd1_kernel(AttnParams p) {
     }
   }
   LAB_STAMP(2);
-#if ATTN_LAB == 9
-  if (lab_on) lab[7] = lab_steps;
-#endif
   // ---- phase 2: K over Q's tile (requested before the barrier: a wave that is done early waits there anyway), then
   //      dQ^T = K^T dS^T per 16-query tile
   {
@@ -1366,7 +1289,7 @@ extern "C" int melgpt_attn_fwd(const void* q, const void* k, const void* v, long
   // MELGPT_ATTN_FWD32=0 / 1 or melgpt_set_attn_fwd32 force one kernel for every shape (tests run both on every shape).
   fwd32_env();
   const bool use32 = g_fwd32 == 1 || (g_fwd32 == -1 && n_unmasked >= T);
-  if (ATTN_LAB == 0 && use32 && dtype == MELGPT_BF16 && !att) {
+  if (use32 && dtype == MELGPT_BF16 && !att) {
     switch (drop_mode(p)) {
       case DM_NONE: st = launch_fwd32<DM_NONE>(p, s); break;
       case DM_HALF: st = launch_fwd32<DM_HALF>(p, s); break;
@@ -1408,7 +1331,7 @@ extern "C" int melgpt_attn_bwd(const void* q, const void* k, const void* v, long
     const char* e = getenv("MELGPT_ATTN_BWD_TWO_PASS");
     g_bwd_two_pass = e ? atoi(e) != 0 : 0;
   }
-  if ((ATTN_LAB == 0 || ATTN_LAB == 9) && !g_bwd_two_pass && dtype == MELGPT_BF16 && n_unmasked == 0 && bwd1_lds_bytes(T) <= 160 * 1024) {
+  if (!g_bwd_two_pass && dtype == MELGPT_BF16 && n_unmasked == 0 && bwd1_lds_bytes(T) <= 160 * 1024) {
     switch (drop_mode(p)) {
       case DM_NONE: st = launch_bwd1<DM_NONE>(p, s); break;
       case DM_HALF: st = launch_bwd1<DM_HALF>(p, s); break;
@@ -1416,13 +1339,9 @@ extern "C" int melgpt_attn_bwd(const void* q, const void* k, const void* v, long
     }
     return st != MELGPT_OK ? st : melgpt_launch_status();
   }
-  if (ATTN_LAB != 4) {  // dQ (writes delta, which the dK/dV kernel reads)
-    st = dtype == MELGPT_F32 ? launch_q_mode<float, true>(p, s) : launch_q_mode<bf16_t, true>(p, s);
-    if (st != MELGPT_OK) return st;
-  }
-  if (ATTN_LAB != 3) {
-    st = dtype == MELGPT_F32 ? launch_dkv_mode<float>(p, s) : launch_dkv_mode<bf16_t>(p, s);
-    if (st != MELGPT_OK) return st;
-  }
+  st = dtype == MELGPT_F32 ? launch_q_mode<float, true>(p, s) : launch_q_mode<bf16_t, true>(p, s);  // dQ (writes delta, which the dK/dV kernel reads)
+  if (st != MELGPT_OK) return st;
+  st = dtype == MELGPT_F32 ? launch_dkv_mode<float>(p, s) : launch_dkv_mode<bf16_t>(p, s);
+  if (st != MELGPT_OK) return st;
   return melgpt_launch_status();
 }

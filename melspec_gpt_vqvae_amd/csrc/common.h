@@ -240,6 +240,3 @@ __device__ __forceinline__ Philox4 philox4x32_10(unsigned long long seed, unsign
 }
 
 extern "C" int melgpt_get_reserved_cus(void);  // abi.hip: CUs the persistent kernels leave free (data-parallel runs)
-extern "C" int melgpt_get_dynamic_tiles(void);  // abi.hip: persistent GEMM draws its tiles from a counter (data-parallel runs)
-constexpr int MELGPT_TILE_CELL_INTS = 2048;      // one scheduler cell: 8 counters (a line each), mailboxes from [256] on
-extern "C" int* melgpt_tile_cell(void);          // abi.hip: next zeroed scheduler cell of the pool, or nullptr

@@ -187,14 +187,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(FusedConvParams q) {
 //     `s_waitcnt vmcnt` + one raw `s_barrier` per K-step.  (The 128-pixel kernel above has one K-step = 0.24 us of
 //     MFMA work in flight against >= 1 us of L2 latency: it runs at the latency, not at the matrix pipe.)
 //   * 8 waves as 4 (pixel rows) x 2 (output-channel halves), each 64 pixels x 64 channels like above.
-#ifndef CONVW_LAB
-#define CONVW_LAB 0  // 1: phase stamps of workgroup 7 into melgpt_convw_dbg (development builds only)
-#endif
-#if CONVW_LAB
-__device__ unsigned long long melgpt_convw_dbg[64];
-__device__ unsigned long long melgpt_convw_dbg2[16];
-__device__ unsigned long long melgpt_convws_dbg[2][16][8];  // [role][tile ordinal][stamp]: workgroup 7, waves 0 and 4
-#endif
 
 constexpr int WNST = 4;
 // Output tile of the persistent kernel: 16 x 16 pixels, or 8 x 32 (W8) where the height pads badly to 16 rows (40 x 424:
@@ -337,9 +329,6 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
   for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     const int tx = tile % q.tiles_x, ty = (tile / q.tiles_x) % q.tiles_y, b = tile / (q.tiles_x * q.tiles_y);
     const int y0 = ty * WTH, x0 = tx * WTW;
-#if CONVW_LAB
-    unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st2 = 0;
-#endif
     if (abt) {
       ab[2 * t] = na;
       ab[2 * t + 1] = nbb;
@@ -369,9 +358,6 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
         rrow[mt][hp] = buf_load16(rres, off);
       }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ab visible; previous tile's epilogue is out of the patch
-#if CONVW_LAB
-    const unsigned long long stA = __builtin_amdgcn_s_memtime();
-#endif
     // ---- stage the input patch (normalise + swish on the fly; out-of-image pixels are zeros AFTER the normalisation)
     f32x4 sc[4];  // (a, b) of channels 8 ch .. 8 ch + 7, interleaved
     if (norm) {
@@ -400,9 +386,6 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
         *(u32x4*)(patch + patch_off<T>(pix, ch, pix_bytes)) = v;
       }
     }
-#if CONVW_LAB
-    st1 = __builtin_amdgcn_s_memtime();
-#endif
     fetch_stats(tile + gridDim.x);
     fetch_patch(tile + gridDim.x);  // lands under this tile's K loop
     // (the first K-step's barrier below publishes the patch)
@@ -468,9 +451,6 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
         }
       }
     }
-#if CONVW_LAB
-    st2 = __builtin_amdgcn_s_memtime();
-#endif
     fold_stats();  // the next tile's (a, b)
     asm volatile("s_barrier" ::: "memory");  // everybody is done reading the patch: it becomes the epilogue's staging
     if constexpr (STATS) {
@@ -536,16 +516,6 @@ __global__ __launch_bounds__(512) void conv3x3_gn_wide_kernel(FusedConvParams q,
     pe.R = nullptr;
     // (valid pixels of a row-block: the launcher picks 8 x 32 only where the second half of the last column tile is whole or empty)
     epilogue_rows<T, 4, 4, EPI_PLAIN16N>(pe, acc, mrow, min(16, q.W - x0), n0 + wn * 64, 0, lane_e, smem + w * 4096);
-#if CONVW_LAB
-    if (blockIdx.x == 7 && t == 0) {
-      const int k = (tile - 7) / gridDim.x;
-      if (k < 15) {
-        melgpt_convw_dbg2[k] = stA;
-        melgpt_convw_dbg[4 * k] = st0; melgpt_convw_dbg[4 * k + 1] = st1; melgpt_convw_dbg[4 * k + 2] = st2;
-        melgpt_convw_dbg[4 * k + 3] = __builtin_amdgcn_s_memtime();
-      }
-    }
-#endif
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -588,12 +558,9 @@ struct WsTile {
 };
 constexpr int WS_SPIN = 1 << 22;
 constexpr float LOG2E_F = 1.4426950408889634f;
-#ifndef WS_LAB
-#define WS_LAB 0   // lab: 1 no affine / swish arithmetic in the staging pass, 2 no LDS-DMA requests (stale weights), 4 no polls in the multiplying waves
-#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <bool STATS, bool W8, bool M16>
+template <bool STATS, bool W8>
 __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, int total_tiles) {
   typedef WsTile<W8> WT;
   constexpr int PP = WS_PP, PW = WT::PW, PH = WT::PH, TH = WT::TH, TW = WT::TW, WS_NPIX = WT::NPIX, WS_PATCH = WT::PATCH;
@@ -629,8 +596,8 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
     return (unsigned)__builtin_amdgcn_readfirstlane((int)min(min(v[0], v[1]), min(v[2], v[3])));
   };
 
-  if (w < 4 && M16) {
-    // ================================================================== multiplying waves, v_mfma_f32_16x16x32 form (round 5)
+  if (w < 4) {
+    // ================================================================== multiplying waves (v_mfma_f32_16x16x32)
     // The same roles, protocol and phases as the 32x32x16 form below, with the K-step's 64 channels as TWO 32-wide sub-steps
     // of 32 MFMAs (4 pixel fragments of 16 x 8 channel fragments of 16).  Why a second form: on random operands the chip
     // holds a higher clock under the 16x16x32 instruction than under 32x32x16 at equal cycles per FLOP (guide, "DVFS
@@ -663,9 +630,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
       }
     };
     auto wait_full = [&](unsigned k) {   // K-step k has landed for every staging wave
-      if (!(WS_LAB & 4)) {
-        for (int it = 0; min4(cnt4[0]) <= k && it < WS_SPIN; ++it) __builtin_amdgcn_s_sleep(1);
-      }
+      for (int it = 0; min4(cnt4[0]) <= k && it < WS_SPIN; ++it) __builtin_amdgcn_s_sleep(1);
       asm volatile("" ::: "memory");
     };
     u32x4 fa0[4], fa1[4], fb[8];
@@ -734,7 +699,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
           asm volatile("" ::: "memory");          // (no fragment load of this stage may sink below its release)
           if (lane == 0) cnt[4 + wm] = kg + 1u;   // behind this wave's last read of the stage (LDS runs a wave's ops in order)
           if (!last) {
-            if ((WS_LAB & 4) || min4(pf) > kg + 1u) asm volatile("" ::: "memory");
+            if (min4(pf) > kg + 1u) asm volatile("" ::: "memory");
             else wait_full(kg + 1u);
             if (kx < 2) loadA(ab, kx + 1, 0, fa0);
             else loadA(abn, 0, 0, fa0);
@@ -794,218 +759,8 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
         }
       }
     }
-  } else if (w < 4) {
-    // ================================================================== multiplying waves
-    const int wm = w, r32 = lane & 31, h = lane >> 5;
-    // patch fragment f (32 pixels = row-blocks 4 wm + 2 f, + 1): lane = pixel r32 of it, 16-byte k-chunk h of the step
-    const char* abase = patch + (W8 ? (wm * 2 * PW + r32) : ((wm * 4 + (r32 >> 4)) * PW + (r32 & 15))) * PP + h * 16;
-    // weight fragment nt: lane = fragment row r32 = channel 32 nt + perm(r32), chunk 2 ks + h of the 128-byte row
-    const int perm = 16 * ((r32 >> 2) & 1) + 4 * (r32 >> 3) + (r32 & 3);
-    const char* bb[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) bb[ks] = ring + row_off(perm, 2 * ks + h);
-    const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.R, p.R ? q.r_bytes : 0u);
-    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.C, q.r_bytes);
-    auto out_off = [&](int tile, int f) -> unsigned {  // byte offset of (this lane's pixel of fragment f, channel 16 h) in y / R
-      const int b = tile / tiles_img, r = tile - b * tiles_img, ty = r / q.tiles_x, tx = r - ty * q.tiles_x;
-      const int y = W8 ? ty * 8 + wm * 2 + f : ty * 16 + wm * 4 + 2 * f + (r32 >> 4), x = W8 ? tx * 32 + r32 : tx * 16 + (r32 & 15);
-      const bool ok = tile < total_tiles && y < q.H && x < q.W;
-      return ok ? (unsigned)(((((long long)b * q.H + y) * q.W + x) * 128 + 16 * h) * 2) : OOB;
-    };
-    u32x4 rr[2][4][2];  // residual of the tile about to be multiplied, in accumulator layout (channels 32 nt + 16 h + 0..15)
-    auto fetch_res = [&](int tile) {
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        const unsigned o = out_off(tile, f);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int e = 0; e < 2; ++e)
-            rr[f][nt][e] = (p.R && o != OOB) ? buf_load16(rres, o + nt * 64 + e * 16) : u32x4{0u, 0u, 0u, 0u};
-      }
-    };
-#if CONVW_LAB
-    unsigned long long spins = 0;
-#endif
-    auto wait_full = [&](unsigned k) {   // K-step k has landed for every staging wave
-      if (!(WS_LAB & 4)) {
-        for (int it = 0; min4(cnt4[0]) <= k && it < WS_SPIN; ++it) {
-          __builtin_amdgcn_s_sleep(1);
-#if CONVW_LAB
-          ++spins;
-#endif
-        }
-      }
-      // (volatile orders the poll against other volatile accesses only: without this the compiler is free to hoist the
-      // plain fragment loads of the stage ABOVE the poll that guards it)
-      asm volatile("" ::: "memory");
-    };
-    u32x4 fa0[2], fa1[2], fb[4];
-    auto loadA = [&](const char* ab, int kx, int ks, u32x4 (&fa)[2]) {
-#pragma unroll
-      for (int f = 0; f < 2; ++f) fa[f] = *(const u32x4*)(ab + (f * FSTEP + kx) * PP + ks * 32);
-    };
-    f32x16 acc[2][4];
-    // one 16-wide step: the next step's patch fragments first, then tile column by tile column - a weight fragment is
-    // re-requested (for the next step: `sbn`) as soon as its two MFMAs are out
-    // (the scheduling fences pin what is written: left alone the compiler sinks every fragment load to just in front of
-    // its first use - fewer live registers, and the LDS latency exposed four times per step)
-    auto step = [&](u32x4 (&fc)[2], const char* sbn, bool reload) {
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-#pragma unroll
-        for (int f = 0; f < 2; ++f) acc[f][nt] = MELGPT_MFMA_32x32x16(fb[nt], fc[f], acc[f][nt]);
-        if (reload) fb[nt] = *(const u32x4*)(sbn + nt * 4096);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    unsigned kg = 0;  // K-steps multiplied so far (over all tiles)
-    fetch_res(t_first);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // half 0 of the first tile is staged
-    for (int tile = t_first; tile < t_last; ++tile) {
-#if CONVW_LAB
-      unsigned long long ws_t[8];
-      ws_t[0] = __builtin_amdgcn_s_memtime();
-#endif
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        f32x4 bv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = *(const f32x4*)(bias_l + nt * 32 + h * 16 + 4 * e);
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-          for (int e = 0; e < 16; e += 2) {
-            const unsigned pk = rr[f][nt][e >> 3][(e >> 1) & 3];
-            acc[f][nt][e] = bf16lo(pk) + bv[e >> 2][e & 3];
-            acc[f][nt][e + 1] = bf16hi(pk) + bv[e >> 2][(e & 3) + 1];
-          }
-      }
-#pragma unroll 1
-      for (int hk = 0; hk < 6; ++hk) {  // (channel half, filter row): three K-steps (kx = 0, 1, 2) each
-        const int half = hk >= 3 ? 1 : 0, ky = hk - 3 * half;
-        const char* ab = abase + ky * PW * PP + half * 128;
-        if (hk == 0 || hk == 3) {
-          // a phase starts: (hk == 3) everybody is done with half 0 and half 1 is staged
-#if CONVW_LAB
-          if (hk == 3) ws_t[1] = __builtin_amdgcn_s_memtime();
-#endif
-          if (hk == 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#if CONVW_LAB
-          if (hk == 3) ws_t[2] = __builtin_amdgcn_s_memtime();
-#endif
-          wait_full(kg);
-          loadA(ab, 0, 0, fa0);
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) fb[nt] = *(const u32x4*)(bb[0] + ((kg & 3u) << 14) + nt * 4096);
-        }
-        const bool last_hk = hk == 2 || hk == 5;
-        const char* abn = ab + PW * PP;  // (not used behind the phase's last filter row)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx, ++kg) {
-          const unsigned so = (kg & 3u) << 14, son = ((kg + 1u) & 3u) << 14;
-          const bool last = last_hk && kx == 2;  // the phase's last K-step: nothing of the next one may be touched yet
-          // the counters of the NEXT K-step are read now and looked at three steps later (they only grow: a value that
-          // already says "landed" stays true; the round trip of a poll in front of the last step cost ~250 cycles per K-step)
-          const u32x4 pf = cnt4[0];
-          loadA(ab, kx, 1, fa1);
-          step(fa0, bb[1] + so, true);
-          loadA(ab, kx, 2, fa0);
-          step(fa1, bb[2] + so, true);
-          loadA(ab, kx, 3, fa1);
-          step(fa0, bb[3] + so, true);
-          asm volatile("" ::: "memory");          // (no fragment load of this stage may sink below its release)
-          if (lane == 0) cnt[4 + wm] = kg + 1u;   // behind this wave's last read of the stage (LDS runs a wave's ops in order)
-          if (!last) {
-            if ((WS_LAB & 4) || min4(pf) > kg + 1u) asm volatile("" ::: "memory");
-            else wait_full(kg + 1u);
-            if (kx < 2) loadA(ab, kx + 1, 0, fa0);
-            else loadA(abn, 0, 0, fa0);
-          }
-          step(fa1, bb[0] + son, !last);
-        }
-      }
-#if CONVW_LAB
-      ws_t[3] = __builtin_amdgcn_s_memtime();
-#endif
-      // ---- epilogue: the next tile's residual first (into registers the K loop does not hold)
-      fetch_res(tile + 1 < t_last ? tile + 1 : total_tiles);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          u32x4 pk[2];
-#pragma unroll
-          for (int e = 0; e < 16; e += 2) pk[e >> 3][(e >> 1) & 3] = pack_bf16x2(acc[f][nt][e], acc[f][nt][e + 1]);
-          const unsigned o = out_off(tile, f);
-          if (o != OOB) {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, pk[0]), ry, o + nt * 64, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, pk[1]), ry, o + nt * 64 + 16, 0, 0);
-          }
-          if constexpr (STATS) {
-            // GroupNorm(32) statistics of THIS conv's output on the values as stored: a lane's registers 4 j .. 4 j + 3 are
-            // group 8 nt + 4 h + j of its pixel
-            if (o != OOB) {
-#pragma unroll
-              for (int e = 0; e < 16; e += 2) {
-                const unsigned v = pk[e >> 3][(e >> 1) & 3];
-                const float v0 = bf16lo(v), v1 = bf16hi(v);
-                s1[e >> 2] += v0 + v1;
-                s2[e >> 2] = fmaf(v1, v1, fmaf(v0, v0, s2[e >> 2]));
-              }
-            }
-          }
-        }
-        if constexpr (STATS) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {   // over the 32 pixels of the lane's half-wave: four DPP steps + the row pair
-            float a = s1[j], c = s2[j];
-            a += dpp_move<0xB1>(a);
-            c += dpp_move<0xB1>(c);
-            a += dpp_move<0x4E>(a);
-            c += dpp_move<0x4E>(c);
-            a += dpp_move<0x141>(a);
-            c += dpp_move<0x141>(c);
-            a += dpp_move<0x140>(a);
-            c += dpp_move<0x140>(c);
-            a += __shfl_xor(a, 16, 64);
-            c += __shfl_xor(c, 16, 64);
-            if (r32 == 0) {
-              stp[(wm * 32 + 8 * nt + 4 * h + j) * 2] = a;
-              stp[(wm * 32 + 8 * nt + 4 * h + j) * 2 + 1] = c;
-            }
-          }
-        }
-      }
-#if CONVW_LAB
-      ws_t[4] = __builtin_amdgcn_s_memtime();
-#endif
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // half 1 is free; half 0 of the next tile is staged
-#if CONVW_LAB
-      ws_t[5] = __builtin_amdgcn_s_memtime();
-      if (blockIdx.x == 7 && t == 0) {
-        const int k = tile - t_first;
-        if (k < 16) {
-          for (int e = 0; e < 6; ++e) melgpt_convws_dbg[0][k][e] = ws_t[e];
-          melgpt_convws_dbg[0][k][6] = spins;
-        }
-      }
-#endif
-      if constexpr (STATS) {
-        if (wm == 0) {
-          const float v = ((stp[lane] + stp[64 + lane]) + stp[128 + lane]) + stp[192 + lane];
-          q.stat_part[(long long)tile * 64 + lane] = v;  // tile = (b * tiles_y + ty) * tiles_x + tx
-        }
-      }
-    }
   } else {
     // ================================================================== staging waves
-#ifndef WS_PRIO
-#define WS_PRIO 0   // lab: s_setprio of the staging waves
-#endif
-    if (WS_PRIO) __builtin_amdgcn_s_setprio(WS_PRIO);
     const int s = w - 4, sthr = t - 256, ch = sthr & 7, prow = sthr >> 3;   // 8 chunks (64 channels) x 32 pixels per trip
     const unsigned long long wb_addr = (unsigned long long)p.B, x_addr = (unsigned long long)q.x;
     const u32x4 rb = {(unsigned)wb_addr, (unsigned)(wb_addr >> 32) & 0xFFFFu, p.b_bytes, 0x00020000u};
@@ -1021,8 +776,8 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
     for (int i = 0; i < 4; ++i) {
       const int piece = s + 4 * i, row = piece * 8 + (lane >> 3), chs = (lane & 7) ^ ((row >> 1) & 7);
       // (the 16x16x32 form reads ring rows in natural order: ring row R then holds channel chan(R), see the multiplying waves)
-      const int src = M16 ? 32 * (row >> 5) + 8 * ((row >> 2) & 3) + 4 * ((row >> 4) & 1) + (row & 3) : row;
-      b_base[i] = (row < p.N && !(WS_LAB & 2)) ? (unsigned)(((long long)src * p.ldb) * 2) + chs * 16 : OOB;
+      const int src = 32 * (row >> 5) + 8 * ((row >> 2) & 3) + 4 * ((row >> 4) & 1) + (row & 3);
+      b_base[i] = row < p.N ? (unsigned)(((long long)src * p.ldb) * 2) + chs * 16 : OOB;
     }
     auto issue_w = [&](int kt, unsigned stage) {  // K-step kt of a tile (channel-half-major)
       const int half = kt >= 9 ? 1 : 0, tap = kt - 9 * half;
@@ -1100,7 +855,6 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
       const unsigned so = (norm && live) ? (unsigned)((b * 32 + half * 16 + 2 * ch) * 4) : OOB;
       asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(r.rs) : "v"(so), "s"(rrs) : "memory");
       asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(r.mn) : "v"(so), "s"(rmn) : "memory");
-      if (WS_LAB & 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     // wait until at most N of this wave's vector-memory operations are outstanding; names every register of r so that no
     // use of them is scheduled above it
@@ -1127,7 +881,7 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
       if (i >= NEWT && shared) return;   // (wave-uniform) columns 0, 1 are copied below instead
       if ((pyx[i] & 255) < 64) {   // (the last edge trip covers 4 or 20 pixels only)
         u32x4 v = r.v[i];
-        if (!(WS_LAB & 1) && norm) {   // branch-free: computed for every pixel, zeroed outside the image
+        if (norm) {   // branch-free: computed for every pixel, zeroed outside the image
           const unsigned keep = (r.ok >> i & 1u) ? 0xFFFFFFFFu : 0u;
           float o[8];
 #pragma unroll
@@ -1150,24 +904,13 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
         *(u32x4*)(patch + doff[i] + half * 128) = v;   // (outside the image: the load returned zeros)
       }
     };
-#if CONVW_LAB
-    unsigned long long ws_pre = 0, ws_pre2 = 0, ws_spin = 0;  // time of reaching the barrier of phase A / B; free-poll spins
-#endif
     // One phase: `use` is staged into channel half `half` while `next` (the half after it) is requested; the nine slots
     // follow the multiplying waves' K-steps sigma0 .. sigma0 + 8: slot j requests K-step sigma0 + j + 3 (tile-local index
     // kt0 + j, mod 18) once K-step sigma0 + j - 1 is free, then publishes K-step sigma0 + j + 1.
     unsigned free_seen = 0;   // K-steps every multiplying wave was seen to have read
     u32x4 pf_free = {0u, 0u, 0u, 0u};
-#if CONVW_LAB
-    unsigned long long pc[5] = {0, 0, 0, 0, 0};  // cycles in: raw loads, free poll, piece issue, landing wait + publish, convert
-#define WS_T(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pc[k] += n_ - tl; tl = n_; }
-#else
 #define WS_T(k)
-#endif
     auto phase = [&](int half, Raw& use, bool use_shared, int next_tile, int next_half, Raw& next, unsigned sigma0, int kt0) {
-#if CONVW_LAB
-      unsigned long long tl = __builtin_amdgcn_s_memtime();
-#endif
       load_raw(next_tile, next_half, next);
       WS_T(0)
 #pragma unroll
@@ -1187,9 +930,6 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
         if (free_seen < sigma) {
           for (int it = 0; (free_seen = min4(cnt4[1])) < sigma && it < WS_SPIN; ++it) {
             __builtin_amdgcn_s_sleep(1);
-#if CONVW_LAB
-            ++ws_spin;
-#endif
           }
         }
         asm volatile("" ::: "memory");
@@ -1214,10 +954,6 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
         if (j == 5) convert(half, 10, use, use_shared);
         WS_T(4)
       }
-#if CONVW_LAB
-      if (half == 1) ws_pre = __builtin_amdgcn_s_memtime();
-      else ws_pre2 = __builtin_amdgcn_s_memtime();
-#endif
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     Raw r0, r1;
@@ -1237,24 +973,8 @@ __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, i
     unsigned sigma0 = 0;
     for (int tile = t_first; tile < t_last; ++tile) {
       const int nxt = tile + 1 < t_last ? tile + 1 : total_tiles;
-#if CONVW_LAB
-      const unsigned long long sa = __builtin_amdgcn_s_memtime();
-#endif
       phase(1, r1, shared_halo(tile), nxt, 0, r0, sigma0, 3);        // A(t): stage half 1 of t, request half 0 of the next tile
-#if CONVW_LAB
-      const unsigned long long sb = __builtin_amdgcn_s_memtime();
-#endif
       phase(0, r0, shared_halo(nxt), nxt, 1, r1, sigma0 + 9u, 12);  // B(t): stage half 0 of the next tile, request its half 1
-#if CONVW_LAB
-      if (blockIdx.x == 7 && t == 256) {
-        const int k = tile - t_first;
-        if (k < 15) {
-          melgpt_convws_dbg[1][k][0] = sa; melgpt_convws_dbg[1][k][1] = ws_pre; melgpt_convws_dbg[1][k][2] = sb;
-          melgpt_convws_dbg[1][k][3] = ws_pre2; melgpt_convws_dbg[1][k][4] = __builtin_amdgcn_s_memtime(); melgpt_convws_dbg[1][k][5] = ws_spin;
-          if (k == 4) for (int e = 0; e < 5; ++e) melgpt_convws_dbg[1][15][e] = pc[e];
-        }
-      }
-#endif
       sigma0 += 18u;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
@@ -1297,7 +1017,6 @@ int launch_fused_wide_t(const FusedConvParams& q0, int B, hipStream_t s) {
   }
   return melgpt_launch_status();
 }
-int g_ws_m16 = -1;   // MFMA shape of the wave-specialised conv's multiplying waves: 1 = 16x16x32 (default), 0 = 32x32x16
 template <bool W8>
 int launch_fused_ws_t(const FusedConvParams& q0, int B, hipStream_t s) {
   typedef WsTile<W8> WT;
@@ -1310,10 +1029,8 @@ int launch_fused_ws_t(const FusedConvParams& q0, int B, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
       return MELGPT_ERR_LAUNCH;
-    if (hipFuncSetAttribute((const void*)conv3x3_gn_ws_kernel<false, W8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WT::LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv3x3_gn_ws_kernel<true, W8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WT::LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv3x3_gn_ws_kernel<false, W8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WT::LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv3x3_gn_ws_kernel<true, W8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WT::LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3x3_gn_ws_kernel<false, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, WT::LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv3x3_gn_ws_kernel<true, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, WT::LDS) != hipSuccess)
       return MELGPT_ERR_LAUNCH;
     ncu = n;
   }
@@ -1321,16 +1038,8 @@ int launch_fused_ws_t(const FusedConvParams& q0, int B, hipStream_t s) {
   if (total > 0x3FFFFFFF) return MELGPT_ERR_UNSUPPORTED;
   const int avail = ncu - melgpt_get_reserved_cus() >= 8 ? ncu - melgpt_get_reserved_cus() : ncu;
   const int gx = (int)(total < avail ? total : avail);
-  // the multiplying waves' MFMA shape: 16x16x32 (default) or the round-4 32x32x16 form (MELGPT_CONV_WS_M16=0); same results
-  // up to the accumulation order of a 16- or a 32-wide k-slice
-  if (g_ws_m16 < 0) g_ws_m16 = !(getenv("MELGPT_CONV_WS_M16") && atoi(getenv("MELGPT_CONV_WS_M16")) == 0);
-  if (g_ws_m16) {
-    if (q.stat_part) hipLaunchKernelGGL((conv3x3_gn_ws_kernel<true, W8, true>), dim3(gx), dim3(512), WT::LDS, s, q, (int)total);
-    else hipLaunchKernelGGL((conv3x3_gn_ws_kernel<false, W8, true>), dim3(gx), dim3(512), WT::LDS, s, q, (int)total);
-  } else {
-    if (q.stat_part) hipLaunchKernelGGL((conv3x3_gn_ws_kernel<true, W8, false>), dim3(gx), dim3(512), WT::LDS, s, q, (int)total);
-    else hipLaunchKernelGGL((conv3x3_gn_ws_kernel<false, W8, false>), dim3(gx), dim3(512), WT::LDS, s, q, (int)total);
-  }
+  if (q.stat_part) hipLaunchKernelGGL((conv3x3_gn_ws_kernel<true, W8>), dim3(gx), dim3(512), WT::LDS, s, q, (int)total);
+  else hipLaunchKernelGGL((conv3x3_gn_ws_kernel<false, W8>), dim3(gx), dim3(512), WT::LDS, s, q, (int)total);
   return melgpt_launch_status();
 }
 int launch_fused_ws(const FusedConvParams& q, int B, hipStream_t s) {
@@ -1410,13 +1119,6 @@ static int conv3x3_gn_impl(const void* x, int B, int H, int W, int Cin, const fl
   }
   if (stat_part) return MELGPT_ERR_UNSUPPORTED;
   return launch_fused<bf16_t>(q, B, s);
-}
-
-extern "C" int melgpt_set_conv_ws_mfma16(int on) {
-  if (g_ws_m16 < 0) g_ws_m16 = !(getenv("MELGPT_CONV_WS_M16") && atoi(getenv("MELGPT_CONV_WS_M16")) == 0);
-  const int prev = g_ws_m16;
-  g_ws_m16 = on != 0;
-  return prev;
 }
 
 extern "C" int melgpt_conv3x3_gn_nhwc(const void* x, int B, int H, int W, int Cin, const float* mean, const float* rstd,

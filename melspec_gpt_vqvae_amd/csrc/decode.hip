@@ -487,238 +487,6 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ x,
   }
 }
 
-// ------------------------------------------------------------------- qkv projection + cached attention step, one launch
-// Decode at 1 .. 4 sequences is a chain of launch-floor nodes (~4.7 us each in a replayed graph, 5 per layer): the qkv
-// projection (pre-LN folded in) and the attention step on the cache are PER HEAD - a head's 192 rows of W_qkv (64 of each
-// of key | query | value: 393 KB at C = 1024) and its cache rows are all its workgroup needs - so one 1024-thread workgroup
-// per (head, sequence) does both: every wave LayerNorms the row (as gemv_rows_kernel's waves do), multiplies 12 of the 192
-// weight rows (all of a wave's rows requested at once: 24 x 16 bytes per lane), leaves the head's k | q | v in LDS; the
-// head's cache rows (one contiguous run in the head-major cache) come in by LDS-DMA under the weight loads - no registers -
-// and waves 0-3 then run attn_decode_kernel's body on them.  Same arithmetic in the same order as the two kernels it
-// replaces (the projection's output rounded to the 16-bit format in between, as the stored row was): same bits.
-// 16-bit lane, head size 64, C <= 1536.
-template <int NJ>  // 16-byte chunks of the row per lane: 2 (C <= 1024) or 3
-__global__ __launch_bounds__(1024) void qkv_attn_decode_kernel(const bf16_t* __restrict__ x, long long ldx,
-                                                               const bf16_t* __restrict__ W, long long ldw,
-                                                               const float* __restrict__ bias, const float* __restrict__ ln_g,
-                                                               const float* __restrict__ ln_b, float ln_eps,
-                                                               bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, int Tmax, int C,
-                                                               int pos, const int* __restrict__ pos_dev, bf16_t* __restrict__ out,
-                                                               float* __restrict__ att_row, float scale) {
-  typedef bf16_t T;
-  constexpr int HS = 64, MAXT = 320, VEC = 8, ROWCH = 8, G = 32, NIT = 10;  // (attention body: attn_decode_kernel's 256 threads)
-  constexpr int RPW = 12, RB = NJ <= 2 ? 12 : 6;                            // weight rows per wave, per batch of requests
-  extern __shared__ __attribute__((aligned(16))) char kv_s[];               // [MAXT][128 B] keys, then values
-  __shared__ float qkv_s[3 * HS];
-  __shared__ float red[2][4];
-  __shared__ float s_new_sh;
-  __shared__ float osum[4][HS];
-  if (pos_dev) pos = *pos_dev;
-  if (pos >= Tmax) return;
-  const int h = blockIdx.x, b = blockIdx.y, H = gridDim.x, tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  T* kb = kc + (((long long)b * H + h) * Tmax) * HS;
-  T* vb = vc + (((long long)b * H + h) * Tmax) * HS;
-  char* Ks = kv_s;
-  char* Vs = kv_s + MAXT * HS * 2;
-  // ---- the row, LayerNorm-ed (gemv_rows_kernel's arithmetic: two passes over the lane's chunks, wave sums)
-  const int K = C, nchunk = K / VEC;
-  const T* xr = x + (long long)b * ldx;
-  u32x4 xv[NJ];
-  bool ok[NJ];
-  long long off[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int c = lane + 64 * j;
-    ok[j] = c < nchunk;
-    off[j] = (long long)(ok[j] ? c : 0) * VEC;
-    xv[j] = *(const u32x4*)(xr + off[j]);
-  }
-  {
-    float s1 = 0.f;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-      if (ok[j]) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s1 += half_lo(xv[j][e]) + half_hi(xv[j][e]);
-      }
-    const float mean = wave_sum(s1) / (float)K;
-    float s2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-      if (ok[j]) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float d0 = half_lo(xv[j][e]) - mean, d1 = half_hi(xv[j][e]) - mean;
-          s2 = fmaf(d0, d0, s2);
-          s2 = fmaf(d1, d1, s2);
-        }
-      }
-    const float rstd = rsqrtf(wave_sum(s2) / (float)K + ln_eps);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const f32x4 g0 = *(const f32x4*)(ln_g + off[j]), g1 = *(const f32x4*)(ln_g + off[j] + 4);
-      const f32x4 b0 = *(const f32x4*)(ln_b + off[j]), b1 = *(const f32x4*)(ln_b + off[j] + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float gg0 = e < 2 ? g0[2 * e] : g1[2 * e - 4], gg1 = e < 2 ? g0[2 * e + 1] : g1[2 * e - 3];
-        const float bb0 = e < 2 ? b0[2 * e] : b1[2 * e - 4], bb1 = e < 2 ? b0[2 * e + 1] : b1[2 * e - 3];
-        const float h0 = (half_lo(xv[j][e]) - mean) * rstd * gg0 + bb0;
-        const float h1 = (half_hi(xv[j][e]) - mean) * rstd * gg1 + bb1;
-        xv[j][e] = pack_bf16x2(h0, h1);
-      }
-    }
-  }
-  // ---- this wave's 12 of the head's 192 rows of W (row r: part r >> 6 of key | query | value, channel h 64 + (r & 63))
-  const int nwe = (nchunk + 127) / 128;  // waves gemv_rows_kernel would split K over: chunk j belongs to "wave" j % nwe
-#pragma unroll
-  for (int bt = 0; bt < RPW / RB; ++bt) {
-    u32x4 wv[RB][NJ];
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const int row = wave * RPW + bt * RB + r;
-      const T* wr = W + (long long)((row >> 6) * C + h * HS + (row & 63)) * ldw;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) wv[r][j] = *(const u32x4*)(wr + off[j]);
-    }
-    if (bt == 0) {
-      // the head's cache rows 0 .. pos - 1: one contiguous run per cache -> LDS, 1 KiB per wave instruction, behind the
-      // weight requests (the compiler's counted waits for those then cover these as well; rows past `pos` read zeros)
-      const unsigned nbytes = (unsigned)pos * (HS * 2);
-      const unsigned long long ka = (unsigned long long)kb, va = (unsigned long long)vb;
-      const u32x4 rk = {(unsigned)ka, (unsigned)(ka >> 32) & 0xFFFFu, nbytes, 0x00020000u};
-      const u32x4 rv = {(unsigned)va, (unsigned)(va >> 32) & 0xFFFFu, nbytes, 0x00020000u};
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int piece = wave + 16 * i;  // (wave-uniform)
-        if (piece * 1024 < (int)nbytes) {
-          const unsigned voff = (unsigned)(piece * 1024 + lane * 16);
-          const unsigned mk = (unsigned)(size_t)LDS_PTR(char, Ks + piece * 1024), mv = (unsigned)(size_t)LDS_PTR(char, Vs + piece * 1024);
-          asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(mk), "v"(voff), "s"(rk) : "memory", "m0");
-          asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(mv), "v"(voff), "s"(rv) : "memory", "m0");
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const int row = wave * RPW + bt * RB + r;
-      float acc[2] = {0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        if (ok[j]) {
-          float& a = acc[nwe == 1 ? 0 : (j & 1)];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            a = fmaf(half_lo(wv[r][j][e]), half_lo(xv[j][e]), a);
-            a = fmaf(half_hi(wv[r][j][e]), half_hi(xv[j][e]), a);
-          }
-        }
-      float sum = wave_sum(acc[0]);
-      if (nwe > 1) sum += wave_sum(acc[1]);
-      if (lane == 0) {
-        const int n = (row >> 6) * C + h * HS + (row & 63);
-        qkv_s[row] = bf16_to_f32(f32_to_bf16(sum + (bias ? bias[n] : 0.f)));  // (the stored row of the two-kernel path)
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the cache rows have landed
-  __syncthreads();
-  // ---- attn_decode_kernel's body on waves 0-3, cache rows out of LDS, the new token's k | q | v out of qkv_s
-  const bool att = tid < 256;  // (waves 0-3: wave-uniform)
-  const int g = (tid & 255) / ROWCH, cch = tid % ROWCH;
-  const int len_m1 = max(pos - 1, 0);
-  float s[NIT];
-  float s_new = 0.f, mx = 0.f;
-  if (att) {
-    if (wave == 0) {
-      const float kn = qkv_s[lane], qn = qkv_s[HS + lane], vn = qkv_s[2 * HS + lane];
-      kb[(long long)pos * HS + lane] = f32_to_bf16(kn);
-      vb[(long long)pos * HS + lane] = f32_to_bf16(vn);
-      const float sn = wave_sum(kn * qn);
-      if (lane == 0) s_new_sh = sn;
-    }
-  }
-  __syncthreads();
-  if (att) {
-    float qv[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) qv[e] = qkv_s[HS + cch * VEC + e];
-    s_new = s_new_sh * scale;
-    mx = s_new;
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int t = min(g + G * i, len_m1);
-      const u32x4 kr = *(const u32x4*)(Ks + t * (HS * 2) + cch * 16);
-      float acc = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc = fmaf(half_lo(kr[e]), qv[2 * e], acc);
-        acc = fmaf(half_hi(kr[e]), qv[2 * e + 1], acc);
-      }
-      acc += dpp_move<0xB1>(acc);
-      acc += dpp_move<0x4E>(acc);
-      acc += dpp_move<0x141>(acc);
-      s[i] = (g + G * i < pos) ? acc * scale : -INFINITY;
-      mx = fmaxf(mx, s[i]);
-    }
-    mx = wave_max(mx);
-    if (lane == 0) red[0][wave] = mx;
-  }
-  __syncthreads();
-  float e_new = 0.f;
-  if (att) {
-    mx = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      s[i] = (g + G * i < pos) ? __expf(s[i] - mx) : 0.f;
-      if (cch == 0) sum += s[i];
-    }
-    e_new = __expf(s_new - mx);
-    sum = wave_sum(sum);
-    if (lane == 0) red[1][wave] = sum;
-  }
-  __syncthreads();
-  float inv = 0.f;
-  if (att) {
-    inv = 1.0f / (((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) + e_new);
-    if (att_row) {
-#pragma unroll
-      for (int i = 0; i < NIT; ++i)
-        if (cch == 0 && g + G * i < pos) att_row[((long long)b * H + h) * Tmax + g + G * i] = s[i] * inv;
-      if (tid == 0) att_row[((long long)b * H + h) * Tmax + pos] = e_new * inv;
-    }
-    float o[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) o[e] = 0.f;
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const float p = s[i] * inv;
-      if (g + G * i >= pos) continue;
-      const u32x4 vr = *(const u32x4*)(Vs + (g + G * i) * (HS * 2) + cch * 16);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[2 * e] = fmaf(p, half_lo(vr[e]), o[2 * e]);
-        o[2 * e + 1] = fmaf(p, half_hi(vr[e]), o[2 * e + 1]);
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-#pragma unroll
-      for (int m = ROWCH; m < 64; m <<= 1) o[e] += __shfl_xor(o[e], m, 64);
-    }
-    if (lane < ROWCH) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) osum[wave][lane * VEC + e] = o[e];
-    }
-  }
-  __syncthreads();
-  if (tid < HS) {
-    const float v = (osum[0][tid] + osum[1][tid]) + (osum[2][tid] + osum[3][tid]) + (e_new * inv) * qkv_s[2 * HS + tid];
-    out[(long long)b * C + h * HS + tid] = f32_to_bf16(v);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------- skinny MFMA linear
 // y (M, N) = epi(x (M, K) W (N, K)^T + bias) (+ residual) for 5 .. 128 rows (decode steps at batch 5 .. 128), bf16.
 // The tiled GEMMs give such a problem one row of 128-wide tiles - 8 to 32 workgroups on a 256-CU chip - and the VALU
@@ -1184,42 +952,6 @@ extern "C" int melgpt_gemv_rows(const void* x, long long ldx, const void* W, lon
   }
 #undef MELGPT_GEMV_LAUNCH
 #undef MELGPT_GEMV_LAUNCH_LN
-  return melgpt_launch_status();
-}
-
-// One decode step's qkv projection (the Block's ln1 folded in) + KV-cached attention for 1 .. 4 sequences in ONE launch
-// (qkv_attn_decode_kernel): x (B, C) residual stream rows, W (3C, C) rows [key | query | value], bias (3C) f32 or null;
-// caches / pos / pos_dev / out / att_row as melgpt_attn_decode.  The same bits as melgpt_gemv_rows + melgpt_attn_decode.
-// MELGPT_ERR_UNSUPPORTED (nothing launched): f32 lane, head size != 64, C > 1536, more than 4 sequences.
-extern "C" int melgpt_qkv_attn_decode(const void* x, long long ldx, const void* W, long long ldw, const float* bias,
-                                      const float* ln_gamma, const float* ln_beta, float ln_eps, void* kcache, void* vcache,
-                                      int B, int H, int head_size, int Tmax, int pos, const int* pos_dev, void* out,
-                                      float* att_row, int dtype, void* stream) {
-  MELGPT_CHECK(x && W && ln_gamma && ln_beta && kcache && vcache && out && B > 0 && H > 0, MELGPT_ERR_BAD_ARG);
-  const int C = H * head_size;
-  if (dtype != MELGPT_BF16 || head_size != 64 || C > 1536 || B > 4 || Tmax <= 0 || Tmax > 320) return MELGPT_ERR_UNSUPPORTED;
-  MELGPT_CHECK(pos >= 0 && pos < Tmax, MELGPT_ERR_BAD_ARG);
-  MELGPT_CHECK(ldx % 8 == 0 && ldw % 8 == 0 && ldx >= C && ldw >= C &&
-                   ((((uintptr_t)x | (uintptr_t)W | (uintptr_t)kcache | (uintptr_t)vcache | (uintptr_t)ln_gamma |
-                      (uintptr_t)ln_beta) & 15) == 0),
-               MELGPT_ERR_ALIGN);
-  const float scale = 1.0f / sqrtf((float)head_size);
-  hipStream_t s = (hipStream_t)stream;
-  constexpr size_t LDS = 2 * 320 * 128;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)qkv_attn_decode_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)qkv_attn_decode_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess)
-      return MELGPT_ERR_LAUNCH;
-    attr = true;
-  }
-#define QAD_LAUNCH(NJ)                                                                                                    \
-  hipLaunchKernelGGL((qkv_attn_decode_kernel<NJ>), dim3(H, B), dim3(1024), LDS, s, (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, \
-                     bias, ln_gamma, ln_beta, ln_eps, (bf16_t*)kcache, (bf16_t*)vcache, Tmax, C, pos, pos_dev, (bf16_t*)out,    \
-                     att_row, scale)
-  if (C <= 1024) QAD_LAUNCH(2);
-  else QAD_LAUNCH(3);
-#undef QAD_LAUNCH
   return melgpt_launch_status();
 }
 

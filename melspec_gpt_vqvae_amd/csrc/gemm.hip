@@ -322,7 +322,7 @@ int pick_tile(const GemmParams& p, int batch, int kmin = 256, int kmin_partial =
   // (80 tiles: Encoder.conv_out at 64 clips - 512 -> 256 channels, 89 tiles - 94 -> 80 us)
   // (the ping-pong loop's K tile is a third shorter: K >= 512 pays there; launches that will take the RING loop - the switch
   // off, or claimed tiles on - keep the ring's threshold)
-  if (tiles192 >= 80 && fill >= 0.8 && p.K >= ((melgpt_get_gemm_pingpong() && !melgpt_get_dynamic_tiles()) ? kmin_partial : 1024)) return 3;
+  if (tiles192 >= 80 && fill >= 0.8 && p.K >= (melgpt_get_gemm_pingpong() ? kmin_partial : 1024)) return 3;
   return 1;
 }
 

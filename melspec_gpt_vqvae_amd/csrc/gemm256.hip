@@ -21,15 +21,9 @@
 
 using namespace gemmk;
 
-#ifndef G256_LAB
-#define G256_LAB 0  // tools/lab/gemm_lab.hip builds ablated variants; the library always builds 0
-#endif
 
 namespace {
 
-#if G256_LAB & 8
-__device__ unsigned long long* g256_dbg;  // lab build only: phase stamps of workgroup 17
-#endif
 
 constexpr int KU = 64;  // bf16 elements of K per unit = 128 bytes per ROW-layout row (full L2 lines per request)
 
@@ -76,14 +70,11 @@ __device__ __forceinline__ rsrc_t make_rsrc4(const void* base, unsigned bytes) {
 }
 __device__ __forceinline__ void dma16(rsrc_t rs, char* lds_wave_base, unsigned voff) {
   const unsigned m0v = (unsigned)(size_t)LDS_PTR(char, lds_wave_base);
-  // Cache policy of the requests (lab switch): " sc1" (served by L2 without allocating in the CU's vector L1) measured
+  // Cache policy of the requests (measured in round 3, then fixed): " sc1" (served by L2 without allocating in the CU's vector L1) measured
   // +0.5 .. 2.5 % per shape on constant operands and NEUTRAL in the training step (GEMM family 88.8-89.4 ms per step
   // either way, three alternating runs) while FETCH_SIZE read 15 % more bytes per step; " nt" -3 .. -15 % (the panels are
   // re-read out of L2 by the other tiles of the XCD's block).  Default policy kept.  profiles/r03_gemm_lab.md
-#ifndef G256_DMA_POLICY
-#define G256_DMA_POLICY ""
-#endif
-  asm volatile("s_nop 2\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" G256_DMA_POLICY " lds"
+  asm volatile("s_nop 2\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                :
                : "s"(m0v), "v"(voff), "s"(rs)
                : "memory", "m0");
@@ -110,8 +101,8 @@ __device__ __forceinline__ void wait_vm_barrier() {
 //
 // Tile order: the 32 workgroups of one XCD (blockIdx & 7, round-robin dispatch) take an RM x RN block of tiles, so
 // one L2 serves RM row panels of A and RN column panels of B instead of 1 + 32.
-template <int ALAY, int BLAY, int MODE, int TM, bool DYN = false>
-__global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m, int tiles_n, int batch, int RN, int* sched) {
+template <int ALAY, int BLAY, int MODE, int TM>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m, int tiles_n, int batch, int RN) {
   constexpr int WN = 4, TN = 4, NW = 8, BM = 32 * TM, BN = 256;  // TM = 8: 256 x 256; TM = 6: 192 x 256 (A row-major only)
   constexpr int HALF = 256 * 128, NSLOT = 5;
   constexpr int PER = HALF / 1024 / NW;   // LDS-DMA pieces per wave per B half-unit (4)
@@ -132,98 +123,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
   const int blocks_n = RN > 0 ? (tiles_n + RN - 1) / RN : 0;
   const int nblocks = RN > 0 ? ((rows_m + RM - 1) / RM) * blocks_n : 0;
   const int xcd = blockIdx.x & 7, jslot = blockIdx.x >> 3;
-  // CLAIMED TILES (the DYN variant, sched != nullptr): instead of a static list every tile is drawn from a counter, so a
-  // workgroup that starts late - its CU was held by an RCCL kernel overlapped with the backward pass - or runs slowly
-  // does not leave a whole list undone: the others take the work.  With XCD blocks (RN > 0) each XCD has its OWN counter
-  // over its own blocks (ticket t of XCD x = slot t % per of its block number t / per, per = G / 8 workgroups), so the
-  // tickets a chip's 32 workgroups draw one after the other are the tiles of one RM x RN block and its L2 serves the
-  // same few panels as with the static lists; without blocks there is one counter over the linear tile order.
-  // Tickets are drawn by wave 0 with a scalar-memory atomic (executed at L2, does not touch vmcnt), one or two items ahead
-  // (see "WHEN a ticket is drawn" below), and handed to the other seven waves through a two-slot mailbox in global memory
-  // (the ring leaves no LDS byte free): written with a posted s_atomic_swap, read with s_atomic_or 0 - both at L2, no cache
-  // to go stale - and always at least one workgroup barrier apart (wave 0 waits for its write in front of that barrier).  Cell layout: counter of queue q at sched[32 q] (a 128-byte line each), mailbox of
-  // workgroup b at sched[256 + 2 b + (item & 1)].  A ticket >= qtotal ends the list.  Every workgroup draws exactly one
-  // dead ticket (it stops drawing then), so a queue sees qtotal + qgroups draws: the one that returns
-  // qtotal + qgroups - 1 is the last and puts the counter back to 0 for the cell's next launch.
-  constexpr bool dyn = DYN;  // a kernel variant of its own: the static-list kernels keep their register budget
-  const int per = G >> 3;    // workgroups per XCD (RN > 0 implies G % 8 == 0)
-  const int qgroups = RN > 0 ? per : G;
-  const int qtotal = RN > 0 ? per * (nblocks > xcd ? (nblocks - xcd + 7) >> 3 : 0) : total;
-  int tk0 = 0x3FFFFFFF, tk1 = 0x3FFFFFFF;  // tickets of this workgroup's even / odd items (wave-uniform)
-  int own0 = 0x3FFFFFFF, own1 = 0x3FFFFFFF;  // wave 0: the tickets it drew (it does not read its own mail)
-  bool drawing = true;                      // wave 0: no dead ticket drawn yet
-  auto satomic = [](int* addr, int v, auto op_c) -> int {
-    constexpr int OP = decltype(op_c)::value;  // 0 add, 1 swap, 2 or (returned value waited for); 3 swap, posted
-    // (operands pinned to SGPRs: everything here is wave-uniform, but the compiler cannot always prove it)
-    const unsigned long long a64 = (unsigned long long)addr;
-    // (the builtin returns int: without the casts a low word with bit 31 set sign-extends over the high word)
-    addr = (int*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a64 >> 32)) << 32) |
-                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a64));
-    v = __builtin_amdgcn_readfirstlane(v);
-    if constexpr (OP == 0) asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(addr) : "memory");
-    else if constexpr (OP == 1) asm volatile("s_atomic_swap %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(addr) : "memory");
-    else if constexpr (OP == 2) asm volatile("s_atomic_or %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(addr) : "memory");
-    else asm volatile("s_atomic_swap %0, %1, 0x0" : : "s"(v), "s"(addr) : "memory");  // performed at L2 by the next lgkmcnt(0)
-    return v;
-  };
-  using op_add = std::integral_constant<int, 0>;
-  using op_swap = std::integral_constant<int, 1>;
-  using op_or = std::integral_constant<int, 2>;
-  using op_post = std::integral_constant<int, 3>;
-  int* counter = sched + (RN > 0 ? 32 * xcd : 0);
-  int* mail = sched + 256 + 2 * (int)blockIdx.x;
-  // ticket -> tile row / column over all batches; false: a slot of a block that hangs over the edge of the tile grid
-  auto ticket_tile = [&](int tl, int& tm, int& tn) -> bool {
-    if (RN > 0) {
-      const int lb = tl / per, j = tl - lb * per, blk = lb * 8 + xcd;
-      const int bm = blk / blocks_n, jm = j / RN;
-      tm = bm * RM + jm;
-      tn = (blk - bm * blocks_n) * RN + (j - jm * RN);
-      return tm < rows_m && tn < tiles_n;
-    }
-    tm = tl / tiles_n;
-    tn = tl - tm * tiles_n;
-    return true;
-  };
-  auto draw = [&](int item) {  // wave 0: ticket for `item` into its mailbox slot
-    int tkt = 0x3FFFFFFF;
-    if (drawing) {
-      int tm, tn;
-      do {  // (tickets of overhanging slots are drawn and dropped)
-        tkt = satomic(counter, 1, op_add{});
-        if (tkt == qtotal + qgroups - 1) satomic(counter, 0, op_swap{});  // the queue's last draw: counter back to 0
-      } while (tkt < qtotal && !ticket_tile(tkt, tm, tn));
-      drawing = tkt < qtotal;
-    }
-    if (item & 1) own1 = tkt;
-    else own0 = tkt;
-    // posted: wave 0 waits for it (lgkmcnt(0)) in front of the next workgroup barrier, and the others read the slot
-    // at least one barrier later
-    satomic(mail + (item & 1), tkt, op_post{});
-  };
-  auto take = [&](int item) {  // every wave: ticket of `item` out of the mailbox (written at least one barrier ago)
-    const int o0 = own0, o1 = own1, odd = -(item & 1);  // (chosen by mask, as in ticket() below)
-    const int tkt = w == 0 ? ((o1 & odd) | (o0 & ~odd)) : satomic(mail + (item & 1), 0, op_or{});
-    if (item & 1) tk1 = tkt;
-    else tk0 = tkt;
-  };
-  // (both tickets read, then chosen by mask: written as `r & 1 ? tk1 : tk0` the compiler selects between the two
-  // ADDRESSES inside the closure, which keeps closure and tickets in scratch memory)
-  auto ticket = [&](int r) {
-    const int a = tk0, b = tk1, odd = -(r & 1);
-    return __builtin_amdgcn_readfirstlane((b & odd) | (a & ~odd));  // wave-uniform by construction: say so
-  };
   auto live = [&](int r) {
-    if constexpr (dyn) return ticket(r) < qtotal;
-    else return RN > 0 ? r * 8 + xcd < nblocks : r * G + (int)blockIdx.x < total;
+    return RN > 0 ? r * 8 + xcd < nblocks : r * G + (int)blockIdx.x < total;
   };
   auto decode = [&](int r, int& bz, int& m0, int& n0) -> bool {
     int tm, tn;
-    if constexpr (dyn) {
-      const int tl = ticket(r);
-      if (tl >= qtotal) return false;
-      ticket_tile(tl, tm, tn);  // (draw() only hands out tickets of real tiles)
-    } else if (RN > 0) {
+    if (RN > 0) {
       const int blk = r * 8 + xcd;
       tm = (blk / blocks_n) * RM + jslot / RN;
       tn = (blk % blocks_n) * RN + jslot % RN;
@@ -240,41 +145,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
     return true;
   };
   auto next_item = [&](int r) {  // first item after r that is a tile, or the first dead one
-    if constexpr (dyn) {
-      return r + 1;  // (its ticket was taken out of the mailbox at the top of the K unit that gets here)
-    } else {
-      int bz, m0, n0;
-      do ++r;
-      while (live(r) && !decode(r, bz, m0, n0));
-      return r;
-    }
+    int bz, m0, n0;
+    do ++r;
+    while (live(r) && !decode(r, bz, m0, n0));
+    return r;
   };
-  // WHEN a ticket is drawn.  Needed: when the load cursor enters item ir + 1, during the last K unit but one of item
-  // ir; the others take it at the top of that unit (iu + 1 == nu), so wave 0 must have drawn it by the top of the unit
-  // before (iu + 2 == nu) - the LATE draw, a claim held for under three K units.  Drawing late costs every tile a second
-  // L2 round trip in front of a barrier (measured: + 3 % on the step's GEMMs), so while MORE THAN ONE ROUND of tickets
-  // is left in the queue (qtotal - last ticket > qgroups: nobody can be left without work by it) wave 0 draws item
-  // ir + 2 EARLY, in the same unit top in which item ir + 1 is taken.  Drawn early without that test, the first
-  // workgroups to start took two tiles each of a 240-tile launch and left the rest of the chip idle (8.1 ms against 4.3).
-  // Launches with fewer than three K units per tile have no room for the late draw: always two items ahead.
-  const bool early = nu < 3;
-  int drawn = -1, t_last = 0;  // wave 0: last item drawn for, and its ticket
-  auto plenty = [&]() { return early || qtotal - t_last > qgroups; };
-  auto draw_next = [&]() {
-    ++drawn;
-    draw(drawn);
-    const int o0 = own0, o1 = own1, odd = -(drawn & 1);
-    t_last = (o1 & odd) | (o0 & ~odd);
-  };
-  if constexpr (dyn) {  // first draws; a barrier between the mailbox writes and the first read
-    if (w == 0) {
-      draw_next();
-      if (plenty()) draw_next();
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    take(0);
-  }
-
   // ---- issue cursor: source plan of the tile whose half-units are being requested.  Piece j of a wave is piece
   // w + 8 j of the half-unit; its rows are 64 j rows (ROW) / 16 j k-rows (K-major) below piece 0's, and the swizzled
   // chunk a lane fetches is the same for every j, so one base offset per operand describes all four pieces.
@@ -295,13 +170,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
     pok = live(r) && decode(r, bz, pm0, pn0);  // dead: every request is out of bounds (zero fills nobody reads)
     ra = make_rsrc4((const char*)p.A + (long long)bz * p.sA * 2, p.a_bytes);
     rb = make_rsrc4((const char*)p.B + (long long)bz * p.sB * 2, p.b_bytes);
-    if constexpr (DYN) {  // wave-uniform by construction (the ticket is): pinned to SGPRs for the LDS-DMA asm blocks
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        ra[e] = __builtin_amdgcn_readfirstlane(ra[e]);
-        rb[e] = __builtin_amdgcn_readfirstlane(rb[e]);
-      }
-    }
     if constexpr (ALAY == LAY_KMAJ) {
       a_base0 = (pok && pm0 + k_lc * 8 < p.M) ? (unsigned)(((long long)k_row0 * p.lda + pm0) * 2) + k_lc * 16 : OOB;
     } else if constexpr (ALAY == LAY_CONV) {
@@ -362,22 +230,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
   };
 
   int first_item = -1;
-  first_item = next_item(first_item);  // (claimed tiles: item 0, ticket taken above)
+  first_item = next_item(first_item);
   // Issue cursor.  The stream of half-units is A(0) B(0) A(1) | B(1) A(2) | B(2) A(3) | ... : three up front, then
   // every K-unit iteration requests the B half of unit `iu` and the A half of the unit after it.
   int ir = first_item, iu = 0;  // item and K-unit of the next B half to request
   int fill = 0;                 // slot of the next half-unit to request
   plan(ir);
   auto next_slot = [&]() { fill = fill + 1 == NSLOT ? 0 : fill + 1; };
-  // claimed tiles: called (by every wave) at the top of a K unit, no LDS read in flight, the cursor in item `ir`
-  auto claim = [&]() {
-    if (iu + 2 == nu) {
-      if (w == 0 && drawn < ir + 1) draw_next();  // late (into the slot of item ir - 1)
-    } else if (iu + 1 == nu) {
-      take(ir + 1);
-      if (w == 0 && drawn < ir + 2 && plenty()) draw_next();  // early (into the slot of item ir)
-    }
-  };
   auto next_unit = [&]() {      // the B half of unit iu is out: move on (possibly to the next tile)
     if (++iu == nu) {
       iu = 0;
@@ -385,10 +244,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
       plan(ir);
     }
   };
-  if constexpr (dyn) if (nu == 1) {  // the prologue's next_unit() below already moves to item 1
-    asm volatile("s_barrier" ::: "memory");  // every wave has taken item 0 out of the slot item 2 is drawn into
-    claim();
-  }
 #pragma unroll
   for (int j = 0; j < PER_A; ++j) issue_a_piece(0, smem, j);           // A(0) -> slot 0
 #pragma unroll
@@ -402,8 +257,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
   for (int r = first_item; live(r); r = next_item(r)) {
     int bz, m0, n0;
     decode(r, bz, m0, n0);
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
-    if ((G256_LAB & 8)) ts0 = __builtin_amdgcn_s_memtime();
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -429,16 +282,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
       // H(2u), H(2u+1) must have landed for every wave and every wave must be past its reads of unit u-1, whose two
       // slots are refilled now.  One younger half-unit (an A half: PER_A operations) may still be in flight.  The half-units
       // requested before the previous tile's epilogue were drained there (vmcnt(0)): barrier only.
-      if constexpr (dyn) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave 0's posted mailbox write (no LDS read is pending here)
       if (first || u > 0) wait_vm_barrier<PER_A>();
       else asm volatile("s_barrier" ::: "memory");
-      if constexpr (dyn) claim();  // (iu + 1 == nu: this unit's next_unit() moves the cursor to the next item)
       // The eight LDS-DMA pieces of this iteration (B of unit iu, then A of the unit after) are issued ONE AT A TIME
       // between groups of MFMAs: a piece occupies the issuing wave for 60-180 cycles, and all 64 of a workgroup's
       // pieces issued together right after the barrier stall every wave for as long as the whole K-unit's MFMAs
       // take (measured: K-unit time = MFMA time + DMA time).  Spread out, the SIMD's other wave keeps the matrix
       // pipe busy meanwhile.
-      constexpr bool DMA_ON = G256_LAB != 1 && G256_LAB != 9;
       char* dst_b = smem + fill * HALF;
       next_slot();
       char* dst_a = smem + fill * HALF;
@@ -446,43 +296,28 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
       const char* sa = smem + slot * HALF;
       const char* sb = smem + (slot + 1 == NSLOT ? 0 : slot + 1) * HALF;
 #pragma unroll
-      for (int ks = 0; ks < (G256_LAB == 10 ? 0 : 2); ++ks) {
+      for (int ks = 0; ks < 2; ++ks) {
         // all 12 fragment reads of this k-step go out back to back, then the MFMAs run at raised priority: the LDS
         // sees a short read burst and is otherwise free for the LDS-DMA writes that are landing.  (Left to itself
         // the compiler reads one A fragment at a time, each behind an lgkmcnt(0), to save registers.)
         u32x4 fa[TM], fb[TN];
-        if (G256_LAB == 12) {  // MFMAs on whatever is in the registers: no LDS reads
 #pragma unroll
-          for (int nt = 0; nt < TN; ++nt) { fb[nt] = u32x4{(unsigned)lane, 1u, 2u, 3u}; asm volatile("" : "+v"(fb[nt])); }
+        for (int nt = 0; nt < TN; ++nt) fb[nt] = load_frag<BLAY, BN>(sb, wn * TN + nt, ks, lane);
 #pragma unroll
-          for (int mt = 0; mt < TM; ++mt) { fa[mt] = u32x4{(unsigned)lane, 1u, 2u, 3u}; asm volatile("" : "+v"(fa[mt])); }
-        } else {
-#pragma unroll
-          for (int nt = 0; nt < TN; ++nt) fb[nt] = load_frag<BLAY, BN>(sb, wn * TN + nt, ks, lane);
-#pragma unroll
-          for (int mt = 0; mt < TM; ++mt) fa[mt] = load_frag<ALAY, BM>(sa, wm * TM + mt, ks, lane);
-        }
+        for (int mt = 0; mt < TM; ++mt) fa[mt] = load_frag<ALAY, BM>(sa, wm * TM + mt, ks, lane);
         __builtin_amdgcn_sched_barrier(0);
-#ifndef G256_PRIO
-#define G256_PRIO 1  // lab: priority of the MFMA phase (0: none, 1: as shipped, 3: highest)
-#endif
-        __builtin_amdgcn_s_setprio(G256_PRIO);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
 #pragma unroll
           for (int nt = 0; nt < TN; ++nt) {
-            if (G256_LAB == 13) asm volatile("" ::"v"(fb[nt]), "v"(fa[mt]));      // lab: LDS-DMA + fragment reads, no MFMA
-            else mma<bf16_t>(acc[mt][nt], fb[nt], fa[mt]);  // rows = n, cols = m
+            mma<bf16_t>(acc[mt][nt], fb[nt], fa[mt]);  // rows = n, cols = m
           }
           // piece k of NP goes out after MFMA row floor((k + 1) TM / NP) - 1
           const int np = ks == 0 ? PER : PER_A;
-#ifndef G256_BFRONT
-#define G256_BFRONT 0
-#endif
-          const bool front = (G256_BFRONT == 1 && ks == 0) || G256_BFRONT == 2;
-          const int k_here = front ? (mt < np ? 1 : 0) : ((mt + 1) * np) / TM - (mt * np) / TM;  // 0 or 1 pieces after this row
-          const int k_idx = front ? mt : (mt * np) / TM;
-          if (DMA_ON && k_here > 0) {
+          const int k_here = ((mt + 1) * np) / TM - (mt * np) / TM;  // 0 or 1 pieces after this row
+          const int k_idx = (mt * np) / TM;
+          if (k_here > 0) {
             __builtin_amdgcn_sched_barrier(0);
             if (ks == 0) issue_b_piece(iu, dst_b, k_idx);
             else issue_a_piece(iu, dst_a, k_idx);
@@ -505,14 +340,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (DMA_ON && ks == 0) next_unit();
-      }
-      if (DMA_ON && G256_LAB == 10) {  // lab: DMA only
-#pragma unroll
-        for (int j = 0; j < PER; ++j) issue_b_piece(iu, dst_b, j);
-        next_unit();
-#pragma unroll
-        for (int j = 0; j < PER_A; ++j) issue_a_piece(iu, dst_a, j);
+        if (ks == 0) next_unit();
       }
       slot = slot + 2 >= NSLOT ? slot + 2 - NSLOT : slot + 2;
     };
@@ -522,7 +350,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
     unit(0);
     for (int u = 1; u < nu; ++u) unit(u);
     first = false;
-    if ((G256_LAB & 8)) ts1 = __builtin_amdgcn_s_memtime();
     // this wave's pieces of the next three half-units have landed; every wave is past its reads of the last unit,
     // whose A slot ( = `fill`, refilled at the next barrier) is the epilogue's staging block
     // (the drain is written with the builtin, not inline asm, so that the compiler's own wait-count bookkeeping
@@ -534,30 +361,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
     // (the K loop owns the whole register file) and every reload is a memory round trip - recompute them per tile
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
-    if ((G256_LAB & 8)) ts2 = __builtin_amdgcn_s_memtime();
-    if (G256_LAB == 6) {  // no epilogue, accumulators kept alive
-      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) sum += acc[a][b];
-      if (sum[0] + sum[1] + sum[2] + sum[3] == 12345.f) *(float*)p.C = sum[0];
-      continue;
-    }
-#ifdef G256_EPI_SOLO  // lab: only workgroup 17 stores its tiles (is the epilogue bound by the chip-wide write burst?)
-    if (blockIdx.x != 17) {
-      GemmParams q = p;
-      q.N = p.alpha == 1.f ? 0 : p.N;
-      epilogue<bf16_t, TM, TN, MODE, ALAY != LAY_CONV>(q, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, bz, lane_e, smem + fill * HALF + w * 4096);
-      continue;
-    }
-#endif
-    if (G256_LAB == 4) {  // full epilogue arithmetic + staging, stores predicated off at run time
-      GemmParams q = p;
-      q.N = p.alpha == 1.f ? 0 : p.N;
-      epilogue<bf16_t, TM, TN, MODE, ALAY != LAY_CONV>(q, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, bz, lane_e, smem + fill * HALF + w * 4096);
-      continue;
-    }
     epilogue<bf16_t, TM, TN, MODE, ALAY != LAY_CONV>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, bz, lane_e, smem + fill * HALF + w * 4096);
     if constexpr (CS) {
       if (p.a_rowsum && (lane_e >> 4) == 0) {  // every tile writes its slice, zeros when it took no K unit
@@ -569,12 +372,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p, int tiles_m,
         }
       }
     }
-#if G256_LAB & 8
-    if (blockIdx.x == 17 && t == 0) {
-      unsigned long long* dbg = g256_dbg + 4 * (r - first_item);
-      dbg[0] = ts0; dbg[1] = ts1; dbg[2] = ts2; dbg[3] = __builtin_amdgcn_s_memtime();
-    }
-#endif
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
@@ -615,28 +412,11 @@ int launch_tm(const GemmParams& p, int batch, int ncu, hipStream_t s) {
       }
     }
   }
-  int* sched = nullptr;
-  if (melgpt_get_dynamic_tiles() && 256 + 2 * grid <= MELGPT_TILE_CELL_INTS)
-    sched = melgpt_tile_cell();  // claimed tiles: this launch's counters + mailboxes (abi.hip); nullptr -> static lists
-  if (!sched) {  // static lists: the ping-pong K loop where it is built (gemm8p.hip), the ring otherwise
-    const int st = launch_gemm8p(p, ALAY, BLAY, MODE, TM, tiles_m, tiles_n, batch, RN, grid, s);
-    if (st != MELGPT_ERR_UNSUPPORTED) return st;
-  }
+  // the ping-pong K loop where it is built (gemm8p.hip), the ring otherwise (the rolled full epilogue, melgpt_set_gemm_pingpong(0))
+  const int st = launch_gemm8p(p, ALAY, BLAY, MODE, TM, tiles_m, tiles_n, batch, RN, grid, s);
+  if (st != MELGPT_ERR_UNSUPPORTED) return st;
   melgpt_count_gemm_loop(0);
-  if (sched) {
-    static bool attr_dyn = false;
-    if (!attr_dyn) {
-      if (hipFuncSetAttribute((const void*)gemm256_kernel<ALAY, BLAY, MODE, TM, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-        return MELGPT_ERR_LAUNCH;
-      attr_dyn = true;
-    }
-    hipLaunchKernelGGL((gemm256_kernel<ALAY, BLAY, MODE, TM, true>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n,
-                       batch, RN, sched);
-  } else {
-    hipLaunchKernelGGL((gemm256_kernel<ALAY, BLAY, MODE, TM, false>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n,
-                       batch, RN, sched);
-  }
+  hipLaunchKernelGGL((gemm256_kernel<ALAY, BLAY, MODE, TM>), dim3(grid), dim3(512), LDS, s, p, tiles_m, tiles_n, batch, RN);
   return melgpt_launch_status();
 }
 

@@ -28,7 +28,7 @@
 //     slots are requested again one phase later); counted waits: phase 2 vmcnt(10) (this K tile's A1: read in phase 3),
 //     phase 3 vmcnt(6) (the next K tile's A0 and B halves: read from phase 4 on)
 // Every wait sits in front of a barrier, and a landed half-tile is read one phase after that barrier at the earliest.
-// P8_ROW_BAL=0 / P8_BNAT_BAL=0 build the unbalanced forms (12 / 4 / 8 / 0 reads, one vmcnt(6) per K tile in phase 4).
+// (The unbalanced forms - 12 / 4 / 8 / 0 reads, one vmcnt(6) per K tile in phase 4 - were removed in round 6: git history.)
 // Also in here: an EDGE variant for K-major operands that end inside a 128-column half-tile (the GPT-VAE XL widths),
 // the convolutions' implicit-im2col A operand (running offsets rebuilt per filter tap), single-round launches (fewer
 // tiles than CUs), the weight gradients' split-K batches with the bias row sums on the A fragments, and a half-height
@@ -68,19 +68,7 @@ __device__ __forceinline__ void dma16(rsrc_t rs, char* lds_wave_base, unsigned v
 }
 
 #define P8_BARRIER() asm volatile("s_barrier" ::: "memory")
-#ifndef P8_ORDER
-#define P8_ORDER 0  // 1: an XCD takes a contiguous run of blocks; 0: every eighth block (the ring kernel's order)
-#endif
-#ifndef P8_ROW_BAL
-#define P8_ROW_BAL 1  // row-major B: fragment reads balanced over the phases (0: the guide's 12 / 4 / 8 / 0 form)
-#endif
-#ifndef P8_BNAT_BAL
-#define P8_BNAT_BAL 1  // K-major B: fragment reads balanced over the phases (0: the 16 / 8 / 8 / 0 form)
-#endif
 
-#ifdef P8_LAB  // lab build only (tools/lab/build_lab_lib.py ... -DP8_LAB): s_memtime stamps of workgroup 17, wave 0
-__device__ unsigned long long p8_dbg[64 * 24];  // per tile: start, K loop done, drained, epilogue done, then one stamp per K tile (<= 20)
-#endif
 
 template <int ALAY, int BLAY, int MODE, int TM, bool EDGE = false, bool NHALF = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, int tiles_n, int batch, int RN, int tail_m0) {
@@ -133,11 +121,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
     int blk, bm, bn;  // block number of this XCD's current item, its block row / column
     int tail;         // 0: in the block lists; 1: at the workgroup's 128-row tile; 2: past it
   };
-  // Which blocks an XCD takes: a CONTIGUOUS run of the row-major block order (P8_ORDER 1: consecutive items of a
-  // workgroup then share their A row panel and only the B panel changes), or every eighth block as gemm256.hip (0).
-  const int blk_first = P8_ORDER ? (int)(((long long)xcd * nblocks) >> 3) : xcd;
-  const int blk_end = P8_ORDER ? (int)(((long long)(xcd + 1) * nblocks) >> 3) : nblocks;
-  constexpr int BSTEP = P8_ORDER ? 1 : 8;
+  // Which blocks an XCD takes: every eighth block of the row-major block order, as gemm256.hip (a contiguous run per XCD -
+  // consecutive items of a workgroup sharing their A row panel - measured no faster, profiles/r04_gemm_lab.md).
+  const int blk_first = xcd;
+  const int blk_end = nblocks;
+  constexpr int BSTEP = 8;
   auto walk_live = [&](const Walk& k) { return k.tail == 0 ? k.blk < blk_end : k.tail == 1; };
   auto walk_tile = [&](const Walk& k, int& bz, int& m0, int& n0, bool& half) -> bool {
     half = false;
@@ -343,15 +331,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
   if (ktail && nu == 1) cut_tail();
   auto advance = [&]() {
     if (++iu == nu) {
-#ifdef P8_LAB
-      const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
-#endif
       iu = 0;
       walk_next(kc);
       plan();
-#ifdef P8_LAB
-      if (blockIdx.x == 17 && t == 0) p8_dbg[64 * 24 - 1] = __builtin_amdgcn_s_memtime() - tp0;
-#endif
     } else {
       if constexpr (CONV) {
         if (++kci == nci) {
@@ -404,9 +386,6 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
       else xb[e] = row_off(wc * 32 + i, 4 * (e & 1) + g);
     }
   }
-#ifdef P8_LAB
-  int lab_tile = 0;
-#endif
 
   Walk km;  // the multiplying cursor's item
   for (walk_first(km); walk_live(km); walk_next(km)) {
@@ -511,7 +490,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
     auto ktile = [&](auto first_c, auto par_c, int u) {
       char* cur = smem + par * BUF;
       char* oth = smem + (BUF - par * BUF);
-      if constexpr (!BNAT && P8_ROW_BAL) {
+      if constexpr (!BNAT) {
         // Row-major B with the reads balanced as for K-major B below (8 / 4 / 8 / 4 instead of 12 / 4 / 8 / 0): phase 4
         // reads the NEXT K tile's B0 subtile out of the other buffer into the registers phase 3 has finished with (the
         // two fragment sets swap roles per K tile: PAR); B0 of the next K tile must then have landed a phase earlier:
@@ -560,42 +539,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         P8_BARRIER();
         mul(first_c, c1{}, c0{}, fbA);
         P8_BARRIER();
-      } else if constexpr (!BNAT) {
-        // phase 1: (A0, B0); B0's reads first - retired before the barrier, its slot is requested again in phase 2
-        ld_b(S_B0, 0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        ld_a(S_A0);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_a(1, oth + S_A1);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MELGPT_WAITN(RD_A)) : "memory");
-        P8_BARRIER();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mul(first_c, c0{}, c0{}, fb0);
-        P8_BARRIER();
-        // phase 2: (A0, B1)
-        ld_b(S_B1, 0, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        advance();
-        issue_b(0, cur + S_B0);
-        P8_BARRIER();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mul(first_c, c0{}, c1{}, fb1);
-        P8_BARRIER();
-        // phase 3: (A1, B1)
-        ld_a(S_A1);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_a(0, cur + S_A0);
-        P8_BARRIER();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mul(first_c, c1{}, c1{}, fb1);
-        P8_BARRIER();
-        // phase 4: (A1, B0); the K tile's counted wait
-        issue_b(1, cur + S_B1);
-        asm volatile("s_waitcnt " MELGPT_VMCNT(6) ::: "memory");
-        P8_BARRIER();
-        mul(first_c, c1{}, c0{}, fb0);
-        P8_BARRIER();
-      } else if constexpr (P8_BNAT_BAL) {
+      } else {
         // K-major B, reads BALANCED over the phases (8 / 8 / 8 / 8 instead of 16 / 8 / 8 / 0 fragment-read instructions
         // with row-major A; `ds_read_b64_tr_b16` moves half the bytes per LDS cycle of ds_read_b128, and phase 1's burst
         // outlasted the partner's 256 MFMA cycles: -7 % cycles per K tile with the burst ablated): phase 4 reads the NEXT
@@ -654,54 +598,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
           if (u == cs_next) cs_next += tiles_n;
         }
         P8_BARRIER();
-      } else {
-        const int bh = wc >> 1 ? S_B1 : S_B0;
-        // phase 1: (A0, sub 0); A0's reads first - retired before the barrier, its slot is requested again in phase 2
-        ld_a(S_A0);
-        __builtin_amdgcn_sched_barrier(0);
-        ld_b(bh, 0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_a(1, oth + S_A1);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MELGPT_WAITN(RD_B)) : "memory");
-        P8_BARRIER();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mul(first_c, c0{}, c0{}, fb0);
-        row_sums(c0{}, u);
-        P8_BARRIER();
-        // phase 2: (A0, sub 1); B's reads retired before the barrier, its slots are requested again in phases 3 and 4
-        ld_b(bh, 2, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        advance();
-        issue_a(0, cur + S_A0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        P8_BARRIER();
-        mul(first_c, c0{}, c1{}, fb1);
-        P8_BARRIER();
-        // phase 3: (A1, sub 1)
-        ld_a(S_A1);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_b(0, cur + S_B0);
-        P8_BARRIER();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mul(first_c, c1{}, c1{}, fb1);
-        row_sums(c1{}, u);
-        P8_BARRIER();
-        // phase 4: (A1, sub 0); the K tile's counted wait
-        issue_b(1, cur + S_B1);
-        asm volatile("s_waitcnt " MELGPT_VMCNT(6) ::: "memory");
-        P8_BARRIER();
-        mul(first_c, c1{}, c0{}, fb0);
-        if constexpr (CS) {
-          if (u == cs_next) cs_next += tiles_n;
-        }
-        P8_BARRIER();
       }
     };
 
-#ifdef P8_LAB
-    const bool stamp = blockIdx.x == 17 && t == 0 && lab_tile < 64;
-    if (stamp) p8_dbg[lab_tile * 24 + 0] = __builtin_amdgcn_s_memtime();
-#endif
     if (wr == 1) P8_BARRIER();  // group 1 runs one barrier behind group 0 inside a tile
     auto flip = [&](int u) {  // the other buffer
       par ^= 1;
@@ -710,13 +609,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         if (ALAY == LAY_KMAJ || e < 2) xa[e] ^= BUF;
         if (BLAY == LAY_KMAJ || e < 2) xb[e] ^= BUF;
       }
-#ifdef P8_LAB
-      if (stamp && u < 20) p8_dbg[lab_tile * 24 + 4 + u] = __builtin_amdgcn_s_memtime();
-#endif
     };
     ktile(std::true_type{}, c0{}, 0);
     flip(0);
-    if constexpr ((BNAT && P8_BNAT_BAL) || (!BNAT && P8_ROW_BAL)) {
+    {
       // (two K tiles per trip: the fragment sets swap roles from one K tile to the next, and a loop whose body picked the
       // role at run time made the register allocator keep both sets alive over the back edge - 70-275 spilled VGPRs)
       int u = 1;
@@ -730,22 +626,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         ktile(std::false_type{}, c1{}, u);
         flip(u);
       }
-    } else {
-      for (int u = 1; u < nu; ++u) {
-        ktile(std::false_type{}, c0{}, u);
-        flip(u);
-      }
     }
     if (wr == 0) P8_BARRIER();  // both groups run the epilogue together
-#ifdef P8_LAB
-    if (stamp) p8_dbg[lab_tile * 24 + 1] = __builtin_amdgcn_s_memtime();
-#endif
     // the next tile's first K tile has landed (phase 4's wait), three half-tiles of its second are in flight: drained
     // here with the builtin (see gemm256.hip) - the epilogue's own loads are counted by the compiler from zero
     __builtin_amdgcn_s_waitcnt(0x0F70);
-#ifdef P8_LAB
-    if (stamp) p8_dbg[lab_tile * 24 + 2] = __builtin_amdgcn_s_memtime();
-#endif
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     {
@@ -776,10 +661,6 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p, int tiles_m, 
         }
       }
     }
-#ifdef P8_LAB
-    if (stamp) p8_dbg[lab_tile * 24 + 3] = __builtin_amdgcn_s_memtime();
-    ++lab_tile;
-#endif
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   MELGPT_CLK_END(clk_gemm8p);
@@ -870,11 +751,6 @@ int launch8p_mode(const GemmParams& p, int mode, int tm, int tiles_m, int tiles_
 
 }  // namespace
 
-#ifdef P8_LAB
-extern "C" int melgpt_p8_dbg(unsigned long long* out) {  // lab build only
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(p8_dbg), sizeof(unsigned long long) * 64 * 24) == hipSuccess ? 0 : -1;
-}
-#endif
 
 // The ping-pong form of one (layout, epilogue mode, tile height) of the persistent GEMM, or MELGPT_ERR_UNSUPPORTED when
 // that combination is served by the ring kernel only (gemm256.hip then launches its own).  MELGPT_GEMM_8P=0 keeps every
@@ -907,7 +783,7 @@ int gemmk::launch_conv8p_n128(const GemmParams& p, hipStream_t s) {
     const char* e = getenv("MELGPT_CONV_N128");
     on = e ? atoi(e) : 1;
   }
-  if (!on || !melgpt_get_gemm_pingpong() || melgpt_get_dynamic_tiles()) return MELGPT_ERR_UNSUPPORTED;
+  if (!on || !melgpt_get_gemm_pingpong()) return MELGPT_ERR_UNSUPPORTED;
   if (p.N > 128 || p.cC % 64 != 0 || p.K < 512 || !p.vec_io || p.out_f32 || p.accumulate || p.C2 || p.drop_scale != 0.f ||
       p.act != MELGPT_ACT_NONE || p.a_bytes >= 0x80000000u || p.b_bytes >= 0x80000000u)
     return MELGPT_ERR_UNSUPPORTED;

@@ -23,12 +23,6 @@
 // fp32 VALU, not HBM: ~30 MFLOP per clip of butterflies and unpacking against ~1.2 MB of traffic.
 #include "common.h"
 
-#ifndef MEL_LAB
-#define MEL_LAB 0  // 1: phase stamps of one wave (tools/lab/mel_lab.hip)
-#endif
-#if MEL_LAB
-__device__ unsigned long long melgpt_mel_dbg[64];
-#endif
 
 namespace {
 
@@ -124,10 +118,6 @@ __global__ __launch_bounds__(64 * MEL_WAVES) void mel_block_kernel(MelParams p) 
   int* sflag = twave + MAXTILES;                    // [0] dense blocks fit
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int ntiles = (p.n_mels + 15) / 16;
-#if MEL_LAB
-  const unsigned long long ts_entry = __builtin_amdgcn_s_memtime();
-  unsigned long long ts_s1 = 0, ts_s2 = 0;
-#endif
 
   // ---- once per workgroup: band table, tile plan, dense filter blocks
   for (int m = t; m < MAXMEL; m += 64 * MEL_WAVES) {
@@ -169,9 +159,6 @@ __global__ __launch_bounds__(64 * MEL_WAVES) void mel_block_kernel(MelParams p) 
   }
   __syncthreads();
   const bool dense = sflag[0] != 0;
-#if MEL_LAB
-  ts_s1 = __builtin_amdgcn_s_memtime();
-#endif
   if (dense)
     for (int r = 0; r < ntiles; ++r) {
       // thread -> (row ml = t / 16, columns kk = t % 16 + 16 i): 16 consecutive lanes read 64 consecutive bytes of a
@@ -193,9 +180,6 @@ __global__ __launch_bounds__(64 * MEL_WAVES) void mel_block_kernel(MelParams p) 
           if (kk0 + 16 * u < stride) dst[kk0 + 16 * u] = v[u];
       }
     }
-#if MEL_LAB
-  ts_s2 = __builtin_amdgcn_s_memtime();
-#endif
   // ---- once per wave: window and twiddles of the samples / butterflies this lane owns
   float win[16];  // window at samples 128 n1 + 2 lane, +1
 #pragma unroll
@@ -248,21 +232,10 @@ __global__ __launch_bounds__(64 * MEL_WAVES) void mel_block_kernel(MelParams p) 
   const float inv_div = 1.0f / p.div;
   auto emit = [&](int clip, int m, int f, float acc) { mel_emit(p, inv_div, clip, m, f, acc); };
 
-#if MEL_LAB
-  unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
-  int dbg_n = 0;
-  const unsigned long long ts_start = __builtin_amdgcn_s_memtime();
-  if (blockIdx.x == 37 && t == 64) {
-    melgpt_mel_dbg[52] = ts_s1 - ts_entry; melgpt_mel_dbg[53] = ts_s2 - ts_s1; melgpt_mel_dbg[54] = ts_start - ts_s2;
-  }
-#endif
   int blk = blockIdx.x, fi = w;
   cplx nxt[8];
   bool nvalid = gather(blk, fi, nxt);
   while (blk < total_blocks) {
-#if MEL_LAB
-    ts[0] = __builtin_amdgcn_s_memtime();
-#endif
     cplx a[8];
 #pragma unroll
     for (int n1 = 0; n1 < 8; ++n1) a[n1] = cplx{nxt[n1].x * win[2 * n1], nxt[n1].y * win[2 * n1 + 1]};
@@ -276,10 +249,6 @@ __global__ __launch_bounds__(64 * MEL_WAVES) void mel_block_kernel(MelParams p) 
     nvalid = gather(nblk, nfi, nxt);
     float* mg = magall + fi * MSTRIDE;
     if (valid) {
-#if MEL_LAB
-      asm volatile("" ::"v"(a[0]), "v"(a[7]));
-      ts[1] = __builtin_amdgcn_s_memtime();
-#endif
       // ---- 512-point FFT of z, n = 64 n1 + n2, k = k1 + 8 (c + 8 d)
       dft8(a);  // over n1; lane = n2
 #pragma unroll
@@ -299,9 +268,6 @@ __global__ __launch_bounds__(64 * MEL_WAVES) void mel_block_kernel(MelParams p) 
 #pragma unroll
       for (int d = 0; d < 8; ++d) zb[(lane >> 3) + 8 * (lane & 7) + 64 * d] = a[d];  // Z[k1 + 8 c + 64 d]
       __builtin_amdgcn_wave_barrier();
-#if MEL_LAB
-      ts[2] = __builtin_amdgcn_s_memtime();
-#endif
       // ---- one-sided spectrum of the real frame: X[k] = E + W_1024^k O,  E = (Z[k] + conj Z[512-k]) / 2,
       //      O = -i (Z[k] - conj Z[512-k]) / 2
 #pragma unroll
@@ -318,20 +284,8 @@ __global__ __launch_bounds__(64 * MEL_WAVES) void mel_block_kernel(MelParams p) 
     } else if (blk < total_blocks) {
       for (int k = lane; k < NBINS; k += 64) mg[k] = 0.f;  // a frame past the clip's end: finite operand for the MFMAs
     }
-#if MEL_LAB
-    ts[3] = __builtin_amdgcn_s_memtime();
-    if (blockIdx.x == 37 && w == 1 && lane == 0 && dbg_n < 7) {
-      unsigned long long* d = melgpt_mel_dbg + 8 * dbg_n++;
-      d[0] = ts[0] - ts_start; d[1] = ts[1] - ts[0]; d[2] = ts[2] - ts[1]; d[3] = ts[3] - ts[2]; d[4] = ts[5];
-      d[5] = ts[0] - ts[4]; d[6] = fi;
-    }
-    ts[4] = ts[3];
-#endif
     if (nblk != blk) {  // this wave's last frame of the block (the same iteration for all four waves)
       __syncthreads();
-#if MEL_LAB
-      const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
-#endif
       const int clip = blk / p.blocks_per_clip, f0 = (blk - clip * p.blocks_per_clip) * FB;
       if (dense) {
         // ---- mel[16 filters][16 frames] = W[16][4 s] x mag^T[4 s][16]: lane l feeds A[row l&15][k l>>4],
@@ -357,10 +311,6 @@ __global__ __launch_bounds__(64 * MEL_WAVES) void mel_block_kernel(MelParams p) 
           }
           for (; sidx < steps; ++sidx) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * sidx], bp[4 * sidx], acc, 0, 0, 0);
           acc += acc1;
-#if MEL_LAB
-          asm volatile("" ::"v"(acc));
-          if (blockIdx.x == 37 && lane == 0) melgpt_mel_dbg[56 + w] = __builtin_amdgcn_s_memtime() - tm0;
-#endif
           const int f = f0 + (lane & 15);
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
@@ -380,10 +330,6 @@ __global__ __launch_bounds__(64 * MEL_WAVES) void mel_block_kernel(MelParams p) 
           emit(clip, m, f, acc);
         }
       }
-#if MEL_LAB
-      ts[5] = __builtin_amdgcn_s_memtime() - tm0;
-      if (blockIdx.x == 37 && lane == 0) melgpt_mel_dbg[60 + w] = ts[5];
-#endif
       __syncthreads();
     }
     blk = nblk;

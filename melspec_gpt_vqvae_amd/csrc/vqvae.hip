@@ -651,7 +651,10 @@ extern "C" int melgpt_groupnorm_fused(const void* x, const float* gamma, const f
   MELGPT_CHECK((mean == nullptr) == (rstd == nullptr), MELGPT_ERR_BAD_ARG);
   MELGPT_CHECK(dtype == MELGPT_F32 || dtype == MELGPT_BF16, MELGPT_ERR_UNSUPPORTED);
   const int es = dtype == MELGPT_F32 ? 4 : 2;
-  if (C % GN_GROUPS != 0 || (C * es) % 128 != 0 || (C / GN_GROUPS) * es < 16 || (C / GN_GROUPS) * es > 64 || B > 65535 ||
+  // a group must be 1, 2 or 4 whole 16-byte pieces (gn_fused_small_kernel: every piece lies inside ONE group): 16, 32 or
+  // 64 bytes - bf16 C = 384 (24-byte groups), 640 / 768 (40 / 48) and f32 C = 160 / 192 (20 / 24) are declined here
+  const int gbytes = C % GN_GROUPS == 0 ? (C / GN_GROUPS) * es : 0;
+  if (C % GN_GROUPS != 0 || (C * es) % 128 != 0 || (gbytes != 16 && gbytes != 32 && gbytes != 64) || B > 65535 ||
       HW > 128 * GNF_NP || ((((uintptr_t)x | (uintptr_t)y) & 15) != 0))
     return MELGPT_ERR_UNSUPPORTED;
   const dim3 grid(C * es / 128, B);

@@ -34,7 +34,7 @@ def pin_rccl_channels(n=None):
     profiles/r05_overlap_lab_*.jsonl; one rank through a real RCCL group, profiles/r05_c_bench_dp.json): the persistent
     GEMM / conv grids own one CU per workgroup and walk static tile lists, so a CU held by an all-reduce kernel costs the
     launch beside it one workgroup's WHOLE list: the backward MLP chain of a Block 0.94-0.96 -> 1.35-1.43 ms while 16 or 32
-    channels are resident (claimed tiles on the ring loop: 1.42-1.46 - no better), but 0.98 -> 1.06 when as many CUs are
+    channels are resident (tiles claimed from a counter on the ring loop, removed in round 6: 1.42-1.46 - no better), but 0.98 -> 1.06 when as many CUs are
     reserved as the collective has channels (and 1.73 when it has twice as many: the count must be KNOWN, hence the pin).
     The reservation is paid all the time, though: the split-K weight gradients lose their exact one-round fit (256 tiles on
     256 CUs -> 10 batches on 240), +5.7 % on the whole step with nothing resident (94.4 -> 99.7 ms), against +35-47 % on the
@@ -209,10 +209,14 @@ class DataParallel:
     trains under DDP, GPT_VAE_train.py:172-174).  All parameters of the tree live in one flat buffer; every Block,
     wherever it sits in the tree, announces the end of its backward and its two gradient slices are all-reduced
     at once while earlier blocks are still in their GEMMs.  finish() is called once per step before the optimizer
-    (whose grad_scale = 1/world folds the averaging in)."""
+    (whose grad_scale = 1/world folds the averaging in).
+
+    Has-gradient verdict: a grad-set mismatch between ranks that first appears at step N > 1 is raised at step N + 1's
+    finish() - by then optimizer step N has run on diverged replicas.  DRAIN THE VERDICT BEFORE SAVING: call `check()`
+    (or `detach()`) before writing a checkpoint or after the last step of a loop; both wait for and raise the last one."""
 
     def __init__(self, module, group=None, overlap=True, max_bucket_elems: int = 64 << 20, reserve_cus=None,
-                 dynamic_tiles=None, grad_dtype=None):
+                 grad_dtype=None):
         from . import _ffi
         from .flat import ensure_flat
 
@@ -230,24 +234,18 @@ class DataParallel:
         self.world = self.ex.world
         self.overlap = bool(overlap)
         # The persistent GEMM / conv kernels own one CU per workgroup for a whole launch; an RCCL kernel that holds a CU
-        # when such a launch starts leaves one workgroup waiting for another one's ENTIRE static tile list.  Two switches
-        # act while an (overlapped) all-reduce can be in flight - from the first Block's early launch to finish() - and
-        # both are OFF by default since round 5 (measurements: pin_rccl_channels' docstring):
-        #  * `reserve_cus` (MELGPT_RESERVE_CUS; set by pin_rccl_channels together with RCCL's channel bound): the
-        #    persistent grids leave that many CUs to RCCL - the remedy that works (1.35-1.43 -> 1.06 ms per backward MLP
-        #    chain beside a collective) when the collective's channel count is known, at +5.7 % on the step when it is idle;
-        #  * `dynamic_tiles` (MELGPT_DP_DYNAMIC_TILES=1; csrc/gemm256.hip: whoever has a CU takes the next tile): claimed
-        #    tiles force the RING K loop, which beside a collective is no faster (1.42-1.46) than the ping-pong loop on
-        #    static lists (1.35-1.43) and slower alone (0.96-1.07 against 0.94-0.96) - so the data-parallel backward now
-        #    runs the same ping-pong GEMM as a single GPU (`gemm_launches_per_step` in the bench line says which loop ran).
+        # when such a launch starts leaves one workgroup waiting for another one's ENTIRE static tile list.  One switch acts
+        # while an (overlapped) all-reduce can be in flight - from the first Block's early launch to finish() - and it is
+        # OFF by default (measurements: pin_rccl_channels' docstring): `reserve_cus` (MELGPT_RESERVE_CUS; set by
+        # pin_rccl_channels together with RCCL's channel bound): the persistent grids leave that many CUs to RCCL - the
+        # remedy that works (1.35-1.43 -> 1.06 ms per backward MLP chain beside a collective) when the collective's channel
+        # count is known, at +5.7 % on the step when it is idle.  (Tiles claimed from a run-time counter - rounds 2-5 - ran on
+        # the ring loop and were the worst cell of every column of profiles/r05_dp_lab.md: removed in round 6.)
         # The forward pass, the head's and the last Block's backward and the optimizer run on the whole chip.
         active = self.ex.active
         if reserve_cus is None:
             reserve_cus = int(os.environ.get("MELGPT_RESERVE_CUS", "0"))
-        if dynamic_tiles is None:
-            dynamic_tiles = int(os.environ.get("MELGPT_DP_DYNAMIC_TILES", "0")) != 0
         self.reserve_cus = int(reserve_cus)
-        self.dynamic_tiles = bool(dynamic_tiles)
         self._reserved = False
         self._on_gpu = self.fp.device.type == "cuda"
         if self._on_gpu:
@@ -265,6 +263,14 @@ class DataParallel:
         self._mask_host = None
         self._segs = {}
         self.blocks = [m for m in module.modules() if hasattr(m, "_layer_index") and hasattr(m, "attn")]
+        if (active and self._on_gpu and self.world > 1 and self.reserve_cus == 0 and pinned_rccl_channels() == 0
+                and (not dist.is_initialized() or dist.get_rank() == 0)):
+            import sys
+
+            print("melgpt dp: RCCL shares the chip with the persistent GEMM / conv grids and no CUs are reserved for it "
+                  "(measured beside a stand-in collective: backward GEMMs 0.94 -> 1.35-1.43 ms while it is resident). "
+                  "To pair a pinned channel count with as many reserved CUs: MELGPT_RCCL_CHANNELS=16 before init_process_group "
+                  "(dp.pin_rccl_channels); costs +5.7 % on the step when RCCL is idle, so it is not the default.", file=sys.stderr)
         if active and self.overlap:
             for blk in self.blocks:
                 self._segs[id(blk)] = block_segments(self.fp, blk)
@@ -272,13 +278,10 @@ class DataParallel:
 
     def _reserve(self, on):
         """enter / leave the part of a step in which RCCL kernels may share the chip with the compute kernels"""
-        if self._on_gpu and on != self._reserved and (self.reserve_cus > 0 or self.dynamic_tiles):
+        if self._on_gpu and on != self._reserved and self.reserve_cus > 0:
             from . import _ffi
 
-            if self.reserve_cus > 0:
-                _ffi.call("melgpt_set_reserved_cus", self.reserve_cus if on else 0)
-            if self.dynamic_tiles:
-                _ffi.call("melgpt_set_dynamic_tiles", 1 if on else 0)
+            _ffi.call("melgpt_set_reserved_cus", self.reserve_cus if on else 0)
             self._reserved = on
 
     def _on_block_done(self, blk):
@@ -304,30 +307,39 @@ class DataParallel:
         if ev is not None:
             ev.synchronize()
         self._mask_flag = None
-        if int(host.item()) != 0:
+        # the verdict is taken on the HOST from the all-reduced mask (a few hundred floats): no device kernel of torch's
+        if bool(((host != 0) & (host != float(self.world))).any()):
             raise RuntimeError("data-parallel ranks disagree on which parameters received a gradient this step "
                                "(a parameter with .grad None on some ranks only): the replicas would diverge - "
                                "make the unused branch the same on every rank")
 
     def _check_grad_sets(self):
-        """all-reduce the has-gradient bitmask of the flat store's parameters; see __init__."""
-        if self.world <= 1:
+        """all-reduce the has-gradient bitmask of the flat store's parameters; see __init__.  On the GPU the step costs
+        two small copies (pinned host -> device, device -> pinned host) around the all-reduce and NO torch kernel: the mask
+        is written and compared on the host (tests/test_step_kernels_gpu.py runs the census through a 1-rank DataParallel
+        with the exchange forced)."""
+        if not self.ex.active:
             return
         self._raise_if_flagged()        # the previous step's verdict, before its slot is reused
+        n = len(self.fp.params)
         has = torch.tensor([0.0 if p.grad is None else 1.0 for p in self.fp.params], dtype=torch.float32)
-        has = has.to(self.fp.device, non_blocking=True)
-        dist.all_reduce(has, op=dist.ReduceOp.SUM, group=self.ex.group)
-        bad = ((has != 0) & (has != float(self.world))).any().to(torch.int32).reshape(1)
         if self._on_gpu:
-            if self._mask_host is None:
-                self._mask_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]   # (allocated once)
-            host = self._mask_host[self._mask_steps & 1]
-            host.copy_(bad, non_blocking=True)
+            if self._mask_host is None:     # (allocated once: two slots, the previous step's verdict is read before reuse)
+                self._mask_host = [(torch.zeros(n, dtype=torch.float32).pin_memory(), torch.zeros(n, dtype=torch.float32).pin_memory())
+                                   for _ in range(2)]
+                self._mask_dev = [torch.empty(n, dtype=torch.float32, device=self.fp.device) for _ in range(2)]
+            src, dst = self._mask_host[self._mask_steps & 1]
+            dev = self._mask_dev[self._mask_steps & 1]
+            src.copy_(has)
+            dev.copy_(src, non_blocking=True)
+            dist.all_reduce(dev, op=dist.ReduceOp.SUM, group=self.ex.group)
+            dst.copy_(dev, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            self._mask_flag = (host, ev)
+            self._mask_flag = (dst, ev)
         else:
-            self._mask_flag = (bad.clone(), None)
+            dist.all_reduce(has, op=dist.ReduceOp.SUM, group=self.ex.group)
+            self._mask_flag = (has, None)
         self._mask_steps += 1
         if self._mask_steps == 1 or not self._on_gpu:
             self._raise_if_flagged()
@@ -335,9 +347,13 @@ class DataParallel:
     def describe(self):
         """what a bench line needs to explain a scaling record: the exchange's size and the two persistent-kernel switches"""
         return {"exchange_bytes": int(self.ex.bytes_per_step), "exchange_dtype": str(self.ex.wire_dtype or torch.float32)[6:],
-                "dp_tiles": "claimed" if self.dynamic_tiles else "static", "reserved_cus": int(self.reserve_cus),
+                "dp_tiles": "static", "reserved_cus": int(self.reserve_cus),
                 "rccl_channels_pinned": pinned_rccl_channels(),
                 "overlap": bool(self.overlap), "backend": dist.get_backend(self.ex.group) if dist.is_initialized() else None}
+
+    def check(self):
+        """wait for and raise the last step's has-gradient verdict (call before saving a checkpoint / after the last step)"""
+        self._raise_if_flagged()
 
     def detach(self):
         self._raise_if_flagged()

@@ -19,6 +19,18 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []  # (start_event, end_event, flops, tag)
+        self.aux = []      # HBM-bound launches timed beside the family: (start_event, end_event, bytes, flops, tag)
+
+    def aux_by_tag(self):
+        """{tag: (launches, total_ms, algorithmic bytes, flops)} of the launches recorded with `_timed_aux`."""
+        agg = {}
+        for s, e, nbytes, f, tag in self.aux:
+            a = agg.setdefault(tag, [0, 0.0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += s.elapsed_time(e)
+            a[2] += nbytes
+            a[3] += f
+        return {t: tuple(v) for t, v in agg.items()}
 
     def summary(self):
         tot_ms = sum(s.elapsed_time(e) for s, e, _, _ in self.records)
@@ -58,6 +70,27 @@ class _timed:
         if TIMER is not None and self.flops is not None:
             self.e.record()
             TIMER.records.append((self.s, self.e, self.flops, self.tag))
+        return False
+
+
+class _timed_aux:
+    """the same two event records around a launch that is NOT of the GEMM family (attention): its algorithmic HBM
+    bytes and FLOPs go to KernelTimer.aux, never into the family's sums"""
+
+    def __init__(self, nbytes, flops, tag):
+        self.nbytes, self.flops, self.tag = nbytes, flops, tag
+
+    def __enter__(self):
+        if TIMER is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if TIMER is not None and a[0] is None:
+            self.e.record()
+            TIMER.aux.append((self.s, self.e, self.nbytes, self.flops, self.tag))
         return False
 
 
@@ -437,8 +470,13 @@ def attn_fwd(q, k, v, n_head, *, B, T, n_unmasked=0, drop_p=0.0, seed=0, stream_
     out = torch.empty(M, C, dtype=q.dtype, device=q.device)
     lse = torch.empty(B, n_head, T, dtype=torch.float32, device=q.device)
     att = torch.empty(B, n_head, T, T, dtype=torch.float32, device=q.device) if want_att else None
-    call("melgpt_attn_fwd", ptr(q), ptr(k), ptr(v), q.stride(0), ptr(out), C, ptr(lse), ptr(att), B, n_head, T, 64,
-         int(n_unmasked), float(drop_p), int(seed), int(stream_id), dtype_code(q.dtype), stream())
+    es = q.element_size()
+    # algorithmic bytes: q, k, v read once, y written once, one f32 log-sum-exp per (head, row) [+ the map when asked for];
+    # FLOPs on the full T x T square (4 T^2 C per sequence and layer, no causal discount)
+    with _timed_aux(4.0 * M * C * es + 4.0 * B * n_head * T * (1 + (T if want_att else 0)), 4.0 * B * T * T * C,
+                    f"attn fwd {B}x{n_head}x{T}" + (" full" if n_unmasked >= T else "") + (" +att" if want_att else "")):
+        call("melgpt_attn_fwd", ptr(q), ptr(k), ptr(v), q.stride(0), ptr(out), C, ptr(lse), ptr(att), B, n_head, T, 64,
+             int(n_unmasked), float(drop_p), int(seed), int(stream_id), dtype_code(q.dtype), stream())
     return out, lse, att
 
 
@@ -453,34 +491,6 @@ def attn_decode(qkv, kcache, vcache, n_head, pos, att_row=None, pos_dev=None, ou
         out = torch.empty(B, C, dtype=qkv.dtype, device=qkv.device)
     call("melgpt_attn_decode", ptr(qkv), qkv.stride(0), ptr(kcache), ptr(vcache), B, n_head, 64, kcache.shape[1], int(pos),
          ptr(pos_dev), ptr(out), ptr(att_row), dtype_code(qkv.dtype), stream())
-    return out
-
-
-# OFF by default: built as the review proposed (one workgroup per (head, sequence)) and MEASURED SLOWER - 0.93 against
-# 0.58 ms per token at one sequence (profiles/r05_decode_lab.md): 16 workgroups cannot pull a layer's 6.3 MB of qkv weights
-# at more than ~0.4 TB/s (per-CU memory-level parallelism), the weight-streaming GEMV uses all 256 CUs.  Kept as a tested,
-# bit-identical alternative behind the switch.
-QKV_ATTN_FUSED = os.environ.get("MELGPT_DECODE_QKV_ATTN", "0") == "1"
-
-
-def qkv_attn_decode(x, w_qkv, b_qkv, ln, kcache, vcache, n_head, pos, att_row=None, pos_dev=None, force=False):
-    """ln1 -> qkv projection -> KV-cached attention step for 1 .. 4 sequences in ONE launch (melgpt_qkv_attn_decode; the
-    bits of linear_rows(..., ln=...) + attn_decode).  x (B, C), w_qkv (3C, C) rows [key | query | value], caches
-    (B, Tmax, C).  Returns None - nothing launched - where the two-launch path has to serve (the switch is off and not
-    `force`, f32 lane, B > 4, ...)."""
-    B, C = x.shape
-    if not (QKV_ATTN_FUSED or force) or x.dtype != _ffi.HALF_DTYPE or B > 4 or C != 64 * n_head or C > 1536 or x.stride(1) != 1:
-        return None
-    assert w_qkv.shape == (3 * C, C) and w_qkv.stride(1) == 1 and w_qkv.dtype == x.dtype
-    assert kcache.shape == vcache.shape and kcache.shape[0] == B and kcache.shape[2] == C and kcache.is_contiguous()
-    g, b, eps = ln
-    out = torch.empty(B, C, dtype=x.dtype, device=x.device)
-    code = _ffi.lib().melgpt_qkv_attn_decode(ptr(x), x.stride(0), ptr(w_qkv), w_qkv.stride(0), ptr(b_qkv), ptr(g), ptr(b),
-                                            float(eps), ptr(kcache), ptr(vcache), B, n_head, 64, kcache.shape[1], int(pos),
-                                            ptr(pos_dev), ptr(out), ptr(att_row), dtype_code(x.dtype), stream())
-    if code == _ffi.ERR_UNSUPPORTED:
-        return None
-    _ffi.check(code, "melgpt_qkv_attn_decode")
     return out
 
 
@@ -608,9 +618,14 @@ def attn_bwd(q, k, v, out, dout, lse, n_head, *, B, T, dqkv=None, n_unmasked=0, 
     dq, dk, dv = dqkv
     assert dq.stride(0) == dk.stride(0) == dv.stride(0)
     delta = torch.empty(B, n_head, T, dtype=torch.float32, device=q.device)
-    call("melgpt_attn_bwd", ptr(q), ptr(k), ptr(v), q.stride(0), ptr(out), ptr(dout), C, ptr(lse), ptr(delta), ptr(dq),
-         ptr(dk), ptr(dv), dq.stride(0), B, n_head, T, 64, int(n_unmasked), float(drop_p), int(seed), int(stream_id),
-         dtype_code(q.dtype), stream())
+    es = q.element_size()
+    # algorithmic bytes: q, k, v, y, dy read once, dq, dk, dv written once, lse read + delta written and read;
+    # FLOPs by BASELINE.md 3's convention forward : backward = 1 : 2 (the kernel evaluates five products - S, dP, dV, dK, dQ)
+    with _timed_aux(8.0 * M * C * es + 12.0 * B * n_head * T, 8.0 * B * T * T * C,
+                    f"attn bwd {B}x{n_head}x{T}" + (" full" if n_unmasked >= T else "")):
+        call("melgpt_attn_bwd", ptr(q), ptr(k), ptr(v), q.stride(0), ptr(out), ptr(dout), C, ptr(lse), ptr(delta), ptr(dq),
+             ptr(dk), ptr(dv), dq.stride(0), B, n_head, T, 64, int(n_unmasked), float(drop_p), int(seed), int(stream_id),
+             dtype_code(q.dtype), stream())
     return dq, dk, dv
 
 

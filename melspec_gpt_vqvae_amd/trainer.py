@@ -159,6 +159,8 @@ class Fit:
         return os.path.join(getattr(a, "log_root", "lightning_logs"), f"{a.experiment}-{a.dataset}", "checkpoints")
 
     def save(self, name, epoch):
+        if self.dp is not None:
+            self.dp.check()      # every rank: the last step's has-gradient verdict is drained BEFORE a checkpoint is written
         if self.rank != 0:
             return None
         d = self.checkpoint_dir()

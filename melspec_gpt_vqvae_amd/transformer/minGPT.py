@@ -597,13 +597,9 @@ class GPT(nn.Module):
             a, m = blk.attn, blk.mlp
             if want_att and li == last:
                 att_row = torch.zeros(B, a.n_head, self.block_size, dtype=torch.float32, device=x.device)
-            # 1 .. 4 sequences, 16-bit lane: projection and attention step are per head - one launch (same bits)
-            y = ops.qkv_attn_decode(x, W.w_qkv, W.b_qkv, (blk.ln1.weight, blk.ln1.bias, blk.ln1.eps), cache["k"][li],
-                                    cache["v"][li], a.n_head, pos, att_row=att_row if li == last else None, pos_dev=pos_dev)
-            if y is None:
-                qkv = ops.linear_rows(x, W.w_qkv, bias=W.b_qkv, ln=(blk.ln1.weight, blk.ln1.bias, blk.ln1.eps))
-                y = ops.attn_decode(qkv, cache["k"][li], cache["v"][li], a.n_head, pos,
-                                    att_row=att_row if li == last else None, pos_dev=pos_dev)
+            qkv = ops.linear_rows(x, W.w_qkv, bias=W.b_qkv, ln=(blk.ln1.weight, blk.ln1.bias, blk.ln1.eps))
+            y = ops.attn_decode(qkv, cache["k"][li], cache["v"][li], a.n_head, pos,
+                                att_row=att_row if li == last else None, pos_dev=pos_dev)
             x1 = ops.linear_rows(y, W.w_proj, bias=a.proj.bias, residual=x)
             act = ops.linear_rows(x1, W.w_fc1, bias=m[0].bias, act=ops.ACT_GELU,
                                   ln=(blk.ln2.weight, blk.ln2.bias, blk.ln2.eps))

@@ -2,9 +2,11 @@
 
 A plain PyTorch-CPU / numpy / C restatement (fp32) of the reference algorithm
 (karchkha/MelSpec_GPT_VQVAE).  Every function cites the reference file:line it follows.
-Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may
-import or execute anything in this directory, and only as the checker - never as the
-thing measured or shipped.  The product package (`melspec_gpt_vqvae_amd/`) must never
+Only `tests/`, `__graft_entry__.smoke()` and the baseline legs of `bench.py` (`cpu_baseline`: these
+functions on the host cores; `torch_gpu_baseline`: the same functions on `cuda` through stock
+PyTorch-ROCm, in a child process - what a user of the reference gets on the same box) may
+import or execute anything in this directory, and only as the checker / the baseline beside the
+measurement - never as the thing measured or shipped.  The product package (`melspec_gpt_vqvae_amd/`) must never
 import it; `tests/test_layout.py::test_product_never_imports_oracle` enforces that.
 
 Pinning status

@@ -26,9 +26,9 @@ def as_torch_sd(sd, requires_grad=False):
     return out
 
 
-def attention_mask(T, n_unmasked=0):
+def attention_mask(T, n_unmasked=0, device=None):
     """minGPT.py:65-69 - lower-triangular, with a fully visible n_unmasked x n_unmasked corner."""
-    m = torch.tril(torch.ones(T, T))
+    m = torch.tril(torch.ones(T, T, device=device))
     m[:n_unmasked, :n_unmasked] = 1
     return m
 
@@ -46,7 +46,7 @@ def self_attention(sd, prefix, x, n_head, n_unmasked=0, attn_pdrop=0.0, resid_pd
 
     k, q, v = heads(lin("key", x)), heads(lin("query", x)), heads(lin("value", x))
     att = (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(hs))
-    att = att.masked_fill(attention_mask(T, n_unmasked)[None, None] == 0, float("-inf"))
+    att = att.masked_fill(attention_mask(T, n_unmasked, x.device)[None, None] == 0, float("-inf"))
     att = F.softmax(att, dim=-1)
     y = F.dropout(att, attn_pdrop, train) @ v
     y = y.transpose(1, 2).contiguous().view(B, T, C)

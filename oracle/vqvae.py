@@ -28,7 +28,7 @@ def vq_forward(z, emb, commitment_cost=0.25):
     x = z.permute(0, 2, 3, 1).contiguous()
     flat = x.view(-1, emb.shape[1])
     idx = torch.argmin(vq_distances(flat, emb), dim=1).unsqueeze(1)
-    enc = torch.zeros(idx.shape[0], emb.shape[0])
+    enc = torch.zeros(idx.shape[0], emb.shape[0], device=idx.device)
     enc.scatter_(1, idx, 1)
     q = torch.matmul(enc, emb).view(x.shape)
     loss = F.mse_loss(q, x.detach()) + commitment_cost * F.mse_loss(q.detach(), x)

@@ -31,17 +31,15 @@ def main():
     model, batch, loss_fn = dp_models.build(which, "cuda:0")
     from melspec_gpt_vqvae_amd import _ffi
 
-    # the window in which RCCL kernels may share the chip (claimed tiles + reserved CUs on): claimed tiles are what an
-    # RCCL run gets by default (checked below); asked for explicitly when this rendezvous is gloo
+    # the window in which RCCL kernels may share the chip (reserved CUs on): nothing is reserved by default over RCCL
+    # (checked below); asked for explicitly when this rendezvous is gloo
     if backend == "nccl":
         dp = DataParallel(model)      # no reserved CUs (no channel pin in this child): they change the weight gradients' split-K factor, hence the bits
-        claimed = os.environ.get("MELGPT_DP_DYNAMIC_TILES") == "1"
-        assert dp.ex.active and dp.dynamic_tiles == claimed and dp.reserve_cus == 0, \
-            "over RCCL the exchange is live; static lists (the ping-pong GEMM) are the default, claimed tiles the switch"
+        assert dp.ex.active and dp.reserve_cus == 0, "over RCCL the exchange is live on the whole chip by default"
     else:
-        dp = DataParallel(model, dynamic_tiles=True, reserve_cus=8)
+        dp = DataParallel(model, reserve_cus=8)
     L = _ffi.lib()
-    window = [(L.melgpt_get_dynamic_tiles(), L.melgpt_get_reserved_cus())]        # before the backward pass: (0, 0)
+    window = [L.melgpt_get_reserved_cus()]        # before the backward pass: 0
     assert dp.world == world and len(dp.blocks) == (4 if which == "vae" else 2)
     n = next(iter(batch.values())).shape[0] // world
     local = {k: v[rank * n:(rank + 1) * n] for k, v in batch.items()}
@@ -77,9 +75,9 @@ def main():
     loss = loss_fn(model, local)
     loss.backward()
     launched_early = len(dp.ex._done)
-    window.append((L.melgpt_get_dynamic_tiles(), L.melgpt_get_reserved_cus()))    # after the first hook: (1, 8)
+    window.append(L.melgpt_get_reserved_cus())    # after the first hook: 8 (gloo rig) / 0 (RCCL default)
     dp.finish()
-    window.append((L.melgpt_get_dynamic_tiles(), L.melgpt_get_reserved_cus()))    # after finish(): (0, 0)
+    window.append(L.melgpt_get_reserved_cus())    # after finish(): 0
     torch.cuda.synchronize()
     m = dp.reduce_metrics(loss, float(rank), 3.0)
     torch.save({"grad": dp.fp.grad.cpu(), "hook_calls": dp.hook_calls, "launched_early": launched_early,

@@ -4,7 +4,7 @@ fn() -> list of output tensors.  Seeded inputs, so the parent (production librar
 the same sources, csrc/common.h MELGPT_VMCNT0) see the same operands.
 
 Kernels and why they are here: gemm8p_kernel (csrc/gemm8p.hip: LDS-DMA ordered by ONE counted vmcnt per K tile + raw
-s_barriers), gemm256_kernel (csrc/gemm256.hip: ring of five half-unit slots, counted wait per K unit; with claimed tiles:
+s_barriers), gemm256_kernel (csrc/gemm256.hip: ring of five half-unit slots, counted wait per K unit;
 tickets through a global-memory mailbox), conv3x3_gn_ws_kernel (csrc/conv_fused.hip: staging waves publish LDS counters
 behind counted waits), attn_q_kernel / attn_bwd1_kernel (csrc/attn.hip: LDS work counters, hand-placed waits).
 Reference call sites: transformer/minGPT.py:76-88,100-117 (the Linear layers and attention of a Block),
@@ -53,7 +53,7 @@ def _wgrad(M, N, K, seed=2):
 
 
 def _switched(build, setter, value):
-    """the same form with a library switch held at `value` for every call (melgpt_set_attn_fwd32 / melgpt_set_conv_ws_mfma16)"""
+    """the same form with a library switch held at `value` for every call (melgpt_set_attn_fwd32)"""
     def build2(torch, ops, dev):
         from melspec_gpt_vqvae_amd import _ffi
 
@@ -145,9 +145,6 @@ FORMS = {
     "conv3x3+gn 6x80x848 + residual + output statistics": ("conv_ws", _conv(6, 80, 848, stats_out=True, residual=True, seed=31)),
     "conv3x3+gn 12x40x424 (8x32 tiles)": ("conv_ws", _conv(12, 40, 424, seed=32)),
     "conv3x3+gn 12x40x424 + output statistics": ("conv_ws", _conv(12, 40, 424, stats_out=True, seed=33)),
-    "conv3x3+gn 6x80x848 + residual + output statistics, 32x32x16 multiplying waves":
-        ("conv_ws", _switched(_conv(6, 80, 848, stats_out=True, residual=True, seed=34), "melgpt_set_conv_ws_mfma16", 0)),
-    "conv3x3+gn 12x40x424, 32x32x16 multiplying waves": ("conv_ws", _switched(_conv(12, 40, 424, seed=35), "melgpt_set_conv_ws_mfma16", 0)),
     # ---- attention (forward: the 16-row and the 32-row kernel, each forced; backward in one launch for the causal 16-bit lane)
     "attention forward 32x16x265 dropout 0.5 (16-row kernel)": ("attn", _switched(_attn(32, 16, 265, 0.5), "melgpt_set_attn_fwd32", 0)),
     "attention forward 32x16x265 dropout 0.5 (32-row kernel)": ("attn", _switched(_attn(32, 16, 265, 0.5, seed=50), "melgpt_set_attn_fwd32", 1)),
@@ -156,7 +153,7 @@ FORMS = {
     "attention backward 32x16x265 dropout 0 (single pass)": ("attn", _attn(32, 16, 265, 0.0, bwd=True, seed=53)),
     "attention backward 16x23x265 bidirectional, dropout 0.3": ("attn", _attn(16, 23, 265, 0.3, n_unmasked=265, bwd=True, seed=54)),
 }
-# the ring kernel (claimed tiles force it): the forms the data-parallel window can launch
+# the same forms on the RING K loop (melgpt_set_gemm_pingpong(0): the loop eval-time full epilogues and small-K shapes still take)
 RING_FORMS = ["gemm NT 8192x4096x256 (256-row tiles)", "gemm NN 24576x1024x320 (K-major B, 192-row tiles, ragged K)",
               "wgrad 4096x1024 over 8480 rows (split-K batches + bias row sums)"]
 

@@ -23,11 +23,11 @@ def main():
     for name, (_, build) in race_shapes.FORMS.items():
         fn = build(torch, ops, dev)
         out[name] = [race_shapes.checksum(torch, t) for t in fn()]
-    _ffi.lib().melgpt_set_dynamic_tiles(1)      # claimed tiles: the ring kernel
+    _ffi.lib().melgpt_set_gemm_pingpong(0)      # the ring K loop (csrc/gemm256.hip)
     for name in race_shapes.RING_FORMS:
         fn = race_shapes.FORMS[name][1](torch, ops, dev)
-        out["claimed: " + name] = [race_shapes.checksum(torch, t) for t in fn()]
-    _ffi.lib().melgpt_set_dynamic_tiles(0)
+        out["ring: " + name] = [race_shapes.checksum(torch, t) for t in fn()]
+    _ffi.lib().melgpt_set_gemm_pingpong(1)
     torch.cuda.synchronize()
     with open(sys.argv[1], "w") as f:
         json.dump(out, f)

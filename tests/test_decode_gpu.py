@@ -227,45 +227,3 @@ def test_sampling_with_an_unmasked_prefix_does_not_use_a_stale_kv_cache():
     assert np.array_equal(a.cpu().numpy(), ref.numpy())
 
 
-@pytest.mark.parametrize("B,H,pos", [(1, 16, 0), (1, 16, 1), (1, 16, 100), (1, 16, 264), (3, 16, 37), (4, 16, 265), (2, 23, 9),
-                                     (1, 23, 263), (2, 4, 5), (4, 1, 130)])
-def test_qkv_projection_and_cached_attention_in_one_launch_give_the_bits_of_two(B, H, pos):
-    """(the alternative behind MELGPT_DECODE_QKV_ATTN=1: measured slower, kept bit-identical)
-    melgpt_qkv_attn_decode (1 .. 4 sequences, 16-bit lane: one workgroup per (head, sequence) does ln1 -> its 192 rows of
-    W_qkv -> the attention step on its cache rows) against linear_rows(ln=...) + attn_decode: output, attention row and the
-    appended cache rows bit for bit; cache rows at and beyond `pos` hold NaN (they must never reach a result)."""
-    from melspec_gpt_vqvae_amd import ops
-
-    C, Tmax = 64 * H, 266
-    g = torch.Generator(device=DEV).manual_seed(B * 1000 + H * 10 + pos)
-    rnd = lambda *s, sc=1.0: torch.randn(*s, device=DEV, generator=g) * sc
-    x = rnd(B, C).to(torch.bfloat16)
-    w = rnd(3 * C, C, sc=0.05).to(torch.bfloat16)
-    bias, gamma, beta = rnd(3 * C, sc=0.1), 1.0 + rnd(C, sc=0.2), rnd(C, sc=0.1)
-    kc = torch.full((B, Tmax, C), float("nan"), device=DEV, dtype=torch.bfloat16)
-    vc = torch.full((B, Tmax, C), float("nan"), device=DEV, dtype=torch.bfloat16)
-    # (the caches are head-major inside: fill through the kernels' own view - (B, H, Tmax, 64) - rows 0 .. pos - 1)
-    kc.view(B, H, Tmax, 64)[:, :, :pos] = rnd(B, H, pos, 64).to(torch.bfloat16)
-    vc.view(B, H, Tmax, 64)[:, :, :pos] = rnd(B, H, pos, 64).to(torch.bfloat16)
-    if pos >= Tmax:
-        pytest.skip("position beyond the cache")
-    k1, v1, k2, v2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
-    a1 = torch.zeros(B, H, Tmax, device=DEV)
-    a2 = torch.zeros(B, H, Tmax, device=DEV)
-    qkv = ops.linear_rows(x, w, bias=bias, ln=(gamma, beta, 1e-5))
-    y1 = ops.attn_decode(qkv, k1, v1, H, pos, att_row=a1)
-    y2 = ops.qkv_attn_decode(x, w, bias, (gamma, beta, 1e-5), k2, v2, H, pos, att_row=a2, force=True)
-    assert y2 is not None
-    assert torch.isfinite(y2.float()).all()
-    assert torch.equal(y1, y2)
-    assert torch.equal(a1, a2)
-    assert torch.equal(k1.view(B, H, Tmax, 64)[:, :, :pos + 1], k2.view(B, H, Tmax, 64)[:, :, :pos + 1])
-    assert torch.equal(v1.view(B, H, Tmax, 64)[:, :, :pos + 1], v2.view(B, H, Tmax, 64)[:, :, :pos + 1])
-    # the position on the device (graph-replayed decoding)
-    pd = torch.tensor([pos], dtype=torch.int32, device=DEV)
-    k3, v3 = kc.clone(), vc.clone()
-    y3 = ops.qkv_attn_decode(x, w, bias, (gamma, beta, 1e-5), k3, v3, H, 0, pos_dev=pd, force=True)
-    assert torch.equal(y3, y2)
-    # five sequences: declined
-    assert ops.qkv_attn_decode(x[:1].expand(5, C).contiguous(), w, bias, (gamma, beta, 1e-5), kc[:1].expand(5, Tmax, C).contiguous(),
-                               vc[:1].expand(5, Tmax, C).contiguous(), H, 0, force=True) is None

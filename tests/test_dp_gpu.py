@@ -49,8 +49,8 @@ def test_two_ranks_share_one_gpu_gradients_equal_single_process(which, tmp_path)
     for r in res:
         assert r["names"] == fp.names and r["offsets"] == fp.offsets
         assert r["hook_calls"] == n_blocks and r["launched_early"] == 2 * n_blocks     # two slices per Block, before finish()
-        # claimed tiles / reserved CUs are on exactly while an all-reduce can be in flight (first hook .. finish())
-        assert [tuple(w) for w in r["window"]] == [(0, 0), (1, 8), (0, 0)]
+        # the CU reservation is on exactly while an all-reduce can be in flight (first hook .. finish())
+        assert list(r["window"]) == [0, 8, 0]
         got = r["grad"] / world                                                        # the optimizer's grad_scale
         err = float((got - want).abs().max() / want.abs().max())
         assert err < 1e-6, err
@@ -64,24 +64,19 @@ def test_two_ranks_share_one_gpu_gradients_equal_single_process(which, tmp_path)
         assert torch.load(os.path.join(str(tmp_path), f"rank{rnk}_guard.pt"))["refused"]
 
 
-@pytest.mark.parametrize("claimed", [False, True])
-def test_one_rank_over_a_real_rccl_group_bit_identical_to_no_dp(tmp_path, claimed):
+def test_one_rank_over_a_real_rccl_group_bit_identical_to_no_dp(tmp_path):
     """The `nccl` backend (= RCCL) itself: a child rank initialises a real RCCL process group (size 1 - RCCL does not
     allow two ranks on one device), forces the exchange on (MELGPT_DP_FORCE_EXCHANGE=1) and runs the 16-bit-lane backward of
     a VAS-width model through DataParallel with its RCCL defaults: every Block's two slices are all-reduced on RCCL's
-    stream while the earlier Blocks' GEMMs are still running - on STATIC tile lists (the ping-pong GEMM, the default since
-    round 5: window (0,0) throughout) or, with MELGPT_DP_DYNAMIC_TILES=1, drawing CLAIMED tiles on the ring loop (window
-    (0,0) -> (1,0) -> (0,0)).  The flat gradient must equal the no-DP run of this process bit for bit and the hooks fire
+    stream while the earlier Blocks' GEMMs are still running (the same ping-pong GEMM on static tile lists as a single GPU).
+    The flat gradient must equal the no-DP run of this process bit for bit and the hooks fire
     (no reserved CUs here: a smaller grid changes the weight gradients' split-K factor and with it the summation order)."""
     from melspec_gpt_vqvae_amd.flat import ensure_flat
 
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY="0", DP_BACKEND="nccl", MELGPT_DP_FORCE_EXCHANGE="1")
-    env.pop("MELGPT_DP_DYNAMIC_TILES", None)
     env.pop("NCCL_MAX_NCHANNELS", None)
     env.pop("MELGPT_RESERVE_CUS", None)
-    if claimed:
-        env["MELGPT_DP_DYNAMIC_TILES"] = "1"
     proc = subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), "gptclass_vas16", str(tmp_path)], env=env,
                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     model, batch, loss_fn = dp_models.build("gptclass_vas16", "cuda:0")
@@ -95,7 +90,7 @@ def test_one_rank_over_a_real_rccl_group_bit_identical_to_no_dp(tmp_path, claime
     r = torch.load(os.path.join(str(tmp_path), "rank0.pt"))
     assert r["backend"] == "nccl"
     assert r["hook_calls"] == 2 and r["launched_early"] == 4
-    assert [tuple(w) for w in r["window"]] == [(0, 0), (1 if claimed else 0, 0), (0, 0)]
+    assert list(r["window"]) == [0, 0, 0]
     assert r["names"] == fp.names and r["offsets"] == fp.offsets
     assert float(loss) == r["loss"]
     assert torch.equal(r["grad"], want), float((r["grad"] - want).abs().max())
@@ -116,7 +111,7 @@ def test_bench_self_launches_two_ranks_and_prints_one_self_describing_line():
     around it) starts its two ranks itself (launch.spawn_ranks) before touching the GPU; under MELGPT_BENCH_SHARE_GPU=1
     they share cuda:0 and rendezvous over gloo.  Checked: exit status 0, exactly ONE JSON line (rank 0's), the whole-job
     fields (n_gpus, global_batch = 2 x per-GPU batch, parallelism dp2), the run flagged INVALID_debug_shared_gpu, and the
-    fields a SCALE record needs to explain itself (exchange bytes / format, claimed-tile and reserved-CU switches,
+    fields a SCALE record needs to explain itself (exchange bytes / format, the reserved-CU switch,
     exposed_comm_ms); then the same with the 16-bit wire format."""
     import json
 
@@ -134,7 +129,7 @@ def test_bench_self_launches_two_ranks_and_prints_one_self_describing_line():
         assert abs(o["value"] - 64 / (o["ms_per_step"] * 1e-3)) <= 1e-3 * o["value"]
         assert c["exchange_dtype"] == ("float32" if wire == "f32" else "bfloat16") and c["backend"] == "gloo"
         assert c["exchange_bytes"] % nbytes_per_param == 0 and c["exchange_bytes"] // nbytes_per_param > 25_000_000
-        assert c["dp_tiles"] in ("claimed", "static") and c["reserved_cus"] == 0 and c["overlap"] is True
+        assert c["dp_tiles"] == "static" and c["reserved_cus"] == 0 and c["overlap"] is True
         assert o["exposed_comm_ms"] >= 0.0 and np.isfinite(c["final_loss"])
 
 

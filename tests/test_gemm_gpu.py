@@ -441,11 +441,11 @@ def test_reserved_cus_leave_room_for_rccl_and_do_not_change_results():
     assert torch.equal(ops.gemm(a, b), ref)
 
 
-def test_claimed_tiles_give_the_same_bits_as_static_tile_lists():
-    """melgpt_set_dynamic_tiles(1): the persistent GEMM's workgroups draw every tile from per-launch counters (one per XCD, or one for all; scalar
-    atomics + a global-memory mailbox) instead of walking static lists - what dp.DataParallel turns on when RCCL kernels
-    share the chip with the backward pass.  Same tiles, same arithmetic: results must be bit-identical, launch after
-    launch (the counter cell resets itself), for every operand layout / epilogue family / tile height."""
+def test_ring_loop_gives_the_same_bits_as_the_pingpong_loop_with_and_without_reserved_cus():
+    """melgpt_set_gemm_pingpong(0): the persistent GEMM's ring K loop (csrc/gemm256.hip) behind the same tile lists, operand
+    layouts and epilogues as the ping-pong loop (csrc/gemm8p.hip, the default).  Same tiles, same arithmetic: results must be
+    bit-identical, launch after launch, for every operand layout / epilogue family / tile height - on the whole chip and
+    with 16 CUs reserved (what a data-parallel run with a pinned RCCL channel count does during the backward pass)."""
     from melspec_gpt_vqvae_amd import _ffi, ops
 
     torch.manual_seed(8)
@@ -468,19 +468,19 @@ def test_claimed_tiles_give_the_same_bits_as_static_tile_lists():
         return act, dact, y, g, gw, lg, sq
 
     try:
-        # 16 reserved CUs: 240 workgroups, 30 per XCD queue (the weight gradient's split-K factor follows the workgroup
-        # count, so the static reference is taken at the same reservation)
+        # 16 reserved CUs: 240 workgroups, 30 per XCD (the weight gradient's split-K factor follows the workgroup count, so
+        # the reference is taken at the same reservation)
         for reserve, rounds in ((0, 3), (16, 2)):
             _ffi.call("melgpt_set_reserved_cus", reserve)
-            _ffi.call("melgpt_set_dynamic_tiles", 0)
+            _ffi.call("melgpt_set_gemm_pingpong", 1)
             ref = run()
-            _ffi.call("melgpt_set_dynamic_tiles", 1)
-            assert _ffi.lib().melgpt_get_dynamic_tiles() == 1
+            _ffi.call("melgpt_set_gemm_pingpong", 0)
+            assert _ffi.lib().melgpt_get_gemm_pingpong() == 0
             for _ in range(rounds):
                 for x, y in zip(run(), ref):
                     assert torch.equal(x, y)
     finally:
-        _ffi.call("melgpt_set_dynamic_tiles", 0)
+        _ffi.call("melgpt_set_gemm_pingpong", 1)
         _ffi.call("melgpt_set_reserved_cus", 0)
 
 

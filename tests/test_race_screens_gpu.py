@@ -1,6 +1,6 @@
 """Races as a suite property.  Four kernels of this library order their LDS traffic BY HAND - counted s_waitcnt, raw
 s_barrier phases, LDS / global-memory counters - instead of leaving it to the compiler: the ping-pong GEMM
-(csrc/gemm8p.hip), the ring GEMM with claimed tiles (csrc/gemm256.hip), the wave-specialised fused conv
+(csrc/gemm8p.hip), the ring GEMM (csrc/gemm256.hip), the wave-specialised fused conv
 (csrc/conv_fused.hip) and the attention kernels (csrc/attn.hip).  A wait that is one piece short passes almost every
 launch (round 4: one launch in a few thousand differed, found by a lab screen only).  So, in the driver-run suite:
 
@@ -95,25 +95,25 @@ def test_repeat_screen(name):
 
 
 @pytest.mark.parametrize("name", race_shapes.RING_FORMS)
-def test_repeat_screen_ring_kernel_with_claimed_tiles(name):
-    """claimed tiles (melgpt_set_dynamic_tiles: tickets from per-XCD counters, handed to the other waves through a
-    global-memory mailbox) run on the ring K loop; the same bits as the static lists, launch after launch"""
+def test_repeat_screen_ring_kernel(name):
+    """the ring K loop (melgpt_set_gemm_pingpong(0): five half-unit slots, a counted wait per K unit) gives the bits of the
+    ping-pong loop, launch after launch"""
     from melspec_gpt_vqvae_amd import _ffi, ops
 
     L = _ffi.lib()
     fn = race_shapes.FORMS[name][1](torch, ops, DEV)
     static = [t.clone() for t in fn()]
-    L.melgpt_set_dynamic_tiles(1)
+    L.melgpt_set_gemm_pingpong(0)
     try:
         r0, p0 = _counters()
         res = _arms(name, fn, "ring")
         r1, p1 = _counters()
         L.melgpt_set_reserved_cus(0)
-        claimed = fn()
+        ring = fn()
         assert r1 - r0 >= 2 * N_SCREEN and p1 == p0, (name, r1 - r0, p1 - p0)
-        assert all(torch.equal(a, b) for a, b in zip(claimed, static)), "claimed tiles changed the bits"
+        assert all(torch.equal(a, b) for a, b in zip(ring, static)), "the ring loop changed the bits"
     finally:
-        L.melgpt_set_dynamic_tiles(0)
+        L.melgpt_set_gemm_pingpong(1)
         L.melgpt_set_reserved_cus(0)
     assert all(v == 0 for v in res.values()), f"{name}: launches that differ from the first one: {res}"
 
@@ -137,13 +137,13 @@ def test_production_build_equals_the_full_drain_build_bit_for_bit(tmp_path):
         got = [race_shapes.checksum(torch, t) for t in bld(torch, ops, DEV)()]
         if got != ref[name]:
             diff.append(name)
-    L.melgpt_set_dynamic_tiles(1)
+    L.melgpt_set_gemm_pingpong(0)
     try:
         for name in race_shapes.RING_FORMS:
             got = [race_shapes.checksum(torch, t) for t in race_shapes.FORMS[name][1](torch, ops, DEV)()]
-            if got != ref["claimed: " + name]:
-                diff.append("claimed: " + name)
+            if got != ref["ring: " + name]:
+                diff.append("ring: " + name)
     finally:
-        L.melgpt_set_dynamic_tiles(0)
+        L.melgpt_set_gemm_pingpong(1)
     assert len(ref) == len(race_shapes.FORMS) + len(race_shapes.RING_FORMS)
     assert not diff, f"production build differs from the full-drain build on: {diff}"

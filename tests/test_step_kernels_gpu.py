@@ -33,10 +33,12 @@ def _job(layers=2, batch=16):
     return bench.ClassGPTStep(a, torch.device("cuda", 0), torch.bfloat16, 0, 1)
 
 
-def test_no_framework_kernel_runs_inside_the_training_step():
+def census_of_one_step(job):
+    """-> [(aten operator, shapes)] of every dispatched operator with device work during ONE job.step (after 2 warm-up steps).
+    Allowed beside metadata: `copy_` between the host and the device (a memcpy on the copy engine, e.g. the data-parallel
+    has-gradient mask's two pinned copies) and c10d's collectives (the RCCL kernel itself)."""
     from torch.utils._python_dispatch import TorchDispatchMode
 
-    job = _job()
     for _ in range(2):                       # warm-up: lazily built caches (packed weights, codebook image, graphs)
         job.step(time.perf_counter)
     torch.cuda.synchronize()
@@ -47,6 +49,11 @@ def test_no_framework_kernel_runs_inside_the_training_step():
         def __torch_dispatch__(self, func, types, args=(), kwargs=None):
             out = func(*args, **(kwargs or {}))
             name = func.overloadpacket.__name__
+            if name in ("allreduce_", "broadcast_", "barrier"):
+                return out
+            if name == "copy_" and isinstance(args[0], torch.Tensor) and isinstance(args[1], torch.Tensor) and \
+                    args[0].is_cuda != args[1].is_cuda:
+                return out
             if name not in _META:
                 outs = out if isinstance(out, (tuple, list)) else (out,)
                 touts = [o for o in outs if isinstance(o, torch.Tensor)]
@@ -68,7 +75,34 @@ def test_no_framework_kernel_runs_inside_the_training_step():
         loss, _ = job.step(time.perf_counter)
     torch.cuda.synchronize()
     assert torch.isfinite(loss.detach()).all()
+    return seen
+
+
+def test_no_framework_kernel_runs_inside_the_training_step():
+    seen = census_of_one_step(_job())
     assert not seen, f"aten operators with device work inside ClassGPTStep.step: {seen[:20]} ({len(seen)} in all)"
+
+
+def test_no_framework_kernel_runs_inside_the_step_under_data_parallel():
+    """the same census with the step wrapped in dp.DataParallel over a REAL RCCL group of one rank, exchange forced
+    (MELGPT_BENCH_FORCE_DP=1: every Block's early all-reduce, the has-gradient mask's all-reduce, finish()): in a child
+    process, because a process group is process state.  The mask is written and judged on the host - two pinned copies
+    around its all-reduce, no torch kernel."""
+    import json
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("NCCL_MAX_NCHANNELS", "MELGPT_RESERVE_CUS")}
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", MELGPT_BENCH_FORCE_DP="1", MELGPT_CENSUS_CHILD="1")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["dp"] and res["exchange_active"] and res["hook_calls"] >= 2 * 3, res
+    assert not res["seen"], f"aten operators with device work inside the data-parallel step: {res['seen'][:20]}"
 
 
 def test_device_trace_of_a_step_names_only_this_librarys_kernels():
@@ -91,3 +125,20 @@ def test_device_trace_of_a_step_names_only_this_librarys_kernels():
                                                                "MIOpen", "hipblas", "ck::", "triton"))})
     assert not foreign, f"framework / runtime / vendor-library kernels inside the step: {foreign}"
     assert any("gemm8p_kernel" in n or "gemm256_kernel" in n for n in names), names[:10]
+
+
+if __name__ == "__main__" and os.environ.get("MELGPT_CENSUS_CHILD") == "1":
+    import json
+
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    job = _job()
+    assert job.dp is not None
+    seen = census_of_one_step(job)
+    job.dp.check()
+    print(json.dumps({"dp": True, "exchange_active": bool(job.dp.ex.active), "hook_calls": job.dp.hook_calls,
+                      "seen": [[n, [list(x) for x in sh]] for n, sh in seen]}), flush=True)
+    dist.destroy_process_group()

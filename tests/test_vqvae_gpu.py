@@ -84,6 +84,33 @@ def test_groupnorm_in_one_launch_for_small_images(dt, C, HW):
                                     dtype_code(xb.dtype), stream()) == _ffi.ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("dt,C", [("bf16", 384), ("bf16", 640), ("bf16", 768), ("f32", 160), ("f32", 192)])
+def test_groupnorm_fused_declines_groups_that_straddle_16_byte_pieces(dt, C):
+    """Group sizes that are not 1, 2 or 4 whole 16-byte pieces (bf16 C = 384: 24-byte groups; 640 / 768: 40 / 48; f32
+    C = 160 / 192: 20 / 24) pass the row-width test (C * es multiple of 128) but a piece would straddle two groups: the one-launch
+    kernel must decline them with nothing launched, and ops.groupnorm must still be right on them (three-kernel path)."""
+    from melspec_gpt_vqvae_amd import _ffi, ops
+    from melspec_gpt_vqvae_amd.ops import ptr, dtype_code, stream
+
+    B, HW = 2, (5, 53)
+    x = t(synth.normal(31, (B, HW[0], HW[1], C), 1.5, 0.7)).to(DT[dt]).to(DEV)
+    gm, bt = t(synth.normal(32, (C,), 0.1, 1.0)).to(DEV), t(synth.normal(33, (C,), 0.1)).to(DEV)
+    y = torch.full_like(x, 7.0)
+    code = _ffi.lib().melgpt_groupnorm_fused(ptr(x), ptr(gm), ptr(bt), ptr(y), B, HW[0] * HW[1], C, 1e-6, 1, None, None,
+                                             dtype_code(x.dtype), stream())
+    assert code == _ffi.ERR_UNSUPPORTED
+    torch.cuda.synchronize()
+    assert bool((y == 7.0).all()), "declined means nothing was launched"
+    ref = F.group_norm(x.float().cpu().permute(0, 3, 1, 2), 32, gm.cpu(), bt.cpu(), eps=1e-6)
+    ref = (ref * torch.sigmoid(ref)).permute(0, 2, 3, 1)
+    try:
+        got = ops.groupnorm(x, gm, bt, 1e-6, swish=True)
+    except _ffi.MelgptError as e:       # the three-kernel path's own guard (256 % (C / vec) != 0) may refuse the width: loudly
+        assert f"({_ffi.ERR_UNSUPPORTED})" in str(e)
+        return
+    assert rel_err(got.float().cpu().numpy(), ref.numpy()) < (2e-5 if dt == "f32" else 8e-3)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_conv_in_out_single_channel_and_permute(dt):
     from melspec_gpt_vqvae_amd import ops

@@ -31,10 +31,10 @@ int main(void) {
   EXPECT(melgpt_set_reserved_cus(16) == MELGPT_OK && melgpt_get_reserved_cus() == 16);
   EXPECT(melgpt_set_reserved_cus(-1) != MELGPT_OK && melgpt_get_reserved_cus() == 16);
   EXPECT(melgpt_set_reserved_cus(r0) == MELGPT_OK);
-  const int d0 = melgpt_get_dynamic_tiles();
-  melgpt_set_dynamic_tiles(1);
-  EXPECT(melgpt_get_dynamic_tiles() == 1);
-  melgpt_set_dynamic_tiles(d0);
+  const int p0 = melgpt_get_gemm_pingpong();
+  melgpt_set_gemm_pingpong(0);
+  EXPECT(melgpt_get_gemm_pingpong() == 0);
+  melgpt_set_gemm_pingpong(p0);
   melgpt_set_attn_bwd_two_pass(1);
   melgpt_set_attn_bwd_two_pass(0);
   /* workspace / size queries: pure host arithmetic */

@@ -96,6 +96,16 @@ def main():
                           "PROFILE_CMD", "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline"),
               note="hbm_read = 2 x FETCH_SIZE (gfx950 counts wide coalesced reads at half their bytes), hbm_write = "
                    "WRITE_SIZE; KiB -> MB; GEMM family = gemm8p_kernel + gemm256_kernel + gemm_kernel + conv3x3_gn*_kernel")
+    # attention launches of the step (HBM-bound at T = 265, hs = 64): counted bytes per launch, for bench.py's attn_frac_hbm
+    att = {}
+    for kind, keys in (("fwd", ("attn_q_kernel", "attn_fwd32_kernel")), ("bwd", ("attn_bwd1_kernel",))):
+        sel = [v for k, v in table if any(x in k for x in keys) and v["calls"] > 0]
+        calls = sum(v["calls"] for v in sel)
+        if calls and sum(v["fetch_kib"] + v["write_kib"] for v in sel) > 0:
+            att[kind] = round(sum(2 * v["fetch_kib"] + v["write_kib"] for v in sel) * 1024 / 1e6 / calls, 1)
+            att[kind + "_avg_us"] = round(sum(v["ns"] for v in sel) / 1e3 / calls, 2)
+    if att:
+        js["attention_hbm_MB_per_launch"] = att
     # in-kernel clocks (tools/lab/clock_lab.py on the stamped diagnostic build of the same sources), when collected
     cl = os.path.join(root, f"clock_lab_{tag}.jsonl")
     if os.path.exists(cl):
