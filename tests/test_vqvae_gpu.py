@@ -337,8 +337,8 @@ def test_fused_groupnorm_swish_conv3x3(dt, H, W, Cin, Cout, B):
     """halo-tiled conv with GroupNorm+swish applied while staging (csrc/conv_fused.hip) == GN -> swish -> conv2d."""
     from melspec_gpt_vqvae_amd import ops
 
-    if not ops.fused_conv_supported(Cin, DT[dt]):
-        pytest.skip("patch does not fit LDS for this width/dtype: the module falls back to the unfused path")
+    from melspec_gpt_vqvae_amd import _ffi
+
     x = t(synth.normal(1, (B, H, W, Cin), 1.3, 0.5)).to(DT[dt])
     w = t(synth.normal(2, (Cout, Cin, 3, 3), 0.03)).to(DT[dt])
     bias = t(synth.normal(3, (Cout,), 0.1))
@@ -347,6 +347,12 @@ def test_fused_groupnorm_swish_conv3x3(dt, H, W, Cin, Cout, B):
     xd = x.to(DEV)
     stats = ops.groupnorm_stats(xd, 1e-6)
     wp = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    if not ops.fused_conv_supported(Cin, DT[dt]):
+        # the patch does not fit LDS for this width / dtype (f32, 256 channels): the entry point refuses LOUDLY, nothing is
+        # launched (the module takes GroupNorm + the implicit-GEMM conv there: tests of the full encoder / decoder)
+        with pytest.raises(_ffi.MelgptError):
+            ops.conv3x3_gn(xd, stats, gm.to(DEV), bt.to(DEV), wp, bias.to(DEV), swish=True, residual=res.to(DEV))
+        return
     y = ops.conv3x3_gn(xd, stats, gm.to(DEV), bt.to(DEV), wp, bias.to(DEV), swish=True, residual=res.to(DEV))
     h = F.group_norm(x.float().permute(0, 3, 1, 2), 32, gm, bt, eps=1e-6)
     h = h * torch.sigmoid(h)
