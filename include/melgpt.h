@@ -383,11 +383,6 @@ int melgpt_cast(const void* x, int src_dtype, void* y, int dst_dtype, long long 
  * buffers around minGPT.py:170-180; here: guard rows of the AttnBlock's q|k|v buffer, the prepended positions' slice of
  * the positional-embedding gradient) - so that no framework fill kernel runs inside a step. */
 int melgpt_zero_bytes(void* p, long long bytes, void* stream);
-/* Cache warm-up: read p[0 .. bytes) (16-byte aligned; a tail shorter than 16 bytes is ignored) with `workgroups` workgroups
- * of 256 threads and keep nothing - the lines pass through the memory-side cache on their way.  Used by a forked branch of
- * the KV-cached sampling graph (Lit_minGPT.sample, minGPT.py:293-360) on the NEXT layer's weights while the current layer's
- * latency-bound nodes run.  sink: one int of device scratch (written only for one particular XOR of the bytes). */
-int melgpt_prefetch_bytes(const void* p, long long bytes, int workgroups, int* sink, void* stream);
 /* torch.optim.AdamW step (minGPT.py:660-664) fused over a flat f32 buffer; optional bf16 shadow copy. */
 int melgpt_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16,
                  long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,

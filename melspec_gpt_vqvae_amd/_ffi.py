@@ -95,7 +95,6 @@ _PROTOS = {
     "melgpt_dropout_apply_colsum": [_p, _p, _l, _i, _f, _u64, C.c_uint, _p, _i, _p, _i, _p],
     "melgpt_cast": [_p, _i, _p, _i, _l, _p],
     "melgpt_zero_bytes": [_p, _l, _p],
-    "melgpt_prefetch_bytes": [_p, _l, _i, _p, _p],
     "melgpt_adamw": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _f, _p],
     "melgpt_groupnorm_nchunks": [_i],
     "melgpt_groupnorm_stats": [_p, _i, _i, _i, _f, _p, _p, _p, _i, _p],

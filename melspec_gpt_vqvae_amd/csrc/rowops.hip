@@ -1366,32 +1366,6 @@ extern "C" int melgpt_zero_bytes(void* p, long long bytes, void* stream) {
   return melgpt_launch_status();
 }
 
-// ---------------------------------------------------------------- cache warm-up of a byte range
-// Reads p[0 .. bytes) with `workgroups` workgroups and keeps nothing: the lines pass through the memory-side cache (and the
-// L2 of the XCDs the workgroups run on) on their way.  A decode step's nodes are latency-bound on a first-touch HBM round
-// trip and the weights do not depend on the activations: a forked graph branch runs this on layer l + 1's weights while
-// layer l's nodes run (transformer/minGPT.py: decode_sample_graph).  `sink` is written only if the XOR of all words is one
-// particular value (so that the loads are not dead code); one int of scratch.
-__global__ __launch_bounds__(256) void prefetch_bytes_kernel(const u32x4* __restrict__ p, long long nvec, int* sink) {
-  const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, nth = (long long)gridDim.x * 256;
-  u32x4 a = {0u, 0u, 0u, 0u};
-  long long i = tid;
-  for (; i + 3 * nth < nvec; i += 4 * nth) {  // four independent 16-byte loads in flight per lane
-    const u32x4 v0 = p[i], v1 = p[i + nth], v2 = p[i + 2 * nth], v3 = p[i + 3 * nth];
-    a ^= v0 ^ v1 ^ v2 ^ v3;
-  }
-  for (; i < nvec; i += nth) a ^= p[i];
-  const unsigned x = a[0] ^ a[1] ^ a[2] ^ a[3];
-  if (x == 0x9E3779B9u && sink) *sink = (int)x;
-}
-
-extern "C" int melgpt_prefetch_bytes(const void* p, long long bytes, int workgroups, int* sink, void* stream) {
-  MELGPT_CHECK(p && bytes >= 16 && workgroups > 0 && workgroups <= 1024 && sink, MELGPT_ERR_BAD_ARG);
-  MELGPT_CHECK(((uintptr_t)p & 15) == 0, MELGPT_ERR_ALIGN);
-  hipLaunchKernelGGL(prefetch_bytes_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (const u32x4*)p, bytes >> 4, sink);
-  return melgpt_launch_status();
-}
-
 extern "C" int melgpt_cast(const void* x, int src_dtype, void* y, int dst_dtype, long long n, void* stream) {
   MELGPT_CHECK(x && y && n > 0, MELGPT_ERR_BAD_ARG);
   hipStream_t s = (hipStream_t)stream;

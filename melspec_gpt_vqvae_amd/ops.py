@@ -453,22 +453,6 @@ def cast(x, dtype, out=None):
     return out
 
 
-_PREFETCH_SINK = {}
-
-
-def prefetch_bytes(x, workgroups=32):
-    """read the bytes of the contiguous tensor x with `workgroups` workgroups and keep nothing (cache warm-up of weights a
-    later node of the same graph will stream: melgpt_prefetch_bytes)."""
-    assert x.is_contiguous()
-    sink = _PREFETCH_SINK.get(x.device)
-    if sink is None:
-        sink = _PREFETCH_SINK[x.device] = torch.empty(1, dtype=torch.int32, device=x.device)
-    nbytes = x.numel() * x.element_size()
-    off = (-x.data_ptr()) % 16
-    if nbytes - off >= 16:
-        call("melgpt_prefetch_bytes", x.data_ptr() + off, nbytes - off, int(workgroups), ptr(sink), stream())
-
-
 def adamw(param, grad, exp_avg, exp_avg_sq, *, lr, betas, eps, weight_decay, step, param_bf16=None, grad_scale=1.0):
     n = param.numel()
     for t_ in (param, grad, exp_avg, exp_avg_sq):

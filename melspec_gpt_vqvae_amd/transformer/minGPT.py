@@ -96,10 +96,6 @@ class _BlockWeights:
 
 # ========================================================================================== functional core
 _FUSE_MASK = os.environ.get("MELGPT_LN_MASK_FUSE", "1") != "0"   # lab switch (A/B of the masked second output)
-# KV-cached sampling graph: workgroups of the forked weight-prefetch branch (0 = no branch) and the largest batch it is forked
-# for (decode_sample_graph; measured in profiles/r06_decode_lab.md)
-DECODE_PREFETCH_WGS = 0
-DECODE_PREFETCH_MAX_BATCH = 128
 
 
 def _ln_bwd_for_below(owner, dh, x, ln, mu, rs, **kw):
@@ -589,17 +585,14 @@ class GPT(nn.Module):
         cache["pos"] = pos + 1
         return (logits, att_row) if want_att else logits
 
-    def _decode_trunk(self, x, cache, pos, pos_dev, want_att, prefetch=None):
-        """blocks + ln_f + head for one position; x (B, C) in the compute dtype.  prefetch(li): called at the top of layer
-        li's nodes (graph capture only) - forks a branch that warms the cache with the NEXT layer's weights."""
+    def _decode_trunk(self, x, cache, pos, pos_dev, want_att):
+        """blocks + ln_f + head for one position; x (B, C) in the compute dtype."""
         dt = _compute_dtype(self)
         fp = ensure_flat(self)
         B = x.shape[0]
         att_row = None
         last = len(self.blocks) - 1
         for li, blk in enumerate(self.blocks):
-            if prefetch is not None:
-                prefetch(li)
             W = _BlockWeights(blk, fp, dt)
             a, m = blk.attn, blk.mlp
             if want_att and li == last:
@@ -632,37 +625,12 @@ class GPT(nn.Module):
         pos_dev = cache["pos_dev"]
         pe = self.pos_emb[0].contiguous()
 
-        # Weight prefetch on a forked branch (MELGPT_DECODE_PREFETCH = workgroups of the branch's kernel, 0 = off): a decode
-        # node is latency-bound on a first-touch HBM round trip, and the weights do not depend on the activations - while
-        # layer l's five nodes run, a second stream reads layer l + 1's Linear weights (one contiguous 25 MB slice of the
-        # 16-bit shadow) through the memory-side cache; the last layer's slot warms layer 0 for the next token.
-        n_pf = int(os.environ.get("MELGPT_DECODE_PREFETCH", str(DECODE_PREFETCH_WGS))) if dt != torch.float32 else 0
-        pf_stream, pf_slices = None, None
-        if n_pf > 0 and B <= DECODE_PREFETCH_MAX_BATCH:
-            from ..dp import block_segments
-
-            fp = ensure_flat(self)
-            buf = fp.compute_buffer(dt)
-            pf_slices = []
-            for blk in self.blocks:
-                lo, hi = max(block_segments(fp, blk), key=lambda se: se[1] - se[0])    # the Linear weights' slice
-                pf_slices.append(buf[lo:hi])
-            pf_stream = torch.cuda.Stream()
-
-        def prefetch(li):
-            main = torch.cuda.current_stream()
-            pf_stream.wait_stream(main)           # fork: the branch starts when layer li's first node may start
-            with torch.cuda.stream(pf_stream):
-                ops.prefetch_bytes(pf_slices[(li + 1) % len(pf_slices)], workgroups=n_pf)
-
         def body():
             x = ops.embed_decode(idx, self.tok_emb.weight, pe, pos_dev, dt)
-            logits, _ = self._decode_trunk(x, cache, 0, pos_dev, False, prefetch if pf_stream is not None else None)
+            logits, _ = self._decode_trunk(x, cache, 0, pos_dev, False)
             ops.sample_logits_dev(logits, idx, pos_dev, -n_prompt, temperature=temperature, top_k=top_k, sample=sample,
                                   seed=seed, seq=seq)
             ops.incr_i32(pos_dev)
-            if pf_stream is not None:
-                torch.cuda.current_stream().wait_stream(pf_stream)     # join: the branch ends inside the step (and the capture)
 
         if steps <= 0:
             return seq[:, :0]
