@@ -200,16 +200,7 @@ struct WideTile {
 };
 // (host) the shape a layer runs with: 8 x 32 when it computes fewer pixels and the last column tile's second half is
 // either whole or empty (the epilogue takes ONE valid-pixel count per tile)
-// the wave-specialised kernel (conv3x3_gn_ws_kernel below; 16 x 16 tiles only): MELGPT_CONV_WS=0 keeps the round-3 kernel
-static bool conv_ws_on() {
-  static int on = -1;
-  if (on < 0) on = !(getenv("MELGPT_CONV_WS") && atoi(getenv("MELGPT_CONV_WS")) == 0);
-  return on != 0;
-}
 static bool wide_w8(int H, int W) {
-  static int off = -1;  // lab switch: MELGPT_CONV_W8=0 keeps every layer on 16 x 16 tiles
-  if (off < 0) off = getenv("MELGPT_CONV_W8") && atoi(getenv("MELGPT_CONV_W8")) == 0;
-  if (off) return false;
   const long long p16 = (long long)((H + 15) / 16) * ((W + 15) / 16), p8 = (long long)((H + 7) / 8) * ((W + 31) / 32);
   return p8 < p16 && (W % 32 == 0 || W % 32 <= 16);
 }
@@ -1047,7 +1038,7 @@ int launch_fused_ws(const FusedConvParams& q, int B, hipStream_t s) {
 }
 int launch_fused_wide(const FusedConvParams& q, int B, hipStream_t s) {
   // (Cin = 128 is checked by the caller; the wave-specialised kernel also wants exactly 128 output channels)
-  if (conv_ws_on() && q.g.N == 128) return launch_fused_ws(q, B, s);
+  if (q.g.N == 128) return launch_fused_ws(q, B, s);   // the wave-specialised kernel; other widths: the round-3 kernel
   return wide_w8(q.H, q.W) ? launch_fused_wide_t<true>(q, B, s) : launch_fused_wide_t<false>(q, B, s);
 }
 
@@ -1106,11 +1097,9 @@ static int conv3x3_gn_impl(const void* x, int B, int H, int W, int Cin, const fl
   const bool w8 = wide_w8(H, W);
   const size_t wide_lds = (size_t)(w8 ? WideTile<true>::NPIX : WideTile<false>::NPIX) * Cin * 2 + WNST * 16384 + (size_t)Cin * 16 + 1024 + 8 * 1024;
   const long long wide_tiles = (long long)wide_tiles_x(H, W) * wide_tiles_y(H, W) * B;
-  static int wide_off = -1;
-  if (wide_off < 0) wide_off = getenv("MELGPT_CONV_WIDE") && atoi(getenv("MELGPT_CONV_WIDE")) == 0;
   // 16-row tiles pay for the rows they pad: take them only while they compute at most 1/4 more pixels than 8-row tiles
   const long long wide_px = wide_tiles * 256, narrow_px = (long long)q.tiles_x * q.tiles_y * B * TH * TW;
-  if (!wide_off && wide_lds <= 160 * 1024 && wide_tiles >= 512 && wide_px * 4 <= narrow_px * 5 && q.g.vec_io &&
+  if (wide_lds <= 160 * 1024 && wide_tiles >= 512 && wide_px * 4 <= narrow_px * 5 && q.g.vec_io &&
       Cin == 128 &&
       M * Cin * 2 < 0xFFFFFF00LL && M * Cout * 2 < 0xFFFFFF00LL) {   // (outputs past a descriptor's range: the narrow kernel)
     q.x_bytes = (unsigned)(M * Cin * 2);

@@ -302,14 +302,7 @@ int dispatch(const GemmParams& p, int alay, int blay, int batch, hipStream_t s) 
 bool fits32(long long rows, long long ld, int es) { return (rows + 260) * ld * es < 0xFFFFFF00LL; }
 
 // tile configuration for the bf16 lane: 1 = 128x128 (this file), 2 = 256x128, 3 = 256x256 (gemm256.hip).
-// MELGPT_GEMM_TILE=1|2|3 forces one (development / A-B timing).
 int pick_tile(const GemmParams& p, int batch, int kmin = 256, int kmin_partial = 512) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("MELGPT_GEMM_TILE");
-    forced = e ? atoi(e) : 0;
-  }
-  if (forced == 1 || forced == 3) return forced;
   // The persistent 256 x 256 kernel (gemm256.hip) wins once there are enough tiles to occupy the chip and the
   // tile grid is not mostly padding; small or skinny problems stay on the 128 x 128 kernel (two workgroups per CU).
   const long long tiles256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch;

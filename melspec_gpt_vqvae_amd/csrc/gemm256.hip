@@ -453,16 +453,11 @@ int launch_mode(const GemmParams& p, int batch, hipStream_t s) {
       const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + 255) / 256) * batch;
       return ((tiles + ncu - 1) / ncu) * (tm == 6 ? nu * 290 + 830 : nu * 345 + 1000);
     };
-    static int forced = -1;  // MELGPT_GEMM_TM=6|8 pins the tile height (tests cover both)
-    if (forced < 0) {
-      const char* e = getenv("MELGPT_GEMM_TM");
-      forced = e ? atoi(e) : 0;
-    }
     // the full-epilogue kernel with a K-major B operand spills 8 VGPRs at 256 rows, and its reloads sit in the K loop
     // where their vmcnt(0) drains the ring on every unit (GELU' dgrad: 11.1 -> 15.3 ms per step): ties go to 192 rows
     const bool tie6 = MODE == EPI_FULL16 && BLAY == LAY_KMAJ;
     const long long c6 = cost(192, 6), c8 = cost(256, 8);
-    if (forced == 6 || (forced != 8 && (c6 < c8 || (tie6 && c6 == c8)))) return launch_tm<ALAY, BLAY, MODE, 6>(p, batch, ncu, s);
+    if (c6 < c8 || (tie6 && c6 == c8)) return launch_tm<ALAY, BLAY, MODE, 6>(p, batch, ncu, s);
   }
   return launch_tm<ALAY, BLAY, MODE, 8>(p, batch, ncu, s);
 }

@@ -685,12 +685,7 @@ int launch8p_e(const GemmParams& p, int tiles_m, int tiles_n, int batch, int RN,
 // workgroup - returned as the first row of that tail, 0 = none.  (M = 33 920, N = 4096: 8.3 rounds of tiles = 8 rounds +
 // 144 half tiles; the ninth round of 80 full tiles on 256 CUs costs a whole tile time, the half tiles ~ 0.8 of one.)
 static int tail_rows(const GemmParams& p, int tiles_m, int tiles_n, int batch, int RN, int grid) {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("MELGPT_GEMM_TAIL");
-    on = e ? atoi(e) : 1;
-  }
-  if (!on || RN <= 0 || batch != 1 || (grid & 7)) return 0;
+  if (RN <= 0 || batch != 1 || (grid & 7)) return 0;
   const int RM = (grid >> 3) / RN;
   const int blocks_n = (tiles_n + RN - 1) / RN, blocks_m = (tiles_m + RM - 1) / RM;
   const int rounds = (blocks_m * blocks_n + 7) / 8;
@@ -776,14 +771,9 @@ int gemmk::launch_gemm8p(const GemmParams& p, int alay, int blay, int mode, int 
 // The implicit-GEMM convolutions with at most 128 output channels (Downsample: 3x3, stride 2, 128 -> 128 at 80 x 848 and
 // 40 x 424 - 631 TFLOP/s on the 128 x 128 kernel) as 256 x 128 tiles of the ping-pong loop (NHALF).  One tile column, the
 // block lists degenerate to RM = workgroups per XCD consecutive tile rows; fewer tiles than CUs: one tile per workgroup.
-// MELGPT_ERR_UNSUPPORTED: the caller's 128 x 128 kernel serves the launch.  MELGPT_CONV_N128=0 switches the form off.
+// MELGPT_ERR_UNSUPPORTED: the caller's 128 x 128 kernel serves the launch.
 int gemmk::launch_conv8p_n128(const GemmParams& p, hipStream_t s) {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("MELGPT_CONV_N128");
-    on = e ? atoi(e) : 1;
-  }
-  if (!on || !melgpt_get_gemm_pingpong()) return MELGPT_ERR_UNSUPPORTED;
+  if (!melgpt_get_gemm_pingpong()) return MELGPT_ERR_UNSUPPORTED;
   if (p.N > 128 || p.cC % 64 != 0 || p.K < 512 || !p.vec_io || p.out_f32 || p.accumulate || p.C2 || p.drop_scale != 0.f ||
       p.act != MELGPT_ACT_NONE || p.a_bytes >= 0x80000000u || p.b_bytes >= 0x80000000u)
     return MELGPT_ERR_UNSUPPORTED;

@@ -56,7 +56,7 @@ def _ops(seed, M, N, K, b_kmajor=False):
 
 
 # >= 256 tiles (a full grid: the ping-pong kernel walks XCD blocks), ragged M / N / K edges, both tile heights
-# (MELGPT_GEMM_TM is read once per process, so the height is whatever the launch's cost model picks: N = 1024 -> 192 rows)
+# (the height is whatever the launch's cost model picks: N = 1024 -> 192 rows)
 @pytest.mark.parametrize("form,M,N,K", [("nt", 9000, 4096, 328), ("nt", 33920, 1024, 264), ("nt", 20000, 1272, 384),
                                         ("nn", 24576, 1024, 320), ("nn", 8500, 4096, 328), ("nt", 8192, 8192, 512),
                                         # GPT-VAE XL widths: K-major B whose N ends inside a 128-column half-tile
