@@ -31,6 +31,15 @@ def test_library_exports_every_declared_symbol():
     assert all(hasattr(L16, s) for s in syms) and L16.melgpt_abi_version() == 1
     # every bound prototype is declared in the header and vice versa
     assert sorted(_ffi._PROTOS) == syms
+    # ... and the libraries export NO melgpt_ symbol the header does not declare (dynamic symbol table, `nm -D`)
+    import shutil
+    import subprocess
+
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    for flavour in ("bf16", "fp16"):
+        out = subprocess.run([nm, "-D", "--defined-only", build.lib_path(flavour)], capture_output=True, text=True, check=True).stdout
+        exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("melgpt_")})
+        assert exported == syms, (flavour, sorted(set(exported) ^ set(syms)))
 
 
 def test_product_never_imports_oracle():
