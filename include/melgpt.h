@@ -203,6 +203,27 @@ int melgpt_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, const void* 
                        int KW, int stride, int pad_t, int pad_l, int OH, int OW, int upsample,
                        const float* bias, const void* residual, void* y, int dtype, void* stream);
 
+/* Backward of the VQ-VAE's convolution and normalisation sites (LitVQVAE.forward is differentiable in the reference,
+ * vqvae/big_model_attn_gan.py:622-634; no scored configuration trains the VQ-VAE, so these are correctness-first compositions
+ * of the forward kernels - csrc/vqvae_bwd.hip).  NHWC, both numerics lanes.
+ *   melgpt_conv3x3_bwd_data:   dx (B,H,W,Cin) = gradient of conv3x3(stride 1, pad 1) w.r.t. its input, from dy (B,H,W,Cout) and
+ *                              the forward's packed weight (Cout,3,3,Cin).  Cout % 64 == 0 (16-bit) / % 32 (f32), Cin % 8 == 0.
+ *   melgpt_conv3x3_bwd_weight: dw (Cout,3,3,Cin) f32 = gradient w.r.t. the packed weight, dbias (Cout) f32 or NULL = column sums
+ *                              of dy; deterministic (fixed-order partial sums).  Cin, Cout rows 16-byte multiples.
+ *   workspace: melgpt_conv3x3_bwd_workspace(...) bytes, 16-byte aligned (serves either call).
+ *   melgpt_groupnorm_swish_bwd: gradient of y = swish?(GroupNorm(32)(x) * gamma + beta) (Normalize + nonlinearity, :139-140,
+ *                              :164-166) from the forward's statistics (mean, rstd: (B*32,) f32): dx in dtype, dgamma / dbeta (C)
+ *                              f32 or NULL; workspace melgpt_groupnorm_swish_bwd_workspace(B, HW, C) bytes. */
+long long melgpt_conv3x3_bwd_workspace(int B, int H, int W, int Cin, int Cout, int dtype);
+int melgpt_conv3x3_bwd_data(const void* dy, const void* wpack, void* dx, int B, int H, int W, int Cin, int Cout,
+                            void* workspace, int dtype, void* stream);
+int melgpt_conv3x3_bwd_weight(const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int Cin, int Cout,
+                              void* workspace, int dtype, void* stream);
+long long melgpt_groupnorm_swish_bwd_workspace(int B, int HW, int C);
+int melgpt_groupnorm_swish_bwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                               const void* dy, void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int swish,
+                               float* workspace, int dtype, void* stream);
+
 /* ===================================================================== attention (minGPT.py:72-90)
  * q/k/v: (B*T, >= H*64) matrices with row stride ld (elements), head h in columns [64h, 64h+64) - i.e. the
  * three column blocks of a packed QKV projection; no (B,H,T,hs) transposes are ever materialised.

@@ -118,8 +118,14 @@ _PROTOS = {
     "melgpt_conv3x3_gn_stats_workspace": [_i, _i, _i],
     "melgpt_conv3x3_gn_nhwc_stats": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _f, _p, _p, _p, _p],
     "melgpt_groupnorm_finalize": [_p, _i, _i, C.c_double, _f, _p, _p, _p],
+    "melgpt_conv3x3_bwd_workspace": [_i, _i, _i, _i, _i, _i],
+    "melgpt_conv3x3_bwd_data": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p],
+    "melgpt_conv3x3_bwd_weight": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p],
+    "melgpt_groupnorm_swish_bwd_workspace": [_i, _i, _i],
+    "melgpt_groupnorm_swish_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p],
 }
-_RESTYPE = {"melgpt_strerror": C.c_char_p, "melgpt_vq_image_bytes": C.c_int64, "melgpt_linear_lds_workspace": C.c_int64}
+_RESTYPE = {"melgpt_strerror": C.c_char_p, "melgpt_vq_image_bytes": C.c_int64, "melgpt_linear_lds_workspace": C.c_int64,
+            "melgpt_conv3x3_bwd_workspace": C.c_int64, "melgpt_groupnorm_swish_bwd_workspace": C.c_int64}
 
 _lib = None
 

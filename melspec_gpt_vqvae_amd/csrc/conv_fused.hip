@@ -554,8 +554,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <bool STATS, bool W8>
 __global__ __launch_bounds__(512) void conv3x3_gn_ws_kernel(FusedConvParams q, int total_tiles) {
   typedef WsTile<W8> WT;
-  constexpr int PP = WS_PP, PW = WT::PW, PH = WT::PH, TH = WT::TH, TW = WT::TW, WS_NPIX = WT::NPIX, WS_PATCH = WT::PATCH;
-  constexpr int FSTEP = W8 ? PW : 2 * PW;   // patch pixels between the two 32-pixel fragments of a wave
+  constexpr int PP = WS_PP, PW = WT::PW, PH = WT::PH, TH = WT::TH, TW = WT::TW, WS_PATCH = WT::PATCH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const GemmParams& p = q.g;
   char* patch = smem;

@@ -709,6 +709,48 @@ def groupnorm(x, gamma, beta, eps=1e-6, swish=True):
     return y
 
 
+# ----- backward of the VQ-VAE's building blocks (csrc/vqvae_bwd.hip): C-ABI exports with parity tests, NOT wired into
+# LitVQVAE's autograd (no scored configuration trains the VQ-VAE; .backward() through the module is refused loudly)
+def conv3x3_bwd_data(dy, wpack, Cin):
+    """dy (B,H,W,Cout), wpack (Cout,3,3,Cin) in dy's dtype -> dx (B,H,W,Cin): input gradient of conv3x3 (stride 1, pad 1)."""
+    B, H, W, Cout = dy.shape
+    assert dy.is_contiguous() and wpack.is_contiguous() and wpack.shape == (Cout, 3, 3, Cin) and wpack.dtype == dy.dtype
+    nbytes = int(_ffi.lib().melgpt_conv3x3_bwd_workspace(B, H, W, Cin, Cout, dtype_code(dy.dtype)))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    dx = torch.empty(B, H, W, Cin, dtype=dy.dtype, device=dy.device)
+    call("melgpt_conv3x3_bwd_data", ptr(dy), ptr(wpack), ptr(dx), B, H, W, Cin, Cout, ptr(ws), dtype_code(dy.dtype), stream())
+    return dx
+
+
+def conv3x3_bwd_weight(x, dy, want_bias=True):
+    """x (B,H,W,Cin), dy (B,H,W,Cout) -> (dw (Cout,3,3,Cin) f32 in the packed layout, dbias (Cout,) f32 or None)."""
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    assert x.is_contiguous() and dy.is_contiguous() and dy.shape[:3] == x.shape[:3] and dy.dtype == x.dtype
+    nbytes = int(_ffi.lib().melgpt_conv3x3_bwd_workspace(B, H, W, Cin, Cout, dtype_code(x.dtype)))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    dw = torch.empty(Cout, 3, 3, Cin, dtype=torch.float32, device=x.device)
+    db = torch.empty(Cout, dtype=torch.float32, device=x.device) if want_bias else None
+    call("melgpt_conv3x3_bwd_weight", ptr(x), ptr(dy), ptr(dw), ptr(db), B, H, W, Cin, Cout, ptr(ws), dtype_code(x.dtype), stream())
+    return dw, db
+
+
+def groupnorm_swish_bwd(x, stats, gamma, beta, dy, swish=True):
+    """gradient of swish?(GroupNorm(32)(x) * gamma + beta): x, dy (B,H,W,C); stats = (mean, rstd) of the forward
+    (groupnorm_stats) -> (dx, dgamma, dbeta)."""
+    B, H, W, C = x.shape
+    mean, rstd = stats
+    assert x.is_contiguous() and dy.is_contiguous() and dy.shape == x.shape and dy.dtype == x.dtype
+    nbytes = int(_ffi.lib().melgpt_groupnorm_swish_bwd_workspace(B, H * W, C))
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device)
+    db = torch.empty(C, dtype=torch.float32, device=x.device)
+    call("melgpt_groupnorm_swish_bwd", ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dy), ptr(dx), ptr(dg), ptr(db), B, H * W,
+         C, int(swish), ptr(ws), dtype_code(x.dtype), stream())
+    return dx, dg, db
+
+
 def conv_in_c1(x, w, bias, dtype, stats_eps=None):
     """x (B,H,W) f32/bf16 single-channel image; w (Cout,1,3,3) f32 -> (B,H,W,Cout) in dtype.  stats_eps (Cout = 128):
     also the GroupNorm(32) statistics of the output from the same pass -> (y, (mean, rstd)); else (y, None)."""

@@ -581,6 +581,21 @@ def gen_vqvae(ref_vq):
          sd_keys=np.array([k for k in m.state_dict().keys()]))
 
 
+def gen_resblock_grad(ref_vq):
+    """Gradients of the REAL ResnetBlock (vqvae/big_model_attn_gan.py:75-135: norm1 -> swish -> conv1 -> norm2 -> swish ->
+    conv2, + x) by torch autograd on CPU: the pin of melgpt_conv3x3_bwd_{data,weight} / melgpt_groupnorm_swish_bwd."""
+    print("ResnetBlock gradients")
+    C, B, H, W = 64, 2, 10, 22
+    blk = ref_vq.ResnetBlock(in_channels=C, out_channels=C, dropout=0.0, temb_channels=0)
+    load_sd(blk, synth.resblock_state_dict(60, C))
+    x = t(synth.normal(61, (B, C, H, W), 1.2, 0.3)).requires_grad_(True)
+    g = t(synth.normal(62, (B, C, H, W), 0.7))
+    y = blk(x, None)
+    y.backward(g)
+    grads = {("d_" + k.replace(".", "_")): p.grad.numpy() for k, p in blk.named_parameters()}
+    save("resblock_grad", x=x.detach().numpy(), g=g.numpy(), y=y.detach().numpy(), dx=x.grad.numpy(), seed=60, channels=C, **grads)
+
+
 def gen_melgan():
     """MelGAN generator (vocoder/modules.py:38-79): the module imports librosa at the top only for a filter-bank
     helper that the Generator never calls, so a stand-in satisfies the import."""
@@ -675,7 +690,7 @@ def main():
     torch.manual_seed(synth.SEED)
     torch.set_num_threads(8)
     ref_gpt, ref_enc, ref_dec, ref_vq = import_reference()
-    which = set(sys.argv[1:]) or {"vq", "attn", "gpt", "lit", "vae", "vae_mi", "vae_steps", "vae_xl", "vqvae", "melgan", "mel"}
+    which = set(sys.argv[1:]) or {"vq", "attn", "gpt", "lit", "vae", "vae_mi", "vae_steps", "vae_xl", "vqvae", "resblock", "melgan", "mel"}
     if which <= {"melgan", "mel"}:
         if "melgan" in which:
             gen_melgan()
@@ -701,6 +716,8 @@ def main():
         gen_vae_xl(ref_enc, ref_dec)
     if "vqvae" in which:
         gen_vqvae(ref_vq)
+    if "resblock" in which:
+        gen_resblock_grad(ref_vq)
     if "melgan" in which:
         gen_melgan()
     if "mel" in which:

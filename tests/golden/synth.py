@@ -114,6 +114,13 @@ def _res(sd, name, cin, cout, seed):
         _conv(sd, name + ".nin_shortcut", cout, cin, 1, seed + 8)
 
 
+def resblock_state_dict(seed, c):
+    """one ResnetBlock (c -> c channels), keys as in the module (norm1, conv1, norm2, conv2): the gradient fixture's weights"""
+    sd = OrderedDict()
+    _res(sd, "blk", c, c, seed)
+    return OrderedDict((k[len("blk."):], v) for k, v in sd.items())
+
+
 def _attn(sd, name, c, seed):
     _gn(sd, name + ".norm", c, seed)
     for j, nm in enumerate(("q", "k", "v", "proj_out")):

@@ -346,3 +346,19 @@ def test_gpt_vae_eval_inference_dist_and_calc_mi():
     mi = ogpt.vae_calc_mi(t(g["mu"]), t(g["logvar"]), t(g["mi_eps"]))
     assert abs(mi - float(g["mi"])) <= 1e-6 * max(1.0, abs(float(g["mi"])))
     assert abs(ogpt.vae_calc_mi(mu, logvar, t(g["mi_eps"])) - float(g["mi"])) <= 1e-4 * max(1.0, abs(float(g["mi"])))
+
+
+def test_oracle_resnet_block_gradients_match_the_real_reference():
+    """oracle/vqvae.py's resnet_block under torch autograd against the gradients recorded from the reference's ResnetBlock
+    (tests/golden/resblock_grad.npz): the pin behind the GPU parity of the backward exports (tests/test_vqvae_bwd_gpu.py)."""
+    g = golden("resblock_grad")
+    sd_np = synth.resblock_state_dict(int(g["seed"]), int(g["channels"]))
+    sd = {"blk." + k: t(v).clone().requires_grad_(True) for k, v in sd_np.items()}
+    x = t(g["x"]).clone().requires_grad_(True)
+    y = ovq.resnet_block(sd, "blk", x)
+    y.backward(t(g["g"]))
+    assert np.allclose(y.detach().numpy(), g["y"], rtol=1e-5, atol=1e-5)
+    assert np.allclose(x.grad.numpy(), g["dx"], rtol=1e-4, atol=1e-5)
+    for k, v in sd.items():
+        want = g["d_" + k[len("blk."):].replace(".", "_")]
+        assert np.allclose(v.grad.numpy(), want, rtol=1e-4, atol=1e-4 * float(np.abs(want).max())), k
