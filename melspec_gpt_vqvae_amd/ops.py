@@ -33,9 +33,23 @@ class KernelTimer:
         return {t: tuple(v) for t, v in agg.items()}
 
     def summary(self):
-        tot_ms = sum(s.elapsed_time(e) for s, e, _, _ in self.records)
+        """total_ms = the time during which AT LEAST ONE recorded launch was running: the union of the launches' intervals on
+        the device clock (launches of a Block's weight gradients run on a second stream beside the input-gradient chain -
+        transformer/minGPT.py _wgrad - so the plain sum of durations would count shared time twice); serial_ms = that sum."""
         flops = sum(f for _, _, f, _ in self.records)
-        return dict(launches=len(self.records), total_ms=tot_ms, flops=flops)
+        if not self.records:
+            return dict(launches=0, total_ms=0.0, serial_ms=0.0, flops=flops)
+        base = self.records[0][0]
+        iv = sorted((base.elapsed_time(s), base.elapsed_time(e)) for s, e, _, _ in self.records)
+        union, cur_a, cur_b = 0.0, iv[0][0], iv[0][1]
+        for a, b in iv[1:]:
+            if a > cur_b:
+                union += cur_b - cur_a
+                cur_a, cur_b = a, b
+            else:
+                cur_b = max(cur_b, b)
+        union += cur_b - cur_a
+        return dict(launches=len(self.records), total_ms=union, serial_ms=sum(b - a for a, b in iv), flops=flops)
 
     def by_tag(self):
         agg = {}

@@ -23,7 +23,8 @@ _META = {"view", "_unsafe_view", "reshape", "slice", "select", "as_strided", "pe
          "squeeze", "expand", "detach", "alias", "empty", "empty_like", "empty_strided", "new_empty", "new_empty_strided",
          "unbind", "split", "split_with_sizes", "chunk", "narrow", "flatten", "unflatten", "view_as", "_reshape_alias",
          "size", "stride", "is_contiguous", "numel", "storage_offset", "sym_size", "sym_stride", "sym_numel", "dim",
-         "lift_fresh", "_local_scalar_dense", "is_same_size", "result_type", "contiguous", "_to_copy", "to"}
+         "lift_fresh", "_local_scalar_dense", "is_same_size", "result_type", "contiguous", "_to_copy", "to",
+         "record_stream"}    # (record_stream: allocator bookkeeping for the side stream of the weight gradients, no kernel)
 
 
 def _job(layers=2, batch=16):
