@@ -740,6 +740,29 @@ def main():
     timer, ops.TIMER = ops.TIMER, None
     loss_val = float(loss.detach())
 
+    # Kernel-quality reference OUTSIDE the timed region (rank 0, one GPU): three more steps with everything on ONE stream.  In
+    # the timed region a Block's weight gradients run on a second stream beside the attention / LayerNorm backward and the
+    # input-gradient GEMMs (transformer/minGPT.py _wgrad): the step is faster, but a launch that shares the chip lasts
+    # longer, so per-launch rates and the family's time read lower there than the kernels run on their own.
+    single = None
+    if rank == 0 and world == 1 and not FORCE_DP:
+        from melspec_gpt_vqvae_amd.transformer import minGPT as _mg
+
+        if _mg.WGRAD_SIDE:
+            _mg.WGRAD_SIDE = False
+            try:
+                step()
+                ops.TIMER = ops.KernelTimer()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                single = (ops.TIMER, 3, (time.perf_counter() - t1) / 3)
+            finally:
+                ops.TIMER = None
+                _mg.WGRAD_SIDE = True
+
     # the part of the gradient exchange the backward pass did not hide (dp.GradientExchange.exposed_ms), per step
     exposed = job.dp.ex.exposed_ms() if job.dp is not None else []
     exposed_ms = sum(exposed) / len(exposed) if exposed else 0.0
@@ -758,11 +781,14 @@ def main():
         # attention (HBM-bound at T = 265, hs = 64: DESIGN 4): per launch form, live HIP-event time against the algorithmic
         # bytes (ops.attn_fwd / attn_bwd) and, when the committed PMC pass has them, against the counted bytes
         aux = timer.aux_by_tag()
-        attn_flops = sum(v[3] for v in aux.values())
+        attn_flops = sum(v[3] for v in aux.values())          # (FLOPs of the timed region, for step_frac)
+        aux_steps = a.steps
+        if single is not None:      # per-launch times from the single-stream reference steps (the backward kernel shares the
+            aux, aux_steps = single[0].aux_by_tag(), single[1]   # chip with a weight-gradient GEMM in the timed region)
         attn = {}
         for tag, (n, ms, nbytes, fl) in sorted(aux.items()):
             us = 1e3 * ms / n
-            row = {"launches_per_step": round(n / a.steps, 2), "us": round(us, 2), "algorithmic_MB": round(nbytes / n / 1e6, 1),
+            row = {"launches_per_step": round(n / aux_steps, 2), "us": round(us, 2), "algorithmic_MB": round(nbytes / n / 1e6, 1),
                    "frac_hbm": round(nbytes / n / (us * 1e-6) / 8e12, 4), "tflops": round(fl / n / (us * 1e-6) / 1e12, 1)}
             counted = (pmc.get("attention_hbm_MB_per_launch") or {}).get("fwd" if " fwd " in tag else "bwd")
             if counted and " full" not in tag and job.name == "class_gpt":
@@ -772,10 +798,13 @@ def main():
         step_flops = (ks["flops"] + attn_flops) / max(a.steps, 1)
         # per-instantiation table: one row per (layout, shape, epilogue) of the GEMM family, slowest rate first among
         # the rows that matter (>= 0.5 % of the family's time) - names the shape the family's `frac` is held down by
-        rows = [{"shape": tag, "calls_per_step": round(n / a.steps, 2), "ms_per_step": round(ms / a.steps, 3),
-                 "tflop_per_step": round(fl / a.steps / 1e12, 3), "tflops": round(fl / ms / 1e9, 1) if ms > 0 else 0.0}
-                for tag, n, ms, fl in timer.by_tag()]
-        major = [r for r in rows if r["ms_per_step"] * a.steps >= 0.005 * ks["total_ms"]]
+        # (per-shape rates from the single-stream reference steps when they exist: launches that do not share the chip)
+        ptimer, psteps = (single[0], single[1]) if single is not None else (timer, a.steps)
+        pks = ptimer.summary()
+        rows = [{"shape": tag, "calls_per_step": round(n / psteps, 2), "ms_per_step": round(ms / psteps, 3),
+                 "tflop_per_step": round(fl / psteps / 1e12, 3), "tflops": round(fl / ms / 1e9, 1) if ms > 0 else 0.0}
+                for tag, n, ms, fl in ptimer.by_tag()]
+        major = [r for r in rows if r["ms_per_step"] * psteps >= 0.005 * pks["total_ms"]]
         worst = min(major, key=lambda r: r["tflops"]) if major else None
         out = {
             "metric": job.metric,
@@ -813,6 +842,10 @@ def main():
                 # the input-gradient chain since round 6: union of the launch intervals on the device clock) / plain sum
                 "kernel_ms_per_step": round(ks["total_ms"] / max(a.steps, 1), 3),
                 "kernel_serial_ms_per_step": round(ks.get("serial_ms", ks["total_ms"]) / max(a.steps, 1), 3),
+                # the same family on ONE stream (three reference steps outside the timed region): what the kernels do when
+                # no launch shares the chip - `per_shape` / `worst_shape` below are from these steps
+                "frac_single_stream": round(pks["flops"] / (pks["total_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if single is not None and pks["total_ms"] > 0 else None,
+                "ms_per_step_single_stream": round(1e3 * single[2], 3) if single is not None else None,
                 "algorithmic_tflop_per_step": round(ks["flops"] / max(a.steps, 1) / 1e12, 3),
                 "worst_shape": worst, "per_shape": major,
             },
@@ -880,6 +913,7 @@ def main():
         c5 = out.get("config5_e2e_fp16") or {}
         out["summary"] = {
             "seq_per_s": out["value"], "ms_per_step": out["ms_per_step"], "frac": rf["frac"], "step_frac": rf["step_frac"],
+            "frac_single_stream": rf.get("frac_single_stream"), "ms_per_step_single_stream": rf.get("ms_per_step_single_stream"),
             "code_perplexity": cfg.get("code_perplexity"),
             "attn": {k: [v["us"], v.get("frac_hbm_counted", v["frac_hbm"])] for k, v in attn.items()},
             "vq_lookup_frac_hbm": {k: v["frac_hbm"] for k, v in (c2.get("lookup_sweep") or {}).items()},

@@ -144,6 +144,9 @@ def _attention_core(x2d, w_qkv, b_qkv, w_proj, b_proj, *, B, T, n_head, n_unmask
 # workgroups take the CUs the main stream's persistent GEMMs leave idle in their partial last rounds and at their tile
 # boundaries (same kernels, same bits: every launch writes its own slice of the flat gradient).  The Block's end joins the
 # two streams, in front of the data-parallel hook.  Same box, 20 steps: 93.06 -> 91.66 ms (profiles/r06_f_wgrad_side_ab.jsonl).
+# (joined in front of every non-GEMM kernel instead - a weight gradient beside its own input gradient only - the step LOSES:
+# 93.65 against 92.7 ms on one stream; what pays is GEMM work beside the VALU-bound attention backward and the HBM-bound
+# LayerNorm backward, profiles/r06_h_wgrad_join_ab.jsonl)
 WGRAD_SIDE = os.environ.get("MELGPT_WGRAD_SIDE", "1") != "0"
 _SIDE = {}
 
