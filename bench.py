@@ -536,6 +536,12 @@ class ClassGPTStep:
         self.gpt, self.vqvae = build_models(device, dtype, gargs, getattr(a, "codebook", "latents"))
         self.x_mel, self.c = synthetic_batch(a.batch, rank, device)
         self.codes = None                                        # the last step's codes (code_perplexity of the line)
+        # --pipeline-encode (NOT the metric's configuration): the frozen VQ-VAE's encode of the NEXT batch on a second stream
+        # while this batch trains - what a prefetching data pipeline does with extract_codes.py's work; a step then consumes
+        # codes produced during the step before.  Reported as a side measurement only.
+        self.pipe = bool(getattr(a, "pipeline_encode", False))
+        self._side = torch.cuda.Stream(device=device) if self.pipe else None
+        self._next = None
         self.opt = FusedAdamW(self.gpt, lr=gargs.learning_rate, betas=(0.9, 0.95), weight_decay=0.01)
         self.opt.grad_scale = 1.0 / world
         self.dp = DataParallel(self.gpt, grad_dtype=a.grad_dtype) if world > 1 or FORCE_DP else None
@@ -550,9 +556,24 @@ class ClassGPTStep:
         from melspec_gpt_vqvae_amd.transformer.minGPT import cross_entropy
 
         t0 = mark()
-        with torch.no_grad():
-            codes = self.vqvae.encode_to_codes(self.x_mel)       # (B,5,53) int64
-            seq = ops.codes_permute(codes, 5, 53)                # (B,265) time-major (get_x)
+        if self.pipe:
+            main = torch.cuda.current_stream()
+            if self._next is None:
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side), torch.no_grad():
+                    c0 = self.vqvae.encode_to_codes(self.x_mel)
+                    self._next = (c0, ops.codes_permute(c0, 5, 53))
+            main.wait_stream(self._side)                         # this batch's codes (encoded during the step before)
+            codes, seq = self._next
+            codes.record_stream(main)
+            seq.record_stream(main)
+            with torch.cuda.stream(self._side), torch.no_grad():  # the next batch's, beside this batch's training
+                c1 = self.vqvae.encode_to_codes(self.x_mel)
+                self._next = (c1, ops.codes_permute(c1, 5, 53))
+        else:
+            with torch.no_grad():
+                codes = self.vqvae.encode_to_codes(self.x_mel)       # (B,5,53) int64
+                seq = ops.codes_permute(codes, 5, 53)                # (B,265) time-major (get_x)
         self.codes = codes
         t1 = mark()
         with self.gpt.discard_att():                             # as Lit_minGPT.forward does: the (B,H,T,T) map it
@@ -643,6 +664,8 @@ def main():
                     help="frozen VQ-VAE codebook of the class_gpt workload: latents (default) = rows sampled from the encoder's "
                          "own outputs, usage-balanced -> the step's tokens spread over the 128 codes (BASELINE.md 4 asks for "
                          "uniform codes); normal = N(0,1) rows as in rounds 1-5 (tokens collapse: perplexity ~3)")
+    ap.add_argument("--pipeline-encode", action="store_true",
+                    help="NOT the metric's configuration: encode the next batch on a second stream while this one trains (flagged in the line)")
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip torch_gpu_baseline (stock PyTorch-ROCm, same box)")
     ap.add_argument("--torch-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--layers", type=int, default=24, help="debug only; anything but the configuration's depth is flagged")
@@ -855,6 +878,8 @@ def main():
             # switches, and how much of it the backward pass did not hide (max over ranks)
             out["config"].update(dp_info)
             out["exposed_comm_ms"] = round(exposed_ms, 3)
+        if getattr(a, "pipeline_encode", False):
+            out["config"]["NOT_THE_METRIC_pipelined_encode"] = True
         if not job.full:
             out["config"]["INVALID_debug_layers"] = a.layers
         if share:
