@@ -664,6 +664,9 @@ def main():
                     help="frozen VQ-VAE codebook of the class_gpt workload: latents (default) = rows sampled from the encoder's "
                          "own outputs, usage-balanced -> the step's tokens spread over the 128 codes (BASELINE.md 4 asks for "
                          "uniform codes); normal = N(0,1) rows as in rounds 1-5 (tokens collapse: perplexity ~3)")
+    ap.add_argument("--no-reference-steps", action="store_true",
+                    help="skip the three single-stream reference steps behind the timed region (profiled runs: every kernel of the "
+                         "trace then belongs to a default step)")
     ap.add_argument("--pipeline-encode", action="store_true",
                     help="NOT the metric's configuration: encode the next batch on a second stream while this one trains (flagged in the line)")
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip torch_gpu_baseline (stock PyTorch-ROCm, same box)")
@@ -768,7 +771,7 @@ def main():
     # input-gradient GEMMs (transformer/minGPT.py _wgrad): the step is faster, but a launch that shares the chip lasts
     # longer, so per-launch rates and the family's time read lower there than the kernels run on their own.
     single = None
-    if rank == 0 and world == 1 and not FORCE_DP:
+    if rank == 0 and world == 1 and not FORCE_DP and not a.no_reference_steps:
         from melspec_gpt_vqvae_amd.transformer import minGPT as _mg
 
         if _mg.WGRAD_SIDE:

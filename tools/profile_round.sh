@@ -13,6 +13,11 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras $EXTRA"
 export PROFILE_CMD="$CMD"
+# two kernel traces: the default step (a Block's weight gradients on a second stream: launches that share the chip last longer)
+# and the single-stream step (MELGPT_WGRAD_SIDE=0: what bench.py's per_shape / frac_single_stream are measured on); the variable
+# is exported, never passed through `env` (the program itself must follow `--`)
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace2" -o trace2 --output-format csv -- $CMD --no-reference-steps > "$OUT/trace2.log" 2>&1
+export MELGPT_WGRAD_SIDE=0
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- $CMD > "$OUT/trace.log" 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/fetch" -o fetch --output-format csv -- $CMD > "$OUT/fetch.log" 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/write" -o write --output-format csv -- $CMD > "$OUT/write.log" 2>&1
@@ -25,6 +30,7 @@ cd "$REPO"
 if [ -f tools/lab/bin/libmelgpt_clock.so ] && [ -z "$EXTRA" ]; then
   MELGPT_LAB_LIB=$REPO/tools/lab/bin/libmelgpt_clock.so timeout 600 python3 tools/lab/clock_lab.py > "$OUT/clock_lab_$TAG.jsonl" 2> "$OUT/clock_lab.log"
 fi
+unset MELGPT_WGRAD_SIDE
 PROFILE_STEPS=5 python3 tools/profile_summary.py "$OUT" "$TAG"
 find "$OUT" -name "*.csv" -size +4M -delete   # the per-dispatch counter tables are too big to ship back
 ls -la "$OUT"
