@@ -373,13 +373,15 @@ def test_conv_on_wide_kernel_at_size(case):
     assert rel_err(y.float().cpu().numpy(), (ref + res.float()).numpy()) < 2 ** -8
 
 
-def test_downsample_conv_over_two_gib_of_input_runs_as_whole_image_launches():
+@pytest.mark.parametrize("B", [130, 125])
+def test_downsample_conv_over_two_gib_of_input_runs_as_whole_image_launches(B):
     """The 256 x 128-tile form addresses its operand with 32-bit offsets that end at 2 GiB; the training step's Downsample
-    conv at 128 tiles of 80 x 848 x 128 reads 2.2 GB: melgpt_conv2d_nhwc cuts the batch into whole-image launches.  The
-    result must equal the two halves run on their own (bit for bit) and F.conv2d on the first and the last image."""
+    conv at 128 tiles of 80 x 848 x 128 reads 2.2 GB: melgpt_conv2d_nhwc cuts the batch into whole-image launches (B = 125:
+    an UNEVEN cut, 63 + 62).  The result must equal the two parts run on their own (bit for bit) and F.conv2d on the first
+    image, the two images either side of the cut and the last one."""
     from melspec_gpt_vqvae_amd import ops
 
-    B, H, W, C = 130, 80, 848, 128
+    H, W, C = 80, 848, 128
     g = torch.Generator(device=DEV).manual_seed(19)
     x = (torch.randn(B, H, W, C, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
     assert x.numel() * 2 > 2 ** 31
@@ -388,9 +390,10 @@ def test_downsample_conv_over_two_gib_of_input_runs_as_whole_image_launches():
     wp = w.permute(0, 2, 3, 1).contiguous().to(DEV)
     y = ops.conv2d_nhwc(x, wp, bias.to(DEV), stride=2, pad=(0, 0), out_hw=(40, 424))
     assert y.shape == (B, 40, 424, C)
-    for lo, hi in ((0, 65), (65, 130)):
+    cut = (B + 1) // 2
+    for lo, hi in ((0, cut), (cut, B)):
         assert torch.equal(y[lo:hi], ops.conv2d_nhwc(x[lo:hi].contiguous(), wp, bias.to(DEV), stride=2, pad=(0, 0), out_hw=(40, 424)))
-    for b in (0, B - 1):
+    for b in (0, cut - 1, cut, B - 1):
         xin = F.pad(x[b:b + 1].float().cpu().permute(0, 3, 1, 2), (0, 1, 0, 1))
         ref = F.conv2d(xin, w.float(), bias, stride=2).permute(0, 2, 3, 1)
         assert rel_err(y[b:b + 1].float().cpu().numpy(), ref.numpy()) < 2 ** -8
