@@ -219,6 +219,25 @@ int melgpt_conv3x3_bwd_data(const void* dy, const void* wpack, void* dx, int B, 
                             void* workspace, int dtype, void* stream);
 int melgpt_conv3x3_bwd_weight(const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int Cin, int Cout,
                               void* workspace, int dtype, void* stream);
+/* The same for Downsample's convolution (F.pad (0,1,0,1) + conv3x3 stride 2, :151-159): x (B,H,W,Cin), dy (B,OH,OW,Cout) with
+ * OH = (H - 2) / 2 + 1.  bwd_data: a stride-1 convolution of the zero-dilated gradient; bwd_weight: the four phase images of the
+ * padded input make every tap a row offset again. */
+long long melgpt_conv3x3_s2_bwd_workspace(int B, int H, int W, int Cin, int Cout, int dtype);
+int melgpt_conv3x3_s2_bwd_data(const void* dy, const void* wpack, void* dx, int B, int H, int W, int Cin, int Cout,
+                               void* workspace, int dtype, void* stream);
+int melgpt_conv3x3_s2_bwd_weight(const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int Cin, int Cout,
+                                 void* workspace, int dtype, void* stream);
+/* Upsample (nearest x2 + conv3x3, :171-186): y (B,2H,2W,C) = the x2 tensor itself (the weight gradient's operand; the forward
+ * folds it into the addressing), and its adjoint y (B,H,W,C) = 2 x 2 block sums of x (B,2H,2W,C). */
+int melgpt_upsample2_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+int melgpt_sumpool2_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+/* AttnBlock's softmax (:438-440) backward: dscores[r,c] = scale * probs[r,c] * (dprobs[r,c] - sum_c' dprobs[r,c'] probs[r,c']) for
+ * c < n, zeros for n <= c < ld_dscores; probs / dscores in dtype, dprobs f32. */
+int melgpt_softmax_bwd_rows(const void* probs, long long ld_probs, const float* dprobs, long long ld_dprobs, int n, long long rows,
+                            float scale, void* dscores, long long ld_dscores, int dtype, void* stream);
+/* im2col of a ONE-channel image for a 3 x 3 / pad 1 convolution: out ((B H W) x 32), column t < 9 = the tap (t / 3 - 1, t % 3 - 1),
+ * the rest zeros - the gradient side of Encoder.conv_in (1 -> ch, :203-207) and Decoder.conv_out (ch -> 1, :355-359) as GEMMs. */
+int melgpt_im2col_c1(const void* img, void* out, int B, int H, int W, int dtype, void* stream);
 long long melgpt_groupnorm_swish_bwd_workspace(int B, int HW, int C);
 int melgpt_groupnorm_swish_bwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                const void* dy, void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int swish,

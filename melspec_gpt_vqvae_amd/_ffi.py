@@ -121,11 +121,19 @@ _PROTOS = {
     "melgpt_conv3x3_bwd_workspace": [_i, _i, _i, _i, _i, _i],
     "melgpt_conv3x3_bwd_data": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p],
     "melgpt_conv3x3_bwd_weight": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p],
+    "melgpt_conv3x3_s2_bwd_workspace": [_i, _i, _i, _i, _i, _i],
+    "melgpt_conv3x3_s2_bwd_data": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p],
+    "melgpt_conv3x3_s2_bwd_weight": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p],
+    "melgpt_upsample2_nhwc": [_p, _p, _i, _i, _i, _i, _i, _p],
+    "melgpt_sumpool2_nhwc": [_p, _p, _i, _i, _i, _i, _i, _p],
+    "melgpt_softmax_bwd_rows": [_p, _l, _p, _l, _i, _l, _f, _p, _l, _i, _p],
+    "melgpt_im2col_c1": [_p, _p, _i, _i, _i, _i, _p],
     "melgpt_groupnorm_swish_bwd_workspace": [_i, _i, _i],
     "melgpt_groupnorm_swish_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p],
 }
 _RESTYPE = {"melgpt_strerror": C.c_char_p, "melgpt_vq_image_bytes": C.c_int64, "melgpt_linear_lds_workspace": C.c_int64,
-            "melgpt_conv3x3_bwd_workspace": C.c_int64, "melgpt_groupnorm_swish_bwd_workspace": C.c_int64}
+            "melgpt_conv3x3_bwd_workspace": C.c_int64, "melgpt_groupnorm_swish_bwd_workspace": C.c_int64,
+            "melgpt_conv3x3_s2_bwd_workspace": C.c_int64}
 
 _lib = None
 

@@ -749,6 +749,61 @@ def conv3x3_bwd_weight(x, dy, want_bias=True):
     return dw, db
 
 
+def conv3x3_s2_bwd(x, dy, wpack, need_dx=True):
+    """Downsample's convolution (pad (0,1,0,1) + conv3x3 stride 2): x (B,H,W,Cin), dy (B,OH,OW,Cout), wpack (Cout,3,3,Cin) ->
+    (dx or None, dw (Cout,3,3,Cin) f32, dbias (Cout,) f32)."""
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    assert x.is_contiguous() and dy.is_contiguous() and wpack.is_contiguous() and dy.dtype == x.dtype == wpack.dtype
+    assert dy.shape[1:3] == ((H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1)
+    ws = torch.empty(int(_ffi.lib().melgpt_conv3x3_s2_bwd_workspace(B, H, W, Cin, Cout, dtype_code(x.dtype))), dtype=torch.uint8, device=x.device)
+    dx = None
+    if need_dx:
+        dx = torch.empty_like(x)
+        call("melgpt_conv3x3_s2_bwd_data", ptr(dy), ptr(wpack), ptr(dx), B, H, W, Cin, Cout, ptr(ws), dtype_code(x.dtype), stream())
+    dw = torch.empty(Cout, 3, 3, Cin, dtype=torch.float32, device=x.device)
+    db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+    call("melgpt_conv3x3_s2_bwd_weight", ptr(x), ptr(dy), ptr(dw), ptr(db), B, H, W, Cin, Cout, ptr(ws), dtype_code(x.dtype), stream())
+    return dx, dw, db
+
+
+def upsample2(x):
+    """x (B,H,W,C) -> (B,2H,2W,C), nearest."""
+    B, H, W, C = x.shape
+    assert x.is_contiguous()
+    y = torch.empty(B, 2 * H, 2 * W, C, dtype=x.dtype, device=x.device)
+    call("melgpt_upsample2_nhwc", ptr(x), ptr(y), B, H, W, C, dtype_code(x.dtype), stream())
+    return y
+
+
+def sumpool2(x):
+    """x (B,2H,2W,C) -> (B,H,W,C): sums of the 2 x 2 blocks (the adjoint of upsample2)."""
+    B, H2, W2, C = x.shape
+    assert x.is_contiguous() and H2 % 2 == 0 and W2 % 2 == 0
+    y = torch.empty(B, H2 // 2, W2 // 2, C, dtype=x.dtype, device=x.device)
+    call("melgpt_sumpool2_nhwc", ptr(x), ptr(y), B, H2 // 2, W2 // 2, C, dtype_code(x.dtype), stream())
+    return y
+
+
+def softmax_bwd_rows(probs, dprobs, n, scale):
+    """probs (..., rows, ld) in the compute dtype (columns >= n zero), dprobs (..., rows, ld) f32 -> dscores like probs."""
+    assert probs.is_contiguous() and dprobs.is_contiguous() and dprobs.dtype == torch.float32 and probs.shape == dprobs.shape
+    ld = probs.shape[-1]
+    rows = probs.numel() // ld
+    ds = torch.empty_like(probs)
+    call("melgpt_softmax_bwd_rows", ptr(probs), ld, ptr(dprobs), ld, int(n), rows, float(scale), ptr(ds), ld, dtype_code(probs.dtype), stream())
+    return ds
+
+
+def im2col_c1(img, dtype):
+    """img (B,H,W) in `dtype` -> (B*H*W, 32): the nine taps of a 3x3 / pad 1 convolution of a one-channel image, zero-padded to 32."""
+    B, H, W = img.shape
+    assert img.is_contiguous() and img.dtype == dtype
+    out = torch.empty(B * H * W, 32, dtype=dtype, device=img.device)
+    call("melgpt_im2col_c1", ptr(img), ptr(out), B, H, W, dtype_code(dtype), stream())
+    return out
+
+
 def groupnorm_swish_bwd(x, stats, gamma, beta, dy, swish=True):
     """gradient of swish?(GroupNorm(32)(x) * gamma + beta): x, dy (B,H,W,C); stats = (mean, rstd) of the forward
     (groupnorm_stats) -> (dx, dgamma, dbeta)."""

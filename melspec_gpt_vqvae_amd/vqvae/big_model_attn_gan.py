@@ -22,41 +22,12 @@ from ..flat import tensor_version
 from .quantizer import VectorQuantizer  # noqa: F401  (re-exported under the reference's module path)
 
 
+from . import autograd as _ag  # noqa: E402  (the differentiable path: one autograd Function per layer kind)
+
+
 def _require_cuda(x):
     if not x.is_cuda:
         raise _ffi.MelgptError("melspec_gpt_vqvae_amd runs on the GPU only (no CPU / eager fallback)")
-
-
-class _InferenceOnly(torch.autograd.Function):
-    """The VQ-VAE encoder / decoder kernels are forward-only (VQ-VAE training is out of this build's scope: the
-    reference's README trains it elsewhere); the reference's LitVQVAE.forward (big_model_attn_gan.py:622-634) is
-    differentiable end to end.  An output computed while autograd is recording from an input or parameter that requires a
-    gradient is therefore tied to this node, whose backward REFUSES - `.backward()` through encode / decode / forward
-    raises instead of silently leaving the convolutions without gradients.  Forward-only callers that never call
-    backward (feature_extraction/extract_codes.py:48-49 runs encode with autograd on) are not affected."""
-
-    @staticmethod
-    def forward(ctx, out, where, *anchors):
-        ctx.where = where
-        return out.view_as(out)
-
-    @staticmethod
-    def backward(ctx, *grads):
-        raise _ffi.MelgptError(
-            f"{ctx.where}: gradients through the VQ-VAE encoder / decoder are not implemented (inference-only HIP "
-            "path; VQ-VAE training is out of scope) - wrap the call in torch.no_grad(), or freeze the module and detach "
-            "its input")
-
-
-def _inference_only(module, where, out, *inputs):
-    if not torch.is_grad_enabled():
-        return out
-    anchors = [x for x in inputs if isinstance(x, torch.Tensor) and x.requires_grad]
-    if not anchors:
-        anchors = [p for p in module.parameters() if p.requires_grad][:1]
-    if not anchors:
-        return out
-    return _InferenceOnly.apply(out, where, *anchors)
 
 
 def _cdtype(module):
@@ -93,6 +64,28 @@ def _conv(conv, h, *, residual=None, stride=1, pad=None, upsample=False, out_hw=
         pad = (k // 2, k // 2)
     return ops.conv2d_nhwc(h, wp, _f32(conv.bias), stride=stride, pad=pad, upsample=upsample, residual=residual,
                            out_hw=out_hw)
+
+
+class _ToNhwcFn(torch.autograd.Function):
+    """logical (B,C,H,W) tensor of any strides / float dtype -> contiguous (B,H,W,C) in the compute dtype, differentiable
+    (the boundary conversion of the differentiable path; the gradient comes back in the input's dtype and logical shape)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.in_dtype = x.dtype
+        return ops.to_nhwc(x, dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = dy.permute(0, 3, 1, 2)
+        return (g if g.dtype == ctx.in_dtype else g.to(ctx.in_dtype)), None
+
+
+def _to_nhwc_grad(x, dtype):
+    v = x.permute(0, 2, 3, 1)
+    if v.is_contiguous() and x.dtype == dtype:
+        return v                      # a view: autograd follows it
+    return _ToNhwcFn.apply(x, dtype)
 
 
 def _as_nchw(h):
@@ -204,7 +197,9 @@ class ResnetBlock(nn.Module):
     def forward(self, x, temb):
         assert temb is None, "the mel VQ-VAE has no timestep embedding (temb_ch = 0, reference :196)"
         _require_cuda(x)
-        return _inference_only(self, "ResnetBlock.forward", _as_nchw(self._nhwc(ops.to_nhwc(x, _cdtype(self)))), x)
+        if _ag.wants_grad(self, x):
+            return _as_nchw(_ag.resnet_block(self, _to_nhwc_grad(x, _cdtype(self))))
+        return _as_nchw(self._nhwc(ops.to_nhwc(x, _cdtype(self))))
 
 
 class Downsample(nn.Module):
@@ -224,7 +219,9 @@ class Downsample(nn.Module):
 
     def forward(self, x):
         _require_cuda(x)
-        return _inference_only(self, "Downsample.forward", _as_nchw(self._nhwc(ops.to_nhwc(x, _cdtype(self)))), x)
+        if _ag.wants_grad(self, x):
+            return _as_nchw(_ag.Conv3x3Fn.apply(_to_nhwc_grad(x, _cdtype(self)), self.conv.weight, self.conv.bias, None, "s2"))
+        return _as_nchw(self._nhwc(ops.to_nhwc(x, _cdtype(self))))
 
 
 class Upsample(nn.Module):
@@ -241,7 +238,9 @@ class Upsample(nn.Module):
 
     def forward(self, x):
         _require_cuda(x)
-        return _inference_only(self, "Upsample.forward", _as_nchw(self._nhwc(ops.to_nhwc(x, _cdtype(self)))), x)
+        if _ag.wants_grad(self, x):
+            return _as_nchw(_ag.Conv3x3Fn.apply(_to_nhwc_grad(x, _cdtype(self)), self.conv.weight, self.conv.bias, None, "up"))
+        return _as_nchw(self._nhwc(ops.to_nhwc(x, _cdtype(self))))
 
 
 class AttnBlock(nn.Module):
@@ -295,7 +294,9 @@ class AttnBlock(nn.Module):
 
     def forward(self, x):
         _require_cuda(x)
-        return _inference_only(self, "AttnBlock.forward", _as_nchw(self._nhwc(ops.to_nhwc(x, _cdtype(self)))), x)
+        if _ag.wants_grad(self, x):
+            return _as_nchw(_ag.attn_block(self, _to_nhwc_grad(x, _cdtype(self))))
+        return _as_nchw(self._nhwc(ops.to_nhwc(x, _cdtype(self))))
 
 
 class Encoder(nn.Module):
@@ -369,7 +370,9 @@ class Encoder(nn.Module):
 
     def forward(self, x):
         _require_cuda(x)
-        return _inference_only(self, "Encoder.forward", _as_nchw(self._nhwc(x)), x)
+        if _ag.wants_grad(self, x):
+            return _as_nchw(_ag.encoder(self, x, _cdtype(self)))
+        return _as_nchw(self._nhwc(x))
 
 
 class Decoder(nn.Module):
@@ -446,7 +449,10 @@ class Decoder(nn.Module):
 
     def forward(self, z):
         _require_cuda(z)
-        return _inference_only(self, "Decoder.forward", _as_nchw(self._nhwc(z)), z)
+        if _ag.wants_grad(self, z):
+            self.last_z_shape = z.shape
+            return _as_nchw(_ag.decoder(self, _to_nhwc_grad(z, _cdtype(self))))
+        return _as_nchw(self._nhwc(z))
 
 
 # ------------------------------------------------------------------------------ discriminator (checkpoint ABI only)
@@ -549,8 +555,10 @@ class LitVQVAE(_LitBase):
         """reference :604-608 -> z logical (B, D, 5, 53) (channels-last strides: the flat (N, D) matrix the
         codebook kernel wants)."""
         _require_cuda(x)
+        if _ag.wants_grad(self, x):
+            return _as_nchw(_ag.conv1x1(self.quant_conv, _ag.encoder(self._encoder, x, _cdtype(self._encoder))))
         h = self._encoder._nhwc(x)
-        return _inference_only(self, "LitVQVAE.encode", _as_nchw(_conv(self.quant_conv, h)), x)
+        return _as_nchw(_conv(self.quant_conv, h))
 
     def decode(self, quant):
         """reference :610-614."""
@@ -559,8 +567,11 @@ class LitVQVAE(_LitBase):
         if ck is not None:
             return torch.cat([self.decode(quant[a:b]) for a, b in ck], 0)
         dt = _cdtype(self._decoder)
+        if _ag.wants_grad(self, quant):
+            self._decoder.last_z_shape = quant.shape
+            return _as_nchw(_ag.decoder(self._decoder, _ag.conv1x1(self.post_quant_conv, _to_nhwc_grad(quant, dt))))
         q = _conv(self.post_quant_conv, ops.to_nhwc(quant, dt))
-        return _inference_only(self, "LitVQVAE.decode", _as_nchw(self._decoder._nhwc(_as_nchw(q))), quant)
+        return _as_nchw(self._decoder._nhwc(_as_nchw(q)))
 
     @torch.no_grad()
     def encode_to_codes(self, x, fused=None):

@@ -596,6 +596,53 @@ def gen_resblock_grad(ref_vq):
     save("resblock_grad", x=x.detach().numpy(), g=g.numpy(), y=y.detach().numpy(), dx=x.grad.numpy(), seed=60, channels=C, **grads)
 
 
+NARROW = dict(ch=32, z_channels=64)   # module globals of big_model_attn_gan.py patched for the narrow end-to-end model
+
+
+def grad_probe(name, g, k=16):
+    """(norm, k sampled entries at seeded positions) of one gradient tensor: small enough to commit for every parameter"""
+    flat = np.asarray(g, dtype=np.float64).ravel()
+    pos = synth.randint(sum(map(ord, name)), 0, flat.size, (k,))
+    return float(np.sqrt((flat * flat).sum())), flat[pos].astype(np.float32), pos.astype(np.int64)
+
+
+def gen_vqvae_grad(ref_vq):
+    """Gradients of the REAL LitVQVAE.forward (vqvae/big_model_attn_gan.py:622-634) - encoder, quant convs, VectorQuantizer with
+    its straight-through estimator, decoder - for a narrow model (module globals ch = 32, z_channels = 64; one 80 x 848 tile, so
+    that the AttnBlocks sit at 5 x 53): L = vq_loss + sum(x_recon * g).  Per parameter: gradient norm + 16 sampled entries."""
+    print("LitVQVAE gradients (narrow)")
+    saved = {k: getattr(ref_vq, k) for k in NARROW}
+    try:
+        for k, v in NARROW.items():
+            setattr(ref_vq, k, v)
+        m = ref_vq.LitVQVAE(num_embeddings=128, embedding_dim=256)
+    finally:
+        for k, v in saved.items():
+            setattr(ref_vq, k, v)
+    sd = synth.vqvae_state_dict(70, num_embeddings=128, embedding_dim=256, ch=32, z_channels=64)
+    missing = m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    assert all(k.startswith("discriminator.") for k in missing.missing_keys) and not missing.unexpected_keys
+    m.train()
+    x = t(2 * synth.mel_tiles(71, 1)[:, None, :, 6:854] - 1)
+    g = t(synth.normal(72, (1, 1, 80, 848), 0.01))
+    loss, x_recon, info = m(x)
+    L = loss + (x_recon * g).sum()
+    L.backward()
+    # (x = 2 * synth.mel_tiles(71, 1)[:, None, :, 6:854] - 1 and g = synth.normal(72, (1,1,80,848), 0.01) are regenerated from their seeds)
+    out = dict(vq_loss=float(loss), L=float(L), indices=info[2].numpy().astype(np.int16).ravel(),
+               rec_sum=float(x_recon.double().sum()), rec_patch=x_recon.detach()[0, 0, 30:34, 400:408].numpy(), seed=70)
+    names = []
+    for k, p in m.named_parameters():
+        if k.startswith("discriminator.") or p.grad is None:
+            continue
+        nrm, samp, pos = grad_probe(k, p.grad.numpy())
+        key = k.replace(".", "__")
+        out["n__" + key], out["s__" + key], out["p__" + key] = nrm, samp, pos
+        names.append(k)
+    out["names"] = np.array(names)
+    save("vqvae_grad", **out)
+
+
 def gen_melgan():
     """MelGAN generator (vocoder/modules.py:38-79): the module imports librosa at the top only for a filter-bank
     helper that the Generator never calls, so a stand-in satisfies the import."""
@@ -690,7 +737,7 @@ def main():
     torch.manual_seed(synth.SEED)
     torch.set_num_threads(8)
     ref_gpt, ref_enc, ref_dec, ref_vq = import_reference()
-    which = set(sys.argv[1:]) or {"vq", "attn", "gpt", "lit", "vae", "vae_mi", "vae_steps", "vae_xl", "vqvae", "resblock", "melgan", "mel"}
+    which = set(sys.argv[1:]) or {"vq", "attn", "gpt", "lit", "vae", "vae_mi", "vae_steps", "vae_xl", "vqvae", "resblock", "vqvae_grad", "melgan", "mel"}
     if which <= {"melgan", "mel"}:
         if "melgan" in which:
             gen_melgan()
@@ -718,6 +765,8 @@ def main():
         gen_vqvae(ref_vq)
     if "resblock" in which:
         gen_resblock_grad(ref_vq)
+    if "vqvae_grad" in which:
+        gen_vqvae_grad(ref_vq)
     if "melgan" in which:
         gen_melgan()
     if "mel" in which:

@@ -362,3 +362,35 @@ def test_oracle_resnet_block_gradients_match_the_real_reference():
     for k, v in sd.items():
         want = g["d_" + k[len("blk."):].replace(".", "_")]
         assert np.allclose(v.grad.numpy(), want, rtol=1e-4, atol=1e-4 * float(np.abs(want).max())), k
+
+
+def test_oracle_vqvae_end_to_end_gradients_match_the_real_litvqvae():
+    """oracle/vqvae.py (encode -> VectorQuantizer.forward with its straight-through estimator -> decode) under torch autograd
+    against the gradients recorded from the REAL LitVQVAE.forward on the narrow model (tests/golden/vqvae_grad.npz): loss, codes,
+    reconstruction, and the gradient norm + 16 sampled entries of every parameter."""
+    g = golden("vqvae_grad")
+    hp = dict(ch_mult=(1, 1, 2, 2, 4), num_res_blocks=2)
+    sd_np = synth.vqvae_state_dict(int(g["seed"]), num_embeddings=128, embedding_dim=256, ch=32, z_channels=64)
+    sd = {k: t(v).clone().requires_grad_(True) for k, v in sd_np.items()}
+    x = t(2 * synth.mel_tiles(71, 1)[:, None, :, 6:854] - 1)
+    gy = t(synth.normal(72, (1, 1, 80, 848), 0.01))
+    z = ovq.vqvae_encode(sd, x, **hp)
+    loss, q, _, _, idx = ovq.vq_forward(z, sd["_vq_vae._embedding.weight"])
+    rec = ovq.vqvae_decode(sd, q, **hp)
+    L = loss + (rec * gy).sum()
+    L.backward()
+    assert np.array_equal(idx.numpy().ravel().astype(np.int16), g["indices"])
+    assert abs(float(loss) - float(g["vq_loss"])) < 1e-5 and abs(float(L) - float(g["L"])) < 1e-5
+    assert np.allclose(rec.detach()[0, 0, 30:34, 400:408].numpy(), g["rec_patch"], rtol=1e-4, atol=1e-5)
+    names = [str(n) for n in g["names"]]
+    S = float(np.median([float(g["n__" + n.replace(".", "__")]) for n in names]))
+    for name in names:
+        key = name.replace(".", "__")
+        flat = sd[name].grad.double().numpy().ravel()
+        nrm, samp, pos = float(g["n__" + key]), g["s__" + key].astype(np.float64), g["p__" + key]
+        ours = float(np.sqrt((flat * flat).sum()))
+        if nrm < 1e-4 * S:          # analytically zero gradients (key biases; conv biases in front of a one-channel-per-group norm)
+            assert ours < 1e-4 * S, name
+            continue
+        assert abs(ours - nrm) <= 1e-4 * nrm, name
+        assert np.abs(flat[pos] - samp).max() <= 1e-3 * max(np.abs(samp).max(), nrm / np.sqrt(flat.size)), name

@@ -140,6 +140,134 @@ def test_conv3x3_backward_at_the_reference_layer_size():
     assert rel_err(db.cpu().numpy(), b.grad.numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 10, 22, 64, 64), (3, 20, 106, 128, 128), (1, 8, 6, 64, 128)])
+def test_downsample_conv_backward_against_torch_autograd(dt, B, H, W, Cin, Cout):
+    """Downsample: F.pad (0,1,0,1) + conv3x3 stride 2 (big_model_attn_gan.py:151-159)."""
+    from melspec_gpt_vqvae_amd import ops
+
+    dtp = DT[dt]
+    OH, OW = (H - 2) // 2 + 1, (W - 2) // 2 + 1
+    x = t(synth.normal(101, (B, Cin, H, W), 1.0, 0.2)).to(dtp)
+    w = t(synth.normal(102, (Cout, Cin, 3, 3), 0.05)).to(dtp)
+    gy = t(synth.normal(103, (B, Cout, OH, OW), 0.8)).to(dtp)
+    xr, wr = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    b = torch.zeros(Cout, requires_grad=True)
+    y = F.conv2d(F.pad(xr, (0, 1, 0, 1)), wr, b, stride=2)
+    assert y.shape[2:] == (OH, OW)
+    y.backward(gy.float())
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    gd = gy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wp = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dx, dw, db = ops.conv3x3_s2_bwd(xd, gd, wp)
+    tol = TOL[dt]
+    assert rel_err(nchw(dx), xr.grad.numpy()) < tol
+    assert rel_err(oihw(dw), wr.grad.numpy()) < tol
+    assert rel_err(db.cpu().numpy(), b.grad.numpy()) < tol
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_upsample_conv_backward_against_torch_autograd(dt):
+    """Upsample: nearest x2 + conv3x3 (:171-186) = the stride-1 exports on the x2 geometry + upsample2 / its adjoint sumpool2."""
+    from melspec_gpt_vqvae_amd import ops
+
+    dtp = DT[dt]
+    B, H, W, C = 2, 5, 13, 64
+    x = t(synth.normal(111, (B, C, H, W), 1.0, 0.2)).to(dtp)
+    w = t(synth.normal(112, (C, C, 3, 3), 0.05)).to(dtp)
+    gy = t(synth.normal(113, (B, C, 2 * H, 2 * W), 0.8)).to(dtp)
+    xr, wr = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    F.conv2d(F.interpolate(xr, scale_factor=2.0, mode="nearest"), wr, None, padding=1).backward(gy.float())
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    gd = gy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wp = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    xu = ops.upsample2(xd)
+    assert torch.equal(xu.float().cpu().permute(0, 3, 1, 2), F.interpolate(x.float(), scale_factor=2.0, mode="nearest"))
+    dxu = ops.conv3x3_bwd_data(gd, wp, C)
+    dx = ops.sumpool2(dxu)
+    dw, _ = ops.conv3x3_bwd_weight(xu, gd, want_bias=False)
+    tol = TOL[dt]
+    assert rel_err(nchw(dx), xr.grad.numpy()) < tol
+    assert rel_err(oihw(dw), wr.grad.numpy()) < tol
+
+
+def _narrow_litvqvae():
+    """the package's LitVQVAE with the module globals patched to the fixture's narrow sizes (ch = 32, z_channels = 64)"""
+    import melspec_gpt_vqvae_amd.vqvae.big_model_attn_gan as vq
+
+    saved = {k: getattr(vq, k) for k in ("ch", "z_channels")}
+    try:
+        vq.ch, vq.z_channels = 32, 64
+        m = vq.LitVQVAE(num_embeddings=128, embedding_dim=256)
+    finally:
+        for k, v in saved.items():
+            setattr(vq, k, v)
+    sd = synth.vqvae_state_dict(70, num_embeddings=128, embedding_dim=256, ch=32, z_channels=64)
+    res = m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    assert all(k.startswith("discriminator.") for k in res.missing_keys) and not res.unexpected_keys
+    return m.to(DEV).train()
+
+
+def test_litvqvae_forward_is_differentiable_like_the_reference():
+    """LitVQVAE.forward (big_model_attn_gan.py:622-634) end to end on the f32 lane - encoder, quant_conv, VectorQuantizer with
+    its straight-through estimator, post_quant_conv, decoder - against the gradients of the REAL module recorded by
+    tests/golden/make_golden.py (narrow model, one 80 x 848 tile; L = vq_loss + sum(x_recon * g)): the loss, the codes, the
+    reconstruction, and for EVERY one of the 343 parameters the gradient's norm and 16 sampled entries, 1e-4 of the tensor's scale."""
+    g = golden("vqvae_grad")
+    m = _narrow_litvqvae()
+    x = t(2 * synth.mel_tiles(71, 1)[:, None, :, 6:854] - 1, DEV)
+    gy = t(synth.normal(72, (1, 1, 80, 848), 0.01), DEV)
+    loss, x_recon, info = m(x)
+    assert x_recon.shape == x.shape and x_recon.requires_grad and loss.requires_grad
+    assert np.array_equal(info[2].cpu().numpy().ravel().astype(np.int16), g["indices"])
+    L = loss + (x_recon.float() * gy).sum()
+    assert abs(float(loss.detach()) - float(g["vq_loss"])) < 1e-4 * abs(float(g["vq_loss"]))
+    assert abs(float(L.detach()) - float(g["L"])) < 1e-4 * max(1.0, abs(float(g["L"])))
+    assert rel_err(x_recon.detach()[0, 0, 30:34, 400:408].cpu().numpy(), g["rec_patch"]) < 1e-4
+    L.backward()
+    params = dict(m.named_parameters())
+    names = [str(n) for n in g["names"]]
+    S = float(np.median([float(g["n__" + n.replace(".", "__")]) for n in names]))      # typical gradient norm (1.4)
+    bad, zeros = {}, 0
+    for name in names:
+        key = name.replace(".", "__")
+        p = params[name]
+        assert p.grad is not None, name
+        flat = p.grad.detach().double().cpu().numpy().ravel()
+        nrm, samp, pos = float(g["n__" + key]), g["s__" + key].astype(np.float64), g["p__" + key]
+        ours = float(np.sqrt((flat * flat).sum()))
+        if nrm < 1e-4 * S:
+            # analytically ZERO gradients - the key bias of an AttnBlock (softmax is invariant to it) and, at one channel per
+            # GroupNorm group (ch = 32), a conv bias in front of a norm: the reference holds f32 noise (1e-8 .. 2e-5), so must we
+            zeros += 1
+            if ours >= 1e-4 * S:
+                bad[name] = ("zero-gradient parameter", ours)
+            continue
+        scale = nrm / np.sqrt(flat.size)                        # rms entry of the reference gradient
+        e_n = abs(ours - nrm) / nrm
+        e_s = float(np.abs(flat[pos] - samp).max() / max(np.abs(samp).max(), scale))
+        if e_n > 1e-4 or e_s > 1e-3:
+            bad[name] = (e_n, e_s)
+    assert not bad, (len(bad), list(bad.items())[:8])
+    assert zeros == 21 and len(names) == 343
+    assert all(p.grad is None for n, p in params.items() if n.startswith("discriminator."))
+
+
+def test_inference_path_is_untouched_by_autograd_and_frozen_modules_record_nothing():
+    """torch.no_grad() (every production caller) and a frozen module fed a plain input keep the fused inference kernels;
+    with autograd recording the differentiable (unfused) path gives the same result to f32 rounding."""
+    m = _narrow_litvqvae()
+    x = t(2 * synth.mel_tiles(73, 1)[:, None, :, 6:854] - 1, DEV)
+    with torch.no_grad():
+        z0 = m.encode(x)
+    z = m.encode(x)
+    assert z.requires_grad and rel_err(z.detach().cpu().numpy(), z0.cpu().numpy()) < 1e-4
+    for p in m.parameters():
+        p.requires_grad_(False)
+    z1 = m.encode(x)
+    assert not z1.requires_grad and torch.equal(z1, z0)
+
+
 def test_backward_exports_refuse_what_they_do_not_serve():
     from melspec_gpt_vqvae_amd import _ffi, ops
 

@@ -443,12 +443,12 @@ def test_extract_codes_writes_reference_named_files(tmp_path):
     assert extract_all(root, m, DEV, 848) == []         # nothing left to do
 
 
-def test_backward_through_the_inference_only_vqvae_is_refused_not_silently_empty():
-    """The reference's LitVQVAE.forward is differentiable end to end (big_model_attn_gan.py:622-634); here the encoder /
-    decoder kernels are forward-only (VQ-VAE training is out of scope).  Recording autograd through them must not end in
-    silently missing gradients: `.backward()` raises MelgptError.  Forward-only use with autograd on - what
-    feature_extraction/extract_codes.py:48-49 does - keeps working and gives the no_grad bits."""
-    from melspec_gpt_vqvae_amd import _ffi
+def test_backward_through_the_full_size_vqvae_runs_and_frozen_modules_record_nothing():
+    """The reference's LitVQVAE.forward is differentiable end to end (big_model_attn_gan.py:622-634); since round 6 so is this
+    one (vqvae/autograd.py; parity of every gradient on the narrow model: tests/test_vqvae_bwd_gpu.py).  Here the FULL-SIZE
+    model, one tile, f32 lane: forward + backward run, every encoder / decoder / codebook parameter receives a finite gradient;
+    a gradient w.r.t. the decoder's latent input comes back in its layout; a frozen module fed a plain input records nothing
+    and the quantiser alone stays differentiable."""
     from melspec_gpt_vqvae_amd.vqvae.big_model_attn_gan import LitVQVAE
 
     g = golden("vqvae_full")
@@ -458,14 +458,19 @@ def test_backward_through_the_inference_only_vqvae_is_refused_not_silently_empty
     x = t(g["x"][:1], DEV)
     with torch.no_grad():
         z0 = m.encode(x)
-    z = m.encode(x)                                  # autograd on, parameters require a gradient: forward is fine
-    assert z.requires_grad and torch.equal(z.detach(), z0)
+    z = m.encode(x)                                  # autograd on, parameters require a gradient: the differentiable path
+    assert z.requires_grad and rel_err(z.detach().cpu().numpy(), z0.cpu().numpy()) < 1e-4
     loss, x_recon, info = m(x)
     assert x_recon.shape == x.shape and x_recon.requires_grad and loss.requires_grad
-    with pytest.raises(_ffi.MelgptError, match="not implemented"):
-        (loss + x_recon.float().mean()).backward()
-    with pytest.raises(_ffi.MelgptError, match="LitVQVAE.decode"):
-        m.decode(z0.clone().requires_grad_(True)).float().sum().backward()
+    (loss + x_recon.float().mean()).backward()
+    for n, p in m.named_parameters():
+        if n.startswith("discriminator."):
+            assert p.grad is None
+        else:
+            assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.shape == p.shape, n
+    zq = z0.clone().requires_grad_(True)
+    m.decode(zq).float().sum().backward()
+    assert zq.grad is not None and zq.grad.shape == zq.shape and torch.isfinite(zq.grad.float()).all()
     # a frozen module fed a plain input records nothing, and the quantiser alone stays differentiable (its own kernel)
     for p in m.parameters():
         p.requires_grad_(False)
