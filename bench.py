@@ -664,6 +664,8 @@ def main():
                     help="frozen VQ-VAE codebook of the class_gpt workload: latents (default) = rows sampled from the encoder's "
                          "own outputs, usage-balanced -> the step's tokens spread over the 128 codes (BASELINE.md 4 asks for "
                          "uniform codes); normal = N(0,1) rows as in rounds 1-5 (tokens collapse: perplexity ~3)")
+    ap.add_argument("--timer-every", type=int, default=5,
+                    help="HIP-event timing of the GEMM family / attention launches on every n-th step of the timed region (1: every step)")
     ap.add_argument("--no-reference-steps", action="store_true",
                     help="skip the single-stream reference steps behind the timed region (profiled runs: every kernel of the "
                          "trace then belongs to a default step)")
@@ -753,17 +755,25 @@ def main():
         phases[k] = 0.0
     if job.dp is not None:
         job.dp.ex.time_events = True   # two event records per step around finish()'s waits -> exposed_comm_ms
-    ops.TIMER = ops.KernelTimer()
+    # Live HIP-event timing of the family's launches INSIDE the timed region, on every `--timer-every`-th of its steps
+    # (default 5: steps 0, 5, 10, 15 of 20).  An event record is a marker packet in the launch queue: two around each of
+    # the ~380 timed launches of a step cost 1.7-1.8 ms of a 90 ms step when every step carries them (measured A/B,
+    # profiles/r06_w_event_overhead_ab.jsonl) - instrumentation the training step does not have.  `value` is the
+    # throughput of all K steps, marker-carrying ones included.
+    timer = ops.KernelTimer()
+    every = max(1, a.timer_every)
+    tsteps = len(range(0, a.steps, every))
     loops0 = _gemm_loops()
     fence()
     t0 = time.perf_counter()
     loss = None
-    for _ in range(a.steps):
+    for i in range(a.steps):
+        ops.TIMER = timer if i % every == 0 else None
         loss = step()
+    ops.TIMER = None
     fence()
     elapsed = time.perf_counter() - t0
     loops1 = _gemm_loops()
-    timer, ops.TIMER = ops.TIMER, None
     loss_val = float(loss.detach())
 
     # Kernel-quality reference OUTSIDE the timed region (rank 0, one GPU): more steps with everything on ONE stream (the median of five).  In
@@ -814,8 +824,8 @@ def main():
         # attention (HBM-bound at T = 265, hs = 64: DESIGN 4): per launch form, live HIP-event time against the algorithmic
         # bytes (ops.attn_fwd / attn_bwd) and, when the committed PMC pass has them, against the counted bytes
         aux = timer.aux_by_tag()
-        attn_flops = sum(v[3] for v in aux.values())          # (FLOPs of the timed region, for step_frac)
-        aux_steps = a.steps
+        attn_flops = sum(v[3] for v in aux.values())          # (FLOPs of the event-carrying steps, for step_frac)
+        aux_steps = tsteps
         if single is not None:      # per-launch times from the single-stream reference steps (the backward kernel shares the
             aux, aux_steps = single[0].aux_by_tag(), single[1]   # chip with a weight-gradient GEMM in the timed region)
         attn = {}
@@ -828,11 +838,11 @@ def main():
                 row["counted_MB"] = counted
                 row["frac_hbm_counted"] = round(counted * 1e6 / (us * 1e-6) / 8e12, 4)
             attn[tag] = row
-        step_flops = (ks["flops"] + attn_flops) / max(a.steps, 1)
+        step_flops = (ks["flops"] + attn_flops) / max(tsteps, 1)
         # per-instantiation table: one row per (layout, shape, epilogue) of the GEMM family, slowest rate first among
         # the rows that matter (>= 0.5 % of the family's time) - names the shape the family's `frac` is held down by
         # (per-shape rates from the single-stream reference steps when they exist: launches that do not share the chip)
-        ptimer, psteps = (single[0], single[1]) if single is not None else (timer, a.steps)
+        ptimer, psteps = (single[0], single[1]) if single is not None else (timer, tsteps)
         pks = ptimer.summary()
         rows = [{"shape": tag, "calls_per_step": round(n / psteps, 2), "ms_per_step": round(ms / psteps, 3),
                  "tflop_per_step": round(fl / psteps / 1e12, 3), "tflops": round(fl / ms / 1e9, 1) if ms > 0 else 0.0}
@@ -869,17 +879,18 @@ def main():
                 "mfma_busy": pmc.get("mfma_busy"), "mfma_busy_by_kernel": pmc.get("mfma_busy_by_kernel"),
                 "in_kernel_clock_GHz": pmc.get("in_kernel_clock_GHz"),
                 "kernel": "MFMA GEMM family (gemm8p_kernel / gemm256_kernel persistent 256x256 / gemm_kernel 128x128 + implicit-GEMM conv / "
-                          "conv3x3_gn_wide_kernel / conv3x3_gn_kernel with fused GroupNorm+swish), all launches of the timed region",
-                "launches_per_step": ks["launches"] // max(a.steps, 1),
+                          "conv3x3_gn_ws_kernel with fused GroupNorm+swish), every launch of the event-carrying steps of the timed region",
+                "launches_per_step": ks["launches"] // max(tsteps, 1),
+                "event_timed_steps": f"{tsteps} of the {a.steps} timed steps" + (f" (every {every}th)" if every > 1 else ""),
                 # time with at least one family launch running (the Block's weight gradients run on a second stream beside
                 # the input-gradient chain since round 6: union of the launch intervals on the device clock) / plain sum
-                "kernel_ms_per_step": round(ks["total_ms"] / max(a.steps, 1), 3),
-                "kernel_serial_ms_per_step": round(ks.get("serial_ms", ks["total_ms"]) / max(a.steps, 1), 3),
+                "kernel_ms_per_step": round(ks["total_ms"] / max(tsteps, 1), 3),
+                "kernel_serial_ms_per_step": round(ks.get("serial_ms", ks["total_ms"]) / max(tsteps, 1), 3),
                 # the same family on ONE stream (the median of five reference steps outside the timed region): what the kernels do when
                 # no launch shares the chip - `per_shape` / `worst_shape` below are from these steps
                 "frac_single_stream": round(pks["flops"] / (pks["total_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if single is not None and pks["total_ms"] > 0 else None,
                 "ms_per_step_single_stream": round(1e3 * single[2], 3) if single is not None else None,
-                "algorithmic_tflop_per_step": round(ks["flops"] / max(a.steps, 1) / 1e12, 3),
+                "algorithmic_tflop_per_step": round(ks["flops"] / max(tsteps, 1) / 1e12, 3),
                 "worst_shape": worst, "per_shape": major,
             },
         }
