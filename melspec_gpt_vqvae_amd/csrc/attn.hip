@@ -224,6 +224,7 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kerne
   // BWD == false: forward (O, lse, optional att).   BWD == true: dQ (+ delta) from dO, recomputing P from lse.
   using A = AT<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  MELGPT_CLK_BEGIN();
   const int t = threadIdx.x, lane = t & 63, i16 = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z, Tn = p.T, nu = p.n_unmasked;
   const int TP = rup(Tn, 32);
@@ -443,6 +444,7 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 4 : 2) void attn_q_kerne
   }
   lse_q = nlse;
  }  // tile loop
+  if constexpr (!BWD) MELGPT_CLK_END(clk_attn_fwd);
 }
 
 // ============================================================================================ dK / dV
