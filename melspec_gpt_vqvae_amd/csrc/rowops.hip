@@ -658,35 +658,49 @@ __global__ __launch_bounds__(256) void embed_bwd_table_kernel(const T* __restric
 }
 
 // pos_grad[t,:] (+)= sum_b keep(dX[b,t,:])   and   (optional) pre_vals_grad[b,t,:] = keep(dX[b,t,:]) for t < n_pre
+// One wave per (position, group of 64 chunks); the batch is walked in order (fixed summation order) with EIGHT rows'
+// loads requested before the first is used (one row at a time was a chain of B dependent round trips on 67 workgroups:
+// 135 us for the 69 MB of the training step's dX).
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const T* __restrict__ dx, int B, int Ttot, int C,
                                                             float* __restrict__ pos_grad, int accumulate,
                                                             float* __restrict__ pre_grad, int n_pre, float drop_scale,
                                                             unsigned thresh, unsigned long long seed, unsigned sid) {
-  constexpr int N = V16<T>::N;
+  constexpr int N = V16<T>::N, UB = 8;
   const int lane = threadIdx.x & 63;
-  const int tt = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tt >= Ttot) return;
-  for (int ch = lane; ch < C / N; ch += 64) {
-    float acc[N];
+  const int ngrp = (C / N + 63) / 64;
+  const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tt = wv / ngrp, ch = (wv - tt * ngrp) * 64 + lane;
+  if (tt >= Ttot || ch >= C / N) return;
+  float acc[N];
 #pragma unroll
-    for (int e = 0; e < N; ++e) acc[e] = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const long long row = (long long)b * Ttot + tt;
-      float d[N];
-      V16<T>::ld(dx + row * C + ch * N, d);
-      if (drop_scale != 0.f) keep_mask(seed, sid, (unsigned long long)row * C + ch * N, N, thresh, drop_scale, d);
+  for (int e = 0; e < N; ++e) acc[e] = 0.f;
+  auto take = [&](int b, float (&d)[N]) {
+    const long long row = (long long)b * Ttot + tt;
+    if (drop_scale != 0.f) keep_mask(seed, sid, (unsigned long long)row * C + ch * N, N, thresh, drop_scale, d);
 #pragma unroll
-      for (int e = 0; e < N; ++e) acc[e] += d[e];
-      if (pre_grad && tt < n_pre) {
+    for (int e = 0; e < N; ++e) acc[e] += d[e];
+    if (pre_grad && tt < n_pre) {
 #pragma unroll
-        for (int e = 0; e < N; ++e) pre_grad[((long long)b * n_pre + tt) * C + ch * N + e] = d[e];
-      }
+      for (int e = 0; e < N; ++e) pre_grad[((long long)b * n_pre + tt) * C + ch * N + e] = d[e];
     }
-    float* g = pos_grad + (long long)tt * C + ch * N;
+  };
+  int b = 0;
+  for (; b + UB <= B; b += UB) {
+    float d[UB][N];
 #pragma unroll
-    for (int e = 0; e < N; ++e) g[e] = accumulate ? g[e] + acc[e] : acc[e];
+    for (int u = 0; u < UB; ++u) V16<T>::ld(dx + ((long long)(b + u) * Ttot + tt) * C + ch * N, d[u]);
+#pragma unroll
+    for (int u = 0; u < UB; ++u) take(b + u, d[u]);
   }
+  for (; b < B; ++b) {
+    float d[N];
+    V16<T>::ld(dx + ((long long)b * Ttot + tt) * C + ch * N, d);
+    take(b, d);
+  }
+  float* g = pos_grad + (long long)tt * C + ch * N;
+#pragma unroll
+  for (int e = 0; e < N; ++e) g[e] = accumulate ? g[e] + acc[e] : acc[e];
 }
 
 // ================================================================================== cross entropy
@@ -1287,7 +1301,8 @@ extern "C" int melgpt_embed_bwd(const void* dx, const long long* idx, long long 
                                          sc, th, seed, stream_id));
   }
   if (pos_grad) {
-    DISPATCH_T(dtype, hipLaunchKernelGGL(embed_bwd_pos_kernel<T>, dim3((Ttot + 3) / 4), dim3(256), 0, s, (const T*)dx, B,
+    const int vec = dtype == MELGPT_F32 ? 4 : 8, ngrp = (C / vec + 63) / 64;   // one wave per (position, 64 chunks)
+    DISPATCH_T(dtype, hipLaunchKernelGGL(embed_bwd_pos_kernel<T>, dim3((Ttot * ngrp + 3) / 4), dim3(256), 0, s, (const T*)dx, B,
                                          Ttot, C, pos_grad, accumulate, pre_vals_grad, n_pre, sc, th, seed, stream_id));
   }
   return melgpt_launch_status();
