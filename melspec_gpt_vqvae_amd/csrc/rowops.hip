@@ -752,7 +752,15 @@ __global__ void sum_kernel(const float* __restrict__ in, long long n, float scal
                            int accumulate) {
   __shared__ float sh[256];
   float s = 0.f;
-  for (long long i = threadIdx.x; i < n; i += 256) s += in[i];
+  long long i = threadIdx.x;
+  for (; i + 7 * 256 < n; i += 8 * 256) {  // eight loads in flight, added in the order of the plain loop (same bits)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = in[i + u * 256];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; i < n; i += 256) s += in[i];
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
