@@ -239,3 +239,32 @@ def test_rccl_channel_pin_respects_the_users_environment(monkeypatch):
     assert dp.pin_rccl_channels(16) == 24 and os.environ["MELGPT_RESERVE_CUS"] == "8", "what the user exported is respected"
     for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "MELGPT_RESERVE_CUS"):
         monkeypatch.delenv(k, raising=False)
+
+
+def test_kernel_timer_counts_shared_time_once():
+    """bench.py's roofline time is the UNION of the timed launches' intervals on the device clock (a Block's weight
+    gradients run on a second stream beside the input-gradient chain: the plain sum would count shared time twice), per
+    tag it is the plain sum.  Driven with stand-in events (start offsets in milliseconds); no GPU involved."""
+    from melspec_gpt_vqvae_amd import ops
+
+    class Ev:
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    tm = ops.KernelTimer()
+    assert tm.summary() == dict(launches=0, total_ms=0.0, serial_ms=0.0, flops=0)
+    #            main stream: [0, 2) [2, 3)        [6, 7)      side stream: [1, 4)   (recorded out of start order on purpose)
+    for a, b, fl, tag in ((0.0, 2.0, 10.0, "x"), (6.0, 7.0, 5.0, "y"), (1.0, 4.0, 30.0, "w"), (2.0, 3.0, 10.0, "x")):
+        tm.records.append((Ev(a), Ev(b), fl, tag))
+    s = tm.summary()
+    assert s["launches"] == 4 and s["flops"] == 55.0
+    assert s["serial_ms"] == pytest.approx(7.0) and s["total_ms"] == pytest.approx(5.0)   # [0, 4) and [6, 7)
+    rows = {t: (n, ms, fl) for t, n, ms, fl in tm.by_tag()}
+    assert rows == {"x": (2, pytest.approx(3.0), 20.0), "w": (1, pytest.approx(3.0), 30.0), "y": (1, pytest.approx(1.0), 5.0)}
+    assert tm.by_tag()[-1][0] == "y"                      # slowest tag first
+    tm.aux.append((Ev(0.0), Ev(0.5), 100.0, 7.0, "attn"))
+    tm.aux.append((Ev(1.0), Ev(1.5), 100.0, 7.0, "attn"))
+    assert tm.aux_by_tag() == {"attn": (2, pytest.approx(1.0), 200.0, 14.0)}
