@@ -890,6 +890,8 @@ def main():
                 # no launch shares the chip - `per_shape` / `worst_shape` below are from these steps
                 "frac_single_stream": round(pks["flops"] / (pks["total_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if single is not None and pks["total_ms"] > 0 else None,
                 "ms_per_step_single_stream": round(1e3 * single[2], 3) if single is not None else None,
+                "single_stream_note": "the reference steps carry event markers on EVERY launch (+1.7-1.8 ms per step) and a device synchronisation per step: "
+                                      "compare with ms_per_step only through --timer-every 1" if single is not None else None,
                 "algorithmic_tflop_per_step": round(ks["flops"] / max(tsteps, 1) / 1e12, 3),
                 "worst_shape": worst, "per_shape": major,
             },
