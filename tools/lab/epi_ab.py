@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """LAB: the four epilogue-carrying GEMM shapes of a Block (+ their plain twins) at the training size, ms per launch
-(20 back-to-back launches between two events, median of 7), random operands.  A/B knob: MELGPT_GEMM_STAGGER=<percent>."""
+(20 back-to-back launches between two events, median of 7), random operands; the R operands also COLD (pools larger than the
+memory-side cache).  A/B: the library named by MELGPT_LAB_LIB against the in-tree one."""
 import json
 import os
 import sys

@@ -7,7 +7,9 @@
 //             itself cannot be used on one GPU: a group of one rank launches no kernel, and two ranks on one device are
 //             refused.  What matters for the question is the footprint - a few long-lived workgroups that hold CUs the
 //             persistent grid (one 160 KiB-LDS, 512-register workgroup per CU) would otherwise own - and that is modelled.
-// Three settings x {no collective, collective}: static lists, claimed tiles (melgpt_set_dynamic_tiles), 16 reserved CUs.
+// Settings x {no collective, collective}: static lists with 0 / 8 / 16 / 32 reserved CUs (always / around the weight gradients only),
+// both K loops.  (Claimed tiles - melgpt_set_dynamic_tiles, the ring kernel's atomic tile counter - were removed from the library in
+// round 6: the last commit that has them and this rig's arms for them is 2e241d9.)
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/lab/overlap_lab.hip -L melspec_gpt_vqvae_amd/lib
 //        -lmelgpt_hip -Wl,-rpath,'$ORIGIN/../../../melspec_gpt_vqvae_amd/lib' -o tools/lab/bin/overlap_lab
 #include <hip/hip_runtime.h>
@@ -92,21 +94,18 @@ int main(int argc, char** argv) {
   hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
   hipEvent_t e0, e1, c0, c1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&c0)); CK(hipEventCreate(&c1));
 
-  // (round 5: the ping-pong K loop walks static lists only - claimed tiles mean the ring kernel - so the question is now
-  // "ping-pong + static lists (+ reserved CUs) against ring + claimed tiles"; ns_for[] = the weight gradients' split-K
+  // (ns_for[] = the weight gradients' split-K
   // batches ops._wgrad_split picks for the workgroups such a launch gets: 4 on 256, 5 on 248 / 240 CUs)
-  struct Mode { const char* name; int pp, dyn, reserve, wg_res; } modes[] = {
-      {"pingpong, static lists", 1, 0, 0, 0},        {"pingpong, static, 8 reserved CUs", 1, 0, 8, 0},
-      {"pingpong, static, 16 reserved CUs", 1, 0, 16, 0}, {"pingpong, static, 32 reserved CUs", 1, 0, 32, 0},
-      {"pingpong, static, 16 reserved for wgrads only", 1, 0, 0, 16}, {"pingpong, static, 32 reserved for wgrads only", 1, 0, 0, 32},
-      {"ring, claimed tiles", 0, 1, 0, 0},           {"ring, claimed + 16 reserved", 0, 1, 16, 0},
-      {"ring, static lists", 0, 0, 0, 0}};
+  struct Mode { const char* name; int pp, reserve, wg_res; } modes[] = {
+      {"pingpong, static lists", 1, 0, 0},        {"pingpong, static, 8 reserved CUs", 1, 8, 0},
+      {"pingpong, static, 16 reserved CUs", 1, 16, 0}, {"pingpong, static, 32 reserved CUs", 1, 32, 0},
+      {"pingpong, static, 16 reserved for wgrads only", 1, 0, 16}, {"pingpong, static, 32 reserved for wgrads only", 1, 0, 32},
+      {"ring, static lists", 0, 0, 0}};
   const int ns_arg = g_ns;
   printf("{\"bench\": \"backward MLP GEMM chain (2 dgrads%s) x %d beside a stand-in collective of %d channels x 256 threads over 50 MB\", \"wgrad_batches\": %d, \"rows\": [\n", g_ns ? " + 2 wgrads" : "", REPS, G, g_ns);
   for (int round = 0; round < 2; ++round)
     for (auto& m : modes) {
       melgpt_set_gemm_pingpong(m.pp);
-      melgpt_set_dynamic_tiles(m.dyn);
       melgpt_set_reserved_cus(m.reserve);
       g_wg_res = m.wg_res;
       if (ns_arg < 0) g_ns = (m.reserve || m.wg_res) ? 5 : 4;   // (-1: the split the host picks for the grid the launch gets)
@@ -127,7 +126,6 @@ int main(int argc, char** argv) {
       printf("  {\"mode\": \"%s\", \"wgrad_batches\": %d, \"round\": %d, \"chain_alone_ms\": %.3f, \"chain_beside_collective_ms\": %.3f, \"ratio\": %.3f, \"collective_resident_ms\": %.2f},\n",
              m.name, g_ns, round, alone / REPS, beside / REPS, beside / alone, coll);
     }
-  melgpt_set_dynamic_tiles(0);
   melgpt_set_reserved_cus(0);
   melgpt_set_gemm_pingpong(1);
   printf("  {}]}\n");
